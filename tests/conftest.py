@@ -1,0 +1,47 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+REF_GOLDEN = os.path.join(GOLDEN, "reference")
+ROBOTS = os.path.join(ROOT, "optik_amd", "robots")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import binding
+    binding.build()
+    return binding
+
+
+def _load_chain(path, base, ee):
+    from oracle import urdf_chain
+    with open(path) as fh:
+        return urdf_chain.chain_from_urdf(fh.read(), base, ee)
+
+
+ROBOT_SPECS = {
+    "ur3e": (os.path.join(REF_GOLDEN, "ur3e.urdf"), "ur_base_link", "ur_ee_link"),
+    "panda": (os.path.join(ROBOTS, "panda.urdf"), "panda_link0", "panda_link8"),
+    "panda_hand": (os.path.join(ROBOTS, "panda.urdf"), "panda_link0", "panda_hand"),
+    "ur10": (os.path.join(ROBOTS, "ur10.urdf"), "base_link", "ee_link"),
+}
+
+
+@pytest.fixture(scope="session")
+def chains(oracle):
+    """name -> (flat chain dict from the Python URDF oracle, ok_chain for the C oracle)."""
+    out = {}
+    for name, (path, base, ee) in ROBOT_SPECS.items():
+        d = _load_chain(path, base, ee)
+        out[name] = (d, oracle.make_chain(**d))
+    return out
