@@ -1,0 +1,159 @@
+/*
+ * optik_hip.h -- C ABI of the MI355X kernel layer for optik's random-restart IK.
+ *
+ * This is the boundary a host written in the reference's own language binds
+ * (Rust `extern "C"` / cgo-style FFI): plain pointers and
+ * sizes, integer return codes, no C++ or torch types.  It replaces, behind
+ * `Robot::ik` (/root/reference/crates/optik/src/lib.rs:241-415),
+ *   - the rayon fan-out over restart indices        lib.rs:297-301, 393-395
+ *   - the per-restart NLopt SLSQP solve             lib.rs:302-356, 372 (nlopt crate)
+ *   - the ChaCha8 restart seeds                     lib.rs:358-370, 86-91 (rand crates)
+ *   - objective / gradient / FK / Jacobian          objective.rs:40-110, kinematics.rs:123-196
+ *   - classification and winner selection           lib.rs:376-390, 397-413
+ *
+ * Conventions: poses are 7 doubles [tx, ty, tz, qi, qj, qk, qw]; `d_` pointers
+ * are device (HBM) memory, everything else is host memory; batched per-restart
+ * arrays are struct-of-arrays ([component][batch]) so that lane-consecutive
+ * accesses coalesce.  All calls are stream-ordered on `stream` (a hipStream_t
+ * passed as void*, NULL = default stream) and return 0 on success or a negative
+ * OPTIK_HIP_E* code; optik_hip_last_error() describes the last failure of the
+ * calling thread.  There is no CPU fallback: without a usable GPU every compute
+ * entry point fails with OPTIK_HIP_ENODEVICE.
+ */
+#ifndef OPTIK_HIP_H
+#define OPTIK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OPTIK_HIP_MAX_DOF 8
+
+enum {
+    OPTIK_HIP_OK = 0,
+    OPTIK_HIP_EINVAL = -1,     /* bad argument */
+    OPTIK_HIP_EUNSUPPORTED = -2, /* chain shape the kernels do not cover */
+    OPTIK_HIP_ENODEVICE = -3,  /* no HIP device / HIP runtime error */
+    OPTIK_HIP_ENOMEM = -4
+};
+
+/* JointType, kinematics.rs:227-241 */
+enum { OPTIK_JOINT_FIXED = 0, OPTIK_JOINT_REVOLUTE = 1, OPTIK_JOINT_PRISMATIC = 2 };
+
+/* Per-restart status = NLopt's nlopt_result for the SLSQP run (lib.rs:372-379). */
+enum {
+    OPTIK_RES_FAILURE = -1,
+    OPTIK_RES_ROUNDOFF_LIMITED = -4,
+    OPTIK_RES_FORCED_STOP = -5,   /* abandoned: timeout or a lower index succeeded */
+    OPTIK_RES_ITER_CAP = -100,
+    OPTIK_RES_NOT_RUN = 0,
+    OPTIK_RES_STOPVAL_REACHED = 2,
+    OPTIK_RES_FTOL_REACHED = 3,
+    OPTIK_RES_XTOL_REACHED = 4
+};
+
+/* SolverConfig with the layout of CSolverConfig
+ * (crates/optik-cpp/src/lib.rs:10-20; config.rs:22-50): 96 bytes on LP64. */
+typedef struct optik_solver_config {
+    int32_t solution_mode; /* 1 = Quality, 2 = Speed (config.rs:3-8) */
+    int32_t _pad;
+    double max_time;       /* seconds, 0 = unlimited */
+    uint64_t max_restarts; /* 0 = unlimited */
+    double tol_f;
+    double tol_df;
+    double tol_dx;
+    double linear_weight[3];
+    double angular_weight[3];
+} optik_solver_config;
+
+/* Flat kinematic chain (the output of KinematicChain::from_urdf,
+ * kinematics.rs:18-105, uploaded once per robot). */
+typedef struct optik_hip_chain optik_hip_chain;
+
+int optik_hip_device_count(void);
+const char *optik_hip_last_error(void);
+
+/* origins: n_joints x 7 poses (Joint::origin), axes: n_joints x 3 (unit axis of
+ * each chain joint, ignored for fixed), types: OPTIK_JOINT_*, lb/ub: n limits
+ * (Robot::joint_limits, lib.rs:78-84).  Supported: n <= 8 revolute joints plus
+ * an optional trailing fixed joint. */
+int optik_hip_chain_create(const double *origins, const double *axes, const int32_t *types,
+                           int32_t n_joints, const double *lb, const double *ub, int32_t n,
+                           optik_hip_chain **out);
+void optik_hip_chain_destroy(optik_hip_chain *chain);
+int32_t optik_hip_chain_num_positions(const optik_hip_chain *chain);
+
+/* objective + objective_grad (objective.rs:40-110) for B configurations.
+ * d_q [n][B] -> d_f [B], d_g [n][B] (d_g may be NULL).  Only the weights of
+ * `cfg` are read.  ee_offset7 may be NULL (identity). */
+int optik_hip_eval_batch(const optik_hip_chain *chain, const optik_solver_config *cfg,
+                         const double *target7, const double *ee_offset7, const double *d_q,
+                         int64_t B, double *d_f, double *d_g, void *stream);
+
+/* forward_kinematics + joint_jacobian (kinematics.rs:123-196) for B
+ * configurations: d_pose [7][B] (EE pose), d_jac [6n][B] column-major 6 x n per
+ * configuration (may be NULL). */
+int optik_hip_fk_batch(const optik_hip_chain *chain, const double *ee_offset7, const double *d_q,
+                       int64_t B, double *d_pose, double *d_jac, void *stream);
+
+/* Restart seeds: ChaCha8Rng::seed_from_u64(42), set_stream(i), one uniform draw
+ * per joint (lib.rs:358-370, 86-91) for i = first .. first+count-1 -> d_q [n][count]. */
+int optik_hip_seed_batch(const optik_hip_chain *chain, uint64_t first, int64_t count, double *d_q,
+                         void *stream);
+
+/* flags of optik_hip_ik_batch */
+#define OPTIK_HIP_IK_EARLY_EXIT 1u /* Speed: abandon restarts above a known success (lib.rs:382-384) */
+
+/* Outputs of optik_hip_ik_batch; any pointer may be NULL to skip that output.
+ * R = restart_end - restart_begin. */
+typedef struct optik_hip_ik_outputs {
+    /* per restart, struct-of-arrays over T*R columns, column = t*R + (i - restart_begin) */
+    double *d_x;        /* [n][T*R] returned point (NLopt's best-so-far x)   */
+    double *d_f;        /* [T*R]    returned objective value                  */
+    int32_t *d_status;  /* [T*R]    OPTIK_RES_*                               */
+    int32_t *d_evals;   /* [T*R]    objective evaluations (NLopt's count)     */
+    /* per target: the selection of lib.rs:397-413 */
+    double *d_win_x;      /* [T][n]                                           */
+    double *d_win_f;      /* [T]                                              */
+    uint64_t *d_win_idx;  /* [T] winning restart index, UINT64_MAX if none    */
+    double *d_win_key;    /* [T] Quality: ||x - x0||_2 ; Speed: (double)index */
+} optik_hip_ik_outputs;
+
+/* The hot path: for each of T targets run restarts restart_begin..restart_end-1
+ * (index 0 = the caller's seed x0, index i > 0 = ChaCha8 stream i), classify
+ * (lib.rs:376-379) and select (Speed: lowest successful index = the reference's
+ * 1-thread order; Quality: min ||x - x0||_2, ties to the lower index).
+ * d_targets [T][7], d_x0 [T][n].  deadline_s > 0 abandons restarts still running
+ * that many seconds after the kernel starts (max_time, lib.rs:260-264, 308). */
+int optik_hip_ik_batch(optik_hip_chain *chain, const optik_solver_config *cfg,
+                       const double *d_targets, const double *d_x0, int32_t T,
+                       const double *ee_offset7, uint64_t restart_begin, uint64_t restart_end,
+                       uint32_t flags, double deadline_s, const optik_hip_ik_outputs *out,
+                       void *stream);
+
+/* Host-buffer convenience over optik_hip_ik_batch (what Robot::ik calls): copies
+ * targets/x0 in, runs, synchronises, copies the per-target winners out.
+ * win_x [T][n], win_f [T], win_idx [T] (UINT64_MAX = no solution). */
+int optik_hip_ik_host(optik_hip_chain *chain, const optik_solver_config *cfg,
+                      const double *targets, const double *x0, int32_t T, const double *ee_offset7,
+                      uint64_t restart_begin, uint64_t restart_end, uint32_t flags,
+                      double deadline_s, double *win_x, double *win_f, uint64_t *win_idx);
+
+/* Test hook: elementary functions the kernels use, evaluated on the device.
+ * op 0: a/b, 1: sqrt(a), 2: sin(a), 3: cos(a), 4: atan2(a, b) for a > 0, b >= 0. */
+int optik_hip_probe(int32_t op, const double *a, const double *b, int64_t count, double *out);
+
+/* Last launch geometry / timing of optik_hip_ik_batch on this chain (for bench.py). */
+typedef struct optik_hip_launch_info {
+    int32_t grid, block, lds_bytes, tiles;
+    float kernel_ms; /* HIP-event time of the solve kernel when timing is enabled */
+} optik_hip_launch_info;
+void optik_hip_set_timing(optik_hip_chain *chain, int32_t enabled);
+int optik_hip_last_launch(const optik_hip_chain *chain, optik_hip_launch_info *info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

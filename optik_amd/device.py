@@ -1,0 +1,146 @@
+"""Device-buffer front end over the kernel-layer C ABI (``include/optik_hip.h``).
+
+PyTorch is used only as plumbing: HBM allocation, streams, and (in ``bench.py``)
+``torch.distributed``.  All arithmetic happens in the HIP kernels of
+``csrc/ik_kernels.hip``; nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as nat
+
+
+def _stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class HipChain:
+    """A flat kinematic chain uploaded to the GPU (optik_hip_chain)."""
+
+    def __init__(self, types, origins, axes, lb, ub, device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise nat.OptikHipError("no GPU visible to torch; optik_amd has no CPU fallback")
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        types = np.ascontiguousarray(types, dtype=np.int32)
+        origins = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 7)
+        axes = np.ascontiguousarray(axes, dtype=np.float64).reshape(-1, 3)
+        lb = np.ascontiguousarray(lb, dtype=np.float64)
+        ub = np.ascontiguousarray(ub, dtype=np.float64)
+        self.n = int(len(lb))
+        self.lb, self.ub = lb, ub
+        self._h = C.c_void_p()
+        nat.check(nat.lib().optik_hip_chain_create(
+            _dp(origins), _dp(axes), types.ctypes.data_as(C.POINTER(C.c_int32)), len(types),
+            _dp(lb), _dp(ub), self.n, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            nat.lib().optik_hip_chain_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- batched primitives ----------------------------------------------------
+    def eval_batch(self, q, target7, cfg=None, ee_offset7=None, grad=True):
+        """q: [n, B] float64 cuda tensor -> (f [B], g [n, B])."""
+        cfg = cfg or nat.make_config()
+        assert q.is_cuda and q.dtype == torch.float64 and q.shape[0] == self.n and q.is_contiguous()
+        B = q.shape[1]
+        f = torch.empty(B, dtype=torch.float64, device=q.device)
+        g = torch.empty_like(q) if grad else None
+        t7 = np.ascontiguousarray(target7, dtype=np.float64)
+        ee = np.ascontiguousarray(ee_offset7, dtype=np.float64) if ee_offset7 is not None else None
+        nat.check(nat.lib().optik_hip_eval_batch(self._h, C.byref(cfg), _dp(t7),
+                                                 _dp(ee) if ee is not None else None, _ptr(q), B,
+                                                 _ptr(f), _ptr(g), _stream_ptr()))
+        return f, g
+
+    def fk_batch(self, q, ee_offset7=None, jacobian=False):
+        """q: [n, B] -> pose [7, B] (and jac [6n, B], column-major 6 x n per column)."""
+        assert q.is_cuda and q.dtype == torch.float64 and q.shape[0] == self.n and q.is_contiguous()
+        B = q.shape[1]
+        pose = torch.empty((7, B), dtype=torch.float64, device=q.device)
+        jac = torch.empty((6 * self.n, B), dtype=torch.float64, device=q.device) if jacobian else None
+        ee = np.ascontiguousarray(ee_offset7, dtype=np.float64) if ee_offset7 is not None else None
+        nat.check(nat.lib().optik_hip_fk_batch(self._h, _dp(ee) if ee is not None else None, _ptr(q),
+                                               B, _ptr(pose), _ptr(jac), _stream_ptr()))
+        return (pose, jac) if jacobian else pose
+
+    def seed_batch(self, first, count):
+        q = torch.empty((self.n, count), dtype=torch.float64, device=self.device)
+        nat.check(nat.lib().optik_hip_seed_batch(self._h, int(first), int(count), _ptr(q), _stream_ptr()))
+        return q
+
+    # -- the hot path -------------------------------------------------------------
+    def alloc_ik_buffers(self, T, R, per_restart=True):
+        dev = self.device
+        bufs = dict(
+            win_x=torch.empty((T, self.n), dtype=torch.float64, device=dev),
+            win_f=torch.empty(T, dtype=torch.float64, device=dev),
+            win_idx=torch.empty(T, dtype=torch.int64, device=dev),
+            win_key=torch.empty(T, dtype=torch.float64, device=dev))
+        if per_restart:
+            bufs.update(
+                x=torch.empty((self.n, T * R), dtype=torch.float64, device=dev),
+                f=torch.empty(T * R, dtype=torch.float64, device=dev),
+                status=torch.empty(T * R, dtype=torch.int32, device=dev),
+                evals=torch.empty(T * R, dtype=torch.int32, device=dev))
+        return bufs
+
+    def ik_batch(self, cfg, targets, x0, restart_begin, restart_end, flags=0, deadline_s=0.0,
+                 ee_offset7=None, bufs=None, per_restart=True):
+        """targets [T, 7], x0 [T, n] float64 cuda tensors.  Stream-ordered; returns the
+        buffer dict (win_idx is int64 with -1 = UINT64_MAX = no solution)."""
+        assert targets.is_cuda and targets.dtype == torch.float64 and targets.is_contiguous()
+        assert x0.is_cuda and x0.dtype == torch.float64 and x0.is_contiguous()
+        T = targets.shape[0]
+        assert targets.shape == (T, 7) and x0.shape == (T, self.n)
+        R = int(restart_end - restart_begin)
+        if bufs is None:
+            bufs = self.alloc_ik_buffers(T, R, per_restart)
+        o = nat.IkOutputs()
+        o.d_x, o.d_f = _ptr(bufs.get("x")), _ptr(bufs.get("f"))
+        o.d_status, o.d_evals = _ptr(bufs.get("status")), _ptr(bufs.get("evals"))
+        o.d_win_x, o.d_win_f = _ptr(bufs["win_x"]), _ptr(bufs["win_f"])
+        o.d_win_idx, o.d_win_key = _ptr(bufs["win_idx"]), _ptr(bufs["win_key"])
+        ee = np.ascontiguousarray(ee_offset7, dtype=np.float64) if ee_offset7 is not None else None
+        nat.check(nat.lib().optik_hip_ik_batch(
+            self._h, C.byref(cfg), _ptr(targets), _ptr(x0), T, _dp(ee) if ee is not None else None,
+            int(restart_begin), int(restart_end), int(flags), float(deadline_s), C.byref(o),
+            _stream_ptr()))
+        return bufs
+
+    def set_timing(self, enabled=True):
+        nat.lib().optik_hip_set_timing(self._h, 1 if enabled else 0)
+
+    def last_launch(self):
+        info = nat.LaunchInfo()
+        nat.check(nat.lib().optik_hip_last_launch(self._h, C.byref(info)))
+        return dict(grid=info.grid, block=info.block, lds_bytes=info.lds_bytes, tiles=info.tiles,
+                    kernel_ms=info.kernel_ms)
+
+
+def probe(op, a, b=None):
+    """Elementary device functions (test hook).  numpy in, numpy out."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b if b is not None else a, dtype=np.float64)
+    out = np.empty_like(a)
+    nat.check(nat.lib().optik_hip_probe(int(op), _dp(a), _dp(b), a.size, _dp(out)))
+    return out
