@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Headline benchmark: random-restart IK solves/sec (Panda 7-DoF, tol_f = 1e-6).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the hot path over one batch: R = 65 536 restarts
+(BASELINE.json config 2: Panda 7-DoF, SolutionMode::Speed) of one synthetic
+reachable target, every restart run to termination (no early exit), followed by
+the winner selection.  Targets, seeds x0 and all output buffers are resident in
+HBM before the timed region.  With N > 1 (one process per GPU under
+torch.distributed.run) every rank solves its own contiguous restart range
+[rank*R, (rank+1)*R) of the same target -- weak scaling, no data-path
+collective -- and the per-step winner is chosen with one 8-byte RCCL
+min-all-reduce of the selection key over xGMI.
+
+The JSON line carries:
+  roofline      algorithmic HBM bytes of the solve kernel / its mean duration
+                (HIP events on the launch stream, recorded inside the C ABI)
+  cpu_baseline  the CPU oracle (a port of the reference algorithm, NOT the
+                reference binary) timed on this host's cores on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def load_chain(robot):
+    """Flat chain table through the product's own URDF loader (C++, optik_robot_*)."""
+    from optik_amd import Robot
+    spec = {"panda": ("panda.urdf", "panda_link0", "panda_link8"),
+            "ur10": ("ur10.urdf", "base_link", "ee_link")}[robot]
+    path = os.path.join(ROOT, "optik_amd", "robots", spec[0])
+    return Robot.from_urdf_file(path, spec[1], spec[2])
+
+
+def usable_cores():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota
+    (the GPU box exposes 256 logical CPUs under a 16-CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(robot_name, chain_tables, target7, x0, seconds_budget=15.0):
+    """Times the CPU oracle (checker code, used here only as the reported baseline)."""
+    from oracle import binding as ob
+    ob.build()
+    ch = ob.make_chain(**chain_tables)
+    cfg = ob.make_config(solution_mode="speed", tol_f=1e-6)
+    cores = usable_cores()
+    # calibrate on a small sample, then size the timed sample to ~seconds_budget
+    t0 = time.perf_counter()
+    ob.ik(ch, cfg, target7, x0, 1, 1 + 64 * cores, n_threads=cores, early_exit=False)
+    rate = 64 * cores / max(time.perf_counter() - t0, 1e-6)
+    n = int(min(max(rate * seconds_budget, 256 * cores), 4_000_000))
+    t0 = time.perf_counter()
+    res = ob.ik(ch, cfg, target7, x0, 0, n, n_threads=cores, early_exit=False)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "restarts/s", "cores": cores, "kind": "port",
+            "sample": f"{robot_name}: restarts 0..{n - 1} of the bench target, all run to termination, "
+                      f"{cores} threads pulling indices from a shared counter, {dt:.1f} s",
+            "winner": int(res["winner"]) if res["found"] else -1}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--restarts", type=int, default=65536, help="restarts per GPU per step")
+    ap.add_argument("--robot", default="panda", choices=["panda", "ur10"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: optik_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    from optik_amd import _native as nat
+    from optik_amd.parallel import shard_range, select_winner
+
+    robot = load_chain(args.robot)
+    hc = robot.hip_chain(dev)
+    n = robot.num_positions()
+    R = args.restarts
+    K, W = args.steps, args.warmup
+
+    # synthetic workload: reachable targets FK(q*), q* and x0 uniform in the limits
+    rng = np.random.default_rng(0)
+    lb, ub = (np.array(v) for v in robot.joint_limits())
+    n_tgt = K + W
+    q_star = rng.uniform(lb, ub, size=(n_tgt, n))
+    x0_host = rng.uniform(lb, ub, size=(n_tgt, n))
+    pose = hc.fk_batch(torch.tensor(q_star.T.copy(), device=dev))  # [7, n_tgt] on the GPU
+    targets = pose.T.contiguous()
+    x0 = torch.tensor(x0_host, device=dev)
+    cfg = nat.make_config(solution_mode="speed", tol_f=1e-6)
+    begin, end = shard_range(0, R * world, rank, world)
+    bufs = hc.alloc_ik_buffers(1, R, per_restart=True)
+    torch.cuda.synchronize()
+
+    def step(i):
+        hc.ik_batch(cfg, targets[i:i + 1], x0[i:i + 1], begin, end, bufs=bufs)
+        return select_winner(bufs, "speed", distributed)
+
+    for i in range(W):
+        step(i)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    hc.set_timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(W, W + K):
+        winner = step(i)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    kernel_ms, launches = hc.timing_mean()
+    info = hc.last_launch()
+    status = bufs["status"]
+    n_success = int((status == nat.RES_STOPVAL).sum().item())
+    mean_evals = float(bufs["evals"].double().mean().item())
+
+    if rank == 0:
+        total = float(R) * world * K
+        bytes_per_restart = 8 * n + 8 + 4 + 4  # x[n] + f + status + evals written; seeds made in-kernel
+        achieved = bytes_per_restart * R / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        line = {
+            "metric": "random-restart IK solves/sec (Panda 7-DoF, 1e-6 tol)" if args.robot == "panda"
+                      else f"random-restart IK solves/sec ({args.robot}, 1e-6 tol)",
+            "value": total / elapsed,
+            "unit": "restarts/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.robot} 7-DoF, {R} random restarts per GPU per step, one target "
+                                   "per step, SolutionMode::Speed, every restart run to termination"
+                                   if args.robot == "panda" else
+                                   f"{args.robot}, {R} random restarts per GPU per step",
+                       "restarts_per_gpu": R, "tol_f": 1e-6, "parallelism": f"restart-range x{world}",
+                       "success_rate_last_step": n_success / R, "mean_evals_per_restart": mean_evals,
+                       "grid": info["grid"], "block": info["block"], "lds_bytes": info["lds_bytes"]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "ik_solve_kernel", "kernel_ms": kernel_ms, "launches_timed": launches,
+                         "algorithmic_bytes_per_restart": bytes_per_restart},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            tables = robot.chain_tables()
+            line["cpu_baseline"] = cpu_baseline(args.robot, tables, targets[W].cpu().numpy(),
+                                                x0_host[W], args.cpu_seconds)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

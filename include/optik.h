@@ -1,0 +1,75 @@
+/*
+ * optik.h -- the reference's C ABI (crates/optik-cpp/src/lib.rs:26-183), exported by
+ * liboptik_amd.so so that the reference's C++ wrapper (crates/optik-cpp/src/lib.cpp,
+ * include/optik.hpp) and any other binding of `liboptikcpp` can link against the
+ * MI355X implementation unchanged.  All compute goes through the HIP kernels of
+ * include/optik_hip.h; there is no CPU fallback.
+ *
+ * Ownership (as in the reference): a `robot*` is released only by optik_robot_free;
+ * every returned `double*` is a malloc'ed buffer the caller releases with free()
+ * (lib.cpp:72, 87, 100, 115, 129).  Matrices are column-major.  Invalid input
+ * aborts the process with the reference's panic message on stderr (a Rust panic
+ * across `extern "C"` aborts too); "no solution" is NULL.
+ */
+#ifndef OPTIK_H
+#define OPTIK_H
+
+#include <stdint.h>
+
+#include "optik_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct optik_robot optik_robot;           /* Box<Robot>, optik-cpp/src/lib.rs:27-57 */
+typedef optik_solver_config CSolverConfig;        /* optik-cpp/src/lib.rs:10-20 */
+
+/* ---- the 11 symbols of the reference ------------------------------------------ */
+optik_robot *optik_robot_from_urdf_file(const char *path, const char *base_link,
+                                        const char *ee_link);                 /* lib.rs:27-37 */
+optik_robot *optik_robot_from_urdf_str(const char *urdf, const char *base_link,
+                                       const char *ee_link);                  /* lib.rs:40-50 */
+void optik_robot_free(optik_robot *robot);                                    /* lib.rs:53-57 */
+void optik_robot_set_parallelism(optik_robot *robot, unsigned int n);         /* lib.rs:60-65 */
+unsigned int optik_robot_num_positions(const optik_robot *robot);             /* lib.rs:68-73 */
+const double *optik_robot_joint_limits(const optik_robot *robot);             /* lib.rs:76-88: [lb.., ub..] */
+const double *optik_robot_joint_jacobian(const optik_robot *robot, const double *x); /* lib.rs:91-104: 6 x n */
+const double *optik_robot_fk(const optik_robot *robot, const double *x);      /* lib.rs:107-116: 4 x 4 */
+const double *optik_robot_random_configuration(const optik_robot *robot);     /* lib.rs:119-125 */
+const double *optik_robot_ik(const optik_robot *robot, const CSolverConfig *config,
+                             const double *target, const double *x0);         /* lib.rs:128-162 */
+/* Differential IK (lib.rs:165-183) is outside the accelerated hot path (SURVEY 8f
+ * rank 4).  The symbol exists so existing binaries link; it reports the fact on
+ * stderr and returns NULL ("no solution"). */
+const double *optik_robot_diff_ik(const optik_robot *robot, const double *x0, const double *V_WE,
+                                  const double *v_max);
+
+/* ---- extensions used by the Python front end and bench.py --------------------- */
+/* Error-returning constructors / solver: 0 on success, negative on failure with the
+ * message in optik_robot_last_error() (what a pyo3-style binding turns into an
+ * exception instead of aborting). */
+int optik_robot_try_from_urdf_str(const char *urdf, const char *base_link, const char *ee_link,
+                                  optik_robot **out);
+const char *optik_robot_last_error(void);
+/* Robot::ik with the full signature of lib.rs:241-247: ee_offset (4x4 col-major, NULL
+ * = identity), returns x and the residual c.  rc 0 = solution, 1 = none, < 0 = error. */
+int optik_robot_ik_ex(const optik_robot *robot, const CSolverConfig *config, const double *target16,
+                      const double *x0, const double *ee_offset16, double *x_out, double *f_out,
+                      uint64_t *winner_out);
+int optik_robot_fk_ex(const optik_robot *robot, const double *x, const double *ee_offset16,
+                      double *pose16_out);
+int optik_robot_joint_jacobian_ex(const optik_robot *robot, const double *x,
+                                  const double *ee_offset16, double *jac6n_out);
+/* Flat chain table (what KinematicChain::from_urdf produced): n_joints poses, axes,
+ * types; buffers sized for OPTIK_HIP_MAX_DOF + 1 joints. */
+int optik_robot_chain_tables(const optik_robot *robot, int32_t *n_joints, double *origins7,
+                             double *axes3, int32_t *types);
+/* The device-side chain of this robot on the current HIP device (created on first
+ * use; owned by the robot). */
+optik_hip_chain *optik_robot_hip_chain(const optik_robot *robot);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

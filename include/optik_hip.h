@@ -135,11 +135,15 @@ int optik_hip_ik_batch(optik_hip_chain *chain, const optik_solver_config *cfg,
 
 /* Host-buffer convenience over optik_hip_ik_batch (what Robot::ik calls): copies
  * targets/x0 in, runs, synchronises, copies the per-target winners out.
- * win_x [T][n], win_f [T], win_idx [T] (UINT64_MAX = no solution). */
+ * win_x [T][n], win_f [T], win_idx [T] (UINT64_MAX = no solution), win_key [T]
+ * (the selection key; any of them may be NULL).  Calls on one chain are serialised.
+ * optik_hip_ik_batch itself is stream-ordered and keeps its launch workspace in the
+ * chain handle: use one stream per chain handle. */
 int optik_hip_ik_host(optik_hip_chain *chain, const optik_solver_config *cfg,
                       const double *targets, const double *x0, int32_t T, const double *ee_offset7,
                       uint64_t restart_begin, uint64_t restart_end, uint32_t flags,
-                      double deadline_s, double *win_x, double *win_f, uint64_t *win_idx);
+                      double deadline_s, double *win_x, double *win_f, uint64_t *win_idx,
+                      double *win_key);
 
 /* Test hook: elementary functions the kernels use, evaluated on the device.
  * op 0: a/b, 1: sqrt(a), 2: sin(a), 3: cos(a), 4: atan2(a, b) for a > 0, b >= 0. */
@@ -150,8 +154,13 @@ typedef struct optik_hip_launch_info {
     int32_t grid, block, lds_bytes, tiles;
     float kernel_ms; /* HIP-event time of the solve kernel when timing is enabled */
 } optik_hip_launch_info;
+/* Enabling timing records a HIP event pair around every solve-kernel launch on the
+ * launch stream (and resets the recorded set); optik_hip_timing_mean synchronises
+ * on them and returns the mean kernel duration over the launches recorded since
+ * (at most 256 are kept). */
 void optik_hip_set_timing(optik_hip_chain *chain, int32_t enabled);
 int optik_hip_last_launch(const optik_hip_chain *chain, optik_hip_launch_info *info);
+int optik_hip_timing_mean(optik_hip_chain *chain, double *mean_ms, int32_t *count);
 
 #ifdef __cplusplus
 }

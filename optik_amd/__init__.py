@@ -6,5 +6,6 @@ device buffers.  Everything computes in hand-written HIP kernels (csrc/); there 
 CPU fallback.
 """
 from ._native import OptikHipError  # noqa: F401
+from .robot import Robot, SolverConfig  # noqa: F401
 
-__all__ = ["OptikHipError"]
+__all__ = ["OptikHipError", "Robot", "SolverConfig"]

@@ -79,10 +79,11 @@ def lib():
                                      C.POINTER(IkOutputs), vp]
     L.optik_hip_ik_host.argtypes = [vp, C.POINTER(SolverConfigC), dp, dp, C.c_int32, dp,
                                     C.c_uint64, C.c_uint64, C.c_uint32, C.c_double, dp, dp,
-                                    C.POINTER(C.c_uint64)]
+                                    C.POINTER(C.c_uint64), dp]
     L.optik_hip_probe.argtypes = [C.c_int32, dp, dp, C.c_int64, dp]
     L.optik_hip_set_timing.argtypes = [vp, C.c_int32]
     L.optik_hip_last_launch.argtypes = [vp, C.POINTER(LaunchInfo)]
+    L.optik_hip_timing_mean.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     _lib = L
     return L
 

@@ -302,6 +302,7 @@ struct optik_hip_chain {
     double scale[MAX_DOF];
     // launch workspace (grown on demand; one in-flight ik call per chain handle)
     std::mutex mu;
+    std::mutex host_mu;  // serialises optik_hip_ik_host calls (they share the workspace below)
     TileRec *tile_recs = nullptr;
     size_t tile_cap = 0;
     unsigned long long *first_success = nullptr;
@@ -311,8 +312,9 @@ struct optik_hip_chain {
     size_t tmp_cols = 0;
     // timing
     int timing = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool ev_valid = false;
+    static constexpr int EV_POOL = 256;  // event pairs recorded round-robin around the solve kernel
+    hipEvent_t ev0[EV_POOL] = {}, ev1[EV_POOL] = {};
+    int ev_count = 0;                    // launches recorded since the last reset
     optik_hip_launch_info last{};
     int num_cus = 0;
     int wall_clock_khz = 0;
@@ -488,8 +490,10 @@ void optik_hip_chain_destroy(optik_hip_chain *ch) {
     if (ch->first_success) hipFree(ch->first_success);
     if (ch->tmp_x) hipFree(ch->tmp_x);
     if (ch->tmp_f) hipFree(ch->tmp_f);
-    if (ch->ev0) hipEventDestroy(ch->ev0);
-    if (ch->ev1) hipEventDestroy(ch->ev1);
+    for (int i = 0; i < optik_hip_chain::EV_POOL; ++i) {
+        if (ch->ev0[i]) hipEventDestroy(ch->ev0[i]);
+        if (ch->ev1[i]) hipEventDestroy(ch->ev1[i]);
+    }
     delete ch;
 }
 
@@ -642,9 +646,10 @@ int optik_hip_ik_batch(optik_hip_chain *ch, const optik_solver_config *cfg, cons
     const int cap = cus * 2 * 4;
     if (grid > cap) grid = cap;
 
+    const int ev_slot = ch->ev_count % optik_hip_chain::EV_POOL;
     if (ch->timing) {
-        if (!ch->ev0) { HIP_TRY(hipEventCreate(&ch->ev0)); HIP_TRY(hipEventCreate(&ch->ev1)); }
-        HIP_TRY(hipEventRecord(ch->ev0, stream));
+        if (!ch->ev0[ev_slot]) { HIP_TRY(hipEventCreate(&ch->ev0[ev_slot])); HIP_TRY(hipEventCreate(&ch->ev1[ev_slot])); }
+        HIP_TRY(hipEventRecord(ch->ev0[ev_slot], stream));
     }
     int lds = 0;
 #define CALL(NN, TT)                                                                                 \
@@ -653,7 +658,7 @@ int optik_hip_ik_batch(optik_hip_chain *ch, const optik_solver_config *cfg, cons
     OPTIK_DISPATCH(ch, CALL);
 #undef CALL
     HIP_TRY(hipGetLastError());
-    if (ch->timing) { HIP_TRY(hipEventRecord(ch->ev1, stream)); ch->ev_valid = true; }
+    if (ch->timing) { HIP_TRY(hipEventRecord(ch->ev1[ev_slot], stream)); ch->ev_count += 1; }
     ch->last.grid = grid; ch->last.block = WAVE; ch->last.lds_bytes = lds; ch->last.tiles = n_tiles;
 
     if (out->d_win_x || out->d_win_f || out->d_win_idx || out->d_win_key) {
@@ -676,10 +681,12 @@ int optik_hip_ik_batch(optik_hip_chain *ch, const optik_solver_config *cfg, cons
 int optik_hip_ik_host(optik_hip_chain *ch, const optik_solver_config *cfg, const double *targets,
                       const double *x0, int32_t T, const double *ee_offset7, uint64_t restart_begin,
                       uint64_t restart_end, uint32_t flags, double deadline_s, double *win_x, double *win_f,
-                      uint64_t *win_idx) {
+                      uint64_t *win_idx, double *win_key) {
     if (!ch || !targets || !x0 || T < 1) return fail(OPTIK_HIP_EINVAL, "bad argument");
+    // the launch workspace of the chain is in use until the copies below are done
+    std::lock_guard<std::mutex> host_lock(ch->host_mu);
     const int n = ch->n;
-    double *d_t = nullptr, *d_x0 = nullptr, *d_wx = nullptr, *d_wf = nullptr;
+    double *d_t = nullptr, *d_x0 = nullptr, *d_wx = nullptr, *d_wf = nullptr, *d_wk = nullptr;
     uint64_t *d_wi = nullptr;
     int rc = 0;
     auto cleanup = [&]() {
@@ -687,6 +694,7 @@ int optik_hip_ik_host(optik_hip_chain *ch, const optik_solver_config *cfg, const
         if (d_x0) hipFree(d_x0);
         if (d_wx) hipFree(d_wx);
         if (d_wf) hipFree(d_wf);
+        if (d_wk) hipFree(d_wk);
         if (d_wi) hipFree(d_wi);
     };
 #define TRY_CLEAN(expr)                                                                           \
@@ -701,12 +709,13 @@ int optik_hip_ik_host(optik_hip_chain *ch, const optik_solver_config *cfg, const
     TRY_CLEAN(hipMalloc(&d_x0, sizeof(double) * (size_t)n * (size_t)T));
     TRY_CLEAN(hipMalloc(&d_wx, sizeof(double) * (size_t)n * (size_t)T));
     TRY_CLEAN(hipMalloc(&d_wf, sizeof(double) * (size_t)T));
+    TRY_CLEAN(hipMalloc(&d_wk, sizeof(double) * (size_t)T));
     TRY_CLEAN(hipMalloc(&d_wi, sizeof(uint64_t) * (size_t)T));
     TRY_CLEAN(hipMemcpy(d_t, targets, sizeof(double) * 7 * (size_t)T, hipMemcpyHostToDevice));
     TRY_CLEAN(hipMemcpy(d_x0, x0, sizeof(double) * (size_t)n * (size_t)T, hipMemcpyHostToDevice));
     optik_hip_ik_outputs o;
     std::memset(&o, 0, sizeof o);
-    o.d_win_x = d_wx; o.d_win_f = d_wf; o.d_win_idx = d_wi;
+    o.d_win_x = d_wx; o.d_win_f = d_wf; o.d_win_idx = d_wi; o.d_win_key = d_wk;
     rc = optik_hip_ik_batch(ch, cfg, d_t, d_x0, T, ee_offset7, restart_begin, restart_end, flags, deadline_s,
                             &o, nullptr);
     if (rc) { cleanup(); return rc; }
@@ -714,6 +723,7 @@ int optik_hip_ik_host(optik_hip_chain *ch, const optik_solver_config *cfg, const
     if (win_x) TRY_CLEAN(hipMemcpy(win_x, d_wx, sizeof(double) * (size_t)n * (size_t)T, hipMemcpyDeviceToHost));
     if (win_f) TRY_CLEAN(hipMemcpy(win_f, d_wf, sizeof(double) * (size_t)T, hipMemcpyDeviceToHost));
     if (win_idx) TRY_CLEAN(hipMemcpy(win_idx, d_wi, sizeof(uint64_t) * (size_t)T, hipMemcpyDeviceToHost));
+    if (win_key) TRY_CLEAN(hipMemcpy(win_key, d_wk, sizeof(double) * (size_t)T, hipMemcpyDeviceToHost));
 #undef TRY_CLEAN
     cleanup();
     return 0;
@@ -738,17 +748,37 @@ int optik_hip_probe(int32_t op, const double *a, const double *b, int64_t count,
 }
 
 void optik_hip_set_timing(optik_hip_chain *ch, int32_t enabled) {
-    if (ch) ch->timing = enabled;
+    if (!ch) return;
+    std::lock_guard<std::mutex> lock(ch->mu);
+    ch->timing = enabled;
+    ch->ev_count = 0;
+}
+
+int optik_hip_timing_mean(optik_hip_chain *ch, double *mean_ms, int32_t *count) {
+    if (!ch || !mean_ms || !count) return fail(OPTIK_HIP_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> lock(ch->mu);
+    const int n = ch->ev_count < optik_hip_chain::EV_POOL ? ch->ev_count : optik_hip_chain::EV_POOL;
+    double sum = 0.0;
+    for (int i = 0; i < n; ++i) {
+        HIP_TRY(hipEventSynchronize(ch->ev1[i]));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, ch->ev0[i], ch->ev1[i]));
+        sum += ms;
+    }
+    *mean_ms = n ? sum / n : 0.0;
+    *count = n;
+    return 0;
 }
 
 int optik_hip_last_launch(const optik_hip_chain *ch, optik_hip_launch_info *info) {
     if (!ch || !info) return fail(OPTIK_HIP_EINVAL, "bad argument");
     *info = ch->last;
     info->kernel_ms = 0.0f;
-    if (ch->timing && ch->ev_valid) {
-        HIP_TRY(hipEventSynchronize(ch->ev1));
+    if (ch->timing && ch->ev_count > 0) {
+        const int slot = (ch->ev_count - 1) % optik_hip_chain::EV_POOL;
+        HIP_TRY(hipEventSynchronize(ch->ev1[slot]));
         float ms = 0.0f;
-        HIP_TRY(hipEventElapsedTime(&ms, ch->ev0, ch->ev1));
+        HIP_TRY(hipEventElapsedTime(&ms, ch->ev0[slot], ch->ev1[slot]));
         info->kernel_ms = ms;
     }
     return 0;

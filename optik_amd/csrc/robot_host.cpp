@@ -1,0 +1,345 @@
+// robot_host.cpp -- the reference's host API on top of the HIP kernel layer.
+//
+// Mirrors `Robot` (/root/reference/crates/optik/src/lib.rs:36-99, 241-415) and
+// exports the C ABI of crates/optik-cpp/src/lib.rs:26-183 (include/optik.h).
+// What stays on the host is what the reference does once per call or per robot:
+// URDF loading, the seed-limit check, the restart/time budget and the loop over
+// launches.  FK, Jacobian, the restarts and the selection all run in the kernels
+// of ik_kernels.hip -- there is no CPU implementation of them in this library.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <mutex>
+#include <random>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/optik.h"
+#include "urdf_chain.hpp"
+
+using optik_host::Chain;
+using optik_host::HPose;
+
+struct optik_robot {
+    Chain chain;
+    int n = 0;
+    std::vector<double> lb, ub;
+    std::vector<double> origins, axes;  // n_joints x 7, n_joints x 3
+    std::vector<int32_t> types;
+    unsigned parallelism = 0;  // accepted for API compatibility (lib.rs:66-72); unused
+    mutable std::mutex mu;     // guards the lazily created device chain and the scratch
+    mutable optik_hip_chain *dev = nullptr;
+    mutable double *d_scratch = nullptr;  // q[n] | pose[7] | jac[6n]
+    mutable int num_cus = 0;
+};
+
+namespace {
+
+thread_local std::string g_robot_err;
+
+[[noreturn]] void panic(const std::string &msg) {
+    // A Rust panic crossing `extern "C"` aborts the process; keep the message.
+    std::fprintf(stderr, "optik: %s\n", msg.c_str());
+    std::fflush(stderr);
+    std::abort();
+}
+
+int set_err(int code, const std::string &msg) {
+    g_robot_err = msg;
+    return code;
+}
+
+optik_robot *make_robot(const std::string &urdf, const char *base, const char *ee) {
+    auto *r = new optik_robot();
+    try {
+        r->chain = optik_host::chain_from_urdf(urdf, base, ee);
+    } catch (...) {
+        delete r;
+        throw;
+    }
+    r->n = r->chain.num_positions();
+    for (const auto &j : r->chain.joints) {
+        for (int k = 0; k < 3; ++k) r->origins.push_back(j.origin.t[k]);
+        for (int k = 0; k < 4; ++k) r->origins.push_back(j.origin.q[k]);
+        for (int k = 0; k < 3; ++k) r->axes.push_back(j.axis[k]);
+        r->types.push_back(j.kind);
+        if (j.kind != optik_host::FIXED) {  // joint_limits(), lib.rs:78-84
+            r->lb.push_back(j.lower);
+            r->ub.push_back(j.upper);
+        }
+    }
+    return r;
+}
+
+// Device chain of the robot, created on first use.  Returns nullptr and sets the
+// error string on failure.
+optik_hip_chain *device_chain(const optik_robot *r) {
+    std::lock_guard<std::mutex> lock(r->mu);
+    if (r->dev) return r->dev;
+    optik_hip_chain *h = nullptr;
+    const int rc = optik_hip_chain_create(r->origins.data(), r->axes.data(), r->types.data(),
+                                          (int32_t)r->types.size(), r->lb.data(), r->ub.data(), r->n, &h);
+    if (rc) {
+        g_robot_err = std::string("GPU chain creation failed: ") + optik_hip_last_error();
+        return nullptr;
+    }
+    if (hipMalloc(&r->d_scratch, sizeof(double) * (size_t)(r->n + 7 + 6 * r->n)) != hipSuccess) {
+        optik_hip_chain_destroy(h);
+        g_robot_err = "GPU scratch allocation failed";
+        return nullptr;
+    }
+    int devid = 0;
+    (void)hipGetDevice(&devid);
+    (void)hipDeviceGetAttribute(&r->num_cus, hipDeviceAttributeMultiprocessorCount, devid);
+    r->dev = h;
+    return h;
+}
+
+// 4x4 column-major homogeneous matrix -> pose7, with nalgebra's
+// UnitQuaternion::from_rotation_matrix branches (optik-py/src/lib.rs:8-15; the C
+// path's iterative from_matrix, optik-cpp/src/lib.rs:141-142, converges to the same
+// rotation for a proper rotation matrix).
+void pose7_from_mat16(const double *m, double *p) {
+    auto M = [&](int r, int c) { return m[c * 4 + r]; };
+    p[0] = M(0, 3); p[1] = M(1, 3); p[2] = M(2, 3);
+    const double tr = M(0, 0) + M(1, 1) + M(2, 2);
+    double w, i, j, k;
+    if (tr > 0.0) {
+        const double d = std::sqrt(tr + 1.0) * 2.0;
+        w = 0.25 * d; i = (M(2, 1) - M(1, 2)) / d; j = (M(0, 2) - M(2, 0)) / d; k = (M(1, 0) - M(0, 1)) / d;
+    } else if (M(0, 0) > M(1, 1) && M(0, 0) > M(2, 2)) {
+        const double d = std::sqrt(1.0 + M(0, 0) - M(1, 1) - M(2, 2)) * 2.0;
+        w = (M(2, 1) - M(1, 2)) / d; i = 0.25 * d; j = (M(0, 1) + M(1, 0)) / d; k = (M(0, 2) + M(2, 0)) / d;
+    } else if (M(1, 1) > M(2, 2)) {
+        const double d = std::sqrt(1.0 + M(1, 1) - M(0, 0) - M(2, 2)) * 2.0;
+        w = (M(0, 2) - M(2, 0)) / d; i = (M(0, 1) + M(1, 0)) / d; j = 0.25 * d; k = (M(1, 2) + M(2, 1)) / d;
+    } else {
+        const double d = std::sqrt(1.0 + M(2, 2) - M(0, 0) - M(1, 1)) * 2.0;
+        w = (M(1, 0) - M(0, 1)) / d; i = (M(0, 2) + M(2, 0)) / d; j = (M(1, 2) + M(2, 1)) / d; k = 0.25 * d;
+    }
+    const double nrm = std::sqrt(w * w + i * i + j * j + k * k);  // UnitQuaternion::new_normalize
+    p[3] = i / nrm; p[4] = j / nrm; p[5] = k / nrm; p[6] = w / nrm;
+}
+
+// pose7 -> 4x4 column-major (Isometry3::to_matrix, optik-cpp/src/lib.rs:115).
+void mat16_from_pose7(const double *p, double *m) {
+    const double i = p[3], j = p[4], k = p[5], w = p[6];
+    const double ww = w * w, ii = i * i, jj = j * j, kk = k * k;
+    const double ij = i * j * 2.0, wk = w * k * 2.0, wj = w * j * 2.0, ik = i * k * 2.0, jk = j * k * 2.0,
+                 wi = w * i * 2.0;
+    const double R[3][3] = {{ww + ii - jj - kk, ij - wk, wj + ik},
+                            {wk + ij, ww - ii + jj - kk, jk - wi},
+                            {ik - wj, wi + jk, ww - ii - jj + kk}};
+    for (int c = 0; c < 3; ++c) {
+        for (int r = 0; r < 3; ++r) m[c * 4 + r] = R[r][c];
+        m[c * 4 + 3] = 0.0;
+    }
+    m[12] = p[0]; m[13] = p[1]; m[14] = p[2]; m[15] = 1.0;
+}
+
+int fk_on_device(const optik_robot *r, const double *x, const double *ee16, double *pose7, double *jac) {
+    optik_hip_chain *h = device_chain(r);
+    if (!h) return -1;
+    double ee7[7];
+    if (ee16) pose7_from_mat16(ee16, ee7);
+    std::lock_guard<std::mutex> lock(r->mu);
+    double *d_q = r->d_scratch, *d_pose = d_q + r->n, *d_jac = d_pose + 7;
+    if (hipMemcpy(d_q, x, sizeof(double) * (size_t)r->n, hipMemcpyHostToDevice) != hipSuccess)
+        return set_err(-1, "hipMemcpy failed");
+    if (optik_hip_fk_batch(h, ee16 ? ee7 : nullptr, d_q, 1, d_pose, jac ? d_jac : nullptr, nullptr))
+        return set_err(-1, optik_hip_last_error());
+    if (hipDeviceSynchronize() != hipSuccess) return set_err(-1, "kernel failed");
+    if (pose7 && hipMemcpy(pose7, d_pose, sizeof(double) * 7, hipMemcpyDeviceToHost) != hipSuccess)
+        return set_err(-1, "hipMemcpy failed");
+    if (jac && hipMemcpy(jac, d_jac, sizeof(double) * 6 * (size_t)r->n, hipMemcpyDeviceToHost) != hipSuccess)
+        return set_err(-1, "hipMemcpy failed");
+    return 0;
+}
+
+double *malloc_copy(const double *src, size_t count) {
+    double *p = (double *)std::malloc(sizeof(double) * (count ? count : 1));
+    if (!p) panic("out of memory");
+    std::memcpy(p, src, sizeof(double) * count);
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *optik_robot_last_error(void) { return g_robot_err.c_str(); }
+
+int optik_robot_try_from_urdf_str(const char *urdf, const char *base_link, const char *ee_link,
+                                  optik_robot **out) {
+    if (!urdf || !base_link || !ee_link || !out) return set_err(-1, "null argument");
+    try {
+        *out = make_robot(urdf, base_link, ee_link);
+        return 0;
+    } catch (const std::exception &e) {
+        return set_err(-1, e.what());
+    }
+}
+
+optik_robot *optik_robot_from_urdf_str(const char *urdf, const char *base_link, const char *ee_link) {
+    optik_robot *r = nullptr;
+    if (optik_robot_try_from_urdf_str(urdf, base_link, ee_link, &r)) panic(g_robot_err);
+    return r;
+}
+
+optik_robot *optik_robot_from_urdf_file(const char *path, const char *base_link, const char *ee_link) {
+    std::ifstream in(path ? path : "");
+    if (!in) panic("error parsing URDF file!");  // lib.rs:55
+    std::stringstream ss;
+    ss << in.rdbuf();
+    return optik_robot_from_urdf_str(ss.str().c_str(), base_link, ee_link);
+}
+
+void optik_robot_free(optik_robot *r) {
+    if (!r) return;
+    if (r->dev) optik_hip_chain_destroy(r->dev);
+    if (r->d_scratch) (void)hipFree(r->d_scratch);
+    delete r;
+}
+
+void optik_robot_set_parallelism(optik_robot *r, unsigned int n) {
+    // The rayon pool size has no counterpart: the GPU grid is sized from the device.
+    if (r) r->parallelism = n;
+}
+
+unsigned int optik_robot_num_positions(const optik_robot *r) { return r ? (unsigned)r->n : 0u; }
+
+const double *optik_robot_joint_limits(const optik_robot *r) {
+    std::vector<double> v(r->lb);
+    v.insert(v.end(), r->ub.begin(), r->ub.end());
+    return malloc_copy(v.data(), v.size());
+}
+
+int optik_robot_fk_ex(const optik_robot *r, const double *x, const double *ee16, double *pose16) {
+    double p7[7];
+    if (fk_on_device(r, x, ee16, p7, nullptr)) return -1;
+    mat16_from_pose7(p7, pose16);
+    return 0;
+}
+
+int optik_robot_joint_jacobian_ex(const optik_robot *r, const double *x, const double *ee16, double *jac) {
+    return fk_on_device(r, x, ee16, nullptr, jac);
+}
+
+const double *optik_robot_fk(const optik_robot *r, const double *x) {
+    double m[16];
+    if (optik_robot_fk_ex(r, x, nullptr, m)) panic(g_robot_err);
+    return malloc_copy(m, 16);
+}
+
+const double *optik_robot_joint_jacobian(const optik_robot *r, const double *x) {
+    std::vector<double> j(6 * (size_t)r->n);
+    if (optik_robot_joint_jacobian_ex(r, x, nullptr, j.data())) panic(g_robot_err);
+    return malloc_copy(j.data(), j.size());
+}
+
+const double *optik_robot_random_configuration(const optik_robot *r) {
+    // rand::rng(): thread-local, non-deterministic (optik-cpp/src/lib.rs:122)
+    thread_local std::mt19937_64 gen{std::random_device{}()};
+    std::vector<double> q((size_t)r->n);
+    for (int k = 0; k < r->n; ++k) {
+        if (!std::isfinite(r->lb[k]) || !std::isfinite(r->ub[k]))
+            panic("random_configuration: non-finite joint limits");  // rand: Uniform::new_inclusive fails
+        q[k] = std::uniform_real_distribution<double>(r->lb[k], std::nextafter(r->ub[k], INFINITY))(gen);
+        if (q[k] > r->ub[k]) q[k] = r->ub[k];
+    }
+    return malloc_copy(q.data(), q.size());
+}
+
+// Robot::ik, lib.rs:241-415.
+int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const double *target16,
+                      const double *x0, const double *ee16, double *x_out, double *f_out,
+                      uint64_t *winner_out) {
+    if (!r || !config || !target16 || !x0) return set_err(-1, "null argument");
+    // lib.rs:251-254
+    for (int i = 0; i < r->n; ++i)
+        if (x0[i] < r->lb[i] || x0[i] > r->ub[i])
+            return set_err(-2, "seed joint position outside of joint limits");
+    optik_hip_chain *h = device_chain(r);
+    if (!h) return -1;
+    double tgt7[7], ee7[7];
+    pose7_from_mat16(target16, tgt7);
+    if (ee16) pose7_from_mat16(ee16, ee7);
+
+    const auto start = std::chrono::steady_clock::now();
+    auto elapsed = [&]() {
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
+    };
+    const uint64_t max_restarts = config->max_restarts > 0 ? config->max_restarts : UINT64_MAX;  // lib.rs:273-277
+    const bool quality = config->solution_mode == 1;
+    // One launch covers `batch` restart indices: enough 64-lane tiles to fill every CU
+    // a few times over, so a single launch is also the latency-optimal first attempt.
+    const uint64_t batch = (uint64_t)(r->num_cus > 0 ? r->num_cus : 256) * 2 * 64 * 2;
+    bool have = false;
+    double best_key = 0.0, best_f = 0.0;
+    uint64_t best_idx = UINT64_MAX;
+    std::vector<double> best_x((size_t)r->n), wx((size_t)r->n);
+    for (uint64_t begin = 0; begin < max_restarts;) {
+        // lib.rs:393: stop issuing restarts once out of time
+        double deadline = 0.0;
+        if (config->max_time > 0.0) {
+            deadline = config->max_time - elapsed();
+            if (deadline <= 0.0) break;
+        }
+        const uint64_t end = (max_restarts - begin > batch) ? begin + batch : max_restarts;
+        double wf = 0.0, wkey = 0.0;
+        uint64_t widx = UINT64_MAX;
+        const int rc = optik_hip_ik_host(h, config, tgt7, x0, 1, ee16 ? ee7 : nullptr, begin, end,
+                                         quality ? 0u : OPTIK_HIP_IK_EARLY_EXIT, deadline, wx.data(), &wf,
+                                         &widx, &wkey);
+        if (rc) return set_err(-1, optik_hip_last_error());
+        if (widx != UINT64_MAX) {
+            // lib.rs:397-413: Quality keeps the solution closest to the seed, Speed the first one
+            if (!have || wkey < best_key || (wkey == best_key && widx < best_idx)) {
+                have = true; best_key = wkey; best_idx = widx; best_f = wf; best_x = wx;
+            }
+            if (!quality) break;
+        }
+        begin = end;
+    }
+    if (!have) return 1;
+    if (x_out) std::memcpy(x_out, best_x.data(), sizeof(double) * (size_t)r->n);
+    if (f_out) *f_out = best_f;
+    if (winner_out) *winner_out = best_idx;
+    return 0;
+}
+
+const double *optik_robot_ik(const optik_robot *r, const CSolverConfig *config, const double *target,
+                             const double *x0) {
+    std::vector<double> x((size_t)r->n);
+    const int rc = optik_robot_ik_ex(r, config, target, x0, nullptr, x.data(), nullptr, nullptr);
+    if (rc < 0) panic(g_robot_err);
+    if (rc == 1) return nullptr;  // optik-cpp/src/lib.rs:158-160
+    return malloc_copy(x.data(), x.size());
+}
+
+const double *optik_robot_diff_ik(const optik_robot *, const double *, const double *, const double *) {
+    std::fprintf(stderr,
+                 "optik_amd: diff_ik (lib.rs:123-239) is outside the accelerated random-restart IK path "
+                 "and is not provided by this library\n");
+    return nullptr;
+}
+
+int optik_robot_chain_tables(const optik_robot *r, int32_t *n_joints, double *origins7, double *axes3,
+                             int32_t *types) {
+    if (!r || !n_joints) return set_err(-1, "null argument");
+    *n_joints = (int32_t)r->types.size();
+    if (origins7) std::memcpy(origins7, r->origins.data(), sizeof(double) * r->origins.size());
+    if (axes3) std::memcpy(axes3, r->axes.data(), sizeof(double) * r->axes.size());
+    if (types) std::memcpy(types, r->types.data(), sizeof(int32_t) * r->types.size());
+    return 0;
+}
+
+optik_hip_chain *optik_robot_hip_chain(const optik_robot *r) { return r ? device_chain(r) : nullptr; }
+
+}  // extern "C"

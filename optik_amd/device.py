@@ -130,6 +130,12 @@ class HipChain:
     def set_timing(self, enabled=True):
         nat.lib().optik_hip_set_timing(self._h, 1 if enabled else 0)
 
+    def timing_mean(self):
+        """(mean solve-kernel ms, launches) since set_timing(True); HIP events on the launch stream."""
+        ms, cnt = C.c_double(0.0), C.c_int32(0)
+        nat.check(nat.lib().optik_hip_timing_mean(self._h, C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
     def last_launch(self):
         info = nat.LaunchInfo()
         nat.check(nat.lib().optik_hip_last_launch(self._h, C.byref(info)))

@@ -1,0 +1,199 @@
+"""Python front end with the surface of the reference's `optik` module
+(/root/reference/optik.pyi:9-49; implementation crates/optik-py/src/lib.rs:17-155),
+bound with ctypes to the `optik_robot_*` C ABI of liboptik_amd.so (include/optik.h).
+
+Poses are 4x4 homogeneous matrices given as nested lists / arrays in row-major
+order (optik-py/src/lib.rs:8-15); results come back as Python lists, as in the
+reference.  `diff_ik` is outside the accelerated path and raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as nat
+
+U64_MAX = 0xFFFFFFFFFFFFFFFF
+
+
+def _bind(L):
+    if getattr(L, "_robot_bound", False):
+        return L
+    vp, dp = C.c_void_p, C.POINTER(C.c_double)
+    L.optik_robot_try_from_urdf_str.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(vp)]
+    L.optik_robot_last_error.restype = C.c_char_p
+    L.optik_robot_free.argtypes = [vp]
+    L.optik_robot_set_parallelism.argtypes = [vp, C.c_uint]
+    L.optik_robot_num_positions.argtypes = [vp]
+    L.optik_robot_num_positions.restype = C.c_uint
+    L.optik_robot_ik_ex.argtypes = [vp, C.POINTER(nat.SolverConfigC), dp, dp, dp, dp, dp,
+                                    C.POINTER(C.c_uint64)]
+    L.optik_robot_fk_ex.argtypes = [vp, dp, dp, dp]
+    L.optik_robot_joint_jacobian_ex.argtypes = [vp, dp, dp, dp]
+    L.optik_robot_chain_tables.argtypes = [vp, C.POINTER(C.c_int32), dp, dp, C.POINTER(C.c_int32)]
+    L.optik_robot_hip_chain.argtypes = [vp]
+    L.optik_robot_hip_chain.restype = vp
+    L.optik_robot_joint_limits.argtypes = [vp]
+    L.optik_robot_joint_limits.restype = dp
+    L._robot_bound = True
+    return L
+
+
+def _err(L):
+    m = L.optik_robot_last_error()
+    return m.decode() if m else "unknown error"
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _pose16(m):
+    """Row-major nested 4x4 -> column-major flat (parse_pose, optik-py/src/lib.rs:8-15)."""
+    a = np.asarray(m, dtype=np.float64)
+    if a.shape != (4, 4):
+        raise ValueError("pose must be a 4x4 homogeneous matrix")
+    return np.ascontiguousarray(a.T).ravel()
+
+
+class SolverConfig:
+    """optik.pyi:9-20; defaults of optik-py/src/lib.rs:24-31 / config.rs:52-65."""
+
+    def __init__(self, solution_mode="speed", max_time=0.1, max_restarts=U64_MAX, tol_f=1e-6,
+                 tol_df=-1.0, tol_dx=-1.0, linear_weight=(1.0, 1.0, 1.0),
+                 angular_weight=(1.0, 1.0, 1.0)):
+        if solution_mode not in ("speed", "quality"):
+            raise ValueError("solution_mode must be 'speed' or 'quality'")  # config.rs:10-20
+        if max_time == 0.0 and max_restarts == 0:
+            # optik-py/src/lib.rs:45-47
+            raise ValueError("no time or restart limit applied (solver would run forever)")
+        self.solution_mode = solution_mode
+        self.max_time = float(max_time)
+        self.max_restarts = int(max_restarts)
+        self.tol_f, self.tol_df, self.tol_dx = float(tol_f), float(tol_df), float(tol_dx)
+        self.linear_weight = [float(v) for v in linear_weight]
+        self.angular_weight = [float(v) for v in angular_weight]
+
+    def to_c(self):
+        return nat.make_config(self.solution_mode, self.max_time,
+                               0 if self.max_restarts >= U64_MAX else self.max_restarts,
+                               self.tol_f, self.tol_df, self.tol_dx, self.linear_weight,
+                               self.angular_weight)
+
+
+class Robot:
+    """optik.pyi:22-49."""
+
+    def __init__(self, handle):
+        self._L = _bind(nat.lib())
+        self._h = handle
+        self._hip = {}
+
+    @staticmethod
+    def from_urdf_str(urdf: str, base_link: str, ee_link: str) -> "Robot":
+        L = _bind(nat.lib())
+        h = C.c_void_p()
+        rc = L.optik_robot_try_from_urdf_str(urdf.encode(), base_link.encode(), ee_link.encode(),
+                                             C.byref(h))
+        if rc:
+            raise RuntimeError(_err(L))
+        return Robot(h)
+
+    @staticmethod
+    def from_urdf_file(path: str, base_link: str, ee_link: str) -> "Robot":
+        try:
+            with open(path) as fh:
+                text = fh.read()
+        except OSError as e:
+            raise RuntimeError("error parsing URDF file!") from e  # lib.rs:55
+        return Robot.from_urdf_str(text, base_link, ee_link)
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.optik_robot_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def set_parallelism(self, n: int) -> None:
+        self._L.optik_robot_set_parallelism(self._h, int(n))
+
+    def num_positions(self) -> int:
+        return int(self._L.optik_robot_num_positions(self._h))
+
+    def joint_limits(self):
+        n = self.num_positions()
+        p = self._L.optik_robot_joint_limits(self._h)
+        vals = [p[i] for i in range(2 * n)]
+        C.CDLL(None).free(p)
+        return vals[:n], vals[n:]
+
+    def _check_x(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+        if x.size != self.num_positions():
+            # kinematics.rs:129-133
+            raise ValueError("generalized position vector `q` is of incorrect length")
+        return x
+
+    def fk(self, x, ee_offset=None):
+        x = self._check_x(x)
+        ee = _pose16(ee_offset) if ee_offset is not None else None
+        out = np.zeros(16)
+        if self._L.optik_robot_fk_ex(self._h, _dp(x), _dp(ee) if ee is not None else None, _dp(out)):
+            raise RuntimeError(_err(self._L))
+        return out.reshape(4, 4).T.tolist()
+
+    def joint_jacobian(self, x, ee_offset=None):
+        x = self._check_x(x)
+        ee = _pose16(ee_offset) if ee_offset is not None else None
+        n = self.num_positions()
+        out = np.zeros(6 * n)
+        if self._L.optik_robot_joint_jacobian_ex(self._h, _dp(x), _dp(ee) if ee is not None else None,
+                                                 _dp(out)):
+            raise RuntimeError(_err(self._L))
+        return out.reshape(n, 6).T.tolist()
+
+    def ik(self, config: SolverConfig, target, x0, ee_offset=None, return_index=False):
+        """Returns (x, c) or None (optik.pyi:36-42).  `return_index=True` appends the winning
+        restart index (an extension used by the parity tests)."""
+        x0 = self._check_x(x0)
+        tgt = _pose16(target)
+        ee = _pose16(ee_offset) if ee_offset is not None else None
+        cfg = config.to_c()
+        n = self.num_positions()
+        x, f, idx = np.zeros(n), C.c_double(0.0), C.c_uint64(0)
+        rc = self._L.optik_robot_ik_ex(self._h, C.byref(cfg), _dp(tgt), _dp(x0),
+                                       _dp(ee) if ee is not None else None, _dp(x), C.byref(f),
+                                       C.byref(idx))
+        if rc < 0:
+            raise RuntimeError(_err(self._L))  # e.g. "seed joint position outside of joint limits"
+        if rc == 1:
+            return None
+        return (x.tolist(), f.value, idx.value) if return_index else (x.tolist(), f.value)
+
+    def diff_ik(self, x0, V_WE, v_max, ee_offset=None):
+        raise NotImplementedError(
+            "diff_ik (lib.rs:123-239) is outside the accelerated random-restart IK path")
+
+    # -- extensions ---------------------------------------------------------------
+    def chain_tables(self):
+        """Flat chain (types, origins[J,7], axes[J,3], lb, ub) as loaded by the C++ URDF loader."""
+        nj = C.c_int32(0)
+        origins, axes = np.zeros(9 * 7), np.zeros(9 * 3)
+        types = np.zeros(9, dtype=np.int32)
+        self._L.optik_robot_chain_tables(self._h, C.byref(nj), _dp(origins), _dp(axes),
+                                         types.ctypes.data_as(C.POINTER(C.c_int32)))
+        J = nj.value
+        lb, ub = self.joint_limits()
+        return dict(types=types[:J].copy(), origins=origins[:J * 7].reshape(J, 7).copy(),
+                    axes=axes[:J * 3].reshape(J, 3).copy(), lb=np.array(lb), ub=np.array(ub))
+
+    def hip_chain(self, device="cuda:0"):
+        """Device-buffer interface (optik_amd.device.HipChain) for this robot."""
+        from .device import HipChain
+        key = str(device)
+        if key not in self._hip:
+            self._hip[key] = HipChain(device=device, **self.chain_tables())
+        return self._hip[key]

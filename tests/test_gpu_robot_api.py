@@ -1,0 +1,198 @@
+"""-m gpu: the reference-shaped front end (optik.pyi surface over the optik_robot_* C ABI)
+on the real device, written after the reference's own integration tests
+(/root/reference/crates/optik/tests/test_fk.rs, test_ik.rs)."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+from conftest import REF_GOLDEN, ROBOTS
+from gpu_util import assert_bit_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ur3e():
+    from optik_amd import Robot
+    return Robot.from_urdf_file(os.path.join(REF_GOLDEN, "ur3e.urdf"), "ur_base_link", "ur_ee_link")
+
+
+@pytest.fixture(scope="module")
+def panda():
+    from optik_amd import Robot
+    return Robot.from_urdf_file(os.path.join(ROBOTS, "panda.urdf"), "panda_link0", "panda_link8")
+
+
+def _quat_to_R(q):
+    i, j, k, w = q
+    return np.array([[w*w + i*i - j*j - k*k, 2*(i*j - w*k), 2*(w*j + i*k)],
+                     [2*(w*k + i*j), w*w - i*i + j*j - k*k, 2*(j*k - w*i)],
+                     [2*(i*k - w*j), 2*(w*i + j*k), w*w - i*i - j*j + k*k]])
+
+
+def test_fk_golden(ur3e):
+    """tests/test_fk.rs:13-26 on the GPU path: 50 golden UR3e poses, abs 1e-6."""
+    inp = json.load(open(os.path.join(REF_GOLDEN, "test_fk_inputs.json")))
+    out = json.load(open(os.path.join(REF_GOLDEN, "test_fk_outputs.json")))
+    for q, o in zip(inp, out):
+        m = np.array(ur3e.fk(q))
+        np.testing.assert_allclose(m[:3, 3], o["translation"], atol=1e-6, rtol=0)
+        np.testing.assert_allclose(m[:3, :3], _quat_to_R(o["rotation"]), atol=1e-6, rtol=0)
+        assert np.allclose(m[3], [0, 0, 0, 1])
+
+
+def test_jacobian_matches_oracle_and_finite_differences(ur3e, oracle, chains):
+    _, ch = chains["ur3e"]
+    rng = np.random.default_rng(0)
+    for _ in range(5):
+        q = rng.uniform(-1, 1, 6)
+        J = np.array(ur3e.joint_jacobian(q))
+        assert J.shape == (6, 6)
+        assert_bit_equal(J, oracle.joint_jacobian(ch, q), "jacobian")
+    with pytest.raises(ValueError):
+        ur3e.fk([0.0] * 5)
+
+
+def test_invalid_seed(ur3e):
+    """tests/test_ik.rs:10-22."""
+    from optik_amd import SolverConfig
+    _, ub = ur3e.joint_limits()
+    x0 = [0.0] * 6
+    x0[4] = ub[4] + 1.0
+    with pytest.raises(RuntimeError, match="joint limits"):
+        ur3e.ik(SolverConfig(), np.eye(4), x0)
+
+
+def test_stopping_maxtime(ur3e):
+    """tests/test_ik.rs:24-43: impossible goal, max_time = 0.05 s, returns within 0.05 +- 0.1 s."""
+    from optik_amd import SolverConfig
+    tgt = np.eye(4)
+    tgt[:3, 3] = 100.0
+    ur3e.fk([0.0] * 6)  # warm the device up before timing
+    t0 = time.perf_counter()
+    sol = ur3e.ik(SolverConfig(max_time=0.05), tgt, [0.0] * 6)
+    dt = time.perf_counter() - t0
+    assert sol is None
+    assert abs(dt - 0.05) < 0.1, dt
+
+
+def test_determinism_and_oracle_agreement(ur3e, oracle, chains):
+    """tests/test_ik.rs:45-89 (11 identical calls), plus: the solution IS the oracle's."""
+    from optik_amd import SolverConfig
+    _, ch = chains["ur3e"]
+    rng = np.random.default_rng(42)
+    tgt = np.array(ur3e.fk(rng.random(6)))
+    cfg = SolverConfig(max_time=0.0, max_restarts=25)
+    x_sol, c, idx = ur3e.ik(cfg, tgt, [0.0] * 6, return_index=True)
+    for _ in range(10):
+        x_i, _ = ur3e.ik(cfg, tgt, [0.0] * 6)
+        assert x_i == x_sol
+    _, ee = oracle.fk(ch, rng.random(6) * 0)  # noqa: F841 (keeps the oracle chain warm)
+    t7 = _mat_to_pose7(tgt)
+    ref = oracle.ik(ch, oracle.make_config(solution_mode="speed", max_restarts=25), t7, np.zeros(6), 0, 25)
+    assert ref["found"] and ref["winner"] == idx
+    np.testing.assert_allclose(x_sol, ref["x"], atol=1e-6, rtol=0)  # north-star tolerance
+    assert abs(c - ref["f"]) < 1e-12
+
+
+def _mat_to_pose7(m):
+    m = np.asarray(m)
+    tr = np.trace(m[:3, :3])
+    # Shepperd, trace > 0 branch is enough for the FK-generated targets used here
+    if tr > 0:
+        d = np.sqrt(tr + 1.0) * 2.0
+        w = 0.25 * d
+        i, j, k = (m[2, 1] - m[1, 2]) / d, (m[0, 2] - m[2, 0]) / d, (m[1, 0] - m[0, 1]) / d
+    else:
+        idx = int(np.argmax(np.diag(m[:3, :3])))
+        a, b, c = idx, (idx + 1) % 3, (idx + 2) % 3
+        d = np.sqrt(1.0 + m[a, a] - m[b, b] - m[c, c]) * 2.0
+        v = [0.0, 0.0, 0.0]
+        v[a] = 0.25 * d
+        v[b] = (m[a, b] + m[b, a]) / d
+        v[c] = (m[a, c] + m[c, a]) / d
+        w = (m[c, b] - m[b, c]) / d
+        i, j, k = v
+    q = np.array([i, j, k, w])
+    q /= np.linalg.norm(q)
+    return np.concatenate([m[:3, 3], q])
+
+
+def test_solution_forward_backward(ur3e):
+    """tests/test_ik.rs:91-130: tol_f = 1e-12, 25 restarts, FK(ik(T)) == T to 1e-6."""
+    from optik_amd import SolverConfig
+    rng = np.random.default_rng(42)
+    cfg = SolverConfig(solution_mode="speed", tol_f=1e-12, max_time=0.0, max_restarts=25)
+    for _ in range(10):
+        tgt = np.array(ur3e.fk(rng.random(6)))
+        x, c = ur3e.ik(cfg, tgt, [0.0] * 6)
+        np.testing.assert_allclose(np.array(ur3e.fk(x)), tgt, atol=1e-6, rtol=0)
+        assert c < 1e-12
+
+
+def test_solution_quality(ur3e):
+    """tests/test_ik.rs:132-182: Quality is never farther from the seed than Speed."""
+    from optik_amd import SolverConfig
+    rng = np.random.default_rng(42)
+    speed = SolverConfig(solution_mode="speed", max_time=0.0, max_restarts=15)
+    quality = SolverConfig(solution_mode="quality", max_time=0.0, max_restarts=15)
+    for _ in range(20):
+        tgt = np.array(ur3e.fk(rng.random(6)))
+        xs, _ = ur3e.ik(speed, tgt, [0.0] * 6)
+        xq, _ = ur3e.ik(quality, tgt, [0.0] * 6)
+        assert np.linalg.norm(xq) <= np.linalg.norm(xs)
+
+
+def test_panda_default_config_and_ee_offset(panda):
+    """Default SolverConfig (0.1 s budget, unlimited restarts, Speed) on the headline robot,
+    with a non-trivial ee_offset (optik.pyi:36-42)."""
+    from optik_amd import SolverConfig
+    rng = np.random.default_rng(3)
+    lb, ub = (np.array(v) for v in panda.joint_limits())
+    off = np.eye(4)
+    off[:3, 3] = [0.0, 0.05, 0.1]
+    off[:3, :3] = _quat_to_R(np.array([0.0, 0.0, np.sin(0.3), np.cos(0.3)]))
+    solved = 0
+    for _ in range(10):
+        tgt = np.array(panda.fk(rng.uniform(lb, ub), off))
+        sol = panda.ik(SolverConfig(), tgt, rng.uniform(lb, ub).tolist(), off)
+        if sol is not None:
+            x, c = sol
+            assert c < 1e-6 and np.all(np.array(x) >= lb) and np.all(np.array(x) <= ub)
+            # f < 1e-6 is a squared log-error (quirk Q8): pose error below ~1e-3
+            np.testing.assert_allclose(np.array(panda.fk(x, off)), tgt, atol=2e-3, rtol=0)
+            solved += 1
+    assert solved >= 9
+
+
+def test_c_abi_ik_returns_malloced_buffer(ur3e):
+    """optik_robot_ik / optik_robot_fk as the reference's C++ wrapper uses them
+    (crates/optik-cpp/src/lib.cpp:105-120): col-major target, free() the result."""
+    import ctypes as C
+    from optik_amd import _native as nat
+    L = nat.lib()
+    dp = C.POINTER(C.c_double)
+    L.optik_robot_fk.restype = dp
+    L.optik_robot_fk.argtypes = [C.c_void_p, dp]
+    L.optik_robot_ik.restype = dp
+    L.optik_robot_ik.argtypes = [C.c_void_p, C.POINTER(nat.SolverConfigC), dp, dp]
+    q = (C.c_double * 6)(0.1, 0.2, 0.0, 0.3, -0.2, -1.1)
+    m = L.optik_robot_fk(ur3e._h, q)
+    tgt16 = (C.c_double * 16)(*[m[i] for i in range(16)])
+    assert abs(tgt16[15] - 1.0) < 1e-15 and tgt16[3] == 0.0   # column-major homogeneous
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(m)
+    cfg = nat.make_config("speed", 0.0, 64)
+    x0 = (C.c_double * 6)(*([0.0] * 6))
+    sol = L.optik_robot_ik(ur3e._h, C.byref(cfg), tgt16, x0)
+    assert bool(sol)
+    x = [sol[i] for i in range(6)]
+    libc.free(sol)
+    np.testing.assert_allclose(np.array(ur3e.fk(x)), np.array(list(tgt16)).reshape(4, 4).T, atol=2e-3)
+    far = (C.c_double * 16)(*np.eye(4).T.ravel())
+    far[12] = far[13] = far[14] = 100.0
+    assert not bool(L.optik_robot_ik(ur3e._h, C.byref(cfg), far, x0))   # NULL = no solution
