@@ -15,6 +15,11 @@
 
 #include "ik_math.hpp"
 
+// Keeps the machine scheduler from interleaving the iterations of the fully
+// unrolled per-joint loops: without it every joint's temporaries are live at once
+// (2x the registers of the rolled loop) and the restart kernel spills.
+#define OPTIK_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
 namespace optik {
 
 constexpr int MAX_DOF = 8;
@@ -71,6 +76,7 @@ OPTIK_DEV void forward_kinematics(const ChainDev &ch, const EvalParams &ep, cons
         jt.q = qmul(Q4{ch.origin[j][3], ch.origin[j][4], ch.origin[j][5], ch.origin[j][6]}, local);
         state = (j == 0) ? jt : pose_mul(state, jt);  // identity * jt is exact
         kin.tf[j] = state;
+        OPTIK_SCHED_FENCE();
     }
     if (TIP) state = pose_mul(state, load_pose(ch.origin[N]));
     kin.ee = ep.has_ee_offset ? pose_mul(state, load_pose(ep.ee_offset)) : state;
@@ -135,6 +141,7 @@ OPTIK_DEV double eval_fg(const ChainDev &ch, const EvalParams &ep, const Pose ta
 #pragma unroll
         for (int r = 0; r < 6; ++r) acc += e2[r] * jt[r];
         g[k] = acc;
+        OPTIK_SCHED_FENCE();
     }
 
     // f = ||e||^2 (objective.rs:56)

@@ -301,6 +301,7 @@ OPTIK_DEV int lsq_box(const NnlsWs<N> &ws, const double (&l)[N * (N + 1) / 2], c
 #pragma unroll
         for (int k = 0; k < i; ++k) acc += E[k][i] * f[k];
         f[i] = (g[i] - acc) / diag;
+        OPTIK_SCHED_FENCE();
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) f[i] = -f[i];
@@ -331,6 +332,7 @@ OPTIK_DEV int lsq_box(const NnlsWs<N> &ws, const double (&l)[N * (N + 1) / 2], c
                 if (sm != 0.0) { sm *= b; f[i] += sm * up; }
             }
         }
+        OPTIK_SCHED_FENCE();
     }
     // transform G = [I; -I] and h = [lo; -hi]: rows of +-E^-1
     bool singular = false;
@@ -353,46 +355,68 @@ OPTIK_DEV int lsq_box(const NnlsWs<N> &ws, const double (&l)[N * (N + 1) / 2], c
         for (int j = i; j < N; ++j) acc += Gi[i][j] * f[j];
         h[i] = lo[i] - acc;
         h[N + i] = (-hi[i]) - (-acc);
+        OPTIK_SCHED_FENCE();
     }
-    // LDP: state the dual problem in LDS
+    // LDP.  NNLS's first dual check is w_j = h_j (b = e_{n+1}); when no h_j is positive
+    // it returns at once with zero multipliers (y = 0, fac = 1, step 0): that case --
+    // the unconstrained step is feasible -- never touches LDS.  Bit-identical to
+    // running NNLS, whose every product is then an exact zero.
     constexpr int M = 2 * N;
+    bool need_nnls = false;
 #pragma unroll
-    for (int c = 0; c < N; ++c) {
+    for (int r = 0; r < M; ++r) need_nnls = need_nnls || (h[r] > 0.0);
+    int mode = 1;
+    if (need_nnls) {
 #pragma unroll
-        for (int r = 0; r < N; ++r) {
-            const double v = (r >= c) ? Gi[c][r] : 0.0;
-            ws.A(r + 1, c + 1) = v;
-            ws.A(r + 1, N + c + 1) = (r >= c) ? -v : 0.0;
+        for (int c = 0; c < N; ++c) {
+#pragma unroll
+            for (int r = 0; r < N; ++r) {
+                const double v = (r >= c) ? Gi[c][r] : 0.0;
+                ws.A(r + 1, c + 1) = v;
+                ws.A(r + 1, N + c + 1) = (r >= c) ? -v : 0.0;
+            }
+            ws.A(N + 1, c + 1) = h[c];
+            ws.A(N + 1, N + c + 1) = h[N + c];
+            OPTIK_SCHED_FENCE();
         }
-        ws.A(N + 1, c + 1) = h[c];
-        ws.A(N + 1, N + c + 1) = h[N + c];
-    }
 #pragma unroll
-    for (int r = 1; r <= N; ++r) ws.b(r) = 0.0;
-    ws.b(N + 1) = 1.0;
-    double rnorm;
-    const int mode = nnls<N>(ws, rnorm);
+        for (int r = 1; r <= N; ++r) ws.b(r) = 0.0;
+        ws.b(N + 1) = 1.0;
+        double rnorm;
+        OPTIK_SCHED_FENCE();
+        mode = nnls<N>(ws, rnorm);
+        OPTIK_SCHED_FENCE();
+        if (mode == 1 && rnorm <= 0.0) mode = 4;
+        if (mode == 1) {
+            double y[M];
+#pragma unroll
+            for (int r = 0; r < M; ++r) y[r] = ws.x(r + 1);
+            double hy = 0.0;
+#pragma unroll
+            for (int r = 0; r < M; ++r) hy += h[r] * y[r];
+            double fac = 1.0 - hy;
+            const double d1 = 1.0 + fac;
+            if (d1 - 1.0 <= 0.0) {
+                mode = 4;
+            } else {
+                fac = 1.0 / fac;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int r = 0; r <= j; ++r) acc += Gi[r][j] * y[r];
+#pragma unroll
+                    for (int r = 0; r <= j; ++r) acc += (-Gi[r][j]) * y[N + r];
+                    s[j] = fac * acc;
+                    OPTIK_SCHED_FENCE();
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) s[j] = 0.0;
+    }
     if (mode != 1) return mode;
-    if (rnorm <= 0.0) return 4;
-    double y[M];
-#pragma unroll
-    for (int r = 0; r < M; ++r) y[r] = ws.x(r + 1);
-    double hy = 0.0;
-#pragma unroll
-    for (int r = 0; r < M; ++r) hy += h[r] * y[r];
-    double fac = 1.0 - hy;
-    const double d1 = 1.0 + fac;
-    if (d1 - 1.0 <= 0.0) return 4;
-    fac = 1.0 / fac;
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        double acc = 0.0;
-#pragma unroll
-        for (int r = 0; r <= j; ++r) acc += Gi[r][j] * y[r];
-#pragma unroll
-        for (int r = 0; r <= j; ++r) acc += (-Gi[r][j]) * y[N + r];
-        s[j] = fac * acc;
-    }
     // solution of the original problem: s = E^-1 (y + f)
 #pragma unroll
     for (int i = 0; i < N; ++i) s[i] += f[i];
@@ -402,6 +426,7 @@ OPTIK_DEV int lsq_box(const NnlsWs<N> &ws, const double (&l)[N * (N + 1) / 2], c
 #pragma unroll
         for (int j = i + 1; j < N; ++j) acc += E[i][j] * s[j];
         s[i] = (s[i] - acc) / E[i][i];
+        OPTIK_SCHED_FENCE();
     }
     // NLopt: enforce the bounds against roundoff
 #pragma unroll
@@ -427,6 +452,7 @@ OPTIK_DEV void ldl_update(double (&a)[N * (N + 1) / 2], double (&z)[N], double s
             t += v * v / a[lidx<N>(i, i)];
 #pragma unroll
             for (int j = i + 1; j < N; ++j) w[j] -= v * a[lidx<N>(i, j)];
+            OPTIK_SCHED_FENCE();
         }
         if (t >= 0.0) t = EPMACH / sigma;
 #pragma unroll
@@ -463,6 +489,7 @@ OPTIK_DEV void ldl_update(double (&a)[N * (N + 1) / 2], double (&z)[N], double s
             }
             t = tp;
         }
+        OPTIK_SCHED_FENCE();
     }
 }
 
@@ -502,8 +529,11 @@ OPTIK_DEV void bfgs_update(double (&l)[N * (N + 1) / 2], const double (&s)[N], d
 #pragma unroll
         for (int i = 0; i < N; ++i) u[i] += (1.0 - h4) * v[i];
     }
+    OPTIK_SCHED_FENCE();
     ldl_update<N>(l, u, 1.0 / h1);
+    OPTIK_SCHED_FENCE();
     ldl_update<N>(l, v, -1.0 / h2);
+    OPTIK_SCHED_FENCE();
 }
 
 }  // namespace optik

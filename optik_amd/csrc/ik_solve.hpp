@@ -153,7 +153,9 @@ OPTIK_DEV void solve_restart(const ChainDev &ch, const EvalParams &ep, const Sol
         }
         double gn[N];
         double fn = 0.0;
+        OPTIK_SCHED_FENCE();
         if (active) fn = eval_fg<N, TIP>(ch, ep, target, x, gn);
+        OPTIK_SCHED_FENCE();
         if (active) {
             f = fn;
             ++nevals;
@@ -212,7 +214,9 @@ OPTIK_DEV void solve_restart(const ChainDev &ch, const EvalParams &ep, const Sol
                         double u[N];
 #pragma unroll
                         for (int i = 0; i < N; ++i) { u[i] = gn[i] - v[i]; g[i] = gn[i]; }
+                        OPTIK_SCHED_FENCE();
                         bfgs_update<N>(l, s, u);
+                        OPTIK_SCHED_FENCE();
                         need_dir = true;
                     }
                 }
@@ -243,7 +247,9 @@ OPTIK_DEV void solve_restart(const ChainDev &ch, const EvalParams &ep, const Sol
                 double lo[N], hi[N];
 #pragma unroll
                 for (int i = 0; i < N; ++i) { lo[i] = ch.lb[i] - x[i]; hi[i] = ch.ub[i] - x[i]; }
+                OPTIK_SCHED_FENCE();
                 const int lmode = lsq_box<N>(ws, l, g, lo, hi, s);
+                OPTIK_SCHED_FENCE();
                 if (lmode != 1) {
                     // NLopt: modes 5,6,7 -> ROUNDOFF_LIMITED; 3,4,9 -> FAILURE
                     ret = (lmode == 5 || lmode == 6 || lmode == 7) ? RES_ROUNDOFF_LIMITED : RES_FAILURE;
