@@ -133,6 +133,20 @@ int optik_hip_ik_batch(optik_hip_chain *chain, const optik_solver_config *cfg,
                        uint32_t flags, double deadline_s, const optik_hip_ik_outputs *out,
                        void *stream);
 
+/* Streaming engine (throughput path): the same restarts, the same arithmetic and the
+ * same results as optik_hip_ik_batch, executed as phase kernels over a pool of restart
+ * slots in HBM with continuous refill (optik_amd/csrc/ik_engine.hpp).  submit() only
+ * records a job (arguments as optik_hip_ik_batch; all jobs of one run must share
+ * tolerances, weights and ee_offset; buffers must stay valid until run() returns);
+ * run() executes every pending job, runs their selections and blocks until done.
+ * No deadline support: use optik_hip_ik_batch for max_time. */
+int optik_hip_engine_submit(optik_hip_chain *chain, const optik_solver_config *cfg,
+                            const double *d_targets, const double *d_x0, int32_t T,
+                            const double *ee_offset7, uint64_t restart_begin, uint64_t restart_end,
+                            uint32_t flags, const optik_hip_ik_outputs *out);
+int optik_hip_engine_run(optik_hip_chain *chain, void *stream);
+int optik_hip_engine_last_trips(const optik_hip_chain *chain);
+
 /* Host-buffer convenience over optik_hip_ik_batch (what Robot::ik calls): copies
  * targets/x0 in, runs, synchronises, copies the per-target winners out.
  * win_x [T][n], win_f [T], win_idx [T] (UINT64_MAX = no solution), win_key [T]
@@ -161,6 +175,9 @@ typedef struct optik_hip_launch_info {
 void optik_hip_set_timing(optik_hip_chain *chain, int32_t enabled);
 int optik_hip_last_launch(const optik_hip_chain *chain, optik_hip_launch_info *info);
 int optik_hip_timing_mean(optik_hip_chain *chain, double *mean_ms, int32_t *count);
+/* Diagnostic builds (-DOPTIK_PROFILE) accumulate s_memtime cycles per solver phase:
+ * out8 = {refill, eval, update, publish, bfgs, lsq, nnls, trips}; all zero in normal builds. */
+int optik_hip_phase_profile(optik_hip_chain *chain, unsigned long long *out8);
 
 #ifdef __cplusplus
 }

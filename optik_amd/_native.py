@@ -80,6 +80,10 @@ def lib():
     L.optik_hip_ik_host.argtypes = [vp, C.POINTER(SolverConfigC), dp, dp, C.c_int32, dp,
                                     C.c_uint64, C.c_uint64, C.c_uint32, C.c_double, dp, dp,
                                     C.POINTER(C.c_uint64), dp]
+    L.optik_hip_engine_submit.argtypes = [vp, C.POINTER(SolverConfigC), vp, vp, C.c_int32, dp,
+                                          C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(IkOutputs)]
+    L.optik_hip_engine_run.argtypes = [vp, vp]
+    L.optik_hip_engine_last_trips.argtypes = [vp]
     L.optik_hip_probe.argtypes = [C.c_int32, dp, dp, C.c_int64, dp]
     L.optik_hip_set_timing.argtypes = [vp, C.c_int32]
     L.optik_hip_last_launch.argtypes = [vp, C.POINTER(LaunchInfo)]

@@ -1,0 +1,562 @@
+// ik_engine.hpp -- streaming ("continuous batching") form of the restart solver.
+//
+// The single-kernel solver (ik_solve.hpp) keeps a restart in one lane from seed to
+// termination; a wave then pays for every SLSQP phase any of its 64 lanes is in
+// (measured: 36 % VALU lane utilisation, 2 waves per CU because of the NNLS LDS).
+// For throughput the same arithmetic is re-cut along the phases instead:
+//
+//   * a pool of C restart *slots* lives in HBM as struct-of-arrays planes
+//     (plane k of slot s at [k*C + s]): thread s of every kernel owns slot s, so all
+//     state traffic is perfectly coalesced and no compaction lists are needed;
+//   * one *trip* = three kernels over the pool, each doing one phase for the slots
+//     that are in it:
+//       eng_eval_kernel    objective + gradient at x, NLopt bookkeeping / stop tests,
+//                          line-search accept/reject (rejected: next trial point)
+//       eng_update_kernel  accepted: BFGS update + LSQ direction when the step stays
+//                          inside the box (no LDS); finished: refill the slot with the
+//                          next (job, target, restart) work item from the queue
+//       eng_nnls_kernel    only the slots whose step hits a bound: Kraft's
+//                          LSQ -> LDP -> NNLS with the active set in LDS
+//     so the evaluation and update kernels run without LDS at several waves per SIMD
+//     and only the NNLS kernel is LDS-bound -- on a compacted list of slots;
+//   * jobs (one optik_hip_ik_batch call each) submitted before a run share the pool:
+//     a slot that finishes a restart of one job may continue with another job's.
+//
+// Per-restart arithmetic and decisions are the same functions the single-kernel
+// solver calls, so results stay bit-identical to the CPU oracle.
+#pragma once
+
+#include "ik_nnls_coop.hpp"
+#include "ik_solve.hpp"
+
+namespace optik {
+
+// slot states
+enum : int32_t {
+    ST_EMPTY = 0,          // no restart, queue exhausted
+    ST_EVAL_FIRST = 1,     // fresh restart: first evaluation pending
+    ST_EVAL_TRIAL = 2,     // line-search trial point pending evaluation
+    ST_UPDATE_FIRST = 3,   // first evaluation done: initialise B = I, first direction
+    ST_UPDATE_ACCEPT = 4,  // line search accepted: BFGS update + next direction
+    ST_NNLS = 5,           // direction needs the bounded solve (deferred to the NNLS kernel)
+    ST_REFILL = 6,         // restart published; slot wants the next work item
+    ST_DEAD = 7,           // terminated inside an update (status plane); publish next trip
+};
+
+template <int N>
+struct EngLayout {
+    static constexpr int NL = N * (N + 1) / 2;
+    // double planes
+    static constexpr int X = 0, X0 = X + N, G = X0 + N, S = G + N, GN = S + N, XB = GN + N, XP = XB + N,
+                         L = XP + N, F0 = L + NL, H3 = F0 + 1, AL = H3 + 1, FP = AL + 1, MF = FP + 1,
+                         FC = MF + 1, ND = FC + 1;
+    // int32 planes
+    static constexpr int STATE = 0, LINE = 1, IRESET = 2, ITER = 3, NEVALS = 4, STATUS = 5, JOB = 6, NNQ = 7, NI = 8;
+};
+
+// One submitted optik_hip_ik_batch call.
+struct EngJob {
+    const double *targets;             // [T][7]
+    const double *x0;                  // [T][n]
+    unsigned long long item_base;      // first global work item of the job
+    unsigned long long n_items;        // T * R
+    unsigned long long n_restarts;     // R
+    unsigned long long restart_begin;
+    double *out_x;                     // [n][T*R]
+    double *out_f;
+    double *out_key;
+    int32_t *out_status;
+    int32_t *out_evals;
+    unsigned long long *first_success; // [T] or null (Speed early exit)
+    int quality;
+    int pad;
+};
+
+constexpr int ENG_MAX_JOBS = 64;
+
+struct EngArgs {
+    const ChainDev *chain;
+    EvalParams ep;
+    SolveParams sp;
+    uint32_t key[8];
+    double scale[MAX_DOF];
+    double *d;                          // ND planes of C doubles
+    int32_t *i32;                       // NI planes of C ints
+    unsigned long long *item;           // [C] local item (t * R + r) of the slot's restart
+    unsigned long long C;
+    const EngJob *jobs;                 // [n_jobs] in device memory
+    int n_jobs;
+    int pad;
+    unsigned long long total_items;
+    unsigned long long *next_item;      // global queue head
+    // bounded sub-problems of a trip: list / problem / answer buffers, double-buffered by
+    // trip parity (the finish kernel of trip s may defer into the list of trip s+1)
+    unsigned int *nn_count[2];          // list lengths
+    double *nn_prob[2];                 // [C][2n][n+1] dual problems, one contiguous block each
+    double *nn_y[2];                    // [C][2n] multipliers
+    double *nn_meta[2];                 // [C][2] {mode, rnorm}
+    int parity;                         // list consumed by this trip's NNLS kernel
+    int pad2;
+    unsigned int *n_active;             // slots holding a restart after the update kernel (zeroed every trip)
+    unsigned long long *prof;           // OPTIK_PROFILE builds: cycle counters, else null
+};
+
+#define ENG_D(plane, k) a.d[(size_t)((plane) + (k)) * a.C + slot]
+#define ENG_I(plane) a.i32[(size_t)(plane) * a.C + slot]
+
+// Outcome of the direction search for one slot.
+enum : int { DIR_OK = 0, DIR_DEFER = 1, DIR_DEAD = 2 };
+
+// Writes the dual problem of a deferred direction (columns of [G E^-1; h]) as one
+// contiguous block for the cooperative NNLS kernel; returns its list position.
+template <int N>
+OPTIK_DEV unsigned emit_problem(const EngArgs &a, int parity, const LsqPrep<N> &P) {
+    const unsigned q = atomicAdd(a.nn_count[parity], 1u);
+    double *pb = a.nn_prob[parity] + (size_t)q * (2 * N) * (N + 1);
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            const double v = (r >= c) ? P.Gi[c][r] : 0.0;
+            pb[c * (N + 1) + r] = v;
+            pb[(N + c) * (N + 1) + r] = (r >= c) ? -v : 0.0;
+        }
+        pb[c * (N + 1) + N] = P.h[c];
+        pb[(N + c) * (N + 1) + N] = P.h[N + c];
+    }
+    return q;
+}
+
+// LDP tail (Lawson-Hanson ch. 23) from the NNLS answer: transformed-space step.
+template <int N>
+OPTIK_DEV int ldp_from_answer(const LsqPrep<N> &P, const double *y_mem, const double *meta, double (&s)[N]) {
+    constexpr int M = 2 * N;
+    int mode = (int)meta[0];
+    if (mode == 1 && meta[1] <= 0.0) mode = 4;
+    if (mode != 1) return mode;
+    double y[M];
+#pragma unroll
+    for (int r = 0; r < M; ++r) y[r] = y_mem[r];
+    double hy = 0.0;
+#pragma unroll
+    for (int r = 0; r < M; ++r) hy += P.h[r] * y[r];
+    double fac = 1.0 - hy;
+    const double d1 = 1.0 + fac;
+    if (d1 - 1.0 <= 0.0) return 4;
+    fac = 1.0 / fac;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double acc = 0.0;
+#pragma unroll
+        for (int r = 0; r <= j; ++r) acc += P.Gi[r][j] * y[r];
+#pragma unroll
+        for (int r = 0; r <= j; ++r) acc += (-P.Gi[r][j]) * y[N + r];
+        s[j] = fac * acc;
+        OPTIK_SCHED_FENCE();
+    }
+    return 1;
+}
+
+// Kraft labels 110/130 for one slot: (reset,) LSQ direction, descent test.  A direction
+// whose step leaves the box needs NNLS: its dual problem is emitted for the cooperative
+// kernel and the slot is deferred.  `answer` non-null re-enters at the LSQ call of a
+// deferred pass (its ++iter / reset are done) and completes it with the NNLS answer.
+template <int N>
+OPTIK_DEV int direction_search(const EngArgs &a, const ChainDev &ch, int emit_parity, const double *answer_y,
+                               const double *answer_meta, double (&l)[N * (N + 1) / 2], const double (&g)[N],
+                               const double (&x)[N], double f, int &ireset, int &iter, bool reset,
+                               double (&s)[N], double &h3, int32_t &status, unsigned &q_out) {
+    constexpr int NL = N * (N + 1) / 2;
+    const SolveParams &sp = a.sp;
+    double f0 = 0.0;
+    bool have0 = false;
+    bool resume = answer_y != nullptr;
+    for (;;) {
+        if (!resume) {
+            if (reset) {
+                ++ireset;
+                if (ireset > 5) {
+                    // label 255 with acc = 0 -> mode 8; NLopt's relaxed test vs (f0, x0 = x)
+                    status = RES_ROUNDOFF_LIMITED;
+                    if (have0 && __builtin_fabs(f - f0) < sp.ftol_abs && !__builtin_isinf(f0)) status = RES_FTOL_REACHED;
+                    else if (have0 && !(0.0 >= sp.xtol_abs)) status = RES_XTOL_REACHED;  // |x - x0| = 0 everywhere
+                    return DIR_DEAD;
+                }
+#pragma unroll
+                for (int i = 0; i < NL; ++i) l[i] = 0.0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) l[lidx<N>(i, i)] = 1.0;
+            }
+            ++iter;
+        }
+        double lo[N], hi[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) { lo[i] = ch.lb[i] - x[i]; hi[i] = ch.ub[i] - x[i]; }
+        OPTIK_SCHED_FENCE();
+        LsqPrep<N> P;
+        int lmode = lsq_prepare<N>(l, g, lo, hi, P);
+        if (lmode == 1) {
+            if (P.need_nnls) {
+                if (resume) {
+                    lmode = ldp_from_answer<N>(P, answer_y, answer_meta, s);
+                } else {
+                    q_out = emit_problem<N>(a, emit_parity, P);
+                    return DIR_DEFER;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < N; ++j) s[j] = 0.0;
+            }
+        }
+        resume = false;
+        if (lmode != 1) {
+            // NLopt: modes 5,6,7 -> ROUNDOFF_LIMITED; 3,4,9 -> FAILURE
+            status = (lmode == 5 || lmode == 6 || lmode == 7) ? RES_ROUNDOFF_LIMITED : RES_FAILURE;
+            return DIR_DEAD;
+        }
+        lsq_finish<N>(P, lo, hi, s);
+        OPTIK_SCHED_FENCE();
+        f0 = f;
+        have0 = true;
+        double gs = 0.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) gs += g[i] * s[i];
+        h3 = gs;
+        if (h3 >= 0.0) { reset = true; continue; }
+        return DIR_OK;
+    }
+}
+
+// Stores the result of a successful direction search: label 190 with alpha = 1.
+template <int N>
+OPTIK_DEV void store_direction(const EngArgs &a, const ChainDev &ch, size_t slot,
+                               const double (&l)[N * (N + 1) / 2], const double (&g)[N], const double (&x)[N],
+                               const double (&s)[N], double f, double h3, int ireset, int iter) {
+    using E = EngLayout<N>;
+#pragma unroll
+    for (int i = 0; i < E::NL; ++i) ENG_D(E::L, i) = l[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        ENG_D(E::G, i) = g[i];
+        const double si = s[i] * 1.0;  // s *= alpha (alpha = 1)
+        ENG_D(E::S, i) = si;
+        ENG_D(E::X0, i) = x[i];
+        double xi = x[i];
+        xi += si;
+        if (xi < ch.lb[i]) xi = ch.lb[i];
+        else if (xi > ch.ub[i]) xi = ch.ub[i];
+        ENG_D(E::X, i) = xi;
+    }
+    ENG_D(E::F0, 0) = f;
+    ENG_D(E::H3, 0) = 1.0 * h3;
+    ENG_D(E::AL, 0) = 1.0;
+    ENG_I(E::LINE) = 1;
+    ENG_I(E::IRESET) = ireset;
+    ENG_I(E::ITER) = iter;
+    ENG_I(E::STATE) = ST_EVAL_TRIAL;
+}
+
+template <int N>
+OPTIK_DEV void store_deferred(const EngArgs &a, size_t slot, const double (&l)[N * (N + 1) / 2],
+                              const double (&g)[N], int ireset, int iter, unsigned q) {
+    using E = EngLayout<N>;
+#pragma unroll
+    for (int i = 0; i < E::NL; ++i) ENG_D(E::L, i) = l[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) ENG_D(E::G, i) = g[i];
+    ENG_I(E::IRESET) = ireset;
+    ENG_I(E::ITER) = iter;
+    ENG_I(E::NNQ) = (int32_t)q;
+    ENG_I(E::STATE) = ST_NNLS;
+}
+
+// ---- kernel 1: evaluate + decide ------------------------------------------------
+
+template <int N, bool TIP>
+OPTIK_DEV void eng_eval_body(const EngArgs &a, const ChainDev &ch, size_t slot) {
+    using E = EngLayout<N>;
+    const double alfmin = 0.1;
+    const int st = ENG_I(E::STATE);
+    if (st != ST_EVAL_FIRST && st != ST_EVAL_TRIAL && st != ST_DEAD) return;
+    const EngJob &J = a.jobs[ENG_I(E::JOB)];
+    const unsigned long long item = a.item[slot];
+    const unsigned long long tslot = item / J.n_restarts;
+    const unsigned long long index = J.restart_begin + (item - tslot * J.n_restarts);
+    int32_t ret = 0;
+    int nevals = ENG_I(E::NEVALS);
+    double minf = ENG_D(E::MF, 0);
+    if (st == ST_DEAD) {
+        ret = ENG_I(E::STATUS);
+    } else {
+        // lib.rs:308: abandon when a lower-index restart of the same target succeeded
+        if (J.first_success) {
+            const unsigned long long fs = __hip_atomic_load(J.first_success + tslot, __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT);
+            if (fs < index) ret = RES_FORCED_STOP;
+        }
+    }
+    if (ret == 0) {
+        double x[N], gn[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) x[i] = ENG_D(E::X, i);
+        const Pose target = load_pose(J.targets + (size_t)tslot * 7);
+        const double f = eval_fg<N, TIP>(ch, a.ep, target, x, gn);
+        ++nevals;
+        // NLopt: update best point so far; stopval is tested after every evaluation
+        if (f < minf) {
+            minf = f;
+            ENG_D(E::MF, 0) = f;
+#pragma unroll
+            for (int i = 0; i < N; ++i) ENG_D(E::XB, i) = x[i];
+        }
+        if (minf < a.sp.stopval) {
+            ret = RES_STOPVAL_REACHED;
+        } else if (nevals >= MAX_EVALS_CAP) {
+            ret = RES_ITER_CAP;
+        } else if (st == ST_EVAL_FIRST) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) ENG_D(E::GN, i) = gn[i];
+            ENG_D(E::FC, 0) = f;
+            ENG_I(E::STATE) = ST_UPDATE_FIRST;
+        } else {
+            // label 220: L1 merit (m = 0: the objective itself)
+            const double t0 = ENG_D(E::F0, 0);
+            const double h3 = ENG_D(E::H3, 0);
+            double alpha = ENG_D(E::AL, 0);
+            const int line = ENG_I(E::LINE);
+            const double h1 = f - t0;
+            bool accept = false;
+            if (__builtin_isfinite(h1)) {
+                if (h1 <= h3 / 10.0 || line > 10) accept = true;
+                else {
+                    const double al = h3 / ((h3 - h1) * 2.0);
+                    alpha = (al > alfmin) ? al : alfmin;
+                }
+            } else {
+                const double al = alpha * 0.5;
+                alpha = (al > alfmin) ? al : alfmin;
+            }
+            if (accept) {
+                if (line > 1) ++nevals;  // NLopt re-evaluates the accepted point unless it was trial 1
+                const double fprev = ENG_D(E::FP, 0);
+                if (!__builtin_isinf(fprev)) {
+                    if (__builtin_fabs(f - fprev) < a.sp.ftol_abs) ret = RES_FTOL_REACHED;
+                    else if (a.sp.xtol_abs >= 0.0) {
+                        bool allx = true;
+#pragma unroll
+                        for (int i = 0; i < N; ++i)
+                            allx = allx && !(__builtin_fabs(x[i] - ENG_D(E::XP, i)) >= a.sp.xtol_abs);
+                        if (allx) ret = RES_XTOL_REACHED;
+                    }
+                }
+                ENG_D(E::FP, 0) = f;
+                if (a.sp.xtol_abs >= 0.0) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) ENG_D(E::XP, i) = x[i];
+                }
+                if (ret == 0 && nevals >= MAX_EVALS_CAP) ret = RES_ITER_CAP;
+                if (ret == 0) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) ENG_D(E::GN, i) = gn[i];
+                    ENG_D(E::FC, 0) = f;
+                    ENG_I(E::STATE) = ST_UPDATE_ACCEPT;
+                }
+            } else {
+                // label 190: next trial point x = x0 + alpha * s, clipped (NLopt)
+                ENG_I(E::LINE) = line + 1;
+                ENG_D(E::H3, 0) = alpha * h3;
+                ENG_D(E::AL, 0) = alpha;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const double si = ENG_D(E::S, i) * alpha;
+                    ENG_D(E::S, i) = si;
+                    double xi = ENG_D(E::X0, i);
+                    xi += si;
+                    if (xi < ch.lb[i]) xi = ch.lb[i];
+                    else if (xi > ch.ub[i]) xi = ch.ub[i];
+                    ENG_D(E::X, i) = xi;
+                }
+            }
+        }
+        ENG_I(E::NEVALS) = nevals;
+    }
+    if (ret != 0) {
+        // the restart ended: classify (lib.rs:376-379) and publish
+        const bool success = (a.sp.ok_stopval && ret == RES_STOPVAL_REACHED)
+                             || (a.sp.ok_ftol && ret == RES_FTOL_REACHED)
+                             || (a.sp.ok_xtol && ret == RES_XTOL_REACHED);
+        double xb[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) xb[i] = ENG_D(E::XB, i);
+        if (J.out_x) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) J.out_x[(size_t)i * J.n_items + item] = xb[i];
+        }
+        if (J.out_f) J.out_f[item] = minf;
+        if (J.out_status) J.out_status[item] = ret;
+        if (J.out_evals) J.out_evals[item] = nevals;
+        double k = __builtin_huge_val();
+        if (success) {
+            if (J.quality) {
+                const double *x0p = J.x0 + (size_t)tslot * N;
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) { const double d = xb[i] - x0p[i]; acc += d * d; }
+                k = __builtin_sqrt(acc);
+            } else {
+                k = (double)index;
+                if (J.first_success) atomicMin(J.first_success + tslot, index);
+            }
+        }
+        if (J.out_key) J.out_key[item] = k;
+        ENG_I(E::STATE) = ST_REFILL;
+    }
+}
+
+// ---- kernel 2: update (BFGS + unconstrained direction) and refill ---------------
+
+template <int N>
+OPTIK_DEV void eng_update_body(const EngArgs &a, const ChainDev &ch, size_t slot, bool in_range) {
+    using E = EngLayout<N>;
+    int st = in_range ? ENG_I(E::STATE) : ST_EMPTY;
+
+    // refill: the next work item of the queue (one atomic per wave)
+    const bool want = st == ST_REFILL;
+    if (wave_any(want)) {
+        const unsigned long long it = fetch_items(a.next_item, want);
+        if (want) {
+            if (it < a.total_items) {
+                int job = 0;
+                for (int j = 1; j < a.n_jobs; ++j)
+                    if (it >= a.jobs[j].item_base) job = j;
+                const EngJob &J = a.jobs[job];
+                const unsigned long long item = it - J.item_base;
+                const unsigned long long tslot = item / J.n_restarts;
+                const unsigned long long index = J.restart_begin + (item - tslot * J.n_restarts);
+                double x[N];
+                restart_seed<N>(a.key, ch.lb, a.scale, index, x);
+                if (index == 0) {  // lib.rs:366-370: restart 0 starts from the caller's seed
+                    const double *x0p = J.x0 + (size_t)tslot * N;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) x[i] = x0p[i];
+                }
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    ENG_D(E::X, i) = x[i];
+                    ENG_D(E::XB, i) = x[i];
+                    ENG_D(E::XP, i) = x[i];
+                }
+                ENG_D(E::MF, 0) = __builtin_huge_val();
+                ENG_D(E::FP, 0) = __builtin_huge_val();
+                ENG_I(E::NEVALS) = 0;
+                ENG_I(E::ITER) = 0;
+                ENG_I(E::IRESET) = 0;
+                ENG_I(E::LINE) = 0;
+                ENG_I(E::JOB) = job;
+                a.item[slot] = item;
+                st = ST_EVAL_FIRST;
+            } else {
+                st = ST_EMPTY;
+            }
+            ENG_I(E::STATE) = st;
+        }
+    }
+
+    if (st == ST_UPDATE_FIRST || st == ST_UPDATE_ACCEPT) {
+        double l[E::NL], g[N], x[N], s[N];
+        const double f = ENG_D(E::FC, 0);
+        int ireset = ENG_I(E::IRESET), iter = ENG_I(E::ITER);
+#pragma unroll
+        for (int i = 0; i < N; ++i) { x[i] = ENG_D(E::X, i); g[i] = ENG_D(E::GN, i); }
+        if (st == ST_UPDATE_ACCEPT) {
+            // label 260: BFGS update with u = g_new - g_old
+            double u[N];
+#pragma unroll
+            for (int i = 0; i < E::NL; ++i) l[i] = ENG_D(E::L, i);
+#pragma unroll
+            for (int i = 0; i < N; ++i) { s[i] = ENG_D(E::S, i); u[i] = g[i] - ENG_D(E::G, i); }
+            OPTIK_SCHED_FENCE();
+            bfgs_update<N>(l, s, u);
+            OPTIK_SCHED_FENCE();
+        } else {
+#pragma unroll
+            for (int i = 0; i < E::NL; ++i) l[i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) s[i] = 0.0;
+        }
+        double h3 = 0.0;
+        int32_t status = 0;
+        unsigned q = 0;
+        const int out = direction_search<N>(a, ch, a.parity, nullptr, nullptr, l, g, x, f, ireset, iter,
+                                            st == ST_UPDATE_FIRST, s, h3, status, q);
+        if (out == DIR_OK) store_direction<N>(a, ch, slot, l, g, x, s, f, h3, ireset, iter);
+        else if (out == DIR_DEFER) store_deferred<N>(a, slot, l, g, ireset, iter, q);
+        else { ENG_I(E::STATUS) = status; ENG_I(E::ITER) = iter; ENG_I(E::STATE) = ST_DEAD; }
+        st = ST_EVAL_TRIAL;  // (any non-empty value: the slot still holds a restart)
+    }
+    // count the slots that still hold a restart (termination test on the host)
+    const unsigned long long alive = __ballot(st != ST_EMPTY && st != ST_REFILL);
+    if ((threadIdx.x & 63u) == 0 && alive) atomicAdd(a.n_active, (unsigned)__popcll(alive));
+}
+
+// ---- kernel 3: cooperative NNLS over this trip's deferred problems ---------------
+
+template <int N>
+OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a) {
+    constexpr int m = N + 1, n = 2 * N;
+    const unsigned cnt = *a.nn_count[a.parity];
+    const double *prob = a.nn_prob[a.parity];
+    double *ybuf = a.nn_y[a.parity];
+    double *meta = a.nn_meta[a.parity];
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned group = lane / COOP_GROUP, c = lane % COOP_GROUP;
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) / 64u;
+    const unsigned n_waves = (gridDim.x * blockDim.x) / 64u;
+    for (unsigned q0 = wave * 4u; q0 < cnt; q0 += n_waves * 4u) {
+        const unsigned q = q0 + group;
+        const bool live = q < cnt;
+        double col[m];
+#pragma unroll
+        for (int r = 0; r < m; ++r) col[r] = 0.0;
+        if (live && c < (unsigned)n) {
+            const double *pc = prob + ((size_t)q * n + c) * m;
+#pragma unroll
+            for (int r = 0; r < m; ++r) col[r] = pc[r];
+        }
+        double xv;
+        int mode;
+        double rnorm;
+        nnls_coop<N>(live, (int)c + 1, col, xv, mode, rnorm);
+        if (live) {
+            if (c < (unsigned)n) ybuf[(size_t)q * n + c] = xv;
+            if (c == 0) { meta[(size_t)q * 2] = (double)mode; meta[(size_t)q * 2 + 1] = rnorm; }
+        }
+    }
+}
+
+// ---- kernel 4: finish the deferred directions with the NNLS answers ----------------
+
+template <int N>
+OPTIK_DEV void eng_finish_body(const EngArgs &a, const ChainDev &ch, size_t slot) {
+    using E = EngLayout<N>;
+    if (ENG_I(E::STATE) != ST_NNLS) return;
+    double l[E::NL], g[N], x[N], s[N];
+    const double f = ENG_D(E::FC, 0);
+    int ireset = ENG_I(E::IRESET), iter = ENG_I(E::ITER);
+    const unsigned q = (unsigned)ENG_I(E::NNQ);
+#pragma unroll
+    for (int i = 0; i < E::NL; ++i) l[i] = ENG_D(E::L, i);
+#pragma unroll
+    for (int i = 0; i < N; ++i) { x[i] = ENG_D(E::X, i); g[i] = ENG_D(E::G, i); s[i] = 0.0; }
+    double h3 = 0.0;
+    int32_t status = 0;
+    unsigned q2 = 0;
+    const int out = direction_search<N>(a, ch, a.parity ^ 1, a.nn_y[a.parity] + (size_t)q * 2 * N,
+                                        a.nn_meta[a.parity] + (size_t)q * 2, l, g, x, f, ireset, iter, false, s,
+                                        h3, status, q2);
+    if (out == DIR_OK) store_direction<N>(a, ch, slot, l, g, x, s, f, h3, ireset, iter);
+    else if (out == DIR_DEFER) store_deferred<N>(a, slot, l, g, ireset, iter, q2);
+    else { ENG_I(E::STATUS) = status; ENG_I(E::ITER) = iter; ENG_I(E::STATE) = ST_DEAD; }
+}
+
+}  // namespace optik

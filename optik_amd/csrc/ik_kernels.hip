@@ -16,9 +16,10 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/optik_hip.h"
-#include "ik_solve.hpp"
+#include "ik_engine.hpp"
 
 using namespace optik;
 
@@ -39,23 +40,10 @@ struct SolveLaunch {
     const ChainDev *chain;
     EvalParams ep;
     SolveParams sp;
-    uint32_t key[8];               // ChaCha key = seed_from_u64(42)
-    double scale[MAX_DOF];         // rand UniformFloat scale per joint
-    const double *targets;         // [T][7]
-    const double *x0;              // [T][n]
-    unsigned long long restart_begin;
-    unsigned long long n_restarts;  // per target
-    int tiles_per_target;
-    int n_tiles;
-    int quality;                   // selection key: 1 = ||x - x0||, 0 = index
-    int pad;
-    double *out_x;                 // [n][T*R]
-    double *out_f;
-    int32_t *out_status;
-    int32_t *out_evals;
-    TileRec *tile_recs;            // [n_tiles]
-    unsigned long long *first_success;  // [T] or nullptr
-    unsigned long long deadline_ticks;  // relative, 0 = none
+    uint32_t key[8];        // ChaCha key = seed_from_u64(42)
+    double scale[MAX_DOF];  // rand UniformFloat scale per joint
+    WorkQueue wq;
+    unsigned long long deadline_ticks;  // relative to kernel start, 0 = none
 };
 
 __device__ __forceinline__ void stage_chain(ChainDev &dst, const ChainDev *src) {
@@ -67,7 +55,7 @@ __device__ __forceinline__ void stage_chain(ChainDev &dst, const ChainDev *src) 
     __syncthreads();
 }
 
-// (valid, key, idx) argmin across the wave: smaller key wins, ties -> smaller idx.
+// (key, idx) argmin across the wave: smaller key wins, ties -> smaller idx; idx ~0 = none.
 __device__ __forceinline__ void wave_argmin(double &key, unsigned long long &idx) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -78,85 +66,72 @@ __device__ __forceinline__ void wave_argmin(double &key, unsigned long long &idx
     }
 }
 
+// The hot path: every wave pulls (target, restart) work items until the queue is dry.
 template <int N, bool TIP>
 __global__ __launch_bounds__(WAVE) void ik_solve_kernel(const SolveLaunch a) {
     __shared__ ChainDev sch;
     __shared__ double nnls_lds[NnlsLayout<N>::SLOTS * WAVE];
     stage_chain(sch, a.chain);
-    const int lane = threadIdx.x;
-    const NnlsWs<N> ws{nnls_lds + lane};
-    const unsigned long long t_start = a.deadline_ticks ? wall_clock64() : 0ull;
-    AbortCtl ctl;
-    ctl.first_success = a.first_success;
-    ctl.deadline = a.deadline_ticks ? t_start + a.deadline_ticks : 0ull;
-
-    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
-        const int t = tile / a.tiles_per_target;
-        const int chunk = tile - t * a.tiles_per_target;
-        const unsigned long long local = (unsigned long long)chunk * WAVE + (unsigned long long)lane;
-        const bool active = local < a.n_restarts;
-        const unsigned long long index = a.restart_begin + local;
-        const Pose target = load_pose(a.targets + (size_t)t * 7);
-        const double *x0p = a.x0 + (size_t)t * N;
-
-        // lib.rs:366-370: restart 0 starts from the caller's seed
-        double x[N];
-        restart_seed<N>(a.key, sch.lb, a.scale, index, x);
-        if (index == 0) {
-#pragma unroll
-            for (int i = 0; i < N; ++i) x[i] = x0p[i];
-        }
-
-        RestartOut<N> r;
-        solve_restart<N, TIP>(sch, a.ep, a.sp, target, ws, active, x, index, ctl, (unsigned)t, r);
-
-        const size_t col = (size_t)t * a.n_restarts + local;
-        const size_t ld = (size_t)a.n_restarts * (size_t)(a.n_tiles / a.tiles_per_target);
-        if (active) {
-            if (a.out_x) {
-#pragma unroll
-                for (int i = 0; i < N; ++i) a.out_x[(size_t)i * ld + col] = r.x[i];
-            }
-            if (a.out_f) a.out_f[col] = r.f;
-            if (a.out_status) a.out_status[col] = r.result;
-            if (a.out_evals) a.out_evals[col] = r.n_evals;
-        }
-        // selection key (lib.rs:402-407): Quality = ||x - x0||_2, Speed = index
-        double key = 0.0;
-        unsigned long long idx = ~0ull;
-        if (active && r.success) {
-            idx = index;
-            if (a.quality) {
-                double acc = 0.0;
-#pragma unroll
-                for (int i = 0; i < N; ++i) { const double d = r.x[i] - x0p[i]; acc += d * d; }
-                key = __builtin_sqrt(acc);
-            } else {
-                key = (double)index;
-            }
-            if (a.first_success && !a.quality) atomicMin(a.first_success + t, index);
-        }
-        wave_argmin(key, idx);
-        if (lane == 0) { a.tile_recs[tile].idx = idx; a.tile_recs[tile].key = key; }
-    }
+    const NnlsWs<N> ws{nnls_lds + threadIdx.x};
+    WorkQueue wq = a.wq;
+    wq.deadline = a.deadline_ticks ? wall_clock64() + a.deadline_ticks : 0ull;
+    solve_wave<N, TIP>(sch, a.ep, a.sp, a.key, a.scale, wq, ws);
 }
 
 struct SelectLaunch {
-    const TileRec *tile_recs;
+    const double *out_key;   // [T*R] selection key, +inf unless the restart succeeded
+    const double *out_x;     // [n][T*R]
+    const double *out_f;     // [T*R]
+    TileRec *tile_recs;      // [T][tiles_per_target]
     int tiles_per_target;
+    int tile;                // restarts per tile
     int n;
+    int pad;
     unsigned long long restart_begin;
     unsigned long long n_restarts;
-    size_t ld;             // T * R
-    const double *out_x;   // per-restart [n][ld] (may be null)
-    const double *out_f;
-    double *win_x;         // [T][n]
+    size_t ld;               // T * R
+    double *win_x;           // [T][n]
     double *win_f;
     unsigned long long *win_idx;
     double *win_key;
 };
 
-// One 64-lane block per target: argmin over the target's tile records.
+// Stage 1 of the selection (lib.rs:397-413): per-block argmin of the keys of one
+// tile of one target -- wavefront shuffles, then one 16-byte record per block.
+__global__ __launch_bounds__(256) void ik_tile_argmin_kernel(const SelectLaunch a) {
+    __shared__ double s_key[4];
+    __shared__ unsigned long long s_idx[4];
+    const int t = blockIdx.y;
+    const int tile = blockIdx.x;
+    const unsigned long long lo = (unsigned long long)tile * (unsigned long long)a.tile;
+    unsigned long long hi = lo + (unsigned long long)a.tile;
+    if (hi > a.n_restarts) hi = a.n_restarts;
+    double key = 0.0;
+    unsigned long long idx = ~0ull;
+    for (unsigned long long r = lo + threadIdx.x; r < hi; r += blockDim.x) {
+        const double k = a.out_key[(size_t)t * a.n_restarts + r];
+        const unsigned long long i = a.restart_begin + r;
+        const bool ok = k < __builtin_huge_val();
+        if (ok && (idx == ~0ull || k < key || (k == key && i < idx))) { key = k; idx = i; }
+    }
+    wave_argmin(key, idx);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_key[wave] = key; s_idx[wave] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            const bool take = (s_idx[w] != ~0ull)
+                              && (idx == ~0ull || s_key[w] < key || (s_key[w] == key && s_idx[w] < idx));
+            if (take) { key = s_key[w]; idx = s_idx[w]; }
+        }
+        TileRec rec;
+        rec.idx = idx;
+        rec.key = key;
+        a.tile_recs[(size_t)t * a.tiles_per_target + tile] = rec;
+    }
+}
+
+// Stage 2: one 64-lane block per target reduces the tile records and gathers the winner.
 __global__ __launch_bounds__(WAVE) void ik_select_kernel(const SelectLaunch a) {
     const int t = blockIdx.x;
     double key = 0.0;
@@ -179,6 +154,42 @@ __global__ __launch_bounds__(WAVE) void ik_select_kernel(const SelectLaunch a) {
                     (found && a.out_x) ? a.out_x[(size_t)i * a.ld + col] : __builtin_nan("");
         }
     }
+}
+
+// ---- streaming engine kernels (ik_engine.hpp) ---------------------------------
+
+template <int N, bool TIP>
+__global__ __launch_bounds__(256, 2) void eng_eval_kernel(const EngArgs a) {
+    __shared__ ChainDev sch;
+    stage_chain(sch, a.chain);
+    const size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (slot < a.C) eng_eval_body<N, TIP>(a, sch, slot);
+}
+
+template <int N>
+__global__ __launch_bounds__(256, 2) void eng_update_kernel(const EngArgs a) {
+    __shared__ ChainDev sch;
+    stage_chain(sch, a.chain);
+    const size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x;
+    eng_update_body<N>(a, sch, slot < a.C ? slot : 0, slot < a.C);
+}
+
+template <int N>
+__global__ __launch_bounds__(256, 2) void eng_nnls_coop_kernel(const EngArgs a) {
+    eng_nnls_coop_body<N>(a);
+}
+
+template <int N>
+__global__ __launch_bounds__(256, 2) void eng_finish_kernel(const EngArgs a) {
+    __shared__ ChainDev sch;
+    stage_chain(sch, a.chain);
+    const size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (slot < a.C) eng_finish_body<N>(a, sch, slot);
+}
+
+__global__ void eng_init_kernel(int32_t *state, unsigned long long C) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < C) state[i] = ST_REFILL;
 }
 
 struct EvalLaunch {
@@ -308,8 +319,35 @@ struct optik_hip_chain {
     unsigned long long *first_success = nullptr;
     size_t fs_cap = 0;
     // scratch per-restart buffers when the caller does not provide them
-    double *tmp_x = nullptr, *tmp_f = nullptr;
+    double *tmp_x = nullptr, *tmp_f = nullptr, *tmp_key = nullptr;
     size_t tmp_cols = 0;
+    unsigned long long *queue = nullptr;  // work-item counter of the in-flight launch
+    unsigned long long *prof = nullptr;   // phase timers (OPTIK_PROFILE builds)
+    // streaming engine (ik_engine.hpp)
+    struct EngineJobHost {
+        EngJob dev;
+        int T;
+        optik_hip_ik_outputs out;
+        double *own_x = nullptr, *own_f = nullptr, *own_key = nullptr;  // scratch when the caller skips them
+        unsigned long long *own_fs = nullptr;
+    };
+    std::vector<EngineJobHost> eng_jobs;
+    optik_solver_config eng_cfg{};
+    double eng_ee[7] = {0, 0, 0, 0, 0, 0, 1};
+    bool eng_has_ee = false;
+    size_t eng_C = 0;
+    double *eng_d = nullptr;
+    int32_t *eng_i32 = nullptr;
+    unsigned long long *eng_item = nullptr;
+    EngJob *eng_djobs = nullptr;
+    unsigned int *eng_counters = nullptr;  // [0], [1] NNLS list lengths by trip parity, [2] n_active
+    double *eng_prob = nullptr;            // 2 x [C][2n][n+1]
+    double *eng_y = nullptr;               // 2 x [C][2n]
+    double *eng_meta = nullptr;            // 2 x [C][2]
+    unsigned int *eng_pinned = nullptr;    // host-pinned read-back ring
+    hipEvent_t eng_ev[8] = {};
+    int eng_trips = 0;                     // trips of the last run
+    int waves_per_cu = 2;                 // resident 64-lane workgroups per CU (LDS-bound)
     // timing
     int timing = 0;
     static constexpr int EV_POOL = 256;  // event pairs recorded round-robin around the solve kernel
@@ -490,6 +528,18 @@ void optik_hip_chain_destroy(optik_hip_chain *ch) {
     if (ch->first_success) hipFree(ch->first_success);
     if (ch->tmp_x) hipFree(ch->tmp_x);
     if (ch->tmp_f) hipFree(ch->tmp_f);
+    if (ch->tmp_key) hipFree(ch->tmp_key);
+    if (ch->queue) hipFree(ch->queue);
+    if (ch->eng_d) hipFree(ch->eng_d);
+    if (ch->eng_i32) hipFree(ch->eng_i32);
+    if (ch->eng_item) hipFree(ch->eng_item);
+    if (ch->eng_djobs) hipFree(ch->eng_djobs);
+    if (ch->eng_counters) hipFree(ch->eng_counters);
+    if (ch->eng_prob) hipFree(ch->eng_prob);
+    if (ch->eng_y) hipFree(ch->eng_y);
+    if (ch->eng_meta) hipFree(ch->eng_meta);
+    if (ch->eng_pinned) hipHostFree(ch->eng_pinned);
+    for (auto &e : ch->eng_ev) if (e) hipEventDestroy(e);
     for (int i = 0; i < optik_hip_chain::EV_POOL; ++i) {
         if (ch->ev0[i]) hipEventDestroy(ch->ev0[i]);
         if (ch->ev1[i]) hipEventDestroy(ch->ev1[i]);
@@ -569,9 +619,12 @@ int optik_hip_ik_batch(optik_hip_chain *ch, const optik_solver_config *cfg, cons
     hipStream_t stream = (hipStream_t)stream_v;
     std::lock_guard<std::mutex> lock(ch->mu);
 
-    const uint64_t tiles_per_target = (R + WAVE - 1) / WAVE;
+    // selection tiles: 4096 restarts per 256-thread block
+    constexpr int SEL_TILE = 4096;
+    const uint64_t tiles_per_target = (R + SEL_TILE - 1) / SEL_TILE;
     const uint64_t n_tiles64 = tiles_per_target * (uint64_t)T;
-    if (n_tiles64 > 0x7fffffffull) return fail(OPTIK_HIP_EINVAL, "too many restarts in one launch");
+    if (n_tiles64 > 0x7fffffffull || tiles_per_target > 65535ull * 64ull || (uint64_t)T > 65535ull)
+        return fail(OPTIK_HIP_EINVAL, "too many restarts / targets in one launch");
     const int n_tiles = (int)n_tiles64;
     const size_t cols = (size_t)T * (size_t)R;
 
@@ -581,6 +634,8 @@ int optik_hip_ik_batch(optik_hip_chain *ch, const optik_solver_config *cfg, cons
         HIP_TRY(hipMalloc(&ch->tile_recs, sizeof(TileRec) * (size_t)n_tiles));
         ch->tile_cap = (size_t)n_tiles;
     }
+    if (!ch->queue) HIP_TRY(hipMalloc(&ch->queue, sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(ch->queue, 0, sizeof(unsigned long long), stream));
     const bool early = (flags & OPTIK_HIP_IK_EARLY_EXIT) && cfg->solution_mode == 2;
     if (early) {
         if ((size_t)T > ch->fs_cap) {
@@ -591,20 +646,26 @@ int optik_hip_ik_batch(optik_hip_chain *ch, const optik_solver_config *cfg, cons
         }
         HIP_TRY(hipMemsetAsync(ch->first_success, 0xff, sizeof(unsigned long long) * (size_t)T, stream));
     }
-    // the selection needs the per-restart x / f: use scratch if the caller skips them
-    double *px = out->d_x, *pf = out->d_f;
-    const bool want_win = out->d_win_x || out->d_win_f;
-    if (want_win && (!px || !pf)) {
+    // the selection needs the per-restart x / f / key: scratch if the caller skips them
+    const bool want_win = out->d_win_x || out->d_win_f || out->d_win_idx || out->d_win_key;
+    double *px = out->d_x, *pf = out->d_f, *pk = nullptr;
+    if (want_win) {
+        const bool need_xf = (!px || !pf) && (out->d_win_x || out->d_win_f);
         if (cols > ch->tmp_cols) {
             if (ch->tmp_x) HIP_TRY(hipFree(ch->tmp_x));
             if (ch->tmp_f) HIP_TRY(hipFree(ch->tmp_f));
-            ch->tmp_x = ch->tmp_f = nullptr;
-            HIP_TRY(hipMalloc(&ch->tmp_x, sizeof(double) * cols * (size_t)ch->n));
-            HIP_TRY(hipMalloc(&ch->tmp_f, sizeof(double) * cols));
+            if (ch->tmp_key) HIP_TRY(hipFree(ch->tmp_key));
+            ch->tmp_x = ch->tmp_f = ch->tmp_key = nullptr;
+            HIP_TRY(hipMalloc(&ch->tmp_key, sizeof(double) * cols));
             ch->tmp_cols = cols;
         }
-        if (!px) px = ch->tmp_x;
-        if (!pf) pf = ch->tmp_f;
+        if (need_xf && !ch->tmp_x) {
+            HIP_TRY(hipMalloc(&ch->tmp_x, sizeof(double) * ch->tmp_cols * (size_t)ch->n));
+            HIP_TRY(hipMalloc(&ch->tmp_f, sizeof(double) * ch->tmp_cols));
+        }
+        pk = ch->tmp_key;
+        if (!px && out->d_win_x) px = ch->tmp_x;
+        if (!pf && out->d_win_f) pf = ch->tmp_f;
     }
 
     SolveLaunch a;
@@ -619,19 +680,26 @@ int optik_hip_ik_batch(optik_hip_chain *ch, const optik_solver_config *cfg, cons
     a.sp.ok_xtol = cfg->tol_dx >= 0.0;
     std::memcpy(a.key, ch->key, sizeof a.key);
     std::memcpy(a.scale, ch->scale, sizeof a.scale);
-    a.targets = d_targets;
-    a.x0 = d_x0;
-    a.restart_begin = restart_begin;
-    a.n_restarts = R;
-    a.tiles_per_target = (int)tiles_per_target;
-    a.n_tiles = n_tiles;
-    a.quality = (cfg->solution_mode == 1);
-    a.out_x = px;
-    a.out_f = pf;
-    a.out_status = out->d_status;
-    a.out_evals = out->d_evals;
-    a.tile_recs = ch->tile_recs;
-    a.first_success = early ? ch->first_success : nullptr;
+    a.wq.next_item = ch->queue;
+    a.wq.total_items = (unsigned long long)cols;
+    a.wq.n_restarts = R;
+    a.wq.restart_begin = restart_begin;
+    a.wq.targets = d_targets;
+    a.wq.x0 = d_x0;
+    a.wq.first_success = early ? ch->first_success : nullptr;
+    a.wq.deadline = 0;
+    a.wq.quality = (cfg->solution_mode == 1);
+    a.wq.out_x = px;
+    a.wq.out_f = pf;
+    a.wq.out_key = pk;
+    a.wq.out_status = out->d_status;
+    a.wq.out_evals = out->d_evals;
+    a.wq.prof = nullptr;
+#ifdef OPTIK_PROFILE
+    if (!ch->prof) HIP_TRY(hipMalloc(&ch->prof, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(ch->prof, 0, 8 * sizeof(unsigned long long), stream));
+    a.wq.prof = ch->prof;
+#endif
     a.deadline_ticks = 0;
     if (deadline_s > 0.0) {
         const double khz = ch->wall_clock_khz > 0 ? (double)ch->wall_clock_khz : 100000.0;
@@ -639,12 +707,13 @@ int optik_hip_ik_batch(optik_hip_chain *ch, const optik_solver_config *cfg, cons
         if (a.deadline_ticks == 0) a.deadline_ticks = 1;
     }
 
-    // One 64-lane workgroup per tile; 2 workgroups fit a CU (LDS-bound), so cap
-    // the grid at a few waves per CU slot and let workgroups stride over tiles.
+    // Persistent waves: as many 64-lane workgroups as the LDS lets a CU hold (2), times
+    // the CU count; each pulls work items until the queue is dry.
     const int cus = ch->num_cus > 0 ? ch->num_cus : 256;
-    int grid = n_tiles;
-    const int cap = cus * 2 * 4;
-    if (grid > cap) grid = cap;
+    long long grid_ll = (long long)((cols + WAVE - 1) / WAVE);
+    const long long cap = (long long)cus * ch->waves_per_cu;
+    if (grid_ll > cap) grid_ll = cap;
+    const int grid = (int)grid_ll;
 
     const int ev_slot = ch->ev_count % optik_hip_chain::EV_POOL;
     if (ch->timing) {
@@ -661,22 +730,269 @@ int optik_hip_ik_batch(optik_hip_chain *ch, const optik_solver_config *cfg, cons
     if (ch->timing) { HIP_TRY(hipEventRecord(ch->ev1[ev_slot], stream)); ch->ev_count += 1; }
     ch->last.grid = grid; ch->last.block = WAVE; ch->last.lds_bytes = lds; ch->last.tiles = n_tiles;
 
-    if (out->d_win_x || out->d_win_f || out->d_win_idx || out->d_win_key) {
+    if (want_win) {
         SelectLaunch s;
+        std::memset(&s, 0, sizeof s);
+        s.out_key = pk; s.out_x = px; s.out_f = pf;
         s.tile_recs = ch->tile_recs;
         s.tiles_per_target = (int)tiles_per_target;
+        s.tile = SEL_TILE;
         s.n = ch->n;
         s.restart_begin = restart_begin;
         s.n_restarts = R;
         s.ld = cols;
-        s.out_x = px; s.out_f = pf;
         s.win_x = out->d_win_x; s.win_f = out->d_win_f;
         s.win_idx = (unsigned long long *)out->d_win_idx; s.win_key = out->d_win_key;
+        hipLaunchKernelGGL(ik_tile_argmin_kernel, dim3((unsigned)tiles_per_target, (unsigned)T), dim3(256), 0,
+                           stream, s);
+        HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(ik_select_kernel, dim3(T), dim3(WAVE), 0, stream, s);
         HIP_TRY(hipGetLastError());
     }
     return 0;
 }
+
+// ---- streaming engine: submit jobs, then run them through the shared slot pool ----
+
+static void fill_solve_params(const optik_solver_config *cfg, SolveParams &sp) {
+    sp.stopval = cfg->tol_f;
+    sp.ftol_abs = (cfg->tol_df > 0.0) ? cfg->tol_df : 1e-3 * cfg->tol_f;  // lib.rs:283-293
+    sp.xtol_abs = cfg->tol_dx;
+    sp.ok_stopval = cfg->tol_f >= 0.0;
+    sp.ok_ftol = cfg->tol_df >= 0.0;
+    sp.ok_xtol = cfg->tol_dx >= 0.0;
+    sp.pad = 0;
+}
+
+int optik_hip_engine_submit(optik_hip_chain *ch, const optik_solver_config *cfg, const double *d_targets,
+                            const double *d_x0, int32_t T, const double *ee_offset7, uint64_t restart_begin,
+                            uint64_t restart_end, uint32_t flags, const optik_hip_ik_outputs *out) {
+    if (!ch || !cfg || !d_targets || !d_x0 || !out || T < 1) return fail(OPTIK_HIP_EINVAL, "bad argument");
+    if (restart_end <= restart_begin) return fail(OPTIK_HIP_EINVAL, "empty restart range");
+    if (cfg->solution_mode != 1 && cfg->solution_mode != 2)
+        return fail(OPTIK_HIP_EINVAL, "solution_mode must be 1 (Quality) or 2 (Speed)");
+    if (restart_end > 1 || restart_begin > 0)
+        for (int k = 0; k < ch->n; ++k)
+            if (std::isnan(ch->scale[k]))
+                return fail(OPTIK_HIP_EINVAL, "random restarts need finite joint limits (reference: random_range panics)");
+    std::lock_guard<std::mutex> lock(ch->mu);
+    if ((int)ch->eng_jobs.size() >= ENG_MAX_JOBS) return fail(OPTIK_HIP_EINVAL, "too many pending engine jobs");
+    const double ident[7] = {0, 0, 0, 0, 0, 0, 1};
+    const double *ee = ee_offset7 ? ee_offset7 : ident;
+    if (ch->eng_jobs.empty()) {
+        ch->eng_cfg = *cfg;
+        std::memcpy(ch->eng_ee, ee, sizeof ident);
+        ch->eng_has_ee = ee_offset7 != nullptr;
+    } else {
+        const optik_solver_config &c0 = ch->eng_cfg;
+        const bool same = c0.tol_f == cfg->tol_f && c0.tol_df == cfg->tol_df && c0.tol_dx == cfg->tol_dx
+                          && std::memcmp(c0.linear_weight, cfg->linear_weight, sizeof c0.linear_weight) == 0
+                          && std::memcmp(c0.angular_weight, cfg->angular_weight, sizeof c0.angular_weight) == 0
+                          && std::memcmp(ch->eng_ee, ee, sizeof ident) == 0;
+        if (!same) return fail(OPTIK_HIP_EINVAL, "jobs pooled in one engine run must share tolerances, weights and ee_offset");
+    }
+    const uint64_t R = restart_end - restart_begin;
+    optik_hip_chain::EngineJobHost j;
+    std::memset(&j.dev, 0, sizeof j.dev);
+    j.T = T;
+    j.out = *out;
+    const size_t cols = (size_t)T * (size_t)R;
+    const bool want_win = out->d_win_x || out->d_win_f || out->d_win_idx || out->d_win_key;
+    double *px = out->d_x, *pf = out->d_f, *pk = nullptr;
+    if (want_win) {
+        HIP_TRY(hipMalloc(&j.own_key, sizeof(double) * cols));
+        pk = j.own_key;
+        if (!px && out->d_win_x) { HIP_TRY(hipMalloc(&j.own_x, sizeof(double) * cols * (size_t)ch->n)); px = j.own_x; }
+        if (!pf && out->d_win_f) { HIP_TRY(hipMalloc(&j.own_f, sizeof(double) * cols)); pf = j.own_f; }
+    }
+    const bool early = (flags & OPTIK_HIP_IK_EARLY_EXIT) && cfg->solution_mode == 2;
+    if (early) HIP_TRY(hipMalloc(&j.own_fs, sizeof(unsigned long long) * (size_t)T));
+    j.dev.targets = d_targets;
+    j.dev.x0 = d_x0;
+    j.dev.item_base = ch->eng_jobs.empty() ? 0ull : ch->eng_jobs.back().dev.item_base + ch->eng_jobs.back().dev.n_items;
+    j.dev.n_items = cols;
+    j.dev.n_restarts = R;
+    j.dev.restart_begin = restart_begin;
+    j.dev.out_x = px; j.dev.out_f = pf; j.dev.out_key = pk;
+    j.dev.out_status = out->d_status; j.dev.out_evals = out->d_evals;
+    j.dev.first_success = j.own_fs;
+    j.dev.quality = (cfg->solution_mode == 1);
+    ch->eng_jobs.push_back(j);
+    return 0;
+}
+
+int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
+    if (!ch) return fail(OPTIK_HIP_EINVAL, "bad argument");
+    hipStream_t stream = (hipStream_t)stream_v;
+    std::lock_guard<std::mutex> lock(ch->mu);
+    if (ch->eng_jobs.empty()) return 0;
+    const size_t n_jobs = ch->eng_jobs.size();
+    const unsigned long long total = ch->eng_jobs.back().dev.item_base + ch->eng_jobs.back().dev.n_items;
+
+    // pool size: enough slots for every CU to hold several waves of each phase kernel
+    size_t cap = 262144;
+    if (const char *e = std::getenv("OPTIK_ENGINE_SLOTS")) { const long v = std::atol(e); if (v >= 256) cap = (size_t)v; }
+    size_t C = (size_t)((total + 255ull) / 256ull * 256ull);
+    if (C > cap) C = cap;
+    int rc = 0;
+    auto run = [&]() -> int {
+#define DISPATCH_N(CALL6, CALL7) do { if (ch->n == 6) { CALL6; } else if (ch->n == 7) { CALL7; } else return fail(OPTIK_HIP_EUNSUPPORTED, "kernels are built for n in {6,7}"); } while (0)
+        int nd = 0, ni = 0;
+        DISPATCH_N((nd = EngLayout<6>::ND, ni = EngLayout<6>::NI), (nd = EngLayout<7>::ND, ni = EngLayout<7>::NI));
+        if (C > ch->eng_C) {
+            if (ch->eng_d) HIP_TRY(hipFree(ch->eng_d));
+            if (ch->eng_i32) HIP_TRY(hipFree(ch->eng_i32));
+            if (ch->eng_item) HIP_TRY(hipFree(ch->eng_item));
+            if (ch->eng_prob) HIP_TRY(hipFree(ch->eng_prob));
+            if (ch->eng_y) HIP_TRY(hipFree(ch->eng_y));
+            if (ch->eng_meta) HIP_TRY(hipFree(ch->eng_meta));
+            ch->eng_d = nullptr; ch->eng_i32 = nullptr; ch->eng_item = nullptr;
+            ch->eng_prob = ch->eng_y = ch->eng_meta = nullptr;
+            HIP_TRY(hipMalloc(&ch->eng_d, sizeof(double) * (size_t)nd * C));
+            HIP_TRY(hipMalloc(&ch->eng_i32, sizeof(int32_t) * (size_t)ni * C));
+            HIP_TRY(hipMalloc(&ch->eng_item, sizeof(unsigned long long) * C));
+            const size_t nn = (size_t)ch->n;
+            HIP_TRY(hipMalloc(&ch->eng_prob, sizeof(double) * 2 * C * (2 * nn) * (nn + 1)));
+            HIP_TRY(hipMalloc(&ch->eng_y, sizeof(double) * 2 * C * (2 * nn)));
+            HIP_TRY(hipMalloc(&ch->eng_meta, sizeof(double) * 2 * C * 2));
+            ch->eng_C = C;
+        }
+        if (!ch->eng_djobs) HIP_TRY(hipMalloc(&ch->eng_djobs, sizeof(EngJob) * ENG_MAX_JOBS));
+        if (!ch->eng_counters) HIP_TRY(hipMalloc(&ch->eng_counters, 4 * sizeof(unsigned int)));
+        if (!ch->eng_pinned) HIP_TRY(hipHostMalloc(&ch->eng_pinned, 8 * sizeof(unsigned int)));
+        if (!ch->queue) HIP_TRY(hipMalloc(&ch->queue, sizeof(unsigned long long)));
+        for (auto &e : ch->eng_ev) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+
+        std::vector<EngJob> hj(n_jobs);
+        for (size_t i = 0; i < n_jobs; ++i) hj[i] = ch->eng_jobs[i].dev;
+        HIP_TRY(hipMemcpyAsync(ch->eng_djobs, hj.data(), sizeof(EngJob) * n_jobs, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));  // hj goes out of scope; tiny copy
+        HIP_TRY(hipMemsetAsync(ch->queue, 0, sizeof(unsigned long long), stream));
+        for (auto &j : ch->eng_jobs)
+            if (j.own_fs) HIP_TRY(hipMemsetAsync(j.own_fs, 0xff, sizeof(unsigned long long) * (size_t)j.T, stream));
+
+        EngArgs a;
+        std::memset(&a, 0, sizeof a);
+        a.chain = ch->dev;
+        make_eval_params(ch->eng_cfg.linear_weight, ch->eng_cfg.angular_weight, ch->eng_has_ee ? ch->eng_ee : nullptr, a.ep);
+        fill_solve_params(&ch->eng_cfg, a.sp);
+        std::memcpy(a.key, ch->key, sizeof a.key);
+        std::memcpy(a.scale, ch->scale, sizeof a.scale);
+        a.d = ch->eng_d; a.i32 = ch->eng_i32; a.item = ch->eng_item; a.C = C;
+        a.jobs = ch->eng_djobs; a.n_jobs = (int)n_jobs;
+        a.total_items = total;
+        a.next_item = ch->queue;
+        {
+            const size_t nn = (size_t)ch->n;
+            for (int par = 0; par < 2; ++par) {
+                a.nn_count[par] = ch->eng_counters + par;
+                a.nn_prob[par] = ch->eng_prob + (size_t)par * ch->eng_C * (2 * nn) * (nn + 1);
+                a.nn_y[par] = ch->eng_y + (size_t)par * ch->eng_C * (2 * nn);
+                a.nn_meta[par] = ch->eng_meta + (size_t)par * ch->eng_C * 2;
+            }
+        }
+        a.n_active = ch->eng_counters + 2;
+        a.parity = 0;
+        a.prof = nullptr;
+#ifdef OPTIK_PROFILE
+        if (!ch->prof) HIP_TRY(hipMalloc(&ch->prof, 8 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(ch->prof, 0, 8 * sizeof(unsigned long long), stream));
+        a.prof = ch->prof;
+#endif
+
+        const unsigned blocks = (unsigned)((C + 255) / 256);
+        const int cus = ch->num_cus > 0 ? ch->num_cus : 256;
+        const unsigned nn_blocks = (unsigned)(cus * 8);  // 256-thread blocks, 16 problems each
+        HIP_TRY(hipMemsetAsync(ch->eng_counters, 0, 4 * sizeof(unsigned int), stream));
+        hipLaunchKernelGGL(eng_init_kernel, dim3(blocks), dim3(256), 0, stream, ch->eng_i32, (unsigned long long)C);
+        HIP_TRY(hipGetLastError());
+
+        const int CHECK = 4;  // trips between termination checks
+        int trip = 0, pending = 0, ring = 0;
+        bool done = false;
+        const bool tip = ch->tip;
+        while (!done) {
+            for (int k = 0; k < CHECK; ++k, ++trip) {
+                // this trip consumes list[trip & 1]; the other list (consumed last trip) is
+                // reset for the finish kernel's re-deferrals and the next trip's update kernel
+                a.parity = trip & 1;
+                HIP_TRY(hipMemsetAsync(ch->eng_counters + (a.parity ^ 1), 0, sizeof(unsigned int), stream));
+                HIP_TRY(hipMemsetAsync(ch->eng_counters + 2, 0, sizeof(unsigned int), stream));
+                if (trip > 0) {
+                    if (tip) DISPATCH_N(hipLaunchKernelGGL((eng_eval_kernel<6, true>), dim3(blocks), dim3(256), 0, stream, a),
+                                        hipLaunchKernelGGL((eng_eval_kernel<7, true>), dim3(blocks), dim3(256), 0, stream, a));
+                    else DISPATCH_N(hipLaunchKernelGGL((eng_eval_kernel<6, false>), dim3(blocks), dim3(256), 0, stream, a),
+                                    hipLaunchKernelGGL((eng_eval_kernel<7, false>), dim3(blocks), dim3(256), 0, stream, a));
+                }
+                DISPATCH_N(hipLaunchKernelGGL((eng_update_kernel<6>), dim3(blocks), dim3(256), 0, stream, a),
+                           hipLaunchKernelGGL((eng_update_kernel<7>), dim3(blocks), dim3(256), 0, stream, a));
+                DISPATCH_N(hipLaunchKernelGGL((eng_nnls_coop_kernel<6>), dim3(nn_blocks), dim3(256), 0, stream, a),
+                           hipLaunchKernelGGL((eng_nnls_coop_kernel<7>), dim3(nn_blocks), dim3(256), 0, stream, a));
+                DISPATCH_N(hipLaunchKernelGGL((eng_finish_kernel<6>), dim3(blocks), dim3(256), 0, stream, a),
+                           hipLaunchKernelGGL((eng_finish_kernel<7>), dim3(blocks), dim3(256), 0, stream, a));
+            }
+            HIP_TRY(hipGetLastError());
+            // read back n_active of the chunk just issued; look at the previous chunk's value
+            HIP_TRY(hipMemcpyAsync(&ch->eng_pinned[ring], ch->eng_counters + 2, sizeof(unsigned int),
+                                   hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipEventRecord(ch->eng_ev[ring], stream));
+            if (pending) {
+                const int prev = (ring + 7) % 8;
+                HIP_TRY(hipEventSynchronize(ch->eng_ev[prev]));
+                if (ch->eng_pinned[prev] == 0) done = true;
+            }
+            pending = 1;
+            ring = (ring + 1) % 8;
+        }
+        ch->eng_trips = trip;
+
+        // selection of every job (lib.rs:397-413)
+        constexpr int SEL_TILE = 4096;
+        for (auto &j : ch->eng_jobs) {
+            const optik_hip_ik_outputs &o = j.out;
+            if (!(o.d_win_x || o.d_win_f || o.d_win_idx || o.d_win_key)) continue;
+            const uint64_t R = j.dev.n_restarts;
+            const uint64_t tiles_per_target = (R + SEL_TILE - 1) / SEL_TILE;
+            const size_t n_tiles = (size_t)tiles_per_target * (size_t)j.T;
+            if (n_tiles > ch->tile_cap) {
+                HIP_TRY(hipStreamSynchronize(stream));
+                if (ch->tile_recs) HIP_TRY(hipFree(ch->tile_recs));
+                ch->tile_recs = nullptr;
+                HIP_TRY(hipMalloc(&ch->tile_recs, sizeof(TileRec) * n_tiles));
+                ch->tile_cap = n_tiles;
+            }
+            SelectLaunch s;
+            std::memset(&s, 0, sizeof s);
+            s.out_key = j.dev.out_key; s.out_x = j.dev.out_x; s.out_f = j.dev.out_f;
+            s.tile_recs = ch->tile_recs;
+            s.tiles_per_target = (int)tiles_per_target;
+            s.tile = SEL_TILE;
+            s.n = ch->n;
+            s.restart_begin = j.dev.restart_begin;
+            s.n_restarts = R;
+            s.ld = (size_t)j.dev.n_items;
+            s.win_x = o.d_win_x; s.win_f = o.d_win_f;
+            s.win_idx = (unsigned long long *)o.d_win_idx; s.win_key = o.d_win_key;
+            hipLaunchKernelGGL(ik_tile_argmin_kernel, dim3((unsigned)tiles_per_target, (unsigned)j.T), dim3(256), 0, stream, s);
+            hipLaunchKernelGGL(ik_select_kernel, dim3(j.T), dim3(WAVE), 0, stream, s);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipStreamSynchronize(stream));
+        return 0;
+#undef DISPATCH_N
+    };
+    rc = run();
+    for (auto &j : ch->eng_jobs) {
+        if (j.own_x) (void)hipFree(j.own_x);
+        if (j.own_f) (void)hipFree(j.own_f);
+        if (j.own_key) (void)hipFree(j.own_key);
+        if (j.own_fs) (void)hipFree(j.own_fs);
+    }
+    ch->eng_jobs.clear();
+    return rc;
+}
+
+int optik_hip_engine_last_trips(const optik_hip_chain *ch) { return ch ? ch->eng_trips : 0; }
 
 int optik_hip_ik_host(optik_hip_chain *ch, const optik_solver_config *cfg, const double *targets,
                       const double *x0, int32_t T, const double *ee_offset7, uint64_t restart_begin,
@@ -752,6 +1068,17 @@ void optik_hip_set_timing(optik_hip_chain *ch, int32_t enabled) {
     std::lock_guard<std::mutex> lock(ch->mu);
     ch->timing = enabled;
     ch->ev_count = 0;
+}
+
+/* OPTIK_PROFILE builds: phase cycle totals of the last solve launch (8 words:
+ * refill, eval, update, publish, bfgs, lsq, nnls, trips); zeros otherwise. */
+int optik_hip_phase_profile(optik_hip_chain *ch, unsigned long long *out8) {
+    if (!ch || !out8) return fail(OPTIK_HIP_EINVAL, "bad argument");
+    std::memset(out8, 0, 8 * sizeof(unsigned long long));
+    if (!ch->prof) return 0;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out8, ch->prof, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
 }
 
 int optik_hip_timing_mean(optik_hip_chain *ch, double *mean_ms, int32_t *count) {

@@ -29,6 +29,8 @@ namespace optik {
 
 constexpr double EPMACH = 2.220446049250313e-16;
 
+OPTIK_DEV bool wave_any(bool p) { return __ballot(p) != 0ull; }
+
 // LDS slots per lane for the NNLS workspace of an n-DoF problem.
 template <int N>
 struct NnlsLayout {
@@ -65,54 +67,6 @@ struct PackedIndex {
     }
 };
 
-// NLopt's dnrm2 on LDS rows i0..i0+cnt-1 of a column (stride one slot).
-template <typename F>
-OPTIK_DEV double nrm2_by(int cnt, F at) {
-    double xmax = 0.0;
-    for (int i = 0; i < cnt; ++i) { const double a = __builtin_fabs(at(i)); if (a > xmax) xmax = a; }
-    if (xmax == 0.0) return 0.0;
-    const double scale = 1.0 / xmax;
-    double sum = 0.0;
-    for (int i = 0; i < cnt; ++i) { const double xs = scale * at(i); sum += xs * xs; }
-    return xmax * __builtin_sqrt(sum);
-}
-
-// Lawson-Hanson H12, construction phase, on column j of A (pivot lp, rows l1..m).
-template <int N>
-OPTIK_DEV bool h12_construct(const NnlsWs<N> &ws, int j, int lp, int l1, int m, double &up) {
-    if (0 >= lp || lp >= l1 || l1 > m) return false;
-    double cl = __builtin_fabs(ws.A(lp, j));
-    for (int r = l1; r <= m; ++r) { const double sm = __builtin_fabs(ws.A(r, j)); if (sm > cl) cl = sm; }
-    if (cl <= 0.0) return false;
-    const double clinv = 1.0 / cl;
-    double d = ws.A(lp, j) * clinv;
-    double sm = d * d;
-    for (int r = l1; r <= m; ++r) { d = ws.A(r, j) * clinv; sm += d * d; }
-    cl *= __builtin_sqrt(sm);
-    if (ws.A(lp, j) > 0.0) cl = -cl;
-    up = ws.A(lp, j) - cl;
-    ws.A(lp, j) = cl;
-    return true;
-}
-
-// H12 application phase of the transformation stored in column j to a vector
-// accessed through `c(r)` (r = row, 1-based).
-template <int N, typename C>
-OPTIK_DEV void h12_apply(const NnlsWs<N> &ws, int j, int lp, int l1, int m, double up, C c) {
-    if (0 >= lp || lp >= l1 || l1 > m) return;
-    const double cl = __builtin_fabs(ws.A(lp, j));
-    if (cl <= 0.0) return;
-    double b = up * ws.A(lp, j);
-    if (b >= 0.0) return;
-    b = 1.0 / b;
-    double sm = c(lp) * up;
-    for (int r = l1; r <= m; ++r) sm += c(r) * ws.A(r, j);
-    if (sm == 0.0) return;
-    sm *= b;
-    c(lp) += sm * up;
-    for (int r = l1; r <= m; ++r) c(r) += sm * ws.A(r, j);
-}
-
 // BLAS drotg as NLopt's slsqp.c restates it.
 OPTIK_DEV void rotg(double &da, double &db, double &c, double &s) {
     const double roe = (__builtin_fabs(da) > __builtin_fabs(db)) ? da : db;
@@ -133,32 +87,64 @@ OPTIK_DEV void rotg(double &da, double &db, double &c, double &s) {
     db = z;
 }
 
+// Element `idx` (1-based, per-lane) of a register array: a select chain, no scratch.
+template <int M>
+OPTIK_DEV double pick(const double (&a)[M], int idx) {
+    double v = a[0];
+#pragma unroll
+    for (int i = 1; i < M; ++i) v = (idx == i + 1) ? a[i] : v;
+    return v;
+}
+
 // Lawson-Hanson NNLS on the (N+1) x 2N dual problem held in LDS.
 // Returns mode (1 ok, 3 iteration count exceeded); multipliers in ws.x().
+//
+// Same decisions and the same arithmetic, in the same order, as the textbook loop
+// nest (oracle/optik_oracle.c:nnls); what differs is the shape given to the GPU:
+// row loops are unrolled over the m = n+1 rows with per-lane predicates, so a
+// column is fetched with one address and m immediate offsets (m LDS reads in flight
+// instead of a dependent read per element), the Householder vector is held in
+// registers while it is applied, and loops over "the columns still in set Z" run
+// over all 2n columns under a bit mask (their order does not matter).
 template <int N>
 OPTIK_DEV int nnls(const NnlsWs<N> &ws, double &rnorm) {
+    using L = NnlsLayout<N>;
     constexpr int m = N + 1, n = 2 * N;
     const double factor = 0.01;
     int mode = 1, iter = 0;
     const int itmax = 3 * n;
     PackedIndex indx;
     indx.v = 0xFEDCBA9876543210ull;  // indx[pos] = pos
+    unsigned zmask = (1u << n) - 1u;  // bit (col-1) set: column is in set Z
     int iz1 = 1, nsetp = 0, npp1 = 1;
     const int iz2 = n;
     int izmax = 0, j = 0, jj = 0;
     double up = 0.0;
+    double *const Abase = ws.base + L::A0 * 64;
+    auto col = [&](int c) -> double * { return Abase + (c - 1) * (L::R * 64); };  // row r at [(r-1)*64]
+#pragma unroll
     for (int i = 1; i <= n; ++i) ws.x(i) = 0.0;
 
-    for (;;) {  // step two: dual variables of the columns still at their bound
+    for (;;) {  // step two: dual variables w = A'(b - Ax) of the columns in Z
         if (iz1 > iz2 || nsetp >= m) break;
-        for (int iz = iz1; iz <= iz2; ++iz) {
-            j = indx.get(iz);
-            double sdot = 0.0;
-            for (int r = npp1; r <= m; ++r) sdot += ws.A(r, j) * ws.b(r);
-            ws.w(j) = sdot;
+        {
+            double bv[m];
+#pragma unroll
+            for (int r = 0; r < m; ++r) bv[r] = ws.b(r + 1);
+#pragma unroll
+            for (int c = 1; c <= n; ++c) {
+                const double *cp = col(c);
+                double sdot = 0.0;
+#pragma unroll
+                for (int r = 1; r <= m; ++r) {
+                    const double a = cp[(r - 1) * 64];
+                    if (r >= npp1) sdot += a * bv[r - 1];
+                }
+                if (zmask & (1u << (c - 1))) ws.w(c) = sdot;
+            }
         }
         bool found = false;
-        for (;;) {  // step three / four
+        for (;;) {  // step three / four: most positive dual, in position order
             double wmax = 0.0;
             for (int iz = iz1; iz <= iz2; ++iz) {
                 j = indx.get(iz);
@@ -170,55 +156,162 @@ OPTIK_DEV int nnls(const NnlsWs<N> &ws, double &rnorm) {
             if (wmax <= 0.0) break;
             const int iz = izmax;
             j = indx.get(iz);
-            // step five: does column j enter the positive set?
-            const double asave = ws.A(npp1, j);
-            h12_construct<N>(ws, j, npp1, npp1 + 1, m, up);
-            const double unorm = nrm2_by(nsetp, [&](int i) { return ws.A(i + 1, j); });
-            const double t = factor * __builtin_fabs(ws.A(npp1, j));
+            // step five: does column j enter the positive set?  (H12 construction on
+            // column j, pivot row npp1, rows npp1+1..m)
+            double *const cj = col(j);
+            double u[m];
+#pragma unroll
+            for (int r = 0; r < m; ++r) u[r] = cj[r * 64];
+            const double asave = pick<m>(u, npp1);
+            const bool h12_live = npp1 < m;  // "lpivot >= l1 || l1 > m" returns early
+            double ulp = asave;              // U(lpivot) after the construction
+            bool constructed = false;
+            if (h12_live) {
+                double cl = __builtin_fabs(asave);
+#pragma unroll
+                for (int r = 1; r <= m; ++r) {
+                    const double sm = __builtin_fabs(u[r - 1]);
+                    if (r > npp1 && sm > cl) cl = sm;
+                }
+                if (!(cl <= 0.0)) {
+                    const double clinv = 1.0 / cl;
+                    double d = asave * clinv;
+                    double sm = d * d;
+#pragma unroll
+                    for (int r = 1; r <= m; ++r) {
+                        d = u[r - 1] * clinv;
+                        if (r > npp1) sm += d * d;
+                    }
+                    cl *= __builtin_sqrt(sm);
+                    if (asave > 0.0) cl = -cl;
+                    up = asave - cl;
+                    ulp = cl;
+                    constructed = true;
+                }
+            }
+            // unorm = ||A(1..nsetp, j)|| (NLopt's scaled dnrm2)
+            double unorm = 0.0;
+            {
+                double xmax = 0.0;
+#pragma unroll
+                for (int r = 1; r <= m; ++r) {
+                    const double a = __builtin_fabs(u[r - 1]);
+                    if (r <= nsetp && a > xmax) xmax = a;
+                }
+                if (xmax != 0.0) {
+                    const double scale = 1.0 / xmax;
+                    double sum = 0.0;
+#pragma unroll
+                    for (int r = 1; r <= m; ++r) {
+                        const double xs = scale * u[r - 1];
+                        if (r <= nsetp) sum += xs * xs;
+                    }
+                    unorm = xmax * __builtin_sqrt(sum);
+                }
+            }
+            const double t = factor * __builtin_fabs(ulp);
             const double d1 = unorm + t;
+            double zz[m];
+            // b factor of the H12 application (same for every vector it is applied to)
+            double hb = 0.0;
+            bool apply_live = false;
+            if (h12_live && !(__builtin_fabs(ulp) <= 0.0)) {
+                hb = up * ulp;
+                if (!(hb >= 0.0)) { hb = 1.0 / hb; apply_live = true; }
+            }
             if (d1 - unorm > 0.0) {
-                for (int r = 1; r <= m; ++r) ws.z(r) = ws.b(r);
-                h12_apply<N>(ws, j, npp1, npp1 + 1, m, up, [&](int r) -> double & { return ws.z(r); });
-                if (ws.z(npp1) / ws.A(npp1, j) > 0.0) found = true;
+#pragma unroll
+                for (int r = 0; r < m; ++r) zz[r] = ws.b(r + 1);
+                if (apply_live) {
+                    double sm = pick<m>(zz, npp1) * up;
+#pragma unroll
+                    for (int r = 1; r <= m; ++r)
+                        if (r > npp1) sm += zz[r - 1] * u[r - 1];
+                    if (sm != 0.0) {
+                        sm *= hb;
+#pragma unroll
+                        for (int r = 1; r <= m; ++r) {
+                            if (r == npp1) zz[r - 1] += sm * up;
+                            else if (r > npp1) zz[r - 1] += sm * u[r - 1];
+                        }
+                    }
+                }
+                if (pick<m>(zz, npp1) / ulp > 0.0) found = true;
             }
             if (found) {
-                for (int r = 1; r <= m; ++r) ws.b(r) = ws.z(r);
+                // b := Q b; column j joins set P at position iz1
+#pragma unroll
+                for (int r = 0; r < m; ++r) ws.b(r + 1) = zz[r];
                 indx.set(iz, indx.get(iz1));
                 indx.set(iz1, j);
                 ++iz1;
                 nsetp = npp1;
                 ++npp1;
-                for (int jz = iz1; jz <= iz2; ++jz) {
-                    jj = indx.get(jz);
-                    const int cj = jj;
-                    h12_apply<N>(ws, j, nsetp, npp1, m, up,
-                                 [&](int r) -> double & { return ws.A(r, cj); });
+                zmask &= ~(1u << (j - 1));
+                // apply the transformation to the columns left in Z (pivot nsetp, rows npp1..m)
+                if (apply_live) {
+#pragma unroll
+                    for (int c = 1; c <= n; ++c) {
+                        if (!(zmask & (1u << (c - 1)))) continue;
+                        double *cp = col(c);
+                        double cv[m];
+#pragma unroll
+                        for (int r = 0; r < m; ++r) cv[r] = cp[r * 64];
+                        double sm = pick<m>(cv, nsetp) * up;
+#pragma unroll
+                        for (int r = 1; r <= m; ++r)
+                            if (r >= npp1) sm += cv[r - 1] * u[r - 1];
+                        if (sm != 0.0) {
+                            sm *= hb;
+#pragma unroll
+                            for (int r = 1; r <= m; ++r) {
+                                if (r == nsetp) cp[(r - 1) * 64] = cv[r - 1] + sm * up;
+                                else if (r >= npp1) cp[(r - 1) * 64] = cv[r - 1] + sm * u[r - 1];
+                            }
+                        }
+                    }
+                }
+                // column j itself: pivot value, zeros below
+#pragma unroll
+                for (int r = 1; r <= m; ++r) {
+                    if (r == nsetp) cj[(r - 1) * 64] = ulp;
+                    else if (r >= npp1) cj[(r - 1) * 64] = 0.0;
                 }
                 ws.w(j) = 0.0;
-                for (int r = npp1; r <= m; ++r) ws.A(r, j) = 0.0;
                 break;
             }
-            ws.A(npp1, j) = asave;
+            // rejected: A(npp1, j) keeps its value (the construction is discarded)
+            (void)constructed;
             ws.w(j) = 0.0;
         }
         if (!found) break;
 
-        for (;;) {  // step six: solve the triangular system for z
+        for (;;) {  // step six: solve the triangular system R z = Q'b on set P
+            double zz[m];
+#pragma unroll
+            for (int r = 0; r < m; ++r) zz[r] = ws.b(r + 1);
             for (int ip = nsetp; ip >= 1; --ip) {
-                if (ip != nsetp) {
-                    const double zip1 = ws.z(ip + 1);
-                    for (int i = 1; i <= ip; ++i) ws.z(i) -= zip1 * ws.A(i, jj);
-                }
                 jj = indx.get(ip);
-                ws.z(ip) /= ws.A(ip, jj);
+                const double *cp = col(jj);
+                double cv[m];
+#pragma unroll
+                for (int r = 0; r < m; ++r) cv[r] = cp[r * 64];
+                const double zi = pick<m>(zz, ip) / pick<m>(cv, ip);
+#pragma unroll
+                for (int r = 1; r <= m; ++r) {
+                    if (r == ip) zz[r - 1] = zi;
+                    else if (r < ip) zz[r - 1] -= zi * cv[r - 1];
+                }
             }
             ++iter;
             if (iter > itmax) { mode = 3; goto done; }
-            // steps seven..ten: step length
+            // steps seven..ten: step length towards z that keeps x >= 0
             double alpha = 1.0;
             jj = 0;
-            for (int ip = 1; ip <= nsetp; ++ip) {
-                const double zi = ws.z(ip);
+#pragma unroll
+            for (int ip = 1; ip <= m; ++ip) {
+                if (ip > nsetp) continue;
+                const double zi = zz[ip - 1];
                 if (zi > 0.0) continue;
                 const int l = indx.get(ip);
                 const double xl = ws.x(l);
@@ -227,32 +320,44 @@ OPTIK_DEV int nnls(const NnlsWs<N> &ws, double &rnorm) {
                 alpha = t;
                 jj = ip;
             }
-            for (int ip = 1; ip <= nsetp; ++ip) {
+#pragma unroll
+            for (int ip = 1; ip <= m; ++ip) {
+                if (ip > nsetp) continue;
                 const int l = indx.get(ip);
-                ws.x(l) = (1.0 - alpha) * ws.x(l) + alpha * ws.z(ip);
+                ws.x(l) = (1.0 - alpha) * ws.x(l) + alpha * zz[ip - 1];
             }
             if (jj == 0) break;  // back to step two
             // step eleven: move coefficient i from set P to set Z
             int i = indx.get(jj);
             for (;;) {
                 ws.x(i) = 0.0;
+                zmask |= 1u << (i - 1);
                 ++jj;
                 for (j = jj; j <= nsetp; ++j) {
                     const int ii = indx.get(j);
                     indx.set(j - 1, ii);
                     double c, s;
-                    double a0 = ws.A(j - 1, ii), a1 = ws.A(j, ii);
+                    double *const r0 = Abase + (j - 2) * 64;  // row j-1 of column 1
+                    double *const r1 = Abase + (j - 1) * 64;  // row j
+                    double a0 = r0[(ii - 1) * (L::R * 64)], a1 = r1[(ii - 1) * (L::R * 64)];
                     rotg(a0, a1, c, s);
-                    ws.A(j - 1, ii) = a0;
-                    ws.A(j, ii) = a1;
                     const double t = a0;
-                    for (int col = 1; col <= n; ++col) {
-                        const double xi = ws.A(j - 1, col), yi = ws.A(j, col);
-                        ws.A(j - 1, col) = c * xi + s * yi;
-                        ws.A(j, col) = c * yi - s * xi;
+                    // rows j-1, j of every column (column ii takes the (r, z) pair first)
+                    double xa[n], ya[n];
+#pragma unroll
+                    for (int cc = 0; cc < n; ++cc) {
+                        xa[cc] = r0[cc * (L::R * 64)];
+                        ya[cc] = r1[cc * (L::R * 64)];
                     }
-                    ws.A(j - 1, ii) = t;
-                    ws.A(j, ii) = 0.0;
+#pragma unroll
+                    for (int cc = 0; cc < n; ++cc) {
+                        const bool is_ii = (cc == ii - 1);
+                        const double xi = is_ii ? a0 : xa[cc], yi = is_ii ? a1 : ya[cc];
+                        const double nx = c * xi + s * yi;
+                        const double ny = c * yi - s * xi;
+                        r0[cc * (L::R * 64)] = is_ii ? t : nx;
+                        r1[cc * (L::R * 64)] = is_ii ? 0.0 : ny;
+                    }
                     const double bx = ws.b(j - 1), by = ws.b(j);
                     ws.b(j - 1) = c * bx + s * by;
                     ws.b(j) = c * by - s * bx;
@@ -269,12 +374,29 @@ OPTIK_DEV int nnls(const NnlsWs<N> &ws, double &rnorm) {
                 }
                 if (!again) break;
             }
-            for (int r = 1; r <= m; ++r) ws.z(r) = ws.b(r);
         }
     }
 done: {
+        // rnorm = ||b(npp1..m)||
         const int k = (npp1 < m) ? npp1 : m;
-        rnorm = nrm2_by(m - nsetp, [&](int i) { return ws.b(k + i); });
+        const int cnt = m - nsetp;
+        double xmax = 0.0;
+#pragma unroll
+        for (int r = 1; r <= m; ++r) {
+            const double a = __builtin_fabs(ws.b(r));
+            if (r >= k && r < k + cnt && a > xmax) xmax = a;
+        }
+        rnorm = 0.0;
+        if (xmax != 0.0) {
+            const double scale = 1.0 / xmax;
+            double sum = 0.0;
+#pragma unroll
+            for (int r = 1; r <= m; ++r) {
+                const double xs = scale * ws.b(r);
+                if (r >= k && r < k + cnt) sum += xs * xs;
+            }
+            rnorm = xmax * __builtin_sqrt(sum);
+        }
     }
     return mode;
 }
@@ -283,34 +405,48 @@ done: {
 template <int N>
 OPTIK_DEV constexpr int lidx(int i, int j) { return i * N - (i * (i - 1)) / 2 + (j - i); }
 
-// Kraft LSQ for m = 0 and finite bounds:  min ||E s - f||, lo <= s <= hi.
-// Returns the LSQ mode (1 ok).
+// ---- Kraft LSQ for m = 0 and finite bounds:  min ||E s - f||, lo <= s <= hi ------
+// Split in three so the streaming engine can run the LDS-free parts at high
+// occupancy and only the lanes whose step hits a bound through NNLS:
+//   lsq_prepare   E = D^1/2 L', f, Kraft's Householder pass, G E^-1 = +-E^-1, h
+//   lsq_dual      LDP/NNLS on the dual (LDS)  -> the step in the transformed space
+//   lsq_finish    s = E^-1 (y + f), clipped
+// lsq_box chains them (the single-kernel solver).
+
 template <int N>
-OPTIK_DEV int lsq_box(const NnlsWs<N> &ws, const double (&l)[N * (N + 1) / 2], const double (&g)[N],
-                      const double (&lo)[N], const double (&hi)[N], double (&s)[N]) {
-    double E[N][N];  // upper triangular; [i][j] used for j >= i
+struct LsqPrep {
+    double E[N][N];   // upper triangular; [i][j] used for j >= i
     double f[N];
+    double Gi[N][N];  // row i of E^-1, entries j >= i
+    double h[2 * N];  // transformed bound rows
+    bool need_nnls;   // some h_j > 0: the unconstrained step leaves the box
+};
+
+// Returns 1, or 5 when E is numerically singular (Kraft LSI mode 5).
+template <int N>
+OPTIK_DEV int lsq_prepare(const double (&l)[N * (N + 1) / 2], const double (&g)[N], const double (&lo)[N],
+                          const double (&hi)[N], LsqPrep<N> &P) {
     // recover E and f from L and g
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const double diag = __builtin_sqrt(l[lidx<N>(i, i)]);
 #pragma unroll
-        for (int j = i + 1; j < N; ++j) E[i][j] = l[lidx<N>(i, j)] * diag;
-        E[i][i] = diag;
+        for (int j = i + 1; j < N; ++j) P.E[i][j] = l[lidx<N>(i, j)] * diag;
+        P.E[i][i] = diag;
         double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < i; ++k) acc += E[k][i] * f[k];
-        f[i] = (g[i] - acc) / diag;
+        for (int k = 0; k < i; ++k) acc += P.E[k][i] * P.f[k];
+        P.f[i] = (g[i] - acc) / diag;
         OPTIK_SCHED_FENCE();
     }
 #pragma unroll
-    for (int i = 0; i < N; ++i) f[i] = -f[i];
+    for (int i = 0; i < N; ++i) P.f[i] = -P.f[i];
 
     // LSI: "QR" of the already-triangular E (a Householder reflection on a column
     // whose sub-diagonal is zero: flips the sign of row i up to roundoff)
 #pragma unroll
     for (int i = 0; i < N - 1; ++i) {
-        const double p = E[i][i];
+        const double p = P.E[i][i];
         double cl = __builtin_fabs(p);
         if (!(cl <= 0.0)) {
             const double clinv = 1.0 / cl;
@@ -319,17 +455,17 @@ OPTIK_DEV int lsq_box(const NnlsWs<N> &ws, const double (&l)[N * (N + 1) / 2], c
             cl *= __builtin_sqrt(sm0);
             if (p > 0.0) cl = -cl;
             const double up = p - cl;
-            E[i][i] = cl;
+            P.E[i][i] = cl;
             double b = up * cl;
             if (!(b >= 0.0)) {
                 b = 1.0 / b;
 #pragma unroll
                 for (int j = i + 1; j < N; ++j) {
-                    double sm = E[i][j] * up;
-                    if (sm != 0.0) { sm *= b; E[i][j] += sm * up; }
+                    double sm = P.E[i][j] * up;
+                    if (sm != 0.0) { sm *= b; P.E[i][j] += sm * up; }
                 }
-                double sm = f[i] * up;
-                if (sm != 0.0) { sm *= b; f[i] += sm * up; }
+                double sm = P.f[i] * up;
+                if (sm != 0.0) { sm *= b; P.f[i] += sm * up; }
             }
         }
         OPTIK_SCHED_FENCE();
@@ -337,103 +473,130 @@ OPTIK_DEV int lsq_box(const NnlsWs<N> &ws, const double (&l)[N * (N + 1) / 2], c
     // transform G = [I; -I] and h = [lo; -hi]: rows of +-E^-1
     bool singular = false;
 #pragma unroll
-    for (int j = 0; j < N; ++j) singular = singular || !(__builtin_fabs(E[j][j]) >= EPMACH);
+    for (int j = 0; j < N; ++j) singular = singular || !(__builtin_fabs(P.E[j][j]) >= EPMACH);
+    P.need_nnls = false;
     if (singular) return 5;
-    double Gi[N][N];  // row i of E^-1, entries j >= i
-    double h[2 * N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
 #pragma unroll
         for (int j = i; j < N; ++j) {
             double acc = 0.0;
 #pragma unroll
-            for (int k = i; k < j; ++k) acc += Gi[i][k] * E[k][j];
-            Gi[i][j] = (((j == i) ? 1.0 : 0.0) - acc) / E[j][j];
+            for (int k = i; k < j; ++k) acc += P.Gi[i][k] * P.E[k][j];
+            P.Gi[i][j] = (((j == i) ? 1.0 : 0.0) - acc) / P.E[j][j];
         }
         double acc = 0.0;
 #pragma unroll
-        for (int j = i; j < N; ++j) acc += Gi[i][j] * f[j];
-        h[i] = lo[i] - acc;
-        h[N + i] = (-hi[i]) - (-acc);
+        for (int j = i; j < N; ++j) acc += P.Gi[i][j] * P.f[j];
+        P.h[i] = lo[i] - acc;
+        P.h[N + i] = (-hi[i]) - (-acc);
         OPTIK_SCHED_FENCE();
     }
-    // LDP.  NNLS's first dual check is w_j = h_j (b = e_{n+1}); when no h_j is positive
-    // it returns at once with zero multipliers (y = 0, fac = 1, step 0): that case --
-    // the unconstrained step is feasible -- never touches LDS.  Bit-identical to
-    // running NNLS, whose every product is then an exact zero.
+    // NNLS's first dual check is w_j = h_j (b = e_{n+1}); when no h_j is positive it
+    // returns at once with zero multipliers (y = 0, fac = 1, step 0): that case -- the
+    // unconstrained step is feasible -- never touches LDS.  Bit-identical to running
+    // NNLS, whose every product is then an exact zero.
+    bool need = false;
+#pragma unroll
+    for (int r = 0; r < 2 * N; ++r) need = need || (P.h[r] > 0.0);
+    P.need_nnls = need;
+    return 1;
+}
+
+// LDP on the dual problem (LDS).  Writes the transformed-space step into s; mode 1 ok.
+template <int N>
+OPTIK_DEV int lsq_dual(const NnlsWs<N> &ws, const LsqPrep<N> &P, double (&s)[N],
+                       unsigned long long &nnls_cycles) {
     constexpr int M = 2 * N;
-    bool need_nnls = false;
 #pragma unroll
-    for (int r = 0; r < M; ++r) need_nnls = need_nnls || (h[r] > 0.0);
-    int mode = 1;
-    if (need_nnls) {
+    for (int c = 0; c < N; ++c) {
 #pragma unroll
-        for (int c = 0; c < N; ++c) {
-#pragma unroll
-            for (int r = 0; r < N; ++r) {
-                const double v = (r >= c) ? Gi[c][r] : 0.0;
-                ws.A(r + 1, c + 1) = v;
-                ws.A(r + 1, N + c + 1) = (r >= c) ? -v : 0.0;
-            }
-            ws.A(N + 1, c + 1) = h[c];
-            ws.A(N + 1, N + c + 1) = h[N + c];
-            OPTIK_SCHED_FENCE();
+        for (int r = 0; r < N; ++r) {
+            const double v = (r >= c) ? P.Gi[c][r] : 0.0;
+            ws.A(r + 1, c + 1) = v;
+            ws.A(r + 1, N + c + 1) = (r >= c) ? -v : 0.0;
         }
-#pragma unroll
-        for (int r = 1; r <= N; ++r) ws.b(r) = 0.0;
-        ws.b(N + 1) = 1.0;
-        double rnorm;
+        ws.A(N + 1, c + 1) = P.h[c];
+        ws.A(N + 1, N + c + 1) = P.h[N + c];
         OPTIK_SCHED_FENCE();
-        mode = nnls<N>(ws, rnorm);
-        OPTIK_SCHED_FENCE();
-        if (mode == 1 && rnorm <= 0.0) mode = 4;
-        if (mode == 1) {
-            double y[M];
-#pragma unroll
-            for (int r = 0; r < M; ++r) y[r] = ws.x(r + 1);
-            double hy = 0.0;
-#pragma unroll
-            for (int r = 0; r < M; ++r) hy += h[r] * y[r];
-            double fac = 1.0 - hy;
-            const double d1 = 1.0 + fac;
-            if (d1 - 1.0 <= 0.0) {
-                mode = 4;
-            } else {
-                fac = 1.0 / fac;
-#pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int r = 0; r <= j; ++r) acc += Gi[r][j] * y[r];
-#pragma unroll
-                    for (int r = 0; r <= j; ++r) acc += (-Gi[r][j]) * y[N + r];
-                    s[j] = fac * acc;
-                    OPTIK_SCHED_FENCE();
-                }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < N; ++j) s[j] = 0.0;
     }
-    if (mode != 1) return mode;
-    // solution of the original problem: s = E^-1 (y + f)
 #pragma unroll
-    for (int i = 0; i < N; ++i) s[i] += f[i];
+    for (int r = 1; r <= N; ++r) ws.b(r) = 0.0;
+    ws.b(N + 1) = 1.0;
+    double rnorm;
+    OPTIK_SCHED_FENCE();
+#ifdef OPTIK_PROFILE
+    const unsigned long long t_nnls = __builtin_readcyclecounter();
+#endif
+    int mode = nnls<N>(ws, rnorm);
+#ifdef OPTIK_PROFILE
+    nnls_cycles += __builtin_readcyclecounter() - t_nnls;
+#else
+    (void)nnls_cycles;
+#endif
+    OPTIK_SCHED_FENCE();
+    if (mode == 1 && rnorm <= 0.0) mode = 4;
+    if (mode != 1) return mode;
+    double y[M];
+#pragma unroll
+    for (int r = 0; r < M; ++r) y[r] = ws.x(r + 1);
+    double hy = 0.0;
+#pragma unroll
+    for (int r = 0; r < M; ++r) hy += P.h[r] * y[r];
+    double fac = 1.0 - hy;
+    const double d1 = 1.0 + fac;
+    if (d1 - 1.0 <= 0.0) return 4;
+    fac = 1.0 / fac;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double acc = 0.0;
+#pragma unroll
+        for (int r = 0; r <= j; ++r) acc += P.Gi[r][j] * y[r];
+#pragma unroll
+        for (int r = 0; r <= j; ++r) acc += (-P.Gi[r][j]) * y[N + r];
+        s[j] = fac * acc;
+        OPTIK_SCHED_FENCE();
+    }
+    return 1;
+}
+
+// s (transformed space, zero when NNLS was skipped) -> solution of the original
+// problem s = E^-1 (s + f), clipped into [lo, hi] (NLopt).
+template <int N>
+OPTIK_DEV void lsq_finish(const LsqPrep<N> &P, const double (&lo)[N], const double (&hi)[N], double (&s)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) s[i] += P.f[i];
 #pragma unroll
     for (int i = N - 1; i >= 0; --i) {
         double acc = 0.0;
 #pragma unroll
-        for (int j = i + 1; j < N; ++j) acc += E[i][j] * s[j];
-        s[i] = (s[i] - acc) / E[i][i];
+        for (int j = i + 1; j < N; ++j) acc += P.E[i][j] * s[j];
+        s[i] = (s[i] - acc) / P.E[i][i];
         OPTIK_SCHED_FENCE();
     }
-    // NLopt: enforce the bounds against roundoff
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         if (s[i] < lo[i]) s[i] = lo[i];
         else if (s[i] > hi[i]) s[i] = hi[i];
     }
+}
+
+// The whole direction sub-problem.  Returns the LSQ mode (1 ok).
+template <int N>
+OPTIK_DEV int lsq_box(const NnlsWs<N> &ws, const double (&l)[N * (N + 1) / 2], const double (&g)[N],
+                      const double (&lo)[N], const double (&hi)[N], double (&s)[N],
+                      unsigned long long &nnls_cycles) {
+    LsqPrep<N> P;
+    int mode = lsq_prepare<N>(l, g, lo, hi, P);
+    if (mode != 1) return mode;
+    if (P.need_nnls) {
+        mode = lsq_dual<N>(ws, P, s, nnls_cycles);
+        if (mode != 1) return mode;
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) s[j] = 0.0;
+    }
+    lsq_finish<N>(P, lo, hi, s);
     return 1;
 }
 

@@ -30,6 +30,29 @@ enum : int32_t {
 };
 
 constexpr int MAX_EVALS_CAP = 100000;  // same safety cap as the oracle
+constexpr unsigned REFILL_BATCH = 8;   // idle lanes a wave accumulates before it refills
+
+// Optional per-wave phase timers (build with -DOPTIK_PROFILE; tools/phase_profile.py).
+#ifdef OPTIK_PROFILE
+#define OPTIK_PROF_DECL unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long prof_t_ = 0
+#define OPTIK_PROF_BEGIN() prof_t_ = __builtin_readcyclecounter()
+#define OPTIK_PROF_END(slot) prof_[slot] += __builtin_readcyclecounter() - prof_t_
+#define OPTIK_PROF_COUNT(slot, n) prof_[slot] += (n)
+#define OPTIK_PROF_SUB_BEGIN() const unsigned long long prof_s_ = __builtin_readcyclecounter()
+#define OPTIK_PROF_SUB_END(slot) prof_[slot] += __builtin_readcyclecounter() - prof_s_
+#define OPTIK_PROF_FLUSH(ptr)                                                          \
+    if ((ptr) && (threadIdx.x & 63u) == 0) {                                           \
+        for (int i_ = 0; i_ < 8; ++i_) atomicAdd((ptr) + i_, prof_[i_]);               \
+    }
+#else
+#define OPTIK_PROF_DECL
+#define OPTIK_PROF_BEGIN()
+#define OPTIK_PROF_END(slot)
+#define OPTIK_PROF_COUNT(slot, n)
+#define OPTIK_PROF_SUB_BEGIN()
+#define OPTIK_PROF_SUB_END(slot)
+#define OPTIK_PROF_FLUSH(ptr)
+#endif
 
 // Wave-uniform solver parameters (derived from SolverConfig on the host).
 struct SolveParams {
@@ -95,68 +118,136 @@ OPTIK_DEV void restart_seed(const uint32_t (&key)[8], const double *lb, const do
     }
 }
 
-// ---- per-restart result ------------------------------------------------------
+// ---- work queue, per-restart results -----------------------------------------
 
-template <int N>
-struct RestartOut {
-    double x[N];   // best point (NLopt returns the best-so-far x)
-    double f;      // minf
-    int32_t result;
-    int32_t success;
-    int32_t n_evals;
-    int32_t n_iters;
+// Everything a launch shares (kernel arguments -> SGPRs).  Work items are the
+// T * R (target, restart) pairs, item w = t * R + (index - restart_begin); lanes
+// pull items from one global counter, so a lane that finishes a restart starts
+// the next one immediately and a wave never waits for its slowest restart (the
+// GPU analogue of rayon's work stealing, lib.rs:297-300).  Results are keyed by
+// the item, so which lane ran it is irrelevant.
+struct WorkQueue {
+    unsigned long long *next_item;       // global counter, zeroed before the launch
+    unsigned long long total_items;      // T * R
+    unsigned long long n_restarts;       // R (per target)
+    unsigned long long restart_begin;
+    const double *targets;               // [T][7]
+    const double *x0;                    // [T][n]
+    // first_success implements the reference's should_exit flag (lib.rs:269, 308,
+    // 382-384) in its deterministic reading: a restart is abandoned only if a
+    // LOWER index of the same target already succeeded.
+    unsigned long long *first_success;   // [T] or nullptr
+    unsigned long long deadline;         // wall_clock64() ticks, 0 = none
+    int quality;                         // selection key: 1 = ||x - x0||_2, 0 = index
+    int pad;
+    double *out_x;                       // [n][T*R]  best point (NLopt returns best-so-far x)
+    double *out_f;                       // [T*R]     minf
+    double *out_key;                     // [T*R]     selection key, +inf unless success
+    int32_t *out_status;                 // [T*R]
+    int32_t *out_evals;                  // [T*R]
+    unsigned long long *prof;            // [8] phase cycle totals (OPTIK_PROFILE builds), else null
 };
 
-// Control words shared by a launch (HBM).  first_success implements the
-// reference's should_exit flag (lib.rs:269, 308, 382-384) in its deterministic
-// reading: a restart is abandoned only if a LOWER index already succeeded.
-struct AbortCtl {
-    const unsigned long long *first_success;  // per target, or nullptr
-    unsigned long long deadline;               // wall_clock64() ticks, 0 = none
-};
+// Wave-aggregated fetch of one work item per requesting lane: one atomic per wave.
+OPTIK_DEV unsigned long long fetch_items(unsigned long long *counter, bool want) {
+    const unsigned long long mask = __ballot(want);
+    const unsigned n = (unsigned)__popcll(mask);
+    unsigned long long base = 0;
+    if (n) {
+        const int leader = __ffsll((long long)mask) - 1;
+        const int lane = (int)(threadIdx.x & 63u);
+        if (lane == leader) base = atomicAdd(counter, (unsigned long long)n);
+        base = __shfl(base, leader, 64);
+    }
+    const unsigned rank = (unsigned)__popcll(mask & ((1ull << (threadIdx.x & 63u)) - 1ull));
+    return base + rank;
+}
 
-OPTIK_DEV bool wave_any(bool p) { return __ballot(p) != 0ull; }
-
-// Runs one restart per lane to termination.  `active` lanes hold a restart; the
-// others idle through the loop.  x holds the seed on entry.
+// One 64-lane wave solving restarts until the queue is empty.
 template <int N, bool TIP>
-OPTIK_DEV void solve_restart(const ChainDev &ch, const EvalParams &ep, const SolveParams &sp,
-                             const Pose target, const NnlsWs<N> &ws, bool active, double (&x)[N],
-                             uint64_t restart_index, const AbortCtl ctl, unsigned target_slot,
-                             RestartOut<N> &out) {
+OPTIK_DEV void solve_wave(const ChainDev &ch, const EvalParams &ep, const SolveParams &sp,
+                          const uint32_t (&key)[8], const double (&scale)[MAX_DOF], const WorkQueue &wq,
+                          const NnlsWs<N> &ws) {
     constexpr int NL = N * (N + 1) / 2;
     const double alfmin = 0.1;
-    double x0[N], g[N], s[N], v[N], l[NL];
+    // SLSQP state of the lane's current restart
+    double x[N], x0[N], g[N], s[N], l[NL];
     double xbest[N], xprev[N];
     double f = 0.0, f0 = 0.0, t0 = 0.0, h3 = 0.0, alpha = 1.0;
     double minf = __builtin_huge_val(), fprev = __builtin_huge_val();
     int iter = 0, ireset = 0, line = 0, nevals = 0;
-    int32_t ret = 0;
     bool first = true;
+    // the work item
+    Pose target;
+    unsigned long long item = 0, index = 0;
+    unsigned tslot = 0;
+    bool active = false, want = true;
 #pragma unroll
-    for (int i = 0; i < N; ++i) { xbest[i] = x[i]; xprev[i] = x[i]; x0[i] = x[i]; s[i] = 0.0; v[i] = 0.0; g[i] = 0.0; }
+    for (int i = 0; i < N; ++i) { x[i] = 0.0; x0[i] = 0.0; g[i] = 0.0; s[i] = 0.0; xbest[i] = 0.0; xprev[i] = 0.0; }
 #pragma unroll
     for (int i = 0; i < NL; ++i) l[i] = 0.0;
+    target.t = V3{0, 0, 0};
+    target.q = Q4{0, 0, 0, 1};
+    OPTIK_PROF_DECL;
 
-    while (wave_any(active)) {
+    for (;;) {
+        OPTIK_PROF_BEGIN();
+        // ---- refill: lanes without a restart pull the next work item -------------
+        // (the seed generation below runs for the whole wave, so wait until several lanes
+        // are idle -- or none is busy -- before paying for it)
+        const unsigned n_want = (unsigned)__popcll(__ballot(want));
+        if (n_want >= REFILL_BATCH || (n_want > 0 && !wave_any(active))) {
+            const unsigned long long it = fetch_items(wq.next_item, want);
+            if (want) {
+                want = false;
+                if (it < wq.total_items) {
+                    item = it;
+                    tslot = (unsigned)(it / wq.n_restarts);
+                    index = wq.restart_begin + (it - (unsigned long long)tslot * wq.n_restarts);
+                    target = load_pose(wq.targets + (size_t)tslot * 7);
+                    // lib.rs:366-370: restart 0 starts from the caller's seed
+                    restart_seed<N>(key, ch.lb, scale, index, x);
+                    if (index == 0) {
+                        const double *x0p = wq.x0 + (size_t)tslot * N;
+#pragma unroll
+                        for (int i = 0; i < N; ++i) x[i] = x0p[i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < N; ++i) { xbest[i] = x[i]; xprev[i] = x[i]; x0[i] = x[i]; s[i] = 0.0; g[i] = 0.0; }
+                    f = 0.0; f0 = 0.0; t0 = 0.0; h3 = 0.0; alpha = 1.0;
+                    minf = __builtin_huge_val(); fprev = __builtin_huge_val();
+                    iter = 0; ireset = 0; line = 0; nevals = 0;
+                    first = true;
+                    active = true;
+                }
+            }
+        }
+        OPTIK_PROF_END(0);  // refill
+        if (!wave_any(active)) break;
+        OPTIK_PROF_COUNT(7, 1);  // trips
+
+        int32_t ret = 0;
         if (active) {
             // lib.rs:308: abandon when timed out or a lower-index restart succeeded
             bool stop = false;
-            if (ctl.first_success) {
-                const unsigned long long fs =
-                    __hip_atomic_load(ctl.first_success + target_slot, __ATOMIC_RELAXED,
-                                      __HIP_MEMORY_SCOPE_AGENT);
-                stop = fs < restart_index;
+            if (wq.first_success) {
+                const unsigned long long fs = __hip_atomic_load(wq.first_success + tslot, __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_AGENT);
+                stop = fs < index;
             }
-            if (ctl.deadline && wall_clock64() > ctl.deadline) stop = true;
-            if (stop) { ret = RES_FORCED_STOP; active = false; }
+            if (wq.deadline && wall_clock64() > wq.deadline) stop = true;
+            if (stop) ret = RES_FORCED_STOP;
         }
         double gn[N];
         double fn = 0.0;
+        const bool do_eval = active && ret == 0;
         OPTIK_SCHED_FENCE();
-        if (active) fn = eval_fg<N, TIP>(ch, ep, target, x, gn);
+        OPTIK_PROF_BEGIN();
+        if (do_eval) fn = eval_fg<N, TIP>(ch, ep, target, x, gn);
+        OPTIK_PROF_END(1);  // eval
         OPTIK_SCHED_FENCE();
-        if (active) {
+        OPTIK_PROF_BEGIN();
+        if (do_eval) {
             f = fn;
             ++nevals;
             // NLopt: update best point so far; stopval is tested after every evaluation
@@ -213,9 +304,11 @@ OPTIK_DEV void solve_restart(const ChainDev &ch, const EvalParams &ep, const Sol
                         // label 260: BFGS update with u = g_new - g_old
                         double u[N];
 #pragma unroll
-                        for (int i = 0; i < N; ++i) { u[i] = gn[i] - v[i]; g[i] = gn[i]; }
+                        for (int i = 0; i < N; ++i) { u[i] = gn[i] - g[i]; g[i] = gn[i]; }
                         OPTIK_SCHED_FENCE();
+                        OPTIK_PROF_SUB_BEGIN();
                         bfgs_update<N>(l, s, u);
+                        OPTIK_PROF_SUB_END(4);  // BFGS (inside slot 2)
                         OPTIK_SCHED_FENCE();
                         need_dir = true;
                     }
@@ -248,16 +341,21 @@ OPTIK_DEV void solve_restart(const ChainDev &ch, const EvalParams &ep, const Sol
 #pragma unroll
                 for (int i = 0; i < N; ++i) { lo[i] = ch.lb[i] - x[i]; hi[i] = ch.ub[i] - x[i]; }
                 OPTIK_SCHED_FENCE();
-                const int lmode = lsq_box<N>(ws, l, g, lo, hi, s);
+                OPTIK_PROF_SUB_BEGIN();
+                unsigned long long nnls_cycles = 0;
+                const int lmode = lsq_box<N>(ws, l, g, lo, hi, s, nnls_cycles);
+                OPTIK_PROF_SUB_END(5);  // LSQ incl. NNLS (inside slot 2)
+                OPTIK_PROF_COUNT(6, nnls_cycles);
                 OPTIK_SCHED_FENCE();
                 if (lmode != 1) {
                     // NLopt: modes 5,6,7 -> ROUNDOFF_LIMITED; 3,4,9 -> FAILURE
                     ret = (lmode == 5 || lmode == 6 || lmode == 7) ? RES_ROUNDOFF_LIMITED : RES_FAILURE;
                     break;
                 }
+                // (g is also Kraft's v: the gradient at the start of the line search)
                 double gs = 0.0;
 #pragma unroll
-                for (int i = 0; i < N; ++i) { v[i] = g[i]; x0[i] = x[i]; }
+                for (int i = 0; i < N; ++i) x0[i] = x[i];
                 f0 = f;
 #pragma unroll
                 for (int i = 0; i < N; ++i) gs += g[i] * s[i];
@@ -281,20 +379,43 @@ OPTIK_DEV void solve_restart(const ChainDev &ch, const EvalParams &ep, const Sol
                     else if (xi > ch.ub[i]) xi = ch.ub[i];
                     x[i] = xi;
                 }
-            } else {
-                active = false;
             }
         }
-    }
-
+        OPTIK_PROF_END(2);  // bookkeeping + BFGS + direction
+        OPTIK_PROF_BEGIN();
+        // ---- a restart ended: classify (lib.rs:376-379), publish, free the lane ----
+        if (active && ret != 0) {
+            const bool success = (sp.ok_stopval && ret == RES_STOPVAL_REACHED)
+                                 || (sp.ok_ftol && ret == RES_FTOL_REACHED)
+                                 || (sp.ok_xtol && ret == RES_XTOL_REACHED);
+            if (wq.out_x) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) out.x[i] = xbest[i];
-    out.f = minf;
-    out.result = ret;
-    out.success = (sp.ok_stopval && ret == RES_STOPVAL_REACHED) || (sp.ok_ftol && ret == RES_FTOL_REACHED)
-                  || (sp.ok_xtol && ret == RES_XTOL_REACHED);
-    out.n_evals = nevals;
-    out.n_iters = iter;
+                for (int i = 0; i < N; ++i) wq.out_x[(size_t)i * wq.total_items + item] = xbest[i];
+            }
+            if (wq.out_f) wq.out_f[item] = minf;
+            if (wq.out_status) wq.out_status[item] = ret;
+            if (wq.out_evals) wq.out_evals[item] = nevals;
+            // selection key (lib.rs:402-407): Quality = ||x - x0||_2, Speed = index
+            double k = __builtin_huge_val();
+            if (success) {
+                if (wq.quality) {
+                    const double *x0p = wq.x0 + (size_t)tslot * N;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) { const double d = xbest[i] - x0p[i]; acc += d * d; }
+                    k = __builtin_sqrt(acc);
+                } else {
+                    k = (double)index;
+                    if (wq.first_success) atomicMin(wq.first_success + tslot, index);
+                }
+            }
+            if (wq.out_key) wq.out_key[item] = k;
+            active = false;
+            want = true;
+        }
+        OPTIK_PROF_END(3);  // publish
+    }
+    OPTIK_PROF_FLUSH(wq.prof);
 }
 
 }  // namespace optik

@@ -127,6 +127,37 @@ class HipChain:
             _stream_ptr()))
         return bufs
 
+    # -- the streaming engine (throughput path; same results) ---------------------
+    def engine_submit(self, cfg, targets, x0, restart_begin, restart_end, flags=0, ee_offset7=None,
+                      bufs=None, per_restart=True):
+        """Queue one job for the next engine_run().  Same arguments / buffers as ik_batch;
+        the tensors must stay alive until engine_run() returns."""
+        assert targets.is_cuda and targets.dtype == torch.float64 and targets.is_contiguous()
+        assert x0.is_cuda and x0.dtype == torch.float64 and x0.is_contiguous()
+        T = targets.shape[0]
+        assert targets.shape == (T, 7) and x0.shape == (T, self.n)
+        R = int(restart_end - restart_begin)
+        if bufs is None:
+            bufs = self.alloc_ik_buffers(T, R, per_restart)
+        o = nat.IkOutputs()
+        o.d_x, o.d_f = _ptr(bufs.get("x")), _ptr(bufs.get("f"))
+        o.d_status, o.d_evals = _ptr(bufs.get("status")), _ptr(bufs.get("evals"))
+        o.d_win_x, o.d_win_f = _ptr(bufs["win_x"]), _ptr(bufs["win_f"])
+        o.d_win_idx, o.d_win_key = _ptr(bufs["win_idx"]), _ptr(bufs["win_key"])
+        ee = np.ascontiguousarray(ee_offset7, dtype=np.float64) if ee_offset7 is not None else None
+        nat.check(nat.lib().optik_hip_engine_submit(
+            self._h, C.byref(cfg), _ptr(targets), _ptr(x0), T, _dp(ee) if ee is not None else None,
+            int(restart_begin), int(restart_end), int(flags), C.byref(o)))
+        self._pending = getattr(self, "_pending", [])
+        self._pending.append((targets, x0, bufs))  # keep the buffers alive
+        return bufs
+
+    def engine_run(self):
+        """Run every submitted job to completion (blocking) and their selections."""
+        nat.check(nat.lib().optik_hip_engine_run(self._h, _stream_ptr()))
+        self._pending = []
+        return int(nat.lib().optik_hip_engine_last_trips(self._h))
+
     def set_timing(self, enabled=True):
         nat.lib().optik_hip_set_timing(self._h, 1 if enabled else 0)
 

@@ -121,10 +121,22 @@ def _oracle_all(oracle, ch, cfg_kw, tgt, x0, begin, end):
     return oracle.ik(ch, cfg, tgt, x0, begin, end, n_threads=4, early_exit=False, per_restart=True)
 
 
+def _run(hc, path, cfg, tgd, x0d, begin, end, flags=0):
+    """The two GPU paths: the single-kernel solver and the streaming engine."""
+    if path == "kernel":
+        out = hc.ik_batch(cfg, tgd, x0d, begin, end, flags=flags)
+    else:
+        out = hc.engine_submit(cfg, tgd, x0d, begin, end, flags=flags)
+        hc.engine_run()
+    torch.cuda.synchronize()
+    return out
+
+
 @pytest.mark.parametrize("robot,tol_f,R", [("panda", 1e-6, 4096), ("ur10", 1e-12, 2048),
                                            ("ur3e", 1e-6, 2048), ("panda_hand", 1e-8, 2048)])
 @pytest.mark.parametrize("mode", ["speed", "quality"])
-def test_every_restart_bit_exact(dev, oracle, chains, hip_chains, robot, tol_f, R, mode):
+@pytest.mark.parametrize("path", ["kernel", "engine"])
+def test_every_restart_bit_exact(dev, oracle, chains, hip_chains, robot, tol_f, R, mode, path):
     """One target, restarts 0..R-1: status, evaluation count, returned x and f of EVERY
     restart equal the oracle's, and so does the selected winner."""
     from optik_amd import _native as nat
@@ -133,8 +145,7 @@ def test_every_restart_bit_exact(dev, oracle, chains, hip_chains, robot, tol_f, 
     tg, x0 = make_targets(oracle, d, ch, rng, 1)
     kw = dict(solution_mode=mode, tol_f=tol_f)
     cfg = nat.make_config(**kw)
-    out = hip_chains[robot].ik_batch(cfg, torch.tensor(tg, device="cuda"), torch.tensor(x0, device="cuda"), 0, R)
-    torch.cuda.synchronize()
+    out = _run(hip_chains[robot], path, cfg, torch.tensor(tg, device="cuda"), torch.tensor(x0, device="cuda"), 0, R)
     ref = _oracle_all(oracle, ch, kw, tg[0], x0[0], 0, R)
     status = out["status"].cpu().numpy()
     assert np.array_equal(status, ref["status"]), np.argwhere(status != ref["status"])[:10]
@@ -171,7 +182,8 @@ def test_restart_ranges_compose(dev, oracle, chains, hip_chains):
     assert int(idxs[best]) == int(full["win_idx"][0])
 
 
-def test_many_targets_batch(dev, oracle, chains, hip_chains):
+@pytest.mark.parametrize("path", ["kernel", "engine"])
+def test_many_targets_batch(dev, oracle, chains, hip_chains, path):
     """Config-5 shape: T targets x R restarts each; per-target winners match the oracle
     run target by target (Speed: lowest successful index)."""
     from optik_amd import _native as nat
@@ -180,9 +192,8 @@ def test_many_targets_batch(dev, oracle, chains, hip_chains):
     T, R = 24, 96
     tg, x0 = make_targets(oracle, d, ch, rng, T)
     kw = dict(solution_mode="speed", tol_f=1e-6)
-    out = hip_chains["panda"].ik_batch(nat.make_config(**kw), torch.tensor(tg, device="cuda"),
-                                       torch.tensor(x0, device="cuda"), 0, R)
-    torch.cuda.synchronize()
+    out = _run(hip_chains["panda"], path, nat.make_config(**kw), torch.tensor(tg, device="cuda"),
+               torch.tensor(x0, device="cuda"), 0, R)
     win = out["win_idx"].cpu().numpy()
     wx = out["win_x"].cpu().numpy()
     st = out["status"].cpu().numpy().reshape(T, R)
@@ -194,6 +205,37 @@ def test_many_targets_batch(dev, oracle, chains, hip_chains):
             assert_bit_equal(wx[t], ref["x"], f"winner x target {t}")
         else:
             assert win[t] == -1
+
+
+def test_engine_pools_jobs_and_matches_the_single_kernel_path(dev, oracle, chains, hip_chains):
+    """Several jobs submitted before one engine run share the slot pool (continuous
+    batching); every job's outputs equal the single-kernel path's bit for bit, also when
+    the pool is much smaller than the work (slots are refilled many times)."""
+    import os
+    from optik_amd import _native as nat
+    d, ch = chains["panda"]
+    hc = hip_chains["panda"]
+    rng = np.random.default_rng(31)
+    cfg = nat.make_config(solution_mode="quality")
+    jobs = []
+    for T, begin, end in [(1, 0, 3000), (3, 5, 700), (1, 100000, 101000)]:
+        tg, x0 = make_targets(oracle, d, ch, rng, T)
+        jobs.append((torch.tensor(tg, device="cuda"), torch.tensor(x0, device="cuda"), begin, end))
+    ref = [hc.ik_batch(cfg, t, x, b, e) for t, x, b, e in jobs]
+    torch.cuda.synchronize()
+    os.environ["OPTIK_ENGINE_SLOTS"] = "1024"
+    try:
+        outs = [hc.engine_submit(cfg, t, x, b, e) for t, x, b, e in jobs]
+        trips = hc.engine_run()
+    finally:
+        del os.environ["OPTIK_ENGINE_SLOTS"]
+    torch.cuda.synchronize()
+    assert trips > 50
+    for r, o in zip(ref, outs):
+        for k in ("status", "evals", "win_idx"):
+            assert torch.equal(r[k], o[k]), k
+        for k in ("x", "f", "win_x", "win_f", "win_key"):
+            assert torch.equal(r[k].view(torch.int64), o[k].view(torch.int64)), k
 
 
 def test_early_exit_keeps_the_winner(dev, oracle, chains, hip_chains):

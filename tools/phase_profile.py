@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Per-phase cycle breakdown of the solve kernel (diagnostic).
+
+Builds a second copy of the library with -DOPTIK_PROFILE (s_memtime counters around
+the phases of a wave's trip), runs one bench-sized launch and prints where the wave
+cycles go.  Not part of the product path.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CSRC = os.path.join(ROOT, "optik_amd", "csrc")
+LIB = os.path.join(ROOT, "gpurun_out", "liboptik_amd_prof.so")
+
+
+def main():
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    robot = sys.argv[1] if len(sys.argv) > 1 else "panda"
+    R = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+                           "-shared", "-Wno-unused-value", "-pthread", "-DOPTIK_PROFILE", "-x", "hip",
+                           os.path.join(CSRC, "ik_kernels.hip"), os.path.join(CSRC, "robot_host.cpp"), "-o", LIB])
+    from optik_amd import _native as nat
+    nat.LIB_PATH = LIB
+    import numpy as np
+    import torch
+    from optik_amd import Robot
+    spec = {"panda": ("panda.urdf", "panda_link0", "panda_link8"), "ur10": ("ur10.urdf", "base_link", "ee_link")}[robot]
+    rb = Robot.from_urdf_file(os.path.join(ROOT, "optik_amd", "robots", spec[0]), spec[1], spec[2])
+    hc = rb.hip_chain("cuda:0")
+    rng = np.random.default_rng(0)
+    lb, ub = (np.array(v) for v in rb.joint_limits())
+    tgt = hc.fk_batch(torch.tensor(rng.uniform(lb, ub, size=(1, len(lb))).T.copy(), device="cuda:0")).T.contiguous()
+    x0 = torch.tensor(rng.uniform(lb, ub, size=(1, len(lb))), device="cuda:0")
+    cfg = nat.make_config("speed")
+    bufs = hc.alloc_ik_buffers(1, R)
+    for _ in range(2):
+        hc.ik_batch(cfg, tgt, x0, 0, R, bufs=bufs)
+    torch.cuda.synchronize()
+    out = (C.c_ulonglong * 8)()
+    nat.lib().optik_hip_phase_profile.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+    nat.check(nat.lib().optik_hip_phase_profile(hc._h, out))
+    names = ["refill", "eval", "update(total)", "publish", "  bfgs", "  lsq(total)", "    nnls", "trips"]
+    v = list(out)
+    total = v[0] + v[1] + v[2] + v[3]
+    trips = max(v[7], 1)
+    print(f"{robot}: R={R}, wave-trips={trips}, mean evals/restart={float(bufs['evals'].double().mean()):.1f}")
+    for n_, c in zip(names[:7], v[:7]):
+        print(f"  {n_:16s} {c / trips:10.0f} cycles/trip  {100.0 * c / total:5.1f} %")
+    print(f"  total            {total / trips:10.0f} cycles/trip")
+
+
+def engine_profile():
+    """NNLS-kernel phases of the streaming engine: load / solve / store cycles per wave pass."""
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+                           "-shared", "-Wno-unused-value", "-pthread", "-DOPTIK_PROFILE", "-x", "hip",
+                           os.path.join(CSRC, "ik_kernels.hip"), os.path.join(CSRC, "robot_host.cpp"), "-o", LIB])
+    from optik_amd import _native as nat
+    nat.LIB_PATH = LIB
+    import numpy as np
+    import torch
+    from optik_amd import Robot
+    rb = Robot.from_urdf_file(os.path.join(ROOT, "optik_amd", "robots", "panda.urdf"), "panda_link0", "panda_link8")
+    hc = rb.hip_chain("cuda:0")
+    rng = np.random.default_rng(0)
+    lb, ub = (np.array(v) for v in rb.joint_limits())
+    K, R = 4, 65536
+    tgt = hc.fk_batch(torch.tensor(rng.uniform(lb, ub, size=(K, len(lb))).T.copy(), device="cuda:0")).T.contiguous()
+    x0 = torch.tensor(rng.uniform(lb, ub, size=(K, len(lb))), device="cuda:0")
+    cfg = nat.make_config("speed")
+    bufs = [hc.alloc_ik_buffers(1, R) for _ in range(K)]
+    for i in range(K):
+        hc.engine_submit(cfg, tgt[i:i + 1], x0[i:i + 1], 0, R, bufs=bufs[i])
+    trips = hc.engine_run()
+    out = (C.c_ulonglong * 8)()
+    nat.lib().optik_hip_phase_profile.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+    nat.check(nat.lib().optik_hip_phase_profile(hc._h, out))
+    v = list(out)
+    n = max(v[3], 1)
+    print(f"engine nnls kernel: {n} wave passes over {trips} trips: load {v[0]/n:.0f}  solve {v[1]/n:.0f}  store {v[2]/n:.0f} cycles per pass")
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "engine":
+        engine_profile()
+        sys.exit(0)
+    main()
