@@ -7,7 +7,10 @@ A *step* is one pass of the hot path over one batch: R = 65 536 restarts
 (BASELINE.json config 2: Panda 7-DoF, SolutionMode::Speed) of one synthetic
 reachable target, every restart run to termination (no early exit), followed by
 the winner selection.  Targets, seeds x0 and all output buffers are resident in
-HBM before the timed region.  With N > 1 (one process per GPU under
+HBM before the timed region.  With --path engine (default) the K timed steps are
+submitted as K jobs and executed by one run of the streaming engine, which keeps
+its slot pool full across step boundaries (continuous batching); --path kernel
+launches one persistent solve kernel per step, back to back.  With N > 1 (one process per GPU under
 torch.distributed.run) every rank solves its own contiguous restart range
 [rank*R, (rank+1)*R) of the same target -- weak scaling, no data-path
 collective -- and the per-step winner is chosen with one 8-byte RCCL
@@ -85,6 +88,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--restarts", type=int, default=65536, help="restarts per GPU per step")
     ap.add_argument("--robot", default="panda", choices=["panda", "ur10"])
+    ap.add_argument("--path", default="engine", choices=["engine", "kernel"],
+                    help="engine: streaming phase kernels with continuous batching (steps submitted "
+                         "together share the slot pool); kernel: one persistent solve kernel per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -122,23 +128,38 @@ def main():
     x0 = torch.tensor(x0_host, device=dev)
     cfg = nat.make_config(solution_mode="speed", tol_f=1e-6)
     begin, end = shard_range(0, R * world, rank, world)
-    bufs = hc.alloc_ik_buffers(1, R, per_restart=True)
+    n_buf = max(K, W) if args.path == "engine" else 1
+    bufs = [hc.alloc_ik_buffers(1, R, per_restart=True) for _ in range(n_buf)]
     torch.cuda.synchronize()
 
-    def step(i):
-        hc.ik_batch(cfg, targets[i:i + 1], x0[i:i + 1], begin, end, bufs=bufs)
-        return select_winner(bufs, "speed", distributed)
+    def run_steps(first, count):
+        """`count` steps starting at target `first`; returns the per-step global winners."""
+        if args.path == "engine":
+            # every step is its own job (own target, own outputs); jobs submitted together
+            # share the engine's slot pool, then one blocking run executes them all
+            for k in range(count):
+                i = first + k
+                hc.engine_submit(cfg, targets[i:i + 1], x0[i:i + 1], begin, end, bufs=bufs[k])
+            hc.engine_run()
+            stacked = {"win_idx": torch.cat([bufs[k]["win_idx"] for k in range(count)]),
+                       "win_key": torch.cat([bufs[k]["win_key"] for k in range(count)])}
+            return select_winner(stacked, "speed", distributed)  # one collective for all steps
+        winners = []
+        for k in range(count):
+            i = first + k
+            hc.ik_batch(cfg, targets[i:i + 1], x0[i:i + 1], begin, end, bufs=bufs[0])
+            winners.append(select_winner(bufs[0], "speed", distributed))
+        return torch.cat(winners)
 
-    for i in range(W):
-        step(i)
+    if W:
+        run_steps(0, W)
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     hc.set_timing(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(W, W + K):
-        winner = step(i)
+    winners = run_steps(W, K)
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -149,16 +170,46 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    kernel_ms, launches = hc.timing_mean()
-    info = hc.last_launch()
-    status = bufs["status"]
-    n_success = int((status == nat.RES_STOPVAL).sum().item())
-    mean_evals = float(bufs["evals"].double().mean().item())
+    last = bufs[K - 1] if args.path == "engine" else bufs[0]
+    n_success = int((last["status"] == nat.RES_STOPVAL).sum().item())
+    mean_evals = float(last["evals"].double().mean().item())
 
     if rank == 0:
         total = float(R) * world * K
-        bytes_per_restart = 8 * n + 8 + 4 + 4  # x[n] + f + status + evals written; seeds made in-kernel
-        achieved = bytes_per_restart * R / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        out_bytes = 8 * n + 8 + 8 + 4 + 4  # x[n] + f + key + status + evals written per restart
+        if args.path == "engine":
+            st = hc.engine_stats()
+            trips = int(nat.lib().optik_hip_engine_last_trips(hc._h))
+            per_kernel = {k: st[k + "_ms"] for k in ("eval", "update", "nnls", "finish")}
+            dom = max(per_kernel, key=per_kernel.get)
+            m = n + 1
+            # algorithmic HBM bytes of one launch of the dominant kernel
+            if dom == "nnls":
+                units = st["nnls_problems"] / max(trips, 1)              # sub-problems per launch
+                unit_bytes = 8 * (2 * n * m + 2 * n + 2)                   # problem in, multipliers + {mode, rnorm} out
+            else:
+                slots_per_launch = float(R) * K / max(trips, 1) * mean_evals  # slot-trips per launch (approx.)
+                units = slots_per_launch
+                nl = n * (n + 1) // 2
+                unit_bytes = {"eval": 8 * (2 * n + 6), "update": 8 * (2 * nl + 9 * n + 8),
+                              "finish": 8 * (2 * nl + 7 * n + 2 * n + 10)}[dom]
+            kernel_ms = per_kernel[dom]
+            achieved = unit_bytes * units / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": f"eng_{dom}_kernel",
+                    "kernel_ms": kernel_ms, "launches_timed": st["sampled_trips"],
+                    "algorithmic_bytes_per_unit": unit_bytes, "units_per_launch": units,
+                    "unit": "GB/s", "all_kernels_ms": per_kernel, "trips": trips,
+                    "restart_output_bytes": out_bytes}
+            info = {"grid": None, "block": 256, "lds_bytes": 0}
+        else:
+            kernel_ms, launches = hc.timing_mean()
+            info = hc.last_launch()
+            achieved = out_bytes * R / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "ik_solve_kernel",
+                    "kernel_ms": kernel_ms, "launches_timed": launches,
+                    "algorithmic_bytes_per_unit": out_bytes, "units_per_launch": R}
         line = {
             "metric": "random-restart IK solves/sec (Panda 7-DoF, 1e-6 tol)" if args.robot == "panda"
                       else f"random-restart IK solves/sec ({args.robot}, 1e-6 tol)",
@@ -173,22 +224,19 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.robot} 7-DoF, {R} random restarts per GPU per step, one target "
-                                   "per step, SolutionMode::Speed, every restart run to termination"
-                                   if args.robot == "panda" else
-                                   f"{args.robot}, {R} random restarts per GPU per step",
-                       "restarts_per_gpu": R, "tol_f": 1e-6, "parallelism": f"restart-range x{world}",
+            "config": {"workload": f"{args.robot} {n}-DoF, {R} random restarts per GPU per step, one target "
+                                   "per step, SolutionMode::Speed, every restart run to termination",
+                       "path": args.path, "restarts_per_gpu": R, "tol_f": 1e-6,
+                       "parallelism": f"restart-range x{world}",
                        "success_rate_last_step": n_success / R, "mean_evals_per_restart": mean_evals,
                        "grid": info["grid"], "block": info["block"], "lds_bytes": info["lds_bytes"]},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "ik_solve_kernel", "kernel_ms": kernel_ms, "launches_timed": launches,
-                         "algorithmic_bytes_per_restart": bytes_per_restart},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             tables = robot.chain_tables()
             line["cpu_baseline"] = cpu_baseline(args.robot, tables, targets[W].cpu().numpy(),
                                                 x0_host[W], args.cpu_seconds)
+            line["cpu_baseline"]["gpu_winner_same_target"] = int(winners[0].item())
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

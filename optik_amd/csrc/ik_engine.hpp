@@ -98,6 +98,7 @@ struct EngArgs {
     int parity;                         // list consumed by this trip's NNLS kernel
     int pad2;
     unsigned int *n_active;             // slots holding a restart after the update kernel (zeroed every trip)
+    unsigned long long *nn_total;       // running count of bounded sub-problems solved
     unsigned long long *prof;           // OPTIK_PROFILE builds: cycle counters, else null
 };
 
@@ -501,35 +502,45 @@ OPTIK_DEV void eng_update_body(const EngArgs &a, const ChainDev &ch, size_t slot
 
 // ---- kernel 3: cooperative NNLS over this trip's deferred problems ---------------
 
-template <int N>
+template <int N, int CPL>
 OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a) {
     constexpr int m = N + 1, n = 2 * N;
+    constexpr int G = COOP_COLS / CPL;        // lanes per problem
+    constexpr unsigned PPW = 64 / G;          // problems per wave
     const unsigned cnt = *a.nn_count[a.parity];
     const double *prob = a.nn_prob[a.parity];
     double *ybuf = a.nn_y[a.parity];
     double *meta = a.nn_meta[a.parity];
     const unsigned lane = threadIdx.x & 63u;
-    const unsigned group = lane / COOP_GROUP, c = lane % COOP_GROUP;
+    const unsigned group = lane / G, gl = lane % G;
     const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) / 64u;
     const unsigned n_waves = (gridDim.x * blockDim.x) / 64u;
-    for (unsigned q0 = wave * 4u; q0 < cnt; q0 += n_waves * 4u) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.nn_total) atomicAdd(a.nn_total, (unsigned long long)cnt);
+    for (unsigned q0 = wave * PPW; q0 < cnt; q0 += n_waves * PPW) {
         const unsigned q = q0 + group;
         const bool live = q < cnt;
-        double col[m];
+        dvec8 col[CPL];
 #pragma unroll
-        for (int r = 0; r < m; ++r) col[r] = 0.0;
-        if (live && c < (unsigned)n) {
-            const double *pc = prob + ((size_t)q * n + c) * m;
+        for (int k = 0; k < CPL; ++k) {
+            col[k] = 0.0;
+            const unsigned c = gl * CPL + k;
+            if (live && c < (unsigned)n) {
+                const double *pc = prob + ((size_t)q * n + c) * m;
 #pragma unroll
-            for (int r = 0; r < m; ++r) col[r] = pc[r];
+                for (int r = 0; r < m; ++r) col[k][r] = pc[r];
+            }
         }
-        double xv;
-        int mode;
+        double xv[CPL];
+        int mode, iters;
         double rnorm;
-        nnls_coop<N>(live, (int)c + 1, col, xv, mode, rnorm);
+        nnls_coop<N, CPL>(live, (int)(gl * CPL), col, xv, mode, rnorm, iters);
         if (live) {
-            if (c < (unsigned)n) ybuf[(size_t)q * n + c] = xv;
-            if (c == 0) { meta[(size_t)q * 2] = (double)mode; meta[(size_t)q * 2 + 1] = rnorm; }
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const unsigned c = gl * CPL + k;
+                if (c < (unsigned)n) ybuf[(size_t)q * n + c] = xv[k];
+            }
+            if (gl == 0) { meta[(size_t)q * 2] = (double)mode; meta[(size_t)q * 2 + 1] = rnorm; }
         }
     }
 }

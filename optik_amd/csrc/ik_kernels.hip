@@ -157,9 +157,16 @@ __global__ __launch_bounds__(WAVE) void ik_select_kernel(const SelectLaunch a) {
 }
 
 // ---- streaming engine kernels (ik_engine.hpp) ---------------------------------
+// minimum waves per SIMD the register allocator must leave room for (tuned on MI355X)
+#ifndef OPTIK_ENG_EVAL_WAVES
+#define OPTIK_ENG_EVAL_WAVES 2
+#endif
+#ifndef OPTIK_ENG_UPD_WAVES
+#define OPTIK_ENG_UPD_WAVES 1
+#endif
 
 template <int N, bool TIP>
-__global__ __launch_bounds__(256, 2) void eng_eval_kernel(const EngArgs a) {
+__global__ __launch_bounds__(256, OPTIK_ENG_EVAL_WAVES) void eng_eval_kernel(const EngArgs a) {
     __shared__ ChainDev sch;
     stage_chain(sch, a.chain);
     const size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -167,20 +174,27 @@ __global__ __launch_bounds__(256, 2) void eng_eval_kernel(const EngArgs a) {
 }
 
 template <int N>
-__global__ __launch_bounds__(256, 2) void eng_update_kernel(const EngArgs a) {
+__global__ __launch_bounds__(256, OPTIK_ENG_UPD_WAVES) void eng_update_kernel(const EngArgs a) {
     __shared__ ChainDev sch;
     stage_chain(sch, a.chain);
     const size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x;
     eng_update_body<N>(a, sch, slot < a.C ? slot : 0, slot < a.C);
 }
 
+// columns of a bounded sub-problem held per lane (16 / CPL lanes share a problem)
+#ifndef OPTIK_ENG_CPL
+#define OPTIK_ENG_CPL 4
+#endif
+#ifndef OPTIK_ENG_NNLS_WAVES
+#define OPTIK_ENG_NNLS_WAVES 2
+#endif
 template <int N>
-__global__ __launch_bounds__(256, 2) void eng_nnls_coop_kernel(const EngArgs a) {
-    eng_nnls_coop_body<N>(a);
+__global__ __launch_bounds__(256, OPTIK_ENG_NNLS_WAVES) void eng_nnls_coop_kernel(const EngArgs a) {
+    eng_nnls_coop_body<N, OPTIK_ENG_CPL>(a);
 }
 
 template <int N>
-__global__ __launch_bounds__(256, 2) void eng_finish_kernel(const EngArgs a) {
+__global__ __launch_bounds__(256, OPTIK_ENG_UPD_WAVES) void eng_finish_kernel(const EngArgs a) {
     __shared__ ChainDev sch;
     stage_chain(sch, a.chain);
     const size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -347,6 +361,13 @@ struct optik_hip_chain {
     unsigned int *eng_pinned = nullptr;    // host-pinned read-back ring
     hipEvent_t eng_ev[8] = {};
     int eng_trips = 0;                     // trips of the last run
+    // per-kernel HIP-event timing of sampled trips (eval, update, nnls, finish)
+    static constexpr int ENG_EV = 64;
+    hipEvent_t eng_tev[4][ENG_EV][2] = {};
+    int eng_tcount = 0;                    // sampled trips of the last run
+    double eng_kernel_ms[4] = {0, 0, 0, 0};
+    unsigned long long *eng_nn_total = nullptr;  // problems solved by the NNLS kernel (device counter)
+    unsigned long long eng_nn_problems = 0;
     int waves_per_cu = 2;                 // resident 64-lane workgroups per CU (LDS-bound)
     // timing
     int timing = 0;
@@ -540,6 +561,8 @@ void optik_hip_chain_destroy(optik_hip_chain *ch) {
     if (ch->eng_meta) hipFree(ch->eng_meta);
     if (ch->eng_pinned) hipHostFree(ch->eng_pinned);
     for (auto &e : ch->eng_ev) if (e) hipEventDestroy(e);
+    for (auto &k : ch->eng_tev) for (auto &p2 : k) for (auto &e : p2) if (e) hipEventDestroy(e);
+    if (ch->eng_nn_total) hipFree(ch->eng_nn_total);
     for (int i = 0; i < optik_hip_chain::EV_POOL; ++i) {
         if (ch->ev0[i]) hipEventDestroy(ch->ev0[i]);
         if (ch->ev1[i]) hipEventDestroy(ch->ev1[i]);
@@ -861,7 +884,12 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
         if (!ch->eng_counters) HIP_TRY(hipMalloc(&ch->eng_counters, 4 * sizeof(unsigned int)));
         if (!ch->eng_pinned) HIP_TRY(hipHostMalloc(&ch->eng_pinned, 8 * sizeof(unsigned int)));
         if (!ch->queue) HIP_TRY(hipMalloc(&ch->queue, sizeof(unsigned long long)));
+        if (!ch->eng_nn_total) HIP_TRY(hipMalloc(&ch->eng_nn_total, sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(ch->eng_nn_total, 0, sizeof(unsigned long long), stream));
         for (auto &e : ch->eng_ev) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        if (ch->timing)
+            for (auto &k : ch->eng_tev) for (auto &p2 : k) for (auto &e : p2) if (!e) HIP_TRY(hipEventCreate(&e));
+        ch->eng_tcount = 0;
 
         std::vector<EngJob> hj(n_jobs);
         for (size_t i = 0; i < n_jobs; ++i) hj[i] = ch->eng_jobs[i].dev;
@@ -892,6 +920,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             }
         }
         a.n_active = ch->eng_counters + 2;
+        a.nn_total = ch->eng_nn_total;
         a.parity = 0;
         a.prof = nullptr;
 #ifdef OPTIK_PROFILE
@@ -918,18 +947,29 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
                 a.parity = trip & 1;
                 HIP_TRY(hipMemsetAsync(ch->eng_counters + (a.parity ^ 1), 0, sizeof(unsigned int), stream));
                 HIP_TRY(hipMemsetAsync(ch->eng_counters + 2, 0, sizeof(unsigned int), stream));
+                // sample every 4th trip with HIP event pairs around each kernel (launch stream)
+                const bool timed = ch->timing && trip > 0 && (trip % 4 == 0) && ch->eng_tcount < optik_hip_chain::ENG_EV;
+                const int ts = ch->eng_tcount;
+#define TEV(kind, which) do { if (timed) HIP_TRY(hipEventRecord(ch->eng_tev[kind][ts][which], stream)); } while (0)
+                TEV(0, 0);
                 if (trip > 0) {
                     if (tip) DISPATCH_N(hipLaunchKernelGGL((eng_eval_kernel<6, true>), dim3(blocks), dim3(256), 0, stream, a),
                                         hipLaunchKernelGGL((eng_eval_kernel<7, true>), dim3(blocks), dim3(256), 0, stream, a));
                     else DISPATCH_N(hipLaunchKernelGGL((eng_eval_kernel<6, false>), dim3(blocks), dim3(256), 0, stream, a),
                                     hipLaunchKernelGGL((eng_eval_kernel<7, false>), dim3(blocks), dim3(256), 0, stream, a));
                 }
+                TEV(0, 1); TEV(1, 0);
                 DISPATCH_N(hipLaunchKernelGGL((eng_update_kernel<6>), dim3(blocks), dim3(256), 0, stream, a),
                            hipLaunchKernelGGL((eng_update_kernel<7>), dim3(blocks), dim3(256), 0, stream, a));
+                TEV(1, 1); TEV(2, 0);
                 DISPATCH_N(hipLaunchKernelGGL((eng_nnls_coop_kernel<6>), dim3(nn_blocks), dim3(256), 0, stream, a),
                            hipLaunchKernelGGL((eng_nnls_coop_kernel<7>), dim3(nn_blocks), dim3(256), 0, stream, a));
+                TEV(2, 1); TEV(3, 0);
                 DISPATCH_N(hipLaunchKernelGGL((eng_finish_kernel<6>), dim3(blocks), dim3(256), 0, stream, a),
                            hipLaunchKernelGGL((eng_finish_kernel<7>), dim3(blocks), dim3(256), 0, stream, a));
+                TEV(3, 1);
+#undef TEV
+                if (timed) ch->eng_tcount += 1;
             }
             HIP_TRY(hipGetLastError());
             // read back n_active of the chunk just issued; look at the previous chunk's value
@@ -978,6 +1018,16 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipStreamSynchronize(stream));
+        for (int k = 0; k < 4; ++k) {
+            double sum = 0.0;
+            for (int i = 0; i < ch->eng_tcount; ++i) {
+                float ms = 0.0f;
+                HIP_TRY(hipEventElapsedTime(&ms, ch->eng_tev[k][i][0], ch->eng_tev[k][i][1]));
+                sum += ms;
+            }
+            ch->eng_kernel_ms[k] = ch->eng_tcount ? sum / ch->eng_tcount : 0.0;
+        }
+        HIP_TRY(hipMemcpy(&ch->eng_nn_problems, ch->eng_nn_total, sizeof(unsigned long long), hipMemcpyDeviceToHost));
         return 0;
 #undef DISPATCH_N
     };
@@ -993,6 +1043,15 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
 }
 
 int optik_hip_engine_last_trips(const optik_hip_chain *ch) { return ch ? ch->eng_trips : 0; }
+
+int optik_hip_engine_stats(const optik_hip_chain *ch, double *kernel_ms4, int32_t *sampled_trips,
+                           uint64_t *nnls_problems) {
+    if (!ch) return fail(OPTIK_HIP_EINVAL, "bad argument");
+    if (kernel_ms4) for (int k = 0; k < 4; ++k) kernel_ms4[k] = ch->eng_kernel_ms[k];
+    if (sampled_trips) *sampled_trips = ch->eng_tcount;
+    if (nnls_problems) *nnls_problems = ch->eng_nn_problems;
+    return 0;
+}
 
 int optik_hip_ik_host(optik_hip_chain *ch, const optik_solver_config *cfg, const double *targets,
                       const double *x0, int32_t T, const double *ee_offset7, uint64_t restart_begin,

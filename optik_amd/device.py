@@ -158,6 +158,15 @@ class HipChain:
         self._pending = []
         return int(nat.lib().optik_hip_engine_last_trips(self._h))
 
+    def engine_stats(self):
+        """Per-kernel mean ms {eval, update, nnls, finish} over the sampled trips of the last
+        engine_run (needs set_timing(True)), sampled trips, NNLS problems solved."""
+        ms = (C.c_double * 4)()
+        cnt, prob = C.c_int32(0), C.c_uint64(0)
+        nat.check(nat.lib().optik_hip_engine_stats(self._h, ms, C.byref(cnt), C.byref(prob)))
+        return dict(eval_ms=ms[0], update_ms=ms[1], nnls_ms=ms[2], finish_ms=ms[3],
+                    sampled_trips=cnt.value, nnls_problems=prob.value)
+
     def set_timing(self, enabled=True):
         nat.lib().optik_hip_set_timing(self._h, 1 if enabled else 0)
 
