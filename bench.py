@@ -35,6 +35,21 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r1_engine_pmc_traffic.json")
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same
+    command (tools/profile_round.sh; FETCH_SIZE and WRITE_SIZE collected in separate runs).
+    gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts half the bytes of a wide
+    coalesced read, so it is doubled; both counters are in KB."""
+    try:
+        with open(PMC_TRAFFIC_FILE) as fh:
+            k = json.load(fh)["kernels"][kernel]
+        return (2.0 * k["FETCH_SIZE"]["mean_kb_per_launch"] + k["WRITE_SIZE"]["mean_kb_per_launch"]) * 1024.0
+    except (OSError, KeyError, ValueError):
+        return None
+
 
 
 def load_chain(robot):
@@ -195,12 +210,16 @@ def main():
                               "finish": 8 * (2 * nl + 7 * n + 2 * n + 10)}[dom]
             kernel_ms = per_kernel[dom]
             achieved = unit_bytes * units / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+            kname = {"eval": "eng_eval_kernel", "update": "eng_update_kernel", "nnls": "eng_nnls_coop_kernel",
+                     "finish": "eng_finish_kernel"}[dom]
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": f"eng_{dom}_kernel",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kname),
+                    "traffic_source": os.path.relpath(PMC_TRAFFIC_FILE, ROOT), "kernel": kname,
                     "kernel_ms": kernel_ms, "launches_timed": st["sampled_trips"],
+                    "algorithmic_bytes_per_launch": unit_bytes * units,
                     "algorithmic_bytes_per_unit": unit_bytes, "units_per_launch": units,
-                    "unit": "GB/s", "all_kernels_ms": per_kernel, "trips": trips,
-                    "restart_output_bytes": out_bytes}
+                    "unit_name": "bounded sub-problem" if dom == "nnls" else "slot-trip",
+                    "all_kernels_ms": per_kernel, "trips": trips, "restart_output_bytes": out_bytes}
             info = {"grid": None, "block": 256, "lds_bytes": 0}
         else:
             kernel_ms, launches = hc.timing_mean()

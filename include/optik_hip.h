@@ -147,8 +147,8 @@ int optik_hip_engine_submit(optik_hip_chain *chain, const optik_solver_config *c
 int optik_hip_engine_run(optik_hip_chain *chain, void *stream);
 int optik_hip_engine_last_trips(const optik_hip_chain *chain);
 /* Last run, when timing is enabled (optik_hip_set_timing): mean duration in ms of the four
- * phase kernels {eval, update, nnls, finish} over the sampled trips (HIP event pairs on
- * the launch stream, every 4th trip), and the number of bounded sub-problems solved. */
+ * phase kernels {eval, update, nnls, finish} over the trips of the run (HIP event pairs on
+ * the launch stream, first 1024 trips), and the number of bounded sub-problems solved. */
 int optik_hip_engine_stats(const optik_hip_chain *chain, double *kernel_ms4, int32_t *sampled_trips,
                            uint64_t *nnls_problems);
 

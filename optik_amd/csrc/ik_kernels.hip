@@ -362,7 +362,7 @@ struct optik_hip_chain {
     hipEvent_t eng_ev[8] = {};
     int eng_trips = 0;                     // trips of the last run
     // per-kernel HIP-event timing of sampled trips (eval, update, nnls, finish)
-    static constexpr int ENG_EV = 64;
+    static constexpr int ENG_EV = 1024;
     hipEvent_t eng_tev[4][ENG_EV][2] = {};
     int eng_tcount = 0;                    // sampled trips of the last run
     double eng_kernel_ms[4] = {0, 0, 0, 0};
@@ -887,8 +887,6 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
         if (!ch->eng_nn_total) HIP_TRY(hipMalloc(&ch->eng_nn_total, sizeof(unsigned long long)));
         HIP_TRY(hipMemsetAsync(ch->eng_nn_total, 0, sizeof(unsigned long long), stream));
         for (auto &e : ch->eng_ev) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        if (ch->timing)
-            for (auto &k : ch->eng_tev) for (auto &p2 : k) for (auto &e : p2) if (!e) HIP_TRY(hipEventCreate(&e));
         ch->eng_tcount = 0;
 
         std::vector<EngJob> hj(n_jobs);
@@ -947,10 +945,12 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
                 a.parity = trip & 1;
                 HIP_TRY(hipMemsetAsync(ch->eng_counters + (a.parity ^ 1), 0, sizeof(unsigned int), stream));
                 HIP_TRY(hipMemsetAsync(ch->eng_counters + 2, 0, sizeof(unsigned int), stream));
-                // sample every 4th trip with HIP event pairs around each kernel (launch stream)
-                const bool timed = ch->timing && trip > 0 && (trip % 4 == 0) && ch->eng_tcount < optik_hip_chain::ENG_EV;
+                // HIP event pairs around each kernel of every trip (on the launch stream)
+                const bool timed = ch->timing && trip > 0 && ch->eng_tcount < optik_hip_chain::ENG_EV;
                 const int ts = ch->eng_tcount;
-#define TEV(kind, which) do { if (timed) HIP_TRY(hipEventRecord(ch->eng_tev[kind][ts][which], stream)); } while (0)
+                // (the NNLS kernel -- the longest -- is timed on every trip, the others on every 8th)
+                const bool timed_all = timed && (trip % 8 == 0);
+#define TEV(kind, which) do { if (timed && (kind == 2 || timed_all)) { hipEvent_t &tev_ = ch->eng_tev[kind][ts][which]; if (!tev_) HIP_TRY(hipEventCreate(&tev_)); HIP_TRY(hipEventRecord(tev_, stream)); } } while (0)
                 TEV(0, 0);
                 if (trip > 0) {
                     if (tip) DISPATCH_N(hipLaunchKernelGGL((eng_eval_kernel<6, true>), dim3(blocks), dim3(256), 0, stream, a),
@@ -1020,12 +1020,16 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
         HIP_TRY(hipStreamSynchronize(stream));
         for (int k = 0; k < 4; ++k) {
             double sum = 0.0;
+            int cnt = 0;
             for (int i = 0; i < ch->eng_tcount; ++i) {
+                const int trip_i = i + 1;  // sample i was taken on trip i + 1
+                if (k != 2 && trip_i % 8 != 0) continue;
                 float ms = 0.0f;
                 HIP_TRY(hipEventElapsedTime(&ms, ch->eng_tev[k][i][0], ch->eng_tev[k][i][1]));
                 sum += ms;
+                ++cnt;
             }
-            ch->eng_kernel_ms[k] = ch->eng_tcount ? sum / ch->eng_tcount : 0.0;
+            ch->eng_kernel_ms[k] = cnt ? sum / cnt : 0.0;
         }
         HIP_TRY(hipMemcpy(&ch->eng_nn_problems, ch->eng_nn_total, sizeof(unsigned long long), hipMemcpyDeviceToHost));
         return 0;
