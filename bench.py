@@ -116,12 +116,19 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: optik_amd has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # OPTIK_BENCH_BACKEND=gloo + OPTIK_BENCH_ONE_DEVICE=1 exercise the multi-rank path on a
+    # single-GPU box (all ranks share cuda:0); the real runs use nccl (= RCCL) and one GPU per rank
+    backend = os.environ.get("OPTIK_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("OPTIK_BENCH_ONE_DEVICE") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     from optik_amd import _native as nat
     from optik_amd.parallel import shard_range, select_winner
@@ -181,8 +188,9 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if distributed:
+        from optik_amd.parallel import _all_reduce
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        _all_reduce(tmax, dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
     last = bufs[K - 1] if args.path == "engine" else bufs[0]

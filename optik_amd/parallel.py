@@ -35,6 +35,19 @@ def local_key(bufs, mode: str):
     return key, idx
 
 
+def _all_reduce(t, op):
+    """dist.all_reduce in place; with the gloo backend (CPU tests, single-GPU smoke runs of the
+    multi-rank path) device tensors are staged through the host."""
+    import torch.distributed as dist
+    if t.is_cuda and dist.get_backend() == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
 def select_winner(bufs, mode: str, distributed: bool):
     """Global winner index per target (int64 [T], I64_MAX = no solution anywhere).
     Two tiny RCCL min-all-reduces; with one rank it is the local result."""
@@ -43,9 +56,9 @@ def select_winner(bufs, mode: str, distributed: bool):
         return idx
     import torch.distributed as dist
     gkey = key.clone()
-    dist.all_reduce(gkey, op=dist.ReduceOp.MIN)
+    _all_reduce(gkey, dist.ReduceOp.MIN)
     cand = torch.where(key == gkey, idx, torch.full_like(idx, I64_MAX))
-    dist.all_reduce(cand, op=dist.ReduceOp.MIN)
+    _all_reduce(cand, dist.ReduceOp.MIN)
     return cand
 
 
@@ -60,6 +73,6 @@ def gather_winner_x(bufs, winner_idx, begin: int, end: int, distributed: bool):
     mine = (winner_idx >= begin) & (winner_idx < end) & (winner_idx == bufs["win_idx"])
     x = torch.where(mine[:, None], x, torch.zeros_like(x))
     f = torch.where(mine, f, torch.zeros_like(f))
-    dist.all_reduce(x, op=dist.ReduceOp.SUM)
-    dist.all_reduce(f, op=dist.ReduceOp.SUM)
+    _all_reduce(x, dist.ReduceOp.SUM)
+    _all_reduce(f, dist.ReduceOp.SUM)
     return x, f

@@ -1,0 +1,153 @@
+"""-m gpu: BASELINE.json's full-size configurations, checked through size-independent
+properties (the oracle would take minutes at these sizes; the bit-exact comparison against
+it is done at smaller sizes in test_gpu_parity.py):
+
+  * round trip: every restart reported as solved satisfies FK(x) == target to the pose
+    tolerance implied by tol_f, and respects the joint limits;
+  * the two GPU execution paths (single kernel / streaming engine) agree bit for bit --
+    a checksum over every per-restart output;
+  * selection: the reported winner is the lowest solved index (Speed) / the solved restart
+    closest to the seed (Quality), recomputed from the per-restart outputs;
+  * sharding a restart range (the multi-GPU partition) does not change any result.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROBOTS
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def robots():
+    from optik_amd import Robot
+    return {"panda": Robot.from_urdf_file(os.path.join(ROBOTS, "panda.urdf"), "panda_link0", "panda_link8"),
+            "ur10": Robot.from_urdf_file(os.path.join(ROBOTS, "ur10.urdf"), "base_link", "ee_link")}
+
+
+def _targets(robot, hc, T, seed):
+    rng = np.random.default_rng(seed)
+    lb, ub = (np.array(v) for v in robot.joint_limits())
+    q = rng.uniform(lb, ub, size=(T, len(lb)))
+    tg = hc.fk_batch(torch.tensor(q.T.copy(), device="cuda")).T.contiguous()
+    x0 = torch.tensor(rng.uniform(lb, ub, size=(T, len(lb))), device="cuda")
+    return tg, x0, lb, ub
+
+
+def _checksum(out):
+    """Order-sensitive 64-bit mix of every per-restart output (bit patterns)."""
+    parts = [out["x"].view(torch.int64).flatten(), out["f"].view(torch.int64),
+             out["status"].to(torch.int64), out["evals"].to(torch.int64)]
+    h = torch.zeros((), dtype=torch.int64, device=out["f"].device)
+    for p in parts:
+        idx = torch.arange(p.numel(), device=p.device, dtype=torch.int64)
+        h = h * 1000003 + ((p ^ (idx * 0x9E3779B97F4A7C15 % (2 ** 62))).sum())
+    return int(h.item())
+
+
+def _pose_error(hc, x, target7):
+    """max |FK(x) - target| over translation and (sign-aligned) quaternion, per column."""
+    pose = hc.fk_batch(x.contiguous())
+    t = target7.view(7, 1)
+    dt = (pose[:3] - t[:3]).abs().amax(0)
+    dq = torch.minimum((pose[3:] - t[3:]).abs().amax(0), (pose[3:] + t[3:]).abs().amax(0))
+    return torch.maximum(dt, dq)
+
+
+def test_config2_panda_65536_speed(robots):
+    """Panda 7-DoF, 65 536 restarts, SolutionMode::Speed (the bench configuration)."""
+    from optik_amd import _native as nat
+    robot = robots["panda"]
+    hc = robot.hip_chain("cuda:0")
+    tg, x0, lb, ub = _targets(robot, hc, 1, 0)
+    cfg = nat.make_config("speed", tol_f=1e-6)
+    R = 65536
+    a = hc.ik_batch(cfg, tg, x0, 0, R)
+    b = hc.engine_submit(cfg, tg, x0, 0, R)
+    hc.engine_run()
+    torch.cuda.synchronize()
+    assert _checksum(a) == _checksum(b)
+    assert torch.equal(a["win_idx"], b["win_idx"]) and torch.equal(a["win_x"], b["win_x"])
+    ok = a["status"] == nat.RES_STOPVAL
+    assert 0.05 < ok.double().mean().item() < 0.95
+    assert set(a["status"].unique().tolist()) <= {nat.RES_STOPVAL, nat.RES_FTOL, nat.RES_ROUNDOFF, nat.RES_FAILURE}
+    # round trip on every solved restart: f < 1e-6 is a squared log error -> pose error < ~1e-3
+    err = _pose_error(hc, a["x"][:, ok], tg[0])
+    assert err.max().item() < 2e-3
+    assert (a["f"][ok] < 1e-6).all() and (a["f"][~ok] >= 1e-6).all()
+    x = a["x"]
+    assert (x >= torch.tensor(lb, device="cuda")[:, None]).all() and (x <= torch.tensor(ub, device="cuda")[:, None]).all()
+    # Speed: the winner is the lowest solved index (the reference's 1-thread order)
+    assert int(a["win_idx"][0]) == int(torch.nonzero(ok)[0])
+
+
+def test_config3_ur10_one_million_tight_tolerance(robots):
+    """UR10 6-DoF, 2^20 restarts, tol_f = 1e-12 (tests/test_ik.rs:99): isolated solutions."""
+    from optik_amd import _native as nat
+    robot = robots["ur10"]
+    hc = robot.hip_chain("cuda:0")
+    tg, x0, lb, ub = _targets(robot, hc, 1, 3)
+    cfg = nat.make_config("quality", tol_f=1e-12)
+    R = 1 << 20
+    out = hc.engine_submit(cfg, tg, x0, 0, R)
+    hc.engine_run()
+    torch.cuda.synchronize()
+    ok = out["status"] == nat.RES_STOPVAL
+    assert ok.sum().item() > 1000
+    err = _pose_error(hc, out["x"][:, ok], tg[0])
+    assert err.max().item() < 1e-6          # FK(ik(T)) == T to 1e-6, as the reference test asserts
+    # a non-redundant arm has finitely many solutions (8 branches x 2*pi wraps inside the +-2*pi
+    # limits): the solved restarts cluster on a few hundred points
+    xs = out["x"][:, ok].T
+    uniq = torch.unique(torch.round(xs * 1e4), dim=0)
+    assert uniq.shape[0] * 100 < xs.shape[0]
+    # Quality: winner = solved restart closest to the seed, ties to the lower index
+    d = (xs - x0[0]).norm(dim=1)
+    idx = torch.nonzero(ok).flatten()
+    best = d.min()
+    assert int(out["win_idx"][0]) == int(idx[d == best].min())
+    # sharding (8 ranks x 131072) gives the same per-restart results
+    h = _checksum(out)
+    parts = [hc.ik_batch(cfg, tg, x0, g * (R // 8), (g + 1) * (R // 8)) for g in (0, 5)]
+    torch.cuda.synchronize()
+    for g, p in zip((0, 5), parts):
+        sl = slice(g * (R // 8), (g + 1) * (R // 8))
+        assert torch.equal(p["status"], out["status"][sl]) and torch.equal(p["x"], out["x"][:, sl])
+    assert h == _checksum(out)
+
+
+def test_config5_motion_planning_batch(robots):
+    """4096 independent targets x 256 restarts each (512 targets is one GPU's share), Speed."""
+    from optik_amd import _native as nat
+    robot = robots["panda"]
+    hc = robot.hip_chain("cuda:0")
+    T, R = 4096, 256
+    tg, x0, lb, ub = _targets(robot, hc, T, 5)
+    cfg = nat.make_config("speed", tol_f=1e-6)
+    out = hc.engine_submit(cfg, tg, x0, 0, R)
+    hc.engine_run()
+    torch.cuda.synchronize()
+    st = out["status"].view(T, R)
+    ok = st == nat.RES_STOPVAL
+    solved = ok.any(dim=1)
+    assert solved.double().mean().item() > 0.99        # 256 restarts solve (nearly) every reachable target
+    first = torch.where(solved, ok.double().argmax(dim=1), torch.full((T,), -1, device="cuda"))
+    assert torch.equal(first, out["win_idx"])
+    # round trip of every winner against its own target
+    wx = out["win_x"][solved].T.contiguous()
+    pose = hc.fk_batch(wx)
+    t = tg[solved].T
+    dt = (pose[:3] - t[:3]).abs().amax(0)
+    dq = torch.minimum((pose[3:] - t[3:]).abs().amax(0), (pose[3:] + t[3:]).abs().amax(0))
+    assert torch.maximum(dt, dq).max().item() < 2e-3
+    # one GPU's share (targets 512..1023) through the other path: identical winners
+    sub = hc.ik_batch(cfg, tg[512:1024].contiguous(), x0[512:1024].contiguous(), 0, R)
+    torch.cuda.synchronize()
+    assert torch.equal(sub["win_idx"], out["win_idx"][512:1024])
+    assert torch.equal(sub["win_x"], out["win_x"][512:1024])
+    # the random seeds are the same for every target (lib.rs:360): restart i of any two targets
+    # starts from the same configuration, only restart 0 (the caller's seed) differs
+    assert torch.equal(hc.seed_batch(1, 255), hc.seed_batch(1, 255))
