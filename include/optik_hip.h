@@ -77,7 +77,7 @@ const char *optik_hip_last_error(void);
 
 /* origins: n_joints x 7 poses (Joint::origin), axes: n_joints x 3 (unit axis of
  * each chain joint, ignored for fixed), types: OPTIK_JOINT_*, lb/ub: n limits
- * (Robot::joint_limits, lib.rs:78-84).  Supported: n <= 8 revolute joints plus
+ * (Robot::joint_limits, lib.rs:78-84).  Supported: 2 <= n <= 7 revolute joints plus
  * an optional trailing fixed joint. */
 int optik_hip_chain_create(const double *origins, const double *axes, const int32_t *types,
                            int32_t n_joints, const double *lb, const double *ub, int32_t n,

@@ -464,15 +464,22 @@ int ensure_device() {
 }
 
 // Dispatch on (n, trailing fixed joint).
+// Kernels are instantiated for 2 <= n <= 7 revolute joints (n + 1 <= 8 rows fit the
+// register-resident NNLS of the engine), each with and without a trailing fixed joint.
+#define OPTIK_N_RANGE_MSG "kernels are built for 2 <= n <= 7 revolute joints"
+#define OPTIK_DISPATCH_ONE(NN, CALL)                                                   \
+    if (!done_ && n_ == NN) {                                                          \
+        if (tip_) { CALL(NN, true); } else { CALL(NN, false); }                        \
+        done_ = true;                                                                  \
+    }
 #define OPTIK_DISPATCH(CH, CALL)                                                       \
     do {                                                                               \
         const int n_ = (CH)->n;                                                        \
         const bool tip_ = (CH)->tip;                                                   \
-        if (n_ == 6 && !tip_) { CALL(6, false); }                                      \
-        else if (n_ == 6 && tip_) { CALL(6, true); }                                   \
-        else if (n_ == 7 && !tip_) { CALL(7, false); }                                 \
-        else if (n_ == 7 && tip_) { CALL(7, true); }                                   \
-        else return fail(OPTIK_HIP_EUNSUPPORTED, "kernels are built for n in {6,7}");  \
+        bool done_ = false;                                                            \
+        OPTIK_DISPATCH_ONE(2, CALL) OPTIK_DISPATCH_ONE(3, CALL) OPTIK_DISPATCH_ONE(4, CALL) \
+        OPTIK_DISPATCH_ONE(5, CALL) OPTIK_DISPATCH_ONE(6, CALL) OPTIK_DISPATCH_ONE(7, CALL) \
+        if (!done_) return fail(OPTIK_HIP_EUNSUPPORTED, OPTIK_N_RANGE_MSG);            \
     } while (0)
 
 int grid_for(const optik_hip_chain *ch, long long work, int block, int per_cu) {
@@ -859,9 +866,19 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
     if (C > cap) C = cap;
     int rc = 0;
     auto run = [&]() -> int {
-#define DISPATCH_N(CALL6, CALL7) do { if (ch->n == 6) { CALL6; } else if (ch->n == 7) { CALL7; } else return fail(OPTIK_HIP_EUNSUPPORTED, "kernels are built for n in {6,7}"); } while (0)
+        // M(NN) is a statement macro instantiated for the chain's n
+#define DISPATCH_N(M)                                                                            \
+    do {                                                                                         \
+        switch (ch->n) {                                                                         \
+        case 2: M(2); break; case 3: M(3); break; case 4: M(4); break;                           \
+        case 5: M(5); break; case 6: M(6); break; case 7: M(7); break;                           \
+        default: return fail(OPTIK_HIP_EUNSUPPORTED, OPTIK_N_RANGE_MSG);                         \
+        }                                                                                        \
+    } while (0)
         int nd = 0, ni = 0;
-        DISPATCH_N((nd = EngLayout<6>::ND, ni = EngLayout<6>::NI), (nd = EngLayout<7>::ND, ni = EngLayout<7>::NI));
+#define M_LAYOUT(NN) nd = EngLayout<NN>::ND; ni = EngLayout<NN>::NI
+        DISPATCH_N(M_LAYOUT);
+#undef M_LAYOUT
         if (C > ch->eng_C) {
             if (ch->eng_d) HIP_TRY(hipFree(ch->eng_d));
             if (ch->eng_i32) HIP_TRY(hipFree(ch->eng_i32));
@@ -953,20 +970,25 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
 #define TEV(kind, which) do { if (timed && (kind == 2 || timed_all)) { hipEvent_t &tev_ = ch->eng_tev[kind][ts][which]; if (!tev_) HIP_TRY(hipEventCreate(&tev_)); HIP_TRY(hipEventRecord(tev_, stream)); } } while (0)
                 TEV(0, 0);
                 if (trip > 0) {
-                    if (tip) DISPATCH_N(hipLaunchKernelGGL((eng_eval_kernel<6, true>), dim3(blocks), dim3(256), 0, stream, a),
-                                        hipLaunchKernelGGL((eng_eval_kernel<7, true>), dim3(blocks), dim3(256), 0, stream, a));
-                    else DISPATCH_N(hipLaunchKernelGGL((eng_eval_kernel<6, false>), dim3(blocks), dim3(256), 0, stream, a),
-                                    hipLaunchKernelGGL((eng_eval_kernel<7, false>), dim3(blocks), dim3(256), 0, stream, a));
+#define M_EVAL_T(NN) hipLaunchKernelGGL((eng_eval_kernel<NN, true>), dim3(blocks), dim3(256), 0, stream, a)
+#define M_EVAL_F(NN) hipLaunchKernelGGL((eng_eval_kernel<NN, false>), dim3(blocks), dim3(256), 0, stream, a)
+                    if (tip) DISPATCH_N(M_EVAL_T);
+                    else DISPATCH_N(M_EVAL_F);
+#undef M_EVAL_T
+#undef M_EVAL_F
                 }
                 TEV(0, 1); TEV(1, 0);
-                DISPATCH_N(hipLaunchKernelGGL((eng_update_kernel<6>), dim3(blocks), dim3(256), 0, stream, a),
-                           hipLaunchKernelGGL((eng_update_kernel<7>), dim3(blocks), dim3(256), 0, stream, a));
+#define M_UPD(NN) hipLaunchKernelGGL((eng_update_kernel<NN>), dim3(blocks), dim3(256), 0, stream, a)
+                DISPATCH_N(M_UPD);
+#undef M_UPD
                 TEV(1, 1); TEV(2, 0);
-                DISPATCH_N(hipLaunchKernelGGL((eng_nnls_coop_kernel<6>), dim3(nn_blocks), dim3(256), 0, stream, a),
-                           hipLaunchKernelGGL((eng_nnls_coop_kernel<7>), dim3(nn_blocks), dim3(256), 0, stream, a));
+#define M_NNLS(NN) hipLaunchKernelGGL((eng_nnls_coop_kernel<NN>), dim3(nn_blocks), dim3(256), 0, stream, a)
+                DISPATCH_N(M_NNLS);
+#undef M_NNLS
                 TEV(2, 1); TEV(3, 0);
-                DISPATCH_N(hipLaunchKernelGGL((eng_finish_kernel<6>), dim3(blocks), dim3(256), 0, stream, a),
-                           hipLaunchKernelGGL((eng_finish_kernel<7>), dim3(blocks), dim3(256), 0, stream, a));
+#define M_FIN(NN) hipLaunchKernelGGL((eng_finish_kernel<NN>), dim3(blocks), dim3(256), 0, stream, a)
+                DISPATCH_N(M_FIN);
+#undef M_FIN
                 TEV(3, 1);
 #undef TEV
                 if (timed) ch->eng_tcount += 1;

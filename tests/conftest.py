@@ -34,6 +34,11 @@ ROBOT_SPECS = {
     "panda": (os.path.join(ROBOTS, "panda.urdf"), "panda_link0", "panda_link8"),
     "panda_hand": (os.path.join(ROBOTS, "panda.urdf"), "panda_link0", "panda_hand"),
     "ur10": (os.path.join(ROBOTS, "ur10.urdf"), "base_link", "ee_link"),
+    # sub-chains of the Panda: 2..5 revolute joints, no trailing fixed joint
+    "panda2": (os.path.join(ROBOTS, "panda.urdf"), "panda_link0", "panda_link2"),
+    "panda3": (os.path.join(ROBOTS, "panda.urdf"), "panda_link0", "panda_link3"),
+    "panda4": (os.path.join(ROBOTS, "panda.urdf"), "panda_link0", "panda_link4"),
+    "panda5": (os.path.join(ROBOTS, "panda.urdf"), "panda_link0", "panda_link5"),
 }
 
 

@@ -159,6 +159,27 @@ def test_every_restart_bit_exact(dev, oracle, chains, hip_chains, robot, tol_f, 
     assert 0.02 < ref["success"].mean() < 0.98  # both outcomes are exercised
 
 
+@pytest.mark.parametrize("robot", ["panda2", "panda3", "panda4", "panda5"])
+@pytest.mark.parametrize("path", ["kernel", "engine"])
+def test_other_joint_counts_bit_exact(dev, oracle, chains, hip_chains, robot, path):
+    """Kernels are instantiated for 2 <= n <= 7: sub-chains of the Panda (no trailing fixed
+    joint) through both paths, every restart against the oracle."""
+    from optik_amd import _native as nat
+    d, ch = chains[robot]
+    rng = np.random.default_rng(17)
+    tg, x0 = make_targets(oracle, d, ch, rng, 2)
+    kw = dict(solution_mode="quality", tol_f=1e-8)
+    out = _run(hip_chains[robot], path, nat.make_config(**kw), torch.tensor(tg, device="cuda"),
+               torch.tensor(x0, device="cuda"), 0, 384)
+    st = out["status"].cpu().numpy().reshape(2, -1)
+    xs = out["x"].cpu().numpy()
+    for t in range(2):
+        ref = _oracle_all(oracle, ch, kw, tg[t], x0[t], 0, 384)
+        assert np.array_equal(st[t], ref["status"])
+        assert_bit_equal(xs[:, t * 384:(t + 1) * 384], ref["xs"].T, f"x target {t}")
+        assert int(out["win_idx"].cpu()[t]) == (ref["winner"] if ref["found"] else -1)
+
+
 def test_restart_ranges_compose(dev, oracle, chains, hip_chains):
     """Sharding [0,R) into ranges (the multi-GPU partition) gives the same per-restart
     results; a ragged range (not a multiple of 64) is handled."""
