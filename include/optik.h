@@ -57,6 +57,13 @@ const char *optik_robot_last_error(void);
 int optik_robot_ik_ex(const optik_robot *robot, const CSolverConfig *config, const double *target16,
                       const double *x0, const double *ee_offset16, double *x_out, double *f_out,
                       uint64_t *winner_out);
+/* T independent ik() calls with one SolverConfig: targets16 [T][16] (4x4 col-major each),
+ * x0 [T][n] -> x_out [T][n], f_out [T], found_out [T] (0/1).  Every target gets Robot::ik's
+ * semantics; the batch runs on the streaming engine (config 5 of BASELINE.json: many
+ * targets x a few hundred restarts).  rc 0 = ran, < 0 = error. */
+int optik_robot_ik_batch_ex(const optik_robot *robot, const CSolverConfig *config, int32_t T,
+                            const double *targets16, const double *x0, const double *ee_offset16,
+                            double *x_out, double *f_out, int32_t *found_out);
 int optik_robot_fk_ex(const optik_robot *robot, const double *x, const double *ee_offset16,
                       double *pose16_out);
 int optik_robot_joint_jacobian_ex(const optik_robot *robot, const double *x,

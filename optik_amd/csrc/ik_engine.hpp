@@ -69,7 +69,11 @@ struct EngJob {
     int32_t *out_evals;
     unsigned long long *first_success; // [T] or null (Speed early exit)
     int quality;
-    int pad;
+    // queue order of the job's work items: 0 = target-major (item = t*R + r), 1 = restart-major
+    // (item = r*T + t: every target's low restart indices first -- with Speed early exit most
+    // higher indices are then abandoned before they are ever evaluated)
+    int restart_major;
+    unsigned long long n_targets;      // T
 };
 
 constexpr int ENG_MAX_JOBS = 64;
@@ -431,9 +435,12 @@ OPTIK_DEV void eng_update_body(const EngArgs &a, const ChainDev &ch, size_t slot
                 for (int j = 1; j < a.n_jobs; ++j)
                     if (it >= a.jobs[j].item_base) job = j;
                 const EngJob &J = a.jobs[job];
-                const unsigned long long item = it - J.item_base;
-                const unsigned long long tslot = item / J.n_restarts;
-                const unsigned long long index = J.restart_begin + (item - tslot * J.n_restarts);
+                const unsigned long long qi = it - J.item_base;
+                unsigned long long tslot, r;
+                if (J.restart_major) { r = qi / J.n_targets; tslot = qi - r * J.n_targets; }
+                else { tslot = qi / J.n_restarts; r = qi - tslot * J.n_restarts; }
+                const unsigned long long item = tslot * J.n_restarts + r;  // output column
+                const unsigned long long index = J.restart_begin + r;
                 double x[N];
                 restart_seed<N>(a.key, ch.lb, a.scale, index, x);
                 if (index == 0) {  // lib.rs:366-370: restart 0 starts from the caller's seed
@@ -456,6 +463,12 @@ OPTIK_DEV void eng_update_body(const EngArgs &a, const ChainDev &ch, size_t slot
                 ENG_I(E::JOB) = job;
                 a.item[slot] = item;
                 st = ST_EVAL_FIRST;
+                if (J.first_success) {
+                    // lib.rs:308 at the restart's first callback: a lower index already succeeded
+                    const unsigned long long fs = __hip_atomic_load(J.first_success + tslot, __ATOMIC_RELAXED,
+                                                                    __HIP_MEMORY_SCOPE_AGENT);
+                    if (fs < index) { ENG_I(E::STATUS) = RES_FORCED_STOP; st = ST_DEAD; }
+                }
             } else {
                 st = ST_EMPTY;
             }

@@ -847,6 +847,8 @@ int optik_hip_engine_submit(optik_hip_chain *ch, const optik_solver_config *cfg,
     j.dev.out_status = out->d_status; j.dev.out_evals = out->d_evals;
     j.dev.first_success = j.own_fs;
     j.dev.quality = (cfg->solution_mode == 1);
+    j.dev.restart_major = (early && T > 1) ? 1 : 0;
+    j.dev.n_targets = (unsigned long long)T;
     ch->eng_jobs.push_back(j);
     return 0;
 }
@@ -864,6 +866,18 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
     if (const char *e = std::getenv("OPTIK_ENGINE_SLOTS")) { const long v = std::atol(e); if (v >= 256) cap = (size_t)v; }
     size_t C = (size_t)((total + 255ull) / 256ull * 256ull);
     if (C > cap) C = cap;
+    {
+        // Speed jobs with early exit abandon most restarts above the first success: a pool of a
+        // few restarts per target keeps the phase kernels small (their cost is per slot scanned)
+        bool all_early = true;
+        unsigned long long targets = 0;
+        for (const auto &j : ch->eng_jobs) { all_early = all_early && j.own_fs != nullptr; targets += (unsigned long long)j.T; }
+        if (all_early && !std::getenv("OPTIK_ENGINE_SLOTS")) {
+            size_t want = (size_t)((targets * 8ull + 255ull) / 256ull * 256ull);
+            if (want < 16384) want = 16384;
+            if (want < C) C = want;
+        }
+    }
     int rc = 0;
     auto run = [&]() -> int {
         // M(NN) is a statement macro instantiated for the chain's n

@@ -314,6 +314,105 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
     return 0;
 }
 
+// Many independent ik() calls at once (the motion-planning workload of examples/example.rs:
+// a stream of targets, each with its own seed): every target gets the semantics of Robot::ik
+// with the same SolverConfig.  Runs on the streaming engine in rounds of `round` restart
+// indices per target; targets already solved (Speed) drop out of later rounds; max_time is
+// checked between rounds.
+int optik_robot_ik_batch_ex(const optik_robot *r, const CSolverConfig *config, int32_t T,
+                            const double *targets16, const double *x0, const double *ee16, double *x_out,
+                            double *f_out, int32_t *found_out) {
+    if (!r || !config || !targets16 || !x0 || T < 1) return set_err(-1, "bad argument");
+    const int n = r->n;
+    for (int t = 0; t < T; ++t)
+        for (int i = 0; i < n; ++i)
+            if (x0[(size_t)t * n + i] < r->lb[i] || x0[(size_t)t * n + i] > r->ub[i])
+                return set_err(-2, "seed joint position outside of joint limits");
+    optik_hip_chain *h = device_chain(r);
+    if (!h) return -1;
+    double ee7[7];
+    if (ee16) pose7_from_mat16(ee16, ee7);
+    const auto start = std::chrono::steady_clock::now();
+    auto elapsed = [&]() {
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
+    };
+    const uint64_t max_restarts = config->max_restarts > 0 ? config->max_restarts : UINT64_MAX;
+    const bool quality = config->solution_mode == 1;
+    const uint64_t round = 256;  // restart indices per target per engine run
+
+    std::vector<double> tgt7((size_t)T * 7), best_key((size_t)T, 0.0);
+    std::vector<uint64_t> best_idx((size_t)T, UINT64_MAX);
+    for (int t = 0; t < T; ++t) pose7_from_mat16(targets16 + (size_t)t * 16, &tgt7[(size_t)t * 7]);
+    std::vector<int> live((size_t)T);
+    for (int t = 0; t < T; ++t) live[t] = t;
+    for (int t = 0; t < T; ++t) if (found_out) found_out[t] = 0;
+
+    double *d_t = nullptr, *d_x0 = nullptr, *d_wx = nullptr, *d_wf = nullptr, *d_wk = nullptr;
+    uint64_t *d_wi = nullptr;
+    auto cleanup = [&]() {
+        if (d_t) (void)hipFree(d_t);
+        if (d_x0) (void)hipFree(d_x0);
+        if (d_wx) (void)hipFree(d_wx);
+        if (d_wf) (void)hipFree(d_wf);
+        if (d_wk) (void)hipFree(d_wk);
+        if (d_wi) (void)hipFree(d_wi);
+    };
+#define TRYH(expr) do { if ((expr) != hipSuccess) { cleanup(); return set_err(-1, #expr " failed"); } } while (0)
+    TRYH(hipMalloc(&d_t, sizeof(double) * 7 * (size_t)T));
+    TRYH(hipMalloc(&d_x0, sizeof(double) * (size_t)n * (size_t)T));
+    TRYH(hipMalloc(&d_wx, sizeof(double) * (size_t)n * (size_t)T));
+    TRYH(hipMalloc(&d_wf, sizeof(double) * (size_t)T));
+    TRYH(hipMalloc(&d_wk, sizeof(double) * (size_t)T));
+    TRYH(hipMalloc(&d_wi, sizeof(uint64_t) * (size_t)T));
+    std::vector<double> ht, hx, wx, wf, wk;
+    std::vector<uint64_t> wi;
+    for (uint64_t begin = 0; begin < max_restarts && !live.empty();) {
+        if (config->max_time > 0.0 && elapsed() > config->max_time) break;  // lib.rs:393
+        const uint64_t end = (max_restarts - begin > round) ? begin + round : max_restarts;
+        const int L = (int)live.size();
+        ht.resize((size_t)L * 7); hx.resize((size_t)L * n);
+        for (int k = 0; k < L; ++k) {
+            std::memcpy(&ht[(size_t)k * 7], &tgt7[(size_t)live[k] * 7], sizeof(double) * 7);
+            std::memcpy(&hx[(size_t)k * n], &x0[(size_t)live[k] * n], sizeof(double) * (size_t)n);
+        }
+        TRYH(hipMemcpy(d_t, ht.data(), sizeof(double) * ht.size(), hipMemcpyHostToDevice));
+        TRYH(hipMemcpy(d_x0, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice));
+        optik_hip_ik_outputs o;
+        std::memset(&o, 0, sizeof o);
+        o.d_win_x = d_wx; o.d_win_f = d_wf; o.d_win_idx = d_wi; o.d_win_key = d_wk;
+        int rc = optik_hip_engine_submit(h, config, d_t, d_x0, L, ee16 ? ee7 : nullptr, begin, end,
+                                         quality ? 0u : OPTIK_HIP_IK_EARLY_EXIT, &o);
+        if (!rc) rc = optik_hip_engine_run(h, nullptr);
+        if (rc) { cleanup(); return set_err(-1, optik_hip_last_error()); }
+        wx.resize((size_t)L * n); wf.resize((size_t)L); wk.resize((size_t)L); wi.resize((size_t)L);
+        TRYH(hipMemcpy(wx.data(), d_wx, sizeof(double) * wx.size(), hipMemcpyDeviceToHost));
+        TRYH(hipMemcpy(wf.data(), d_wf, sizeof(double) * wf.size(), hipMemcpyDeviceToHost));
+        TRYH(hipMemcpy(wk.data(), d_wk, sizeof(double) * wk.size(), hipMemcpyDeviceToHost));
+        TRYH(hipMemcpy(wi.data(), d_wi, sizeof(uint64_t) * wi.size(), hipMemcpyDeviceToHost));
+        std::vector<int> still;
+        for (int k = 0; k < L; ++k) {
+            const int t = live[k];
+            if (wi[k] != UINT64_MAX) {
+                const bool better = best_idx[t] == UINT64_MAX || wk[k] < best_key[t]
+                                    || (wk[k] == best_key[t] && wi[k] < best_idx[t]);
+                if (better) {
+                    best_idx[t] = wi[k]; best_key[t] = wk[k];
+                    if (x_out) std::memcpy(&x_out[(size_t)t * n], &wx[(size_t)k * n], sizeof(double) * (size_t)n);
+                    if (f_out) f_out[t] = wf[k];
+                    if (found_out) found_out[t] = 1;
+                }
+                if (!quality) continue;  // Speed: the first solution ends this target
+            }
+            still.push_back(t);
+        }
+        live.swap(still);
+        begin = end;
+    }
+#undef TRYH
+    cleanup();
+    return 0;
+}
+
 const double *optik_robot_ik(const optik_robot *r, const CSolverConfig *config, const double *target,
                              const double *x0) {
     std::vector<double> x((size_t)r->n);

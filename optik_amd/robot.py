@@ -29,6 +29,8 @@ def _bind(L):
     L.optik_robot_num_positions.restype = C.c_uint
     L.optik_robot_ik_ex.argtypes = [vp, C.POINTER(nat.SolverConfigC), dp, dp, dp, dp, dp,
                                     C.POINTER(C.c_uint64)]
+    L.optik_robot_ik_batch_ex.argtypes = [vp, C.POINTER(nat.SolverConfigC), C.c_int32, dp, dp, dp, dp, dp,
+                                          C.POINTER(C.c_int32)]
     L.optik_robot_fk_ex.argtypes = [vp, dp, dp, dp]
     L.optik_robot_joint_jacobian_ex.argtypes = [vp, dp, dp, dp]
     L.optik_robot_chain_tables.argtypes = [vp, C.POINTER(C.c_int32), dp, dp, C.POINTER(C.c_int32)]
@@ -172,6 +174,28 @@ class Robot:
         if rc == 1:
             return None
         return (x.tolist(), f.value, idx.value) if return_index else (x.tolist(), f.value)
+
+    def ik_batch(self, config: SolverConfig, targets, x0s, ee_offset=None):
+        """Many ik() calls at once (extension): `targets` [T] 4x4 row-major poses, `x0s` [T][n]
+        seeds -> list of (x, c) or None per target, each with the semantics of ik()."""
+        tg = np.asarray(targets, dtype=np.float64)
+        if tg.ndim != 3 or tg.shape[1:] != (4, 4):
+            raise ValueError("targets must be [T, 4, 4]")
+        T = tg.shape[0]
+        n = self.num_positions()
+        x0s = np.ascontiguousarray(x0s, dtype=np.float64).reshape(T, n)
+        tg16 = np.ascontiguousarray(tg.transpose(0, 2, 1)).reshape(T, 16)  # column-major per pose
+        ee = _pose16(ee_offset) if ee_offset is not None else None
+        cfg = config.to_c()
+        x = np.zeros((T, n))
+        f = np.zeros(T)
+        found = np.zeros(T, dtype=np.int32)
+        rc = self._L.optik_robot_ik_batch_ex(self._h, C.byref(cfg), T, _dp(tg16), _dp(x0s),
+                                             _dp(ee) if ee is not None else None, _dp(x), _dp(f),
+                                             found.ctypes.data_as(C.POINTER(C.c_int32)))
+        if rc < 0:
+            raise RuntimeError(_err(self._L))
+        return [(x[t].tolist(), float(f[t])) if found[t] else None for t in range(T)]
 
     def diff_ik(self, x0, V_WE, v_max, ee_offset=None):
         raise NotImplementedError(

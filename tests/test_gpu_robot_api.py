@@ -196,3 +196,36 @@ def test_c_abi_ik_returns_malloced_buffer(ur3e):
     far = (C.c_double * 16)(*np.eye(4).T.ravel())
     far[12] = far[13] = far[14] = 100.0
     assert not bool(L.optik_robot_ik(ur3e._h, C.byref(cfg), far, x0))   # NULL = no solution
+
+
+def test_ik_batch_equals_individual_calls(panda, oracle, chains):
+    """Robot.ik_batch (engine, restart-major queue, early exit) returns for every target exactly
+    what ik() returns for it alone -- and what the oracle's restart loop returns."""
+    from optik_amd import SolverConfig
+    _, ch = chains["panda"]
+    rng = np.random.default_rng(8)
+    lb, ub = (np.array(v) for v in panda.joint_limits())
+    T = 48
+    targets = [np.array(panda.fk(rng.uniform(lb, ub))) for _ in range(T)]
+    x0s = rng.uniform(lb, ub, size=(T, 7))
+    for mode in ("speed", "quality"):
+        cfg = SolverConfig(solution_mode=mode, max_time=0.0, max_restarts=40)
+        batch = panda.ik_batch(cfg, targets, x0s)
+        assert len(batch) == T
+        for t in (0, 7, 19, 33, 47):
+            single = panda.ik(cfg, targets[t], x0s[t].tolist())
+            assert (batch[t] is None) == (single is None)
+            if single is not None:
+                assert batch[t][0] == single[0] and batch[t][1] == single[1]
+        # against the oracle (targets enter through the 4x4 -> pose conversion of the host layer)
+        for t in (3, 11):
+            ref = oracle.ik(ch, oracle.make_config(solution_mode=mode, max_restarts=40), _mat_to_pose7(targets[t]),
+                            x0s[t], 0, 40)
+            assert ref["found"] == (batch[t] is not None)
+            if ref["found"]:
+                np.testing.assert_allclose(batch[t][0], ref["x"], atol=1e-6, rtol=0)
+    # a target nobody can reach stays None; the others are unaffected
+    far = np.eye(4)
+    far[:3, 3] = 50.0
+    res = panda.ik_batch(SolverConfig(max_time=0.0, max_restarts=16), [targets[0], far], x0s[:2])
+    assert res[1] is None and res[0] is not None
