@@ -67,6 +67,31 @@ OPTIK_DEV Pose pose_inv_mul(const Pose a, const Pose b) {
     return o;
 }
 
+// Small per-lane vectors are LLVM vector values, not arrays: element selection by a
+// per-lane index then stays a chain of v_cndmask on registers.  (With C arrays the
+// optimiser rewrites select(load a[i], load a[j]) into a load through a selected
+// pointer, which forces the whole array into scratch / LDS.)
+typedef double dvec8 __attribute__((ext_vector_type(8)));
+
+OPTIK_DEV double vpick(const dvec8 a, int idx) {  // a[idx-1], idx per lane, 1-based
+    double v = a[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) v = (idx == i + 1) ? a[i] : v;
+    return v;
+}
+
+OPTIK_DEV void vput(dvec8 &a, int idx, double v) {  // a[idx-1] = v
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (idx == i + 1) ? v : a[i];
+}
+
+OPTIK_DEV dvec8 vsel(bool c, const dvec8 a, const dvec8 b) {
+    dvec8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = c ? a[i] : b[i];
+    return o;
+}
+
 // ---- elementary functions (same operation sequence as the oracle) ---------
 
 OPTIK_DEV double k_sin(double x, double y) {

@@ -110,6 +110,7 @@ template <int N>
 OPTIK_DEV int nnls(const NnlsWs<N> &ws, double &rnorm) {
     using L = NnlsLayout<N>;
     constexpr int m = N + 1, n = 2 * N;
+    static_assert(m <= 8, "row vectors are dvec8");
     const double factor = 0.01;
     int mode = 1, iter = 0;
     const int itmax = 3 * n;
@@ -159,10 +160,10 @@ OPTIK_DEV int nnls(const NnlsWs<N> &ws, double &rnorm) {
             // step five: does column j enter the positive set?  (H12 construction on
             // column j, pivot row npp1, rows npp1+1..m)
             double *const cj = col(j);
-            double u[m];
+            dvec8 u = 0.0;
 #pragma unroll
             for (int r = 0; r < m; ++r) u[r] = cj[r * 64];
-            const double asave = pick<m>(u, npp1);
+            const double asave = vpick(u, npp1);
             const bool h12_live = npp1 < m;  // "lpivot >= l1 || l1 > m" returns early
             double ulp = asave;              // U(lpivot) after the construction
             bool constructed = false;
@@ -211,7 +212,7 @@ OPTIK_DEV int nnls(const NnlsWs<N> &ws, double &rnorm) {
             }
             const double t = factor * __builtin_fabs(ulp);
             const double d1 = unorm + t;
-            double zz[m];
+            dvec8 zz = 0.0;
             // b factor of the H12 application (same for every vector it is applied to)
             double hb = 0.0;
             bool apply_live = false;
@@ -223,7 +224,7 @@ OPTIK_DEV int nnls(const NnlsWs<N> &ws, double &rnorm) {
 #pragma unroll
                 for (int r = 0; r < m; ++r) zz[r] = ws.b(r + 1);
                 if (apply_live) {
-                    double sm = pick<m>(zz, npp1) * up;
+                    double sm = vpick(zz, npp1) * up;
 #pragma unroll
                     for (int r = 1; r <= m; ++r)
                         if (r > npp1) sm += zz[r - 1] * u[r - 1];
@@ -236,7 +237,7 @@ OPTIK_DEV int nnls(const NnlsWs<N> &ws, double &rnorm) {
                         }
                     }
                 }
-                if (pick<m>(zz, npp1) / ulp > 0.0) found = true;
+                if (vpick(zz, npp1) / ulp > 0.0) found = true;
             }
             if (found) {
                 // b := Q b; column j joins set P at position iz1
@@ -254,10 +255,10 @@ OPTIK_DEV int nnls(const NnlsWs<N> &ws, double &rnorm) {
                     for (int c = 1; c <= n; ++c) {
                         if (!(zmask & (1u << (c - 1)))) continue;
                         double *cp = col(c);
-                        double cv[m];
+                        dvec8 cv = 0.0;
 #pragma unroll
                         for (int r = 0; r < m; ++r) cv[r] = cp[r * 64];
-                        double sm = pick<m>(cv, nsetp) * up;
+                        double sm = vpick(cv, nsetp) * up;
 #pragma unroll
                         for (int r = 1; r <= m; ++r)
                             if (r >= npp1) sm += cv[r - 1] * u[r - 1];
@@ -287,16 +288,16 @@ OPTIK_DEV int nnls(const NnlsWs<N> &ws, double &rnorm) {
         if (!found) break;
 
         for (;;) {  // step six: solve the triangular system R z = Q'b on set P
-            double zz[m];
+            dvec8 zz = 0.0;
 #pragma unroll
             for (int r = 0; r < m; ++r) zz[r] = ws.b(r + 1);
             for (int ip = nsetp; ip >= 1; --ip) {
                 jj = indx.get(ip);
                 const double *cp = col(jj);
-                double cv[m];
+                dvec8 cv = 0.0;
 #pragma unroll
                 for (int r = 0; r < m; ++r) cv[r] = cp[r * 64];
-                const double zi = pick<m>(zz, ip) / pick<m>(cv, ip);
+                const double zi = vpick(zz, ip) / vpick(cv, ip);
 #pragma unroll
                 for (int r = 1; r <= m; ++r) {
                     if (r == ip) zz[r - 1] = zi;
