@@ -14,7 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "liboptik_amd.so")
 SOURCES = ["ik_kernels.hip", "robot_host.cpp"]
-HEADERS = ["ik_math.hpp", "ik_eval.hpp", "ik_slsqp.hpp", "ik_solve.hpp", "urdf_chain.hpp",
+HEADERS = ["ik_math.hpp", "ik_eval.hpp", "ik_slsqp.hpp", "ik_solve.hpp", "ik_nnls_coop.hpp", "ik_engine.hpp",
+           "urdf_chain.hpp",
            os.path.join("..", "..", "include", "optik_hip.h"),
            os.path.join("..", "..", "include", "optik.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",

@@ -51,7 +51,7 @@ struct EngLayout {
                          L = XP + N, F0 = L + NL, H3 = F0 + 1, AL = H3 + 1, FP = AL + 1, MF = FP + 1,
                          FC = MF + 1, ND = FC + 1;
     // int32 planes
-    static constexpr int STATE = 0, LINE = 1, IRESET = 2, ITER = 3, NEVALS = 4, STATUS = 5, JOB = 6, NNQ = 7, NI = 8;
+    static constexpr int STATE = 0, LINE = 1, IRESET = 2, ITER = 3, NEVALS = 4, STATUS = 5, JOB = 6, NNQ = 7, NNIT = 8, NI = 9;
 };
 
 // One submitted optik_hip_ik_batch call.
@@ -77,6 +77,11 @@ struct EngJob {
 };
 
 constexpr int ENG_MAX_JOBS = 64;
+// Bounded sub-problems are listed by the iteration count their restart's previous
+// sub-problem took (76% repeat it, 92% within one): the NNLS kernel walks the classes from
+// the largest down, so a wave's 16 problems take similar numbers of passes and the long
+// ones start first.  Scheduling only -- every problem is solved independently.
+constexpr int NN_CLASSES = 8;
 
 struct EngArgs {
     const ChainDev *chain;
@@ -95,10 +100,11 @@ struct EngArgs {
     unsigned long long *next_item;      // global queue head
     // bounded sub-problems of a trip: list / problem / answer buffers, double-buffered by
     // trip parity (the finish kernel of trip s may defer into the list of trip s+1)
-    unsigned int *nn_count[2];          // list lengths
+    unsigned int *nn_count[2];          // list lengths; [1 .. NN_CLASSES] after each: class sizes
+    unsigned int *nn_order[2];          // [NN_CLASSES][C] list positions by predicted class
     double *nn_prob[2];                 // [C][2n][n+1] dual problems, one contiguous block each
     double *nn_y[2];                    // [C][2n] multipliers
-    double *nn_meta[2];                 // [C][2] {mode, rnorm}
+    double *nn_meta[2];                 // [C][2] {mode + 8 * passes, rnorm}
     int parity;                         // list consumed by this trip's NNLS kernel
     int pad2;
     unsigned int *n_active;             // slots holding a restart after the update kernel (zeroed every trip)
@@ -115,8 +121,10 @@ enum : int { DIR_OK = 0, DIR_DEFER = 1, DIR_DEAD = 2 };
 // Writes the dual problem of a deferred direction (columns of [G E^-1; h]) as one
 // contiguous block for the cooperative NNLS kernel; returns its list position.
 template <int N>
-OPTIK_DEV unsigned emit_problem(const EngArgs &a, int parity, const LsqPrep<N> &P) {
+OPTIK_DEV unsigned emit_problem(const EngArgs &a, int parity, const LsqPrep<N> &P, int pred) {
+    // the predicted class rides in the answer record until the NNLS kernel overwrites it
     const unsigned q = atomicAdd(a.nn_count[parity], 1u);
+    a.nn_meta[parity][(size_t)q * 2] = (double)(pred < 0 ? 0 : (pred >= NN_CLASSES ? NN_CLASSES - 1 : pred));
     double *pb = a.nn_prob[parity] + (size_t)q * (2 * N) * (N + 1);
 #pragma unroll
     for (int c = 0; c < N; ++c) {
@@ -136,7 +144,7 @@ OPTIK_DEV unsigned emit_problem(const EngArgs &a, int parity, const LsqPrep<N> &
 template <int N>
 OPTIK_DEV int ldp_from_answer(const LsqPrep<N> &P, const double *y_mem, const double *meta, double (&s)[N]) {
     constexpr int M = 2 * N;
-    int mode = (int)meta[0];
+    int mode = ((int)meta[0]) & 7;
     if (mode == 1 && meta[1] <= 0.0) mode = 4;
     if (mode != 1) return mode;
     double y[M];
@@ -170,7 +178,7 @@ template <int N>
 OPTIK_DEV int direction_search(const EngArgs &a, const ChainDev &ch, int emit_parity, const double *answer_y,
                                const double *answer_meta, double (&l)[N * (N + 1) / 2], const double (&g)[N],
                                const double (&x)[N], double f, int &ireset, int &iter, bool reset,
-                               double (&s)[N], double &h3, int32_t &status, unsigned &q_out) {
+                               double (&s)[N], double &h3, int32_t &status, unsigned &q_out, int pred) {
     constexpr int NL = N * (N + 1) / 2;
     const SolveParams &sp = a.sp;
     double f0 = 0.0;
@@ -205,7 +213,7 @@ OPTIK_DEV int direction_search(const EngArgs &a, const ChainDev &ch, int emit_pa
                 if (resume) {
                     lmode = ldp_from_answer<N>(P, answer_y, answer_meta, s);
                 } else {
-                    q_out = emit_problem<N>(a, emit_parity, P);
+                    q_out = emit_problem<N>(a, emit_parity, P, pred);
                     return DIR_DEFER;
                 }
             } else {
@@ -460,6 +468,7 @@ OPTIK_DEV void eng_update_body(const EngArgs &a, const ChainDev &ch, size_t slot
                 ENG_I(E::ITER) = 0;
                 ENG_I(E::IRESET) = 0;
                 ENG_I(E::LINE) = 0;
+                ENG_I(E::NNIT) = 1;
                 ENG_I(E::JOB) = job;
                 a.item[slot] = item;
                 st = ST_EVAL_FIRST;
@@ -502,7 +511,7 @@ OPTIK_DEV void eng_update_body(const EngArgs &a, const ChainDev &ch, size_t slot
         int32_t status = 0;
         unsigned q = 0;
         const int out = direction_search<N>(a, ch, a.parity, nullptr, nullptr, l, g, x, f, ireset, iter,
-                                            st == ST_UPDATE_FIRST, s, h3, status, q);
+                                            st == ST_UPDATE_FIRST, s, h3, status, q, ENG_I(E::NNIT));
         if (out == DIR_OK) store_direction<N>(a, ch, slot, l, g, x, s, f, h3, ireset, iter);
         else if (out == DIR_DEFER) store_deferred<N>(a, slot, l, g, ireset, iter, q);
         else { ENG_I(E::STATUS) = status; ENG_I(E::ITER) = iter; ENG_I(E::STATE) = ST_DEAD; }
@@ -529,9 +538,21 @@ OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a) {
     const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) / 64u;
     const unsigned n_waves = (gridDim.x * blockDim.x) / 64u;
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.nn_total) atomicAdd(a.nn_total, (unsigned long long)cnt);
+    const unsigned int *cls_cnt = a.nn_count[a.parity] + 1;
+    const unsigned int *order = a.nn_order[a.parity];
     for (unsigned q0 = wave * PPW; q0 < cnt; q0 += n_waves * PPW) {
-        const unsigned q = q0 + group;
-        const bool live = q < cnt;
+        const bool live = q0 + group < cnt;
+        // the (q0 + group)-th problem in class order, largest predicted pass count first
+        unsigned q = 0;
+        {
+            unsigned i = q0 + group;
+            bool placed = !live;
+            for (int c = NN_CLASSES - 1; c >= 0; --c) {
+                const unsigned cc = cls_cnt[c];
+                if (!placed && i < cc) { q = order[(size_t)c * a.C + i]; placed = true; }
+                if (!placed) i -= cc;
+            }
+        }
         dvec8 col[CPL];
 #pragma unroll
         for (int k = 0; k < CPL; ++k) {
@@ -553,7 +574,50 @@ OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a) {
                 const unsigned c = gl * CPL + k;
                 if (c < (unsigned)n) ybuf[(size_t)q * n + c] = xv[k];
             }
-            if (gl == 0) { meta[(size_t)q * 2] = (double)mode; meta[(size_t)q * 2 + 1] = rnorm; }
+            if (gl == 0) { meta[(size_t)q * 2] = (double)(mode + 8 * iters); meta[(size_t)q * 2 + 1] = rnorm; }
+        }
+    }
+}
+
+// ---- kernel 2b: list the trip's problems by predicted class (counting sort) ---------
+
+constexpr int BUCKET_SUB = 4;  // 64-problem batches per wave (one atomic instruction per wave)
+
+OPTIK_DEV void eng_bucket_body(const EngArgs &a) {
+    const unsigned cnt = *a.nn_count[a.parity];
+    unsigned int *cls_cnt = a.nn_count[a.parity] + 1;
+    unsigned int *order = a.nn_order[a.parity];
+    const double *meta = a.nn_meta[a.parity];
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) / 64u;
+    const unsigned n_waves = (gridDim.x * blockDim.x) / 64u;
+    for (unsigned i0 = wave * (64u * BUCKET_SUB); i0 < cnt; i0 += n_waves * (64u * BUCKET_SUB)) {
+        int cls[BUCKET_SUB];
+        unsigned rank[BUCKET_SUB];
+#pragma unroll
+        for (int b = 0; b < BUCKET_SUB; ++b) {
+            const unsigned i = i0 + (unsigned)b * 64u + lane;
+            cls[b] = i < cnt ? (int)meta[(size_t)i * 2] : -1;
+        }
+        unsigned mine = 0;  // lane c < NN_CLASSES: problems of class c in this wave's batches
+#pragma unroll
+        for (int b = 0; b < BUCKET_SUB; ++b) {
+            const unsigned before = (unsigned)__shfl((int)mine, cls[b] < 0 ? 0 : cls[b], 64);
+            rank[b] = before;
+#pragma unroll
+            for (int c = 0; c < NN_CLASSES; ++c) {
+                const unsigned long long mk = __ballot(cls[b] == c);
+                if ((int)lane == c) mine += (unsigned)__popcll(mk);
+                if (cls[b] == c) rank[b] += (unsigned)__popcll(mk & below);
+            }
+        }
+        unsigned base = 0;
+        if (lane < (unsigned)NN_CLASSES && mine) base = atomicAdd(cls_cnt + lane, mine);
+#pragma unroll
+        for (int b = 0; b < BUCKET_SUB; ++b) {
+            const unsigned cb = (unsigned)__shfl((int)base, cls[b] < 0 ? 0 : cls[b], 64);
+            if (cls[b] >= 0) order[(size_t)cls[b] * a.C + cb + rank[b]] = i0 + (unsigned)b * 64u + lane;
         }
     }
 }
@@ -575,9 +639,11 @@ OPTIK_DEV void eng_finish_body(const EngArgs &a, const ChainDev &ch, size_t slot
     double h3 = 0.0;
     int32_t status = 0;
     unsigned q2 = 0;
+    const int passes = ((int)a.nn_meta[a.parity][(size_t)q * 2]) >> 3;
+    ENG_I(E::NNIT) = passes;
     const int out = direction_search<N>(a, ch, a.parity ^ 1, a.nn_y[a.parity] + (size_t)q * 2 * N,
                                         a.nn_meta[a.parity] + (size_t)q * 2, l, g, x, f, ireset, iter, false, s,
-                                        h3, status, q2);
+                                        h3, status, q2, passes);
     if (out == DIR_OK) store_direction<N>(a, ch, slot, l, g, x, s, f, h3, ireset, iter);
     else if (out == DIR_DEFER) store_deferred<N>(a, slot, l, g, ireset, iter, q2);
     else { ENG_I(E::STATUS) = status; ENG_I(E::ITER) = iter; ENG_I(E::STATE) = ST_DEAD; }

@@ -188,8 +188,15 @@ __global__ __launch_bounds__(256, OPTIK_ENG_UPD_WAVES) void eng_update_kernel(co
 #ifndef OPTIK_ENG_NNLS_WAVES
 #define OPTIK_ENG_NNLS_WAVES 2
 #endif
+// One wave per workgroup: the waves of a workgroup hold their CU slots until the slowest
+// of them (the largest iteration count among its problems) is done.
+#ifndef OPTIK_ENG_NNLS_BLOCK
+#define OPTIK_ENG_NNLS_BLOCK 64
+#endif
+__global__ __launch_bounds__(256) void eng_bucket_kernel(const EngArgs a) { eng_bucket_body(a); }
+
 template <int N>
-__global__ __launch_bounds__(256, OPTIK_ENG_NNLS_WAVES) void eng_nnls_coop_kernel(const EngArgs a) {
+__global__ __launch_bounds__(OPTIK_ENG_NNLS_BLOCK, OPTIK_ENG_NNLS_WAVES) void eng_nnls_coop_kernel(const EngArgs a) {
     eng_nnls_coop_body<N, OPTIK_ENG_CPL>(a);
 }
 
@@ -354,7 +361,8 @@ struct optik_hip_chain {
     int32_t *eng_i32 = nullptr;
     unsigned long long *eng_item = nullptr;
     EngJob *eng_djobs = nullptr;
-    unsigned int *eng_counters = nullptr;  // [0], [1] NNLS list lengths by trip parity, [2] n_active
+    unsigned int *eng_counters = nullptr;  // per trip parity {list length, class sizes}, then n_active
+    unsigned int *eng_order = nullptr;     // 2 x [NN_CLASSES][C]
     double *eng_prob = nullptr;            // 2 x [C][2n][n+1]
     double *eng_y = nullptr;               // 2 x [C][2n]
     double *eng_meta = nullptr;            // 2 x [C][2]
@@ -563,6 +571,7 @@ void optik_hip_chain_destroy(optik_hip_chain *ch) {
     if (ch->eng_item) hipFree(ch->eng_item);
     if (ch->eng_djobs) hipFree(ch->eng_djobs);
     if (ch->eng_counters) hipFree(ch->eng_counters);
+    if (ch->eng_order) hipFree(ch->eng_order);
     if (ch->eng_prob) hipFree(ch->eng_prob);
     if (ch->eng_y) hipFree(ch->eng_y);
     if (ch->eng_meta) hipFree(ch->eng_meta);
@@ -900,6 +909,8 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             if (ch->eng_prob) HIP_TRY(hipFree(ch->eng_prob));
             if (ch->eng_y) HIP_TRY(hipFree(ch->eng_y));
             if (ch->eng_meta) HIP_TRY(hipFree(ch->eng_meta));
+            if (ch->eng_order) HIP_TRY(hipFree(ch->eng_order));
+            ch->eng_order = nullptr;
             ch->eng_d = nullptr; ch->eng_i32 = nullptr; ch->eng_item = nullptr;
             ch->eng_prob = ch->eng_y = ch->eng_meta = nullptr;
             HIP_TRY(hipMalloc(&ch->eng_d, sizeof(double) * (size_t)nd * C));
@@ -909,10 +920,12 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             HIP_TRY(hipMalloc(&ch->eng_prob, sizeof(double) * 2 * C * (2 * nn) * (nn + 1)));
             HIP_TRY(hipMalloc(&ch->eng_y, sizeof(double) * 2 * C * (2 * nn)));
             HIP_TRY(hipMalloc(&ch->eng_meta, sizeof(double) * 2 * C * 2));
+            HIP_TRY(hipMalloc(&ch->eng_order, sizeof(unsigned int) * 2 * NN_CLASSES * C));
             ch->eng_C = C;
         }
         if (!ch->eng_djobs) HIP_TRY(hipMalloc(&ch->eng_djobs, sizeof(EngJob) * ENG_MAX_JOBS));
-        if (!ch->eng_counters) HIP_TRY(hipMalloc(&ch->eng_counters, 4 * sizeof(unsigned int)));
+        constexpr int CB = 1 + NN_CLASSES;  // counters per trip parity
+        if (!ch->eng_counters) HIP_TRY(hipMalloc(&ch->eng_counters, (2 * CB + 2) * sizeof(unsigned int)));
         if (!ch->eng_pinned) HIP_TRY(hipHostMalloc(&ch->eng_pinned, 8 * sizeof(unsigned int)));
         if (!ch->queue) HIP_TRY(hipMalloc(&ch->queue, sizeof(unsigned long long)));
         if (!ch->eng_nn_total) HIP_TRY(hipMalloc(&ch->eng_nn_total, sizeof(unsigned long long)));
@@ -942,13 +955,14 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
         {
             const size_t nn = (size_t)ch->n;
             for (int par = 0; par < 2; ++par) {
-                a.nn_count[par] = ch->eng_counters + par;
+                a.nn_count[par] = ch->eng_counters + par * CB;
+                a.nn_order[par] = ch->eng_order + (size_t)par * NN_CLASSES * ch->eng_C;
                 a.nn_prob[par] = ch->eng_prob + (size_t)par * ch->eng_C * (2 * nn) * (nn + 1);
                 a.nn_y[par] = ch->eng_y + (size_t)par * ch->eng_C * (2 * nn);
                 a.nn_meta[par] = ch->eng_meta + (size_t)par * ch->eng_C * 2;
             }
         }
-        a.n_active = ch->eng_counters + 2;
+        a.n_active = ch->eng_counters + 2 * CB;
         a.nn_total = ch->eng_nn_total;
         a.parity = 0;
         a.prof = nullptr;
@@ -960,8 +974,8 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
 
         const unsigned blocks = (unsigned)((C + 255) / 256);
         const int cus = ch->num_cus > 0 ? ch->num_cus : 256;
-        const unsigned nn_blocks = (unsigned)(cus * 8);  // 256-thread blocks, 16 problems each
-        HIP_TRY(hipMemsetAsync(ch->eng_counters, 0, 4 * sizeof(unsigned int), stream));
+        const unsigned nn_blocks = (unsigned)(cus * 8 * (256 / OPTIK_ENG_NNLS_BLOCK));  // 32 waves per CU
+        HIP_TRY(hipMemsetAsync(ch->eng_counters, 0, (2 * CB + 2) * sizeof(unsigned int), stream));
         hipLaunchKernelGGL(eng_init_kernel, dim3(blocks), dim3(256), 0, stream, ch->eng_i32, (unsigned long long)C);
         HIP_TRY(hipGetLastError());
 
@@ -974,8 +988,8 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
                 // this trip consumes list[trip & 1]; the other list (consumed last trip) is
                 // reset for the finish kernel's re-deferrals and the next trip's update kernel
                 a.parity = trip & 1;
-                HIP_TRY(hipMemsetAsync(ch->eng_counters + (a.parity ^ 1), 0, sizeof(unsigned int), stream));
-                HIP_TRY(hipMemsetAsync(ch->eng_counters + 2, 0, sizeof(unsigned int), stream));
+                HIP_TRY(hipMemsetAsync(ch->eng_counters + (a.parity ^ 1) * CB, 0, CB * sizeof(unsigned int), stream));
+                HIP_TRY(hipMemsetAsync(ch->eng_counters + 2 * CB, 0, sizeof(unsigned int), stream));
                 // HIP event pairs around each kernel of every trip (on the launch stream)
                 const bool timed = ch->timing && trip > 0 && ch->eng_tcount < optik_hip_chain::ENG_EV;
                 const int ts = ch->eng_tcount;
@@ -995,8 +1009,10 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
 #define M_UPD(NN) hipLaunchKernelGGL((eng_update_kernel<NN>), dim3(blocks), dim3(256), 0, stream, a)
                 DISPATCH_N(M_UPD);
 #undef M_UPD
-                TEV(1, 1); TEV(2, 0);
-#define M_NNLS(NN) hipLaunchKernelGGL((eng_nnls_coop_kernel<NN>), dim3(nn_blocks), dim3(256), 0, stream, a)
+                TEV(1, 1);
+                hipLaunchKernelGGL(eng_bucket_kernel, dim3((unsigned)cus), dim3(256), 0, stream, a);
+                TEV(2, 0);
+#define M_NNLS(NN) hipLaunchKernelGGL((eng_nnls_coop_kernel<NN>), dim3(nn_blocks), dim3(OPTIK_ENG_NNLS_BLOCK), 0, stream, a)
                 DISPATCH_N(M_NNLS);
 #undef M_NNLS
                 TEV(2, 1); TEV(3, 0);
@@ -1009,7 +1025,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             }
             HIP_TRY(hipGetLastError());
             // read back n_active of the chunk just issued; look at the previous chunk's value
-            HIP_TRY(hipMemcpyAsync(&ch->eng_pinned[ring], ch->eng_counters + 2, sizeof(unsigned int),
+            HIP_TRY(hipMemcpyAsync(&ch->eng_pinned[ring], ch->eng_counters + 2 * CB, sizeof(unsigned int),
                                    hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipEventRecord(ch->eng_ev[ring], stream));
             if (pending) {
