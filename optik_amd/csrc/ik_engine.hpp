@@ -82,6 +82,10 @@ constexpr int ENG_MAX_JOBS = 64;
 // the largest down, so a wave's 16 problems take similar numbers of passes and the long
 // ones start first.  Scheduling only -- every problem is solved independently.
 constexpr int NN_CLASSES = 8;
+// A problem that needs more than the launch's pass budget is suspended and continues in
+// the next trip's launch (its slot just stays in ST_NNLS): no launch waits for the rare
+// 10+ pass problem.  Carry record: b[8], up, nsetp, iter, then xv[16], pos[16].
+constexpr int NN_CARRY = 48;
 
 struct EngArgs {
     const ChainDev *chain;
@@ -104,12 +108,16 @@ struct EngArgs {
     unsigned int *nn_order[2];          // [NN_CLASSES][C] list positions by predicted class
     double *nn_prob[2];                 // [C][2n][n+1] dual problems, one contiguous block each
     double *nn_y[2];                    // [C][2n] multipliers
-    double *nn_meta[2];                 // [C][2] {mode + 8 * passes, rnorm}
+    double *nn_meta[2];                 // [C][2] {mode + 8 * passes, rnorm}; before the solve {class, 0 | -1 = resume}
+    double *nn_carry[2];                // [C][NN_CARRY] state of suspended problems (see eng_nnls_coop_body)
+    int nn_budget;                      // solve passes per problem per launch (stragglers continue next trip)
+    int pad3;
     int parity;                         // list consumed by this trip's NNLS kernel
     int pad2;
     unsigned int *n_active;             // slots holding a restart after the update kernel (zeroed every trip)
     unsigned long long *nn_total;       // running count of bounded sub-problems solved
     unsigned long long *prof;           // OPTIK_PROFILE builds: cycle counters, else null
+    unsigned long long *trace;          // OPTIK_NNLS_TRACE builds: per-wave {start, end, hw id, passes} of one trip
 };
 
 #define ENG_D(plane, k) a.d[(size_t)((plane) + (k)) * a.C + slot]
@@ -125,6 +133,7 @@ OPTIK_DEV unsigned emit_problem(const EngArgs &a, int parity, const LsqPrep<N> &
     // the predicted class rides in the answer record until the NNLS kernel overwrites it
     const unsigned q = atomicAdd(a.nn_count[parity], 1u);
     a.nn_meta[parity][(size_t)q * 2] = (double)(pred < 0 ? 0 : (pred >= NN_CLASSES ? NN_CLASSES - 1 : pred));
+    a.nn_meta[parity][(size_t)q * 2 + 1] = 0.0;
     double *pb = a.nn_prob[parity] + (size_t)q * (2 * N) * (N + 1);
 #pragma unroll
     for (int c = 0; c < N; ++c) {
@@ -540,6 +549,11 @@ OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a) {
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.nn_total) atomicAdd(a.nn_total, (unsigned long long)cnt);
     const unsigned int *cls_cnt = a.nn_count[a.parity] + 1;
     const unsigned int *order = a.nn_order[a.parity];
+#ifdef OPTIK_NNLS_TRACE
+    const unsigned long long t_begin = wall_clock64();
+    const unsigned long long c_begin = clock64();
+    int max_passes = -1;
+#endif
     for (unsigned q0 = wave * PPW; q0 < cnt; q0 += n_waves * PPW) {
         const bool live = q0 + group < cnt;
         // the (q0 + group)-th problem in class order, largest predicted pass count first
@@ -553,30 +567,100 @@ OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a) {
                 if (!placed) i -= cc;
             }
         }
+        const bool resume = live && meta[(size_t)q * 2 + 1] < 0.0;
         dvec8 col[CPL];
+        CoopCarry<CPL> cs;
+        const double *cr = a.nn_carry[a.parity] + (size_t)q * NN_CARRY;
+        cs.b = 0.0;
+        cs.up = 0.0;
+        cs.nsetp = 0;
+        cs.iter = 0;
+        if (resume) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) cs.b[r] = cr[r];
+            cs.up = cr[8];
+            cs.nsetp = (int)cr[9];
+            cs.iter = (int)cr[10];
+        }
 #pragma unroll
         for (int k = 0; k < CPL; ++k) {
             col[k] = 0.0;
+            cs.xv[k] = 0.0;
+            cs.pos[k] = 0;
             const unsigned c = gl * CPL + k;
             if (live && c < (unsigned)n) {
                 const double *pc = prob + ((size_t)q * n + c) * m;
 #pragma unroll
                 for (int r = 0; r < m; ++r) col[k][r] = pc[r];
             }
+            if (resume) {
+                cs.xv[k] = cr[16 + c];
+                cs.pos[k] = (int)cr[32 + c];
+            }
         }
-        double xv[CPL];
         int mode, iters;
         double rnorm;
-        nnls_coop<N, CPL>(live, (int)(gl * CPL), col, xv, mode, rnorm, iters);
-        if (live) {
+        // a suspended problem continues in the next trip: new list position in the other
+        // parity's buffers, matrix and state stored from inside the solver
+        auto park = [&](const dvec8 (&pcol)[CPL], const CoopCarry<CPL> &st) {
+            const int op = a.parity ^ 1;
+            unsigned q2 = 0;
+            if (gl == 0) q2 = atomicAdd(a.nn_count[op], 1u);
+            q2 = (unsigned)Group<G>::bcast((int)q2, 0);
+            double *cw = a.nn_carry[op] + (size_t)q2 * NN_CARRY;
 #pragma unroll
             for (int k = 0; k < CPL; ++k) {
                 const unsigned c = gl * CPL + k;
-                if (c < (unsigned)n) ybuf[(size_t)q * n + c] = xv[k];
+                if (c < (unsigned)n) {
+                    double *pc = a.nn_prob[op] + ((size_t)q2 * n + c) * m;
+#pragma unroll
+                    for (int r = 0; r < m; ++r) pc[r] = pcol[k][r];
+                }
+                cw[16 + c] = st.xv[k];
+                cw[32 + c] = (double)st.pos[k];
+            }
+            if (gl == 0) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) cw[r] = st.b[r];
+                cw[8] = st.up;
+                cw[9] = (double)st.nsetp;
+                cw[10] = (double)st.iter;
+                a.nn_meta[op][(size_t)q2 * 2] = (double)(NN_CLASSES - 1);  // scheduled with the long ones
+                a.nn_meta[op][(size_t)q2 * 2 + 1] = -1.0;
+                meta[(size_t)q * 2] = (double)(NNLS_SUSPENDED + 8 * st.iter);
+                meta[(size_t)q * 2 + 1] = (double)q2;
+            }
+        };
+        nnls_coop<N, CPL>(live, resume, a.nn_budget, (int)(gl * CPL), col, cs, mode, rnorm, iters, park);
+        if (live && mode != NNLS_SUSPENDED) {
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const unsigned c = gl * CPL + k;
+                if (c < (unsigned)n) ybuf[(size_t)q * n + c] = cs.xv[k];
             }
             if (gl == 0) { meta[(size_t)q * 2] = (double)(mode + 8 * iters); meta[(size_t)q * 2 + 1] = rnorm; }
         }
+#ifdef OPTIK_NNLS_TRACE
+        {
+            int mp = live ? iters : -1;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(mp, off, 64); mp = o > mp ? o : mp; }
+            max_passes = mp > max_passes ? mp : max_passes;
+        }
+#endif
     }
+#ifdef OPTIK_NNLS_TRACE
+    if (a.trace && lane == 0) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        a.trace[(size_t)wave * 4 + 0] = t_begin;
+        a.trace[(size_t)wave * 4 + 1] = wall_clock64();
+        a.trace[(size_t)wave * 4 + 2] = ((unsigned long long)xcc << 32) | hw;
+        a.trace[(size_t)wave * 4 + 3] = ((unsigned long long)(clock64() - c_begin) << 16) | (unsigned long long)(max_passes & 0xffff);
+    }
+#endif
 }
 
 // ---- kernel 2b: list the trip's problems by predicted class (counting sort) ---------
@@ -639,7 +723,12 @@ OPTIK_DEV void eng_finish_body(const EngArgs &a, const ChainDev &ch, size_t slot
     double h3 = 0.0;
     int32_t status = 0;
     unsigned q2 = 0;
-    const int passes = ((int)a.nn_meta[a.parity][(size_t)q * 2]) >> 3;
+    const int code = (int)a.nn_meta[a.parity][(size_t)q * 2];
+    if ((code & 7) == NNLS_SUSPENDED) {  // still being solved: follow it to the next trip's list
+        ENG_I(E::NNQ) = (int32_t)a.nn_meta[a.parity][(size_t)q * 2 + 1];
+        return;
+    }
+    const int passes = code >> 3;
     ENG_I(E::NNIT) = passes;
     const int out = direction_search<N>(a, ch, a.parity ^ 1, a.nn_y[a.parity] + (size_t)q * 2 * N,
                                         a.nn_meta[a.parity] + (size_t)q * 2, l, g, x, f, ireset, iter, false, s,

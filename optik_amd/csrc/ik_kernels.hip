@@ -363,6 +363,8 @@ struct optik_hip_chain {
     EngJob *eng_djobs = nullptr;
     unsigned int *eng_counters = nullptr;  // per trip parity {list length, class sizes}, then n_active
     unsigned int *eng_order = nullptr;     // 2 x [NN_CLASSES][C]
+    double *eng_carry = nullptr;           // 2 x [C][NN_CARRY]
+    unsigned long long *nnls_trace = nullptr;  // OPTIK_NNLS_TRACE builds
     double *eng_prob = nullptr;            // 2 x [C][2n][n+1]
     double *eng_y = nullptr;               // 2 x [C][2n]
     double *eng_meta = nullptr;            // 2 x [C][2]
@@ -572,6 +574,7 @@ void optik_hip_chain_destroy(optik_hip_chain *ch) {
     if (ch->eng_djobs) hipFree(ch->eng_djobs);
     if (ch->eng_counters) hipFree(ch->eng_counters);
     if (ch->eng_order) hipFree(ch->eng_order);
+    if (ch->eng_carry) hipFree(ch->eng_carry);
     if (ch->eng_prob) hipFree(ch->eng_prob);
     if (ch->eng_y) hipFree(ch->eng_y);
     if (ch->eng_meta) hipFree(ch->eng_meta);
@@ -910,7 +913,8 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             if (ch->eng_y) HIP_TRY(hipFree(ch->eng_y));
             if (ch->eng_meta) HIP_TRY(hipFree(ch->eng_meta));
             if (ch->eng_order) HIP_TRY(hipFree(ch->eng_order));
-            ch->eng_order = nullptr;
+            if (ch->eng_carry) HIP_TRY(hipFree(ch->eng_carry));
+            ch->eng_order = nullptr; ch->eng_carry = nullptr;
             ch->eng_d = nullptr; ch->eng_i32 = nullptr; ch->eng_item = nullptr;
             ch->eng_prob = ch->eng_y = ch->eng_meta = nullptr;
             HIP_TRY(hipMalloc(&ch->eng_d, sizeof(double) * (size_t)nd * C));
@@ -921,10 +925,11 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             HIP_TRY(hipMalloc(&ch->eng_y, sizeof(double) * 2 * C * (2 * nn)));
             HIP_TRY(hipMalloc(&ch->eng_meta, sizeof(double) * 2 * C * 2));
             HIP_TRY(hipMalloc(&ch->eng_order, sizeof(unsigned int) * 2 * NN_CLASSES * C));
+            HIP_TRY(hipMalloc(&ch->eng_carry, sizeof(double) * 2 * NN_CARRY * C));
             ch->eng_C = C;
         }
         if (!ch->eng_djobs) HIP_TRY(hipMalloc(&ch->eng_djobs, sizeof(EngJob) * ENG_MAX_JOBS));
-        constexpr int CB = 1 + NN_CLASSES;  // counters per trip parity
+        constexpr int CB = 2 + NN_CLASSES;  // counters per trip parity: list length, class sizes, batch cursor
         if (!ch->eng_counters) HIP_TRY(hipMalloc(&ch->eng_counters, (2 * CB + 2) * sizeof(unsigned int)));
         if (!ch->eng_pinned) HIP_TRY(hipHostMalloc(&ch->eng_pinned, 8 * sizeof(unsigned int)));
         if (!ch->queue) HIP_TRY(hipMalloc(&ch->queue, sizeof(unsigned long long)));
@@ -957,15 +962,19 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             for (int par = 0; par < 2; ++par) {
                 a.nn_count[par] = ch->eng_counters + par * CB;
                 a.nn_order[par] = ch->eng_order + (size_t)par * NN_CLASSES * ch->eng_C;
+                a.nn_carry[par] = ch->eng_carry + (size_t)par * NN_CARRY * ch->eng_C;
                 a.nn_prob[par] = ch->eng_prob + (size_t)par * ch->eng_C * (2 * nn) * (nn + 1);
                 a.nn_y[par] = ch->eng_y + (size_t)par * ch->eng_C * (2 * nn);
                 a.nn_meta[par] = ch->eng_meta + (size_t)par * ch->eng_C * 2;
             }
         }
         a.n_active = ch->eng_counters + 2 * CB;
+        a.nn_budget = 6;
+        if (const char *e = getenv("OPTIK_ENG_NNLS_BUDGET")) a.nn_budget = atoi(e) > 0 ? atoi(e) : 1;
         a.nn_total = ch->eng_nn_total;
         a.parity = 0;
         a.prof = nullptr;
+        a.trace = nullptr;
 #ifdef OPTIK_PROFILE
         if (!ch->prof) HIP_TRY(hipMalloc(&ch->prof, 8 * sizeof(unsigned long long)));
         HIP_TRY(hipMemsetAsync(ch->prof, 0, 8 * sizeof(unsigned long long), stream));
@@ -974,7 +983,10 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
 
         const unsigned blocks = (unsigned)((C + 255) / 256);
         const int cus = ch->num_cus > 0 ? ch->num_cus : 256;
-        const unsigned nn_blocks = (unsigned)(cus * 8 * (256 / OPTIK_ENG_NNLS_BLOCK));  // 32 waves per CU
+        unsigned nn_waves_per_cu = 32;
+        if (const char *e = getenv("OPTIK_ENG_NNLS_WAVES_PER_CU")) nn_waves_per_cu = (unsigned)atoi(e);
+        if (nn_waves_per_cu < 1) nn_waves_per_cu = 1;
+        const unsigned nn_blocks = (unsigned)cus * nn_waves_per_cu * 64u / OPTIK_ENG_NNLS_BLOCK;
         HIP_TRY(hipMemsetAsync(ch->eng_counters, 0, (2 * CB + 2) * sizeof(unsigned int), stream));
         hipLaunchKernelGGL(eng_init_kernel, dim3(blocks), dim3(256), 0, stream, ch->eng_i32, (unsigned long long)C);
         HIP_TRY(hipGetLastError());
@@ -1010,6 +1022,15 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
                 DISPATCH_N(M_UPD);
 #undef M_UPD
                 TEV(1, 1);
+#ifdef OPTIK_NNLS_TRACE
+                {   // per-wave timeline of one steady-state trip (debug builds only)
+                    static unsigned long long *tr = nullptr;
+                    const int t0 = getenv("OPTIK_NNLS_TRACE_TRIP") ? atoi(getenv("OPTIK_NNLS_TRACE_TRIP")) : 150;
+                    if (!tr) { HIP_TRY(hipMalloc(&tr, sizeof(unsigned long long) * 4 * 65536)); HIP_TRY(hipMemset(tr, 0, sizeof(unsigned long long) * 4 * 65536)); }
+                    a.trace = (trip == t0) ? tr : nullptr;
+                    ch->nnls_trace = tr;
+                }
+#endif
                 hipLaunchKernelGGL(eng_bucket_kernel, dim3((unsigned)cus), dim3(256), 0, stream, a);
                 TEV(2, 0);
 #define M_NNLS(NN) hipLaunchKernelGGL((eng_nnls_coop_kernel<NN>), dim3(nn_blocks), dim3(OPTIK_ENG_NNLS_BLOCK), 0, stream, a)
@@ -1083,6 +1104,13 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             }
             ch->eng_kernel_ms[k] = cnt ? sum / cnt : 0.0;
         }
+#ifdef OPTIK_NNLS_TRACE
+        if (const char *tf = getenv("OPTIK_NNLS_TRACE_FILE")) {
+            std::vector<unsigned long long> h(4 * 65536);
+            HIP_TRY(hipMemcpy(h.data(), ch->nnls_trace, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            if (FILE *fp = fopen(tf, "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), fp); fclose(fp); }
+        }
+#endif
         HIP_TRY(hipMemcpy(&ch->eng_nn_problems, ch->eng_nn_total, sizeof(unsigned long long), hipMemcpyDeviceToHost));
         return 0;
 #undef DISPATCH_N

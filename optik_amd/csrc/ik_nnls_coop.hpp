@@ -51,13 +51,34 @@ struct Group {
     }
 };
 
+// What a suspended problem carries to its next launch besides the (transformed) matrix:
+// everything else the loop holds at step two.  Group-uniform fields are replicated.
+template <int CPL>
+struct CoopCarry {
+    dvec8 b;
+    double up;
+    int nsetp, iter;
+    int pos[CPL];
+    double xv[CPL];
+};
+
+constexpr int NNLS_SUSPENDED = 7;  // mode: pass budget of this launch used up, state in `cs`
+
 // Solves the problem whose columns cid0+1 .. cid0+CPL (1-based ids; ids > 2N are padding)
-// this lane holds in col[].  `live` = the group has a problem.  On return xv[] are the
-// lane's multipliers; group-uniform results: mode (1 ok, 3 iteration cap), rnorm, and
-// the number of solve passes (for scheduling statistics).
-template <int N, int CPL>
-OPTIK_DEV void nnls_coop(bool live, int cid0, dvec8 (&col)[CPL], double (&xv)[CPL], int &mode_out,
-                         double &rnorm_out, int &iters_out) {
+// this lane holds in col[].  `live` = the group has a problem; `resume` = cs holds the
+// state of a suspended problem (else it is initialised here).  At most `budget` solve
+// passes are started from step two in this call; a problem that needs more returns mode
+// NNLS_SUSPENDED with col[] / cs ready to be resumed -- the arithmetic sequence of a
+// problem does not depend on where it is cut.  On return cs.xv[] are the lane's
+// multipliers; group-uniform results: mode (1 ok, 3 iteration cap), rnorm, and the total
+// number of solve passes.
+//
+// `park(col, cs)` is called by the lanes of a group at the moment it is suspended, with cs
+// filled in (the caller stores matrix and state there and then: keeping the matrix live
+// past the loop just to store it costs ~280 B of scratch per lane).
+template <int N, int CPL, class Park>
+OPTIK_DEV void nnls_coop(bool live, bool resume, int budget, int cid0, dvec8 (&col)[CPL], CoopCarry<CPL> &cs,
+                         int &mode_out, double &rnorm_out, int &iters_out, Park &&park) {
     constexpr int m = N + 1, n = 2 * N;
     constexpr int G = COOP_COLS / CPL;
     static_assert(m <= 8, "a column is one dvec8");
@@ -68,41 +89,51 @@ OPTIK_DEV void nnls_coop(bool live, int cid0, dvec8 (&col)[CPL], double (&xv)[CP
     // group-uniform state (replicated in every lane of the group)
     dvec8 b = 0.0;
     b[m - 1] = 1.0;
-    int nsetp = 0, npp1 = 1, iter = 0, mode = 1;
-    double up = 0.0;
+    b = vsel(resume, cs.b, b);
+    int nsetp = resume ? cs.nsetp : 0, iter = resume ? cs.iter : 0, mode = 1;
+    int npp1 = nsetp + 1;
+    double up = resume ? cs.up : 0.0;
+    const int iter_stop = iter + budget;
+    double (&xv)[CPL] = cs.xv;
     // per-column state
     int pos[CPL];      // position of the column in the permutation (indx[pos] = id)
     bool inZ[CPL], isc[CPL];
     double wv[CPL];
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
-        pos[k] = cid0 + k + 1;
-        isc[k] = pos[k] <= n;
-        inZ[k] = isc[k];
+        isc[k] = cid0 + k + 1 <= n;
+        pos[k] = resume ? cs.pos[k] : cid0 + k + 1;
+        inZ[k] = isc[k] && pos[k] > nsetp;  // set P holds positions 1 .. nsetp
         wv[k] = 0.0;
-        xv[k] = 0.0;
+        xv[k] = resume ? xv[k] : 0.0;
     }
-    dvec8 zz = 0.0;
     int rem_jj = 0;  // step eleven: position being removed
     // phases: 0 = step two (recompute duals, then choose), 1 = step three (choose again),
-    // 2 = step six (solve), 3 = step eleven (remove), 4 = done
+    // 2 = step six (solve), 3 = step eleven (remove), 4 = done, 5 = suspended at step two
     int phase = live ? 0 : 4;
 
-    while (wave_any(phase != 4)) {
+    // The loop body is straight-line code: every conditional update is a select, and rows /
+    // columns an update must not touch get an exact no-op instead of a branch -- products
+    // with a zero weight, and `x + (-0.0)` (which returns x bit-for-bit, signed zeros
+    // included) where an addend has to be neutralised.  Divergent branches here cost more
+    // in exec-mask handling and register copies than the arithmetic they skip.
+    while (wave_any(phase < 4)) {
         // ---------------- steps two .. five --------------------------------------------
         if (wave_any(phase == 0 || phase == 1)) {
             const bool inA = (phase == 0 || phase == 1);
             if (inA && (nsetp + 1 > n || nsetp >= m)) phase = 4;  // iz1 > iz2 || nsetp >= m
             const bool run = (phase == 0 || phase == 1);
-            if (phase == 0) {
+            if (wave_any(phase == 0)) {
+                // step two: duals of the columns in Z over rows npp1 .. m
+                dvec8 bm = 0.0;
+#pragma unroll
+                for (int r = 1; r <= m; ++r) bm[r - 1] = (r >= npp1) ? b[r - 1] : 0.0;
 #pragma unroll
                 for (int k = 0; k < CPL; ++k) {
-                    if (!inZ[k]) continue;
                     double sdot = 0.0;
 #pragma unroll
-                    for (int r = 1; r <= m; ++r)
-                        if (r >= npp1) sdot += col[k][r - 1] * b[r - 1];
-                    wv[k] = sdot;
+                    for (int r = 1; r <= m; ++r) sdot += col[k][r - 1] * bm[r - 1];
+                    wv[k] = (phase == 0 && inZ[k]) ? sdot : wv[k];
                 }
             }
             // step three: largest positive dual among Z, ties to the smallest position
@@ -113,174 +144,206 @@ OPTIK_DEV void nnls_coop(bool live, int cid0, dvec8 (&col)[CPL], double (&xv)[CP
                 const bool c = run && inZ[k] && wv[k] > 0.0;
                 const double w = c ? wv[k] : 0.0;
                 const int p = c ? pos[k] : 0x7fffffff;
-                if ((w > bw) || (w == bw && p < bp)) { bw = w; bp = p; }
+                const bool better = (w > bw) || (w == bw && p < bp);
+                bw = better ? w : bw;
+                bp = better ? p : bp;
             }
 #pragma unroll
             for (int off = G / 2; off >= 1; off >>= 1) {
                 const double ow = __shfl_xor(bw, off, 64);
                 const int op = __shfl_xor(bp, off, 64);
-                if ((ow > bw) || (ow == bw && op < bp)) { bw = ow; bp = op; }
+                const bool better = (ow > bw) || (ow == bw && op < bp);
+                bw = better ? ow : bw;
+                bp = better ? op : bp;
             }
             const bool none = !(bw > 0.0);
             if (run && none) phase = 4;  // step four: every dual <= 0 -> done
-            const bool cand = run && !none;
+            // out of budget with work left: suspend before anything is modified (the duals
+            // are recomputed from the same data on resume)
+            if (phase == 0 && iter >= iter_stop) {
+                phase = 5;
+                cs.b = b;
+                cs.up = up;
+                cs.nsetp = nsetp;
+                cs.iter = iter;
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) cs.pos[k] = pos[k];
+                park(col, cs);
+            }
+            const bool cand = run && !none && phase != 5;
             // step five: Householder construction on the chosen column j (position bp)
-            int myk = -1;
+            bool hitk[CPL];
+            bool hit_any = false;
             dvec8 mine = 0.0;
 #pragma unroll
             for (int k = 0; k < CPL; ++k) {
-                const bool hit = cand && inZ[k] && pos[k] == bp;
-                myk = hit ? k : myk;
-                mine = vsel(hit, col[k], mine);
+                hitk[k] = cand && inZ[k] && pos[k] == bp;
+                hit_any = hit_any || hitk[k];
+                mine = vsel(hitk[k], col[k], mine);
             }
-            const int jl = Gr::find(myk >= 0);
+            const int jl = Gr::find(hit_any);
             const dvec8 u = Gr::bcast(mine, jl < 0 ? 0 : jl);
-            if (cand) {
-                const double asave = vpick(u, npp1);
-                const bool h12_live = npp1 < m;
-                double ulp = asave;
-                if (h12_live) {
-                    double cl = __builtin_fabs(asave);
+            // (all lanes run the construction; only `cand` groups keep its results)
+            const double asave = vpick(u, npp1);
+            const bool h12_live = npp1 < m;
+            dvec8 um = 0.0, ul = 0.0;  // u below the pivot row / above it, zero elsewhere
 #pragma unroll
-                    for (int r = 1; r <= m; ++r) {
-                        const double sm = __builtin_fabs(u[r - 1]);
-                        if (r > npp1 && sm > cl) cl = sm;
-                    }
-                    if (!(cl <= 0.0)) {
-                        const double clinv = 1.0 / cl;
-                        double d = asave * clinv;
-                        double sm = d * d;
+            for (int r = 1; r <= m; ++r) {
+                um[r - 1] = (r > npp1) ? u[r - 1] : 0.0;
+                ul[r - 1] = (r <= nsetp) ? u[r - 1] : 0.0;
+            }
+            double cl = __builtin_fabs(asave);
 #pragma unroll
-                        for (int r = 1; r <= m; ++r) {
-                            d = u[r - 1] * clinv;
-                            if (r > npp1) sm += d * d;
-                        }
-                        cl *= __builtin_sqrt(sm);
-                        if (asave > 0.0) cl = -cl;
-                        up = asave - cl;
-                        ulp = cl;
-                    }
+            for (int r = 1; r <= m; ++r) {
+                const double sm = __builtin_fabs(um[r - 1]);
+                cl = (sm > cl) ? sm : cl;
+            }
+            const bool pivot = h12_live && !(cl <= 0.0);
+            double ulp = asave;
+            {
+                const double clinv = 1.0 / cl;
+                double d = asave * clinv;
+                double sm = d * d;
+#pragma unroll
+                for (int r = 1; r <= m; ++r) {
+                    d = um[r - 1] * clinv;
+                    sm += d * d;
                 }
-                double unorm = 0.0;
-                {
-                    double xmax = 0.0;
+                double c2 = cl * __builtin_sqrt(sm);
+                c2 = (asave > 0.0) ? -c2 : c2;
+                up = (cand && pivot) ? asave - c2 : up;
+                ulp = pivot ? c2 : ulp;
+            }
+            double unorm = 0.0;
+            {
+                double xmax = 0.0;
 #pragma unroll
-                    for (int r = 1; r <= m; ++r) {
-                        const double av = __builtin_fabs(u[r - 1]);
-                        if (r <= nsetp && av > xmax) xmax = av;
-                    }
-                    if (xmax != 0.0) {
-                        const double scale = 1.0 / xmax;
-                        double sum = 0.0;
-#pragma unroll
-                        for (int r = 1; r <= m; ++r) {
-                            const double xs = scale * u[r - 1];
-                            if (r <= nsetp) sum += xs * xs;
-                        }
-                        unorm = xmax * __builtin_sqrt(sum);
-                    }
+                for (int r = 1; r <= m; ++r) {
+                    const double av = __builtin_fabs(ul[r - 1]);
+                    xmax = (av > xmax) ? av : xmax;
                 }
-                const double t = factor * __builtin_fabs(ulp);
-                const double d1 = unorm + t;
-                double hb = 0.0;
-                bool apply_live = false;
-                if (h12_live && !(__builtin_fabs(ulp) <= 0.0)) {
-                    hb = up * ulp;
-                    if (!(hb >= 0.0)) { hb = 1.0 / hb; apply_live = true; }
+                const double scale = 1.0 / xmax;
+                double sum = 0.0;
+#pragma unroll
+                for (int r = 1; r <= m; ++r) {
+                    const double xs = scale * ul[r - 1];
+                    sum += xs * xs;
                 }
-                bool found = false;
-                dvec8 zt = b;
-                if (d1 - unorm > 0.0) {
-                    if (apply_live) {
-                        double sm = vpick(zt, npp1) * up;
+                unorm = (xmax != 0.0) ? xmax * __builtin_sqrt(sum) : 0.0;
+            }
+            const double t = factor * __builtin_fabs(ulp);
+            const double d1 = unorm + t;
+            const double hprod = up * ulp;
+            const bool apply_live = cand && h12_live && !(__builtin_fabs(ulp) <= 0.0) && !(hprod >= 0.0);
+            const double hb = apply_live ? 1.0 / hprod : 0.0;
+            const bool ok1 = d1 - unorm > 0.0;
+            // the transformation as a weight per row: up at the pivot row, u below, 0 above
+            dvec8 w = 0.0;
 #pragma unroll
-                        for (int r = 1; r <= m; ++r)
-                            if (r > npp1) sm += zt[r - 1] * u[r - 1];
-                        if (sm != 0.0) {
-                            sm *= hb;
+            for (int r = 1; r <= m; ++r) w[r - 1] = (r == npp1) ? up : um[r - 1];
+            // b := Q b on a copy
+            dvec8 zt = b;
+            {
+                double sm = 0.0;
 #pragma unroll
-                            for (int r = 1; r <= m; ++r) {
-                                if (r == npp1) zt[r - 1] += sm * up;
-                                else if (r > npp1) zt[r - 1] += sm * u[r - 1];
-                            }
-                        }
-                    }
-                    if (vpick(zt, npp1) / ulp > 0.0) found = true;
+                for (int r = 1; r <= m; ++r) {
+                    const double pr = zt[r - 1] * w[r - 1];
+                    sm = (r == 1) ? pr : sm + pr;
                 }
-                if (found) {
-                    // b := Q b; column j takes position iz1 = nsetp + 1, the column there takes j's
-                    b = zt;
-                    const int iz1 = nsetp + 1;
+                const bool act = apply_live && ok1 && sm != 0.0;
+                const double smh = act ? sm * hb : 0.0;
 #pragma unroll
-                    for (int k = 0; k < CPL; ++k) {
-                        const bool me = (k == myk);
-                        if (isc[k] && pos[k] == iz1 && !me) pos[k] = bp;
-                        if (me) { pos[k] = iz1; inZ[k] = false; }
-                    }
-                    nsetp = npp1;
-                    ++npp1;
-#pragma unroll
-                    for (int k = 0; k < CPL; ++k) {
-                        if (apply_live && inZ[k]) {
-                            double sm = vpick(col[k], nsetp) * up;
-#pragma unroll
-                            for (int r = 1; r <= m; ++r)
-                                if (r >= npp1) sm += col[k][r - 1] * u[r - 1];
-                            if (sm != 0.0) {
-                                sm *= hb;
-#pragma unroll
-                                for (int r = 1; r <= m; ++r) {
-                                    if (r == nsetp) col[k][r - 1] += sm * up;
-                                    else if (r >= npp1) col[k][r - 1] += sm * u[r - 1];
-                                }
-                            }
-                        }
-                        if (k == myk) {
-#pragma unroll
-                            for (int r = 1; r <= m; ++r) {
-                                if (r == nsetp) col[k][r - 1] = ulp;
-                                else if (r >= npp1) col[k][r - 1] = 0.0;
-                            }
-                            wv[k] = 0.0;
-                        }
-                    }
-                    zz = b;
-                    phase = 2;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < CPL; ++k)
-                        if (k == myk) wv[k] = 0.0;
-                    phase = 1;  // choose again without recomputing the duals
+                for (int r = 1; r <= m; ++r) {
+                    const double add = smh * w[r - 1];
+                    zt[r - 1] = (act && r >= npp1) ? zt[r - 1] + add : zt[r - 1];
                 }
             }
+            const bool found = cand && ok1 && (vpick(zt, npp1) / ulp > 0.0);
+            // b := Q b; column j takes position iz1 = nsetp + 1, the column there takes j's
+            b = vsel(found, zt, b);
+            {
+                const int iz1 = nsetp + 1;
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) {
+                    const bool me = found && hitk[k];
+                    const bool other = found && isc[k] && pos[k] == iz1 && !hitk[k];
+                    pos[k] = other ? bp : pos[k];
+                    pos[k] = me ? iz1 : pos[k];
+                    inZ[k] = me ? false : inZ[k];
+                }
+            }
+            nsetp = found ? npp1 : nsetp;
+            npp1 = nsetp + 1;
+            // rows the transformation leaves alone get -0.0 added (sign bit forced on a zero)
+            unsigned rowkeep[8];
+            dvec8 newv = 0.0;  // the chosen column after the transformation
+#pragma unroll
+            for (int r = 1; r <= m; ++r) {
+                rowkeep[r - 1] = (r < nsetp) ? 0x80000000u : 0u;
+                newv[r - 1] = (r == nsetp) ? ulp : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                double sm = 0.0;
+#pragma unroll
+                for (int r = 1; r <= m; ++r) {
+                    const double pr = col[k][r - 1] * w[r - 1];
+                    sm = (r == 1) ? pr : sm + pr;
+                }
+                const bool act = found && apply_live && inZ[k] && sm != 0.0;
+                const double smh = act ? sm * hb : 0.0;
+                const unsigned colkeep = act ? 0u : 0x80000000u;
+                const bool chosen = found && hitk[k];
+#pragma unroll
+                for (int r = 1; r <= m; ++r) {
+                    const double add = smh * w[r - 1];  // +-0 wherever the row or column is kept
+                    const double addz = __hiloint2double((int)((unsigned)__double2hiint(add) | rowkeep[r - 1] | colkeep),
+                                                         __double2loint(add));
+                    const double v = col[k][r - 1] + addz;
+                    col[k][r - 1] = (chosen && r >= nsetp) ? newv[r - 1] : v;
+                }
+                wv[k] = (cand && hitk[k]) ? 0.0 : wv[k];
+            }
+            // found: solve (step six); else choose again without recomputing the duals
+            phase = cand ? (found ? 2 : 1) : phase;
         }
         // ---------------- steps six .. ten ---------------------------------------------
         if (wave_any(phase == 2)) {
             const bool run = phase == 2;
-            // step six: solve the triangular system on set P (positions nsetp .. 1)
-            int nmax = run ? nsetp : 0;
+            dvec8 zz = b;  // (steps five / eleven leave z := b)
+            int nmax = 0;
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(nmax, off, 64); nmax = o > nmax ? o : nmax; }
-            for (int ip = nmax; ip >= 1; --ip) {
+            for (int v = 1; v <= m; ++v)
+                if (wave_any(run && nsetp >= v)) nmax = v;
+            // step six: solve the triangular system on set P (positions nsetp .. 1)
+            double zown[CPL];
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) zown[k] = 0.0;
+#pragma unroll
+            for (int ip = m; ip >= 1; --ip) {
+                if (ip > nmax) continue;
                 const bool step = run && ip <= nsetp;
+                bool hk[CPL];
                 bool hit_any = false;
                 dvec8 mine = 0.0;
 #pragma unroll
                 for (int k = 0; k < CPL; ++k) {
-                    const bool hit = step && isc[k] && !inZ[k] && pos[k] == ip;
-                    hit_any = hit_any || hit;
-                    mine = vsel(hit, col[k], mine);
+                    hk[k] = step && isc[k] && !inZ[k] && pos[k] == ip;
+                    hit_any = hit_any || hk[k];
+#pragma unroll
+                    for (int r = 1; r <= ip; ++r) mine[r - 1] = hk[k] ? col[k][r - 1] : mine[r - 1];
                 }
                 const int ol = Gr::find(hit_any);
-                const dvec8 cv = Gr::bcast(mine, ol < 0 ? 0 : ol);
-                if (step) {
-                    const double zi = vpick(zz, ip) / vpick(cv, ip);
+                const int src = Gr::base() + (ol < 0 ? 0 : ol);
+                dvec8 cv = 0.0;
 #pragma unroll
-                    for (int r = 1; r <= m; ++r) {
-                        if (r == ip) zz[r - 1] = zi;
-                        else if (r < ip) zz[r - 1] -= zi * cv[r - 1];
-                    }
-                }
+                for (int r = 1; r <= ip; ++r) cv[r - 1] = __shfl(mine[r - 1], src, 64);
+                const double zi = zz[ip - 1] / cv[ip - 1];
+                zz[ip - 1] = step ? zi : zz[ip - 1];
+#pragma unroll
+                for (int r = 1; r < ip; ++r) zz[r - 1] = step ? zz[r - 1] - zi * cv[r - 1] : zz[r - 1];
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) zown[k] = hk[k] ? zi : zown[k];
             }
             if (run) {
                 ++iter;
@@ -288,43 +351,35 @@ OPTIK_DEV void nnls_coop(bool live, int cid0, dvec8 (&col)[CPL], double (&xv)[CP
             }
             const bool go = phase == 2;
             // steps seven..ten: step length; scan the positions in order, as the serial code does
-            double zown[CPL], tcand[CPL];
-            bool neg[CPL];
-#pragma unroll
-            for (int k = 0; k < CPL; ++k) {
-                const bool inP = isc[k] && !inZ[k];
-                zown[k] = vpick(zz, pos[k] > m ? m : (pos[k] < 1 ? 1 : pos[k]));
-                neg[k] = go && inP && !(zown[k] > 0.0);
-                tcand[k] = neg[k] ? (-xv[k] / (zown[k] - xv[k])) : 0.0;
-            }
             double alpha = 1.0;
             int jj = 0;
-            for (int ip = 1; ip <= nmax; ++ip) {
+#pragma unroll
+            for (int ip = 1; ip <= m; ++ip) {
+                if (ip > nmax) continue;
                 const bool step = go && ip <= nsetp;
-                bool hit_any = false, hneg = false;
-                double ht = 0.0;
+                bool hit_any = false;
+                double hx = 0.0;
 #pragma unroll
                 for (int k = 0; k < CPL; ++k) {
                     const bool hit = step && isc[k] && !inZ[k] && pos[k] == ip;
                     hit_any = hit_any || hit;
-                    hneg = hit ? neg[k] : hneg;
-                    ht = hit ? tcand[k] : ht;
+                    hx = hit ? xv[k] : hx;
                 }
                 const int ol = Gr::find(hit_any);
-                const int src = ol < 0 ? 0 : ol;
-                const double t = Gr::bcast(ht, src);
-                const int isneg = Gr::bcast(hneg ? 1 : 0, src);
-                if (step && ol >= 0 && isneg) {
-                    if (!(alpha < t)) { alpha = t; jj = ip; }
-                }
+                const double xp = Gr::bcast(hx, ol < 0 ? 0 : ol);
+                const double zp = zz[ip - 1];
+                const double tq = -xp / (zp - xp);
+                const bool take = step && ol >= 0 && !(zp > 0.0) && !(alpha < tq);
+                alpha = take ? tq : alpha;
+                jj = take ? ip : jj;
             }
 #pragma unroll
-            for (int k = 0; k < CPL; ++k)
-                if (go && isc[k] && !inZ[k]) xv[k] = (1.0 - alpha) * xv[k] + alpha * zown[k];
-            if (go) {
-                if (jj == 0) phase = 0;  // back to step two
-                else { rem_jj = jj; phase = 3; }
+            for (int k = 0; k < CPL; ++k) {
+                const double nx = (1.0 - alpha) * xv[k] + alpha * zown[k];
+                xv[k] = (go && isc[k] && !inZ[k]) ? nx : xv[k];
             }
+            rem_jj = (go && jj != 0) ? jj : rem_jj;
+            phase = go ? (jj == 0 ? 0 : 3) : phase;  // back to step two, or remove position jj
         }
         // ---------------- step eleven ----------------------------------------------------
         if (wave_any(phase == 3)) {
@@ -404,7 +459,6 @@ OPTIK_DEV void nnls_coop(bool live, int cid0, dvec8 (&col)[CPL], double (&xv)[CP
                 if (bad != 0x7fffffff) {
                     rem_jj = bad;  // again
                 } else {
-                    zz = b;
                     phase = 2;
                 }
             }
@@ -433,7 +487,7 @@ OPTIK_DEV void nnls_coop(bool live, int cid0, dvec8 (&col)[CPL], double (&xv)[CP
         }
         rnorm_out = rn;
     }
-    mode_out = mode;
+    mode_out = phase == 5 ? NNLS_SUSPENDED : mode;
     iters_out = iter;
 }
 

@@ -10,4 +10,4 @@ mkdir -p $OUT
 CMD="python bench.py --steps 5 --warmup 1 --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY \
   -f csv -d $OUT -o bench -- $CMD > $OUT/stdout.txt 2>&1
-python tools/pmc_sq_summary.py $OUT
+python tools/pmc_sq_summary.py $OUT > /dev/null; python tools/pmc_sq_top.py $OUT
