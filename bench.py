@@ -52,6 +52,9 @@ def pmc_traffic(kernel):
 
 
 
+ENGINE_POOL = 48  # steps whose restarts share one engine run
+
+
 def load_chain(robot):
     """Flat chain table through the product's own URDF loader (C++, optik_robot_*)."""
     from optik_amd import Robot
@@ -159,10 +162,12 @@ def main():
         if args.path == "engine":
             # every step is its own job (own target, own outputs); jobs submitted together
             # share the engine's slot pool, then one blocking run executes them all
-            for k in range(count):
-                i = first + k
-                hc.engine_submit(cfg, targets[i:i + 1], x0[i:i + 1], begin, end, bufs=bufs[k])
-            hc.engine_run()
+            # (at most ENGINE_POOL jobs per run: the engine's job table holds 64)
+            for g0 in range(0, count, ENGINE_POOL):
+                for k in range(g0, min(g0 + ENGINE_POOL, count)):
+                    i = first + k
+                    hc.engine_submit(cfg, targets[i:i + 1], x0[i:i + 1], begin, end, bufs=bufs[k])
+                hc.engine_run()
             stacked = {"win_idx": torch.cat([bufs[k]["win_idx"] for k in range(count)]),
                        "win_key": torch.cat([bufs[k]["win_key"] for k in range(count)])}
             return select_winner(stacked, "speed", distributed)  # one collective for all steps

@@ -96,7 +96,8 @@ struct EngArgs {
     double *d;                          // ND planes of C doubles
     int32_t *i32;                       // NI planes of C ints
     unsigned long long *item;           // [C] local item (t * R + r) of the slot's restart
-    unsigned long long C;
+    unsigned long long C;               // pool capacity = stride of the planes
+    unsigned long long n_slots;         // live prefix [0, n_slots) the per-slot kernels cover (shrinks while the pool drains)
     const EngJob *jobs;                 // [n_jobs] in device memory
     int n_jobs;
     int pad;
@@ -117,6 +118,9 @@ struct EngArgs {
     unsigned int *n_active;             // slots holding a restart after the update kernel (zeroed every trip)
     unsigned long long *nn_total;       // running count of bounded sub-problems solved
     unsigned long long *prof;           // OPTIK_PROFILE builds: cycle counters, else null
+    unsigned int *trip_log;             // diagnostics (OPTIK_ENG_TRIP_LOG): [trip][2] = {slots in use, sub-problems}
+    int trip;
+    int pad4;
     unsigned long long *trace;          // OPTIK_NNLS_TRACE builds: per-wave {start, end, hw id, passes} of one trip
 };
 
@@ -676,6 +680,10 @@ OPTIK_DEV void eng_bucket_body(const EngArgs &a) {
     const unsigned long long below = (1ull << lane) - 1ull;
     const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) / 64u;
     const unsigned n_waves = (gridDim.x * blockDim.x) / 64u;
+    if (a.trip_log && blockIdx.x == 0 && threadIdx.x == 0) {
+        a.trip_log[2 * a.trip] = *a.n_active;
+        a.trip_log[2 * a.trip + 1] = cnt;
+    }
     for (unsigned i0 = wave * (64u * BUCKET_SUB); i0 < cnt; i0 += n_waves * (64u * BUCKET_SUB)) {
         int cls[BUCKET_SUB];
         unsigned rank[BUCKET_SUB];
@@ -704,6 +712,52 @@ OPTIK_DEV void eng_bucket_body(const EngArgs &a) {
             if (cls[b] >= 0) order[(size_t)cls[b] * a.C + cb + rank[b]] = i0 + (unsigned)b * 64u + lane;
         }
     }
+}
+
+// ---- pool compaction (drain phase) -----------------------------------------------------
+// Once the queue is empty the restarts still running are scattered over the pool and every
+// wave of the per-slot kernels keeps a few live lanes.  The host then shrinks the live
+// prefix: restarts above the new bound move into free slots below it (a slot is a plain
+// record; which slot a restart occupies has no effect on its arithmetic).
+
+struct CompactArgs {
+    double *d;
+    int32_t *i32;
+    unsigned long long *item;
+    unsigned long long C, n_slots, n_new;
+    int nd, ni;
+    unsigned int *counts;   // [0] free slots listed, [1] restarts to move
+    unsigned int *free_list, *move_list;
+};
+
+OPTIK_DEV void compact_scan_body(const CompactArgs &c) {
+    const unsigned long long slot = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = slot < c.n_slots;
+    const int st = in ? c.i32[slot] : ST_EMPTY;  // plane 0 = STATE
+    const bool is_free = in && slot < c.n_new && st == ST_EMPTY;
+    const bool is_move = in && slot >= c.n_new && st != ST_EMPTY;
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long mf = __ballot(is_free), mm = __ballot(is_move);
+    unsigned bf = 0, bm = 0;
+    if (lane == 0) {
+        if (mf) bf = atomicAdd(c.counts + 0, (unsigned)__popcll(mf));
+        if (mm) bm = atomicAdd(c.counts + 1, (unsigned)__popcll(mm));
+    }
+    bf = (unsigned)__shfl((int)bf, 0, 64);
+    bm = (unsigned)__shfl((int)bm, 0, 64);
+    if (is_free) c.free_list[bf + (unsigned)__popcll(mf & below)] = (unsigned)slot;
+    if (is_move) c.move_list[bm + (unsigned)__popcll(mm & below)] = (unsigned)slot;
+}
+
+OPTIK_DEV void compact_move_body(const CompactArgs &c) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c.counts[1]) return;
+    const size_t src = c.move_list[i], dst = c.free_list[i];
+    for (int p = 0; p < c.nd; ++p) c.d[(size_t)p * c.C + dst] = c.d[(size_t)p * c.C + src];
+    for (int p = 0; p < c.ni; ++p) c.i32[(size_t)p * c.C + dst] = c.i32[(size_t)p * c.C + src];
+    c.item[dst] = c.item[src];
+    c.i32[src] = ST_EMPTY;
 }
 
 // ---- kernel 4: finish the deferred directions with the NNLS answers ----------------

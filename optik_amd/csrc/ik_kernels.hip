@@ -10,6 +10,7 @@
 //   probe_kernel      elementary functions (test hook)
 // No CPU fallback exists: every entry point fails loudly without a device.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 
 #include <cmath>
 #include <cstdio>
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256, OPTIK_ENG_EVAL_WAVES) void eng_eval_kernel(con
     __shared__ ChainDev sch;
     stage_chain(sch, a.chain);
     const size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (slot < a.C) eng_eval_body<N, TIP>(a, sch, slot);
+    if (slot < a.n_slots) eng_eval_body<N, TIP>(a, sch, slot);
 }
 
 template <int N>
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(256, OPTIK_ENG_UPD_WAVES) void eng_update_kernel(co
     __shared__ ChainDev sch;
     stage_chain(sch, a.chain);
     const size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x;
-    eng_update_body<N>(a, sch, slot < a.C ? slot : 0, slot < a.C);
+    eng_update_body<N>(a, sch, slot < a.n_slots ? slot : 0, slot < a.n_slots);
 }
 
 // columns of a bounded sub-problem held per lane (16 / CPL lanes share a problem)
@@ -205,8 +206,11 @@ __global__ __launch_bounds__(256, OPTIK_ENG_UPD_WAVES) void eng_finish_kernel(co
     __shared__ ChainDev sch;
     stage_chain(sch, a.chain);
     const size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (slot < a.C) eng_finish_body<N>(a, sch, slot);
+    if (slot < a.n_slots) eng_finish_body<N>(a, sch, slot);
 }
+
+__global__ __launch_bounds__(256) void eng_compact_scan_kernel(const CompactArgs c) { compact_scan_body(c); }
+__global__ __launch_bounds__(256) void eng_compact_move_kernel(const CompactArgs c) { compact_move_body(c); }
 
 __global__ void eng_init_kernel(int32_t *state, unsigned long long C) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -365,6 +369,9 @@ struct optik_hip_chain {
     unsigned int *eng_order = nullptr;     // 2 x [NN_CLASSES][C]
     double *eng_carry = nullptr;           // 2 x [C][NN_CARRY]
     unsigned long long *nnls_trace = nullptr;  // OPTIK_NNLS_TRACE builds
+    unsigned int *eng_trip_log = nullptr;      // OPTIK_ENG_TRIP_LOG diagnostics
+    unsigned int *eng_compact = nullptr;       // [2] counters, then free list [C], move list [C]
+    int eng_compactions = 0;
     double *eng_prob = nullptr;            // 2 x [C][2n][n+1]
     double *eng_y = nullptr;               // 2 x [C][2n]
     double *eng_meta = nullptr;            // 2 x [C][2]
@@ -575,6 +582,8 @@ void optik_hip_chain_destroy(optik_hip_chain *ch) {
     if (ch->eng_counters) hipFree(ch->eng_counters);
     if (ch->eng_order) hipFree(ch->eng_order);
     if (ch->eng_carry) hipFree(ch->eng_carry);
+    if (ch->eng_trip_log) hipFree(ch->eng_trip_log);
+    if (ch->eng_compact) hipFree(ch->eng_compact);
     if (ch->eng_prob) hipFree(ch->eng_prob);
     if (ch->eng_y) hipFree(ch->eng_y);
     if (ch->eng_meta) hipFree(ch->eng_meta);
@@ -914,6 +923,8 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             if (ch->eng_meta) HIP_TRY(hipFree(ch->eng_meta));
             if (ch->eng_order) HIP_TRY(hipFree(ch->eng_order));
             if (ch->eng_carry) HIP_TRY(hipFree(ch->eng_carry));
+            if (ch->eng_compact) HIP_TRY(hipFree(ch->eng_compact));
+            ch->eng_compact = nullptr;
             ch->eng_order = nullptr; ch->eng_carry = nullptr;
             ch->eng_d = nullptr; ch->eng_i32 = nullptr; ch->eng_item = nullptr;
             ch->eng_prob = ch->eng_y = ch->eng_meta = nullptr;
@@ -926,6 +937,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             HIP_TRY(hipMalloc(&ch->eng_meta, sizeof(double) * 2 * C * 2));
             HIP_TRY(hipMalloc(&ch->eng_order, sizeof(unsigned int) * 2 * NN_CLASSES * C));
             HIP_TRY(hipMalloc(&ch->eng_carry, sizeof(double) * 2 * NN_CARRY * C));
+            HIP_TRY(hipMalloc(&ch->eng_compact, sizeof(unsigned int) * (2 + 2 * C)));
             ch->eng_C = C;
         }
         if (!ch->eng_djobs) HIP_TRY(hipMalloc(&ch->eng_djobs, sizeof(EngJob) * ENG_MAX_JOBS));
@@ -953,7 +965,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
         fill_solve_params(&ch->eng_cfg, a.sp);
         std::memcpy(a.key, ch->key, sizeof a.key);
         std::memcpy(a.scale, ch->scale, sizeof a.scale);
-        a.d = ch->eng_d; a.i32 = ch->eng_i32; a.item = ch->eng_item; a.C = C;
+        a.d = ch->eng_d; a.i32 = ch->eng_i32; a.item = ch->eng_item; a.C = C; a.n_slots = C;
         a.jobs = ch->eng_djobs; a.n_jobs = (int)n_jobs;
         a.total_items = total;
         a.next_item = ch->queue;
@@ -975,13 +987,24 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
         a.parity = 0;
         a.prof = nullptr;
         a.trace = nullptr;
+        a.trip_log = nullptr;
+        a.trip = 0;
+        const char *trip_log_path = getenv("OPTIK_ENG_TRIP_LOG");
+        constexpr int TRIP_LOG_MAX = 65536;
+        if (trip_log_path) {
+            if (!ch->eng_trip_log) HIP_TRY(hipMalloc(&ch->eng_trip_log, sizeof(unsigned int) * 2 * TRIP_LOG_MAX));
+            HIP_TRY(hipMemsetAsync(ch->eng_trip_log, 0, sizeof(unsigned int) * 2 * TRIP_LOG_MAX, stream));
+            a.trip_log = ch->eng_trip_log;
+        }
 #ifdef OPTIK_PROFILE
         if (!ch->prof) HIP_TRY(hipMalloc(&ch->prof, 8 * sizeof(unsigned long long)));
         HIP_TRY(hipMemsetAsync(ch->prof, 0, 8 * sizeof(unsigned long long), stream));
         a.prof = ch->prof;
 #endif
 
-        const unsigned blocks = (unsigned)((C + 255) / 256);
+        unsigned blocks = (unsigned)((C + 255) / 256);  // per-slot kernels: covers the live prefix
+        ch->eng_compactions = 0;
+        const bool allow_compact = !getenv("OPTIK_ENG_NO_COMPACT");
         const int cus = ch->num_cus > 0 ? ch->num_cus : 256;
         unsigned nn_waves_per_cu = 32;
         if (const char *e = getenv("OPTIK_ENG_NNLS_WAVES_PER_CU")) nn_waves_per_cu = (unsigned)atoi(e);
@@ -1000,6 +1023,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
                 // this trip consumes list[trip & 1]; the other list (consumed last trip) is
                 // reset for the finish kernel's re-deferrals and the next trip's update kernel
                 a.parity = trip & 1;
+                a.trip = trip < TRIP_LOG_MAX ? trip : TRIP_LOG_MAX - 1;
                 HIP_TRY(hipMemsetAsync(ch->eng_counters + (a.parity ^ 1) * CB, 0, CB * sizeof(unsigned int), stream));
                 HIP_TRY(hipMemsetAsync(ch->eng_counters + 2 * CB, 0, sizeof(unsigned int), stream));
                 // HIP event pairs around each kernel of every trip (on the launch stream)
@@ -1052,7 +1076,27 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             if (pending) {
                 const int prev = (ring + 7) % 8;
                 HIP_TRY(hipEventSynchronize(ch->eng_ev[prev]));
-                if (ch->eng_pinned[prev] == 0) done = true;
+                const unsigned long long in_use = ch->eng_pinned[prev];
+                if (in_use == 0) done = true;
+                // drain: part of the live prefix no longer holds a restart (the count only
+                // falls once the queue is empty, so the lagging value is an upper bound)
+                unsigned long long n_new = (in_use + 255) / 256 * 256;
+                if (n_new < 1024) n_new = 1024;
+                if (!done && allow_compact && n_new * 5 <= a.n_slots * 4) {  // worth >= 20% of every per-slot launch
+                    CompactArgs c;
+                    c.d = ch->eng_d; c.i32 = ch->eng_i32; c.item = ch->eng_item;
+                    c.C = C; c.n_slots = a.n_slots; c.n_new = n_new; c.nd = nd; c.ni = ni;
+                    c.counts = ch->eng_compact;
+                    c.free_list = ch->eng_compact + 2;
+                    c.move_list = ch->eng_compact + 2 + C;
+                    HIP_TRY(hipMemsetAsync(ch->eng_compact, 0, 2 * sizeof(unsigned int), stream));
+                    hipLaunchKernelGGL(eng_compact_scan_kernel, dim3((unsigned)((a.n_slots + 255) / 256)), dim3(256), 0, stream, c);
+                    hipLaunchKernelGGL(eng_compact_move_kernel, dim3((unsigned)((a.n_slots - n_new + 255) / 256)), dim3(256), 0, stream, c);
+                    HIP_TRY(hipGetLastError());
+                    a.n_slots = n_new;
+                    blocks = (unsigned)((n_new + 255) / 256);
+                    ch->eng_compactions += 1;
+                }
             }
             pending = 1;
             ring = (ring + 1) % 8;
@@ -1103,6 +1147,23 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
                 ++cnt;
             }
             ch->eng_kernel_ms[k] = cnt ? sum / cnt : 0.0;
+        }
+        if (trip_log_path) {
+            // per trip: slots in use, sub-problems, and the sampled kernel times (ms; 0 = not sampled)
+            std::vector<unsigned int> h(2 * (size_t)std::min(trip, TRIP_LOG_MAX));
+            HIP_TRY(hipMemcpy(h.data(), ch->eng_trip_log, h.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
+            if (FILE *fp = fopen(trip_log_path, "w")) {
+                fprintf(fp, "trip,slots_in_use,sub_problems,eval_ms,update_ms,nnls_ms,finish_ms\n");
+                for (int t = 0; t < (int)(h.size() / 2); ++t) {
+                    float ms[4] = {0, 0, 0, 0};
+                    const int i = t - 1;
+                    if (i >= 0 && i < ch->eng_tcount)
+                        for (int k = 0; k < 4; ++k)
+                            if (k == 2 || t % 8 == 0) hipEventElapsedTime(&ms[k], ch->eng_tev[k][i][0], ch->eng_tev[k][i][1]);
+                    fprintf(fp, "%d,%u,%u,%.4f,%.4f,%.4f,%.4f\n", t, h[2 * t], h[2 * t + 1], ms[0], ms[1], ms[2], ms[3]);
+                }
+                fclose(fp);
+            }
         }
 #ifdef OPTIK_NNLS_TRACE
         if (const char *tf = getenv("OPTIK_NNLS_TRACE_FILE")) {
