@@ -84,8 +84,10 @@ constexpr int ENG_MAX_JOBS = 64;
 constexpr int NN_CLASSES = 8;
 // A problem that needs more than the launch's pass budget is suspended and continues in
 // the next trip's launch (its slot just stays in ST_NNLS): no launch waits for the rare
-// 10+ pass problem.  Carry record: b[8], up, nsetp, iter, then xv[16], pos[16].
-constexpr int NN_CARRY = 48;
+// 10+ pass problem.  Carry record: the transformed matrix [112], then b[8], up, nsetp, iter,
+// xv[16] at +16, pos[16] at +32.
+constexpr int NN_CARRY_STATE = 112;
+constexpr int NN_CARRY = NN_CARRY_STATE + 48;
 
 struct EngArgs {
     const ChainDev *chain;
@@ -103,14 +105,17 @@ struct EngArgs {
     int pad;
     unsigned long long total_items;
     unsigned long long *next_item;      // global queue head
-    // bounded sub-problems of a trip: list / problem / answer buffers, double-buffered by
-    // trip parity (the finish kernel of trip s may defer into the list of trip s+1)
+    // bounded sub-problems: one record per slot (a slot has at most one outstanding); the
+    // lists of a trip are double-buffered by trip parity (the finish kernel of trip s and a
+    // suspended solve both defer into the list of trip s+1)
     unsigned int *nn_count[2];          // list lengths; [1 .. NN_CLASSES] after each: class sizes
-    unsigned int *nn_order[2];          // [NN_CLASSES][C] list positions by predicted class
-    double *nn_prob[2];                 // [C][2n][n+1] dual problems, one contiguous block each
-    double *nn_y[2];                    // [C][2n] multipliers
-    double *nn_meta[2];                 // [C][2] {mode + 8 * passes, rnorm}; before the solve {class, 0 | -1 = resume}
-    double *nn_carry[2];                // [C][NN_CARRY] state of suspended problems (see eng_nnls_coop_body)
+    unsigned int *nn_list[2];           // [C] slots with a problem for the trip, in emission order
+    unsigned int *nn_cls[2];            // [C] predicted class of each list entry
+    unsigned int *nn_order[2];          // [NN_CLASSES][C] the list's slots by predicted class
+    double *nn_prob;                    // [C][2n][n+1] dual problem of the slot, one contiguous block
+    double *nn_y;                       // [C][2n] multipliers
+    double *nn_meta;                    // [C][2] {mode + 8 * passes, rnorm | -1 = suspended, resume from nn_carry}
+    double *nn_carry;                   // [C][NN_CARRY] matrix and state of a suspended solve
     int nn_budget;                      // solve passes per problem per launch (stragglers continue next trip)
     int pad3;
     int parity;                         // list consumed by this trip's NNLS kernel
@@ -130,15 +135,22 @@ struct EngArgs {
 // Outcome of the direction search for one slot.
 enum : int { DIR_OK = 0, DIR_DEFER = 1, DIR_DEAD = 2 };
 
-// Writes the dual problem of a deferred direction (columns of [G E^-1; h]) as one
-// contiguous block for the cooperative NNLS kernel; returns its list position.
+// Lists the slot for the NNLS launch of trip parity `parity`, with its predicted class.
 template <int N>
-OPTIK_DEV unsigned emit_problem(const EngArgs &a, int parity, const LsqPrep<N> &P, int pred) {
-    // the predicted class rides in the answer record until the NNLS kernel overwrites it
+OPTIK_DEV void list_problem(const EngArgs &a, int parity, size_t slot, int pred) {
     const unsigned q = atomicAdd(a.nn_count[parity], 1u);
-    a.nn_meta[parity][(size_t)q * 2] = (double)(pred < 0 ? 0 : (pred >= NN_CLASSES ? NN_CLASSES - 1 : pred));
-    a.nn_meta[parity][(size_t)q * 2 + 1] = 0.0;
-    double *pb = a.nn_prob[parity] + (size_t)q * (2 * N) * (N + 1);
+    a.nn_list[parity][q] = (unsigned)slot;
+    ENG_I(EngLayout<N>::NNQ) = (int32_t)q;  // (the pool compaction re-points the entry when it moves the slot)
+    a.nn_cls[parity][q] = (unsigned)(pred < 0 ? 0 : (pred >= NN_CLASSES ? NN_CLASSES - 1 : pred));
+}
+
+// Writes the dual problem of a deferred direction (columns of [G E^-1; h]) as one
+// contiguous block for the cooperative NNLS kernel and lists the slot.
+template <int N>
+OPTIK_DEV void emit_problem(const EngArgs &a, int parity, size_t slot, const LsqPrep<N> &P, int pred) {
+    list_problem<N>(a, parity, slot, pred);
+    a.nn_meta[slot * 2 + 1] = 0.0;  // a fresh problem, not a resumed one
+    double *pb = a.nn_prob + slot * (2 * N) * (N + 1);
 #pragma unroll
     for (int c = 0; c < N; ++c) {
 #pragma unroll
@@ -150,7 +162,6 @@ OPTIK_DEV unsigned emit_problem(const EngArgs &a, int parity, const LsqPrep<N> &
         pb[c * (N + 1) + N] = P.h[c];
         pb[(N + c) * (N + 1) + N] = P.h[N + c];
     }
-    return q;
 }
 
 // LDP tail (Lawson-Hanson ch. 23) from the NNLS answer: transformed-space step.
@@ -188,10 +199,10 @@ OPTIK_DEV int ldp_from_answer(const LsqPrep<N> &P, const double *y_mem, const do
 // kernel and the slot is deferred.  `answer` non-null re-enters at the LSQ call of a
 // deferred pass (its ++iter / reset are done) and completes it with the NNLS answer.
 template <int N>
-OPTIK_DEV int direction_search(const EngArgs &a, const ChainDev &ch, int emit_parity, const double *answer_y,
+OPTIK_DEV int direction_search(const EngArgs &a, const ChainDev &ch, size_t slot, int emit_parity, const double *answer_y,
                                const double *answer_meta, double (&l)[N * (N + 1) / 2], const double (&g)[N],
                                const double (&x)[N], double f, int &ireset, int &iter, bool reset,
-                               double (&s)[N], double &h3, int32_t &status, unsigned &q_out, int pred) {
+                               double (&s)[N], double &h3, int32_t &status, int pred) {
     constexpr int NL = N * (N + 1) / 2;
     const SolveParams &sp = a.sp;
     double f0 = 0.0;
@@ -226,7 +237,7 @@ OPTIK_DEV int direction_search(const EngArgs &a, const ChainDev &ch, int emit_pa
                 if (resume) {
                     lmode = ldp_from_answer<N>(P, answer_y, answer_meta, s);
                 } else {
-                    q_out = emit_problem<N>(a, emit_parity, P, pred);
+                    emit_problem<N>(a, emit_parity, slot, P, pred);
                     return DIR_DEFER;
                 }
             } else {
@@ -284,7 +295,7 @@ OPTIK_DEV void store_direction(const EngArgs &a, const ChainDev &ch, size_t slot
 
 template <int N>
 OPTIK_DEV void store_deferred(const EngArgs &a, size_t slot, const double (&l)[N * (N + 1) / 2],
-                              const double (&g)[N], int ireset, int iter, unsigned q) {
+                              const double (&g)[N], int ireset, int iter) {
     using E = EngLayout<N>;
 #pragma unroll
     for (int i = 0; i < E::NL; ++i) ENG_D(E::L, i) = l[i];
@@ -292,7 +303,6 @@ OPTIK_DEV void store_deferred(const EngArgs &a, size_t slot, const double (&l)[N
     for (int i = 0; i < N; ++i) ENG_D(E::G, i) = g[i];
     ENG_I(E::IRESET) = ireset;
     ENG_I(E::ITER) = iter;
-    ENG_I(E::NNQ) = (int32_t)q;
     ENG_I(E::STATE) = ST_NNLS;
 }
 
@@ -522,11 +532,10 @@ OPTIK_DEV void eng_update_body(const EngArgs &a, const ChainDev &ch, size_t slot
         }
         double h3 = 0.0;
         int32_t status = 0;
-        unsigned q = 0;
-        const int out = direction_search<N>(a, ch, a.parity, nullptr, nullptr, l, g, x, f, ireset, iter,
-                                            st == ST_UPDATE_FIRST, s, h3, status, q, ENG_I(E::NNIT));
+        const int out = direction_search<N>(a, ch, slot, a.parity, nullptr, nullptr, l, g, x, f, ireset, iter,
+                                            st == ST_UPDATE_FIRST, s, h3, status, ENG_I(E::NNIT));
         if (out == DIR_OK) store_direction<N>(a, ch, slot, l, g, x, s, f, h3, ireset, iter);
-        else if (out == DIR_DEFER) store_deferred<N>(a, slot, l, g, ireset, iter, q);
+        else if (out == DIR_DEFER) store_deferred<N>(a, slot, l, g, ireset, iter);
         else { ENG_I(E::STATUS) = status; ENG_I(E::ITER) = iter; ENG_I(E::STATE) = ST_DEAD; }
         st = ST_EVAL_TRIAL;  // (any non-empty value: the slot still holds a restart)
     }
@@ -543,9 +552,8 @@ OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a) {
     constexpr int G = COOP_COLS / CPL;        // lanes per problem
     constexpr unsigned PPW = 64 / G;          // problems per wave
     const unsigned cnt = *a.nn_count[a.parity];
-    const double *prob = a.nn_prob[a.parity];
-    double *ybuf = a.nn_y[a.parity];
-    double *meta = a.nn_meta[a.parity];
+    double *ybuf = a.nn_y;
+    double *meta = a.nn_meta;
     const unsigned lane = threadIdx.x & 63u;
     const unsigned group = lane / G, gl = lane % G;
     const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) / 64u;
@@ -560,7 +568,7 @@ OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a) {
 #endif
     for (unsigned q0 = wave * PPW; q0 < cnt; q0 += n_waves * PPW) {
         const bool live = q0 + group < cnt;
-        // the (q0 + group)-th problem in class order, largest predicted pass count first
+        // the slot of the (q0 + group)-th problem in class order, largest predicted pass count first
         unsigned q = 0;
         {
             unsigned i = q0 + group;
@@ -574,7 +582,9 @@ OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a) {
         const bool resume = live && meta[(size_t)q * 2 + 1] < 0.0;
         dvec8 col[CPL];
         CoopCarry<CPL> cs;
-        const double *cr = a.nn_carry[a.parity] + (size_t)q * NN_CARRY;
+        const double *cr = a.nn_carry + (size_t)q * NN_CARRY + NN_CARRY_STATE;
+        // the matrix: the emitted problem, or the transformed one of a suspended solve
+        const double *prob = resume ? a.nn_carry + (size_t)q * NN_CARRY : a.nn_prob + (size_t)q * n * m;
         cs.b = 0.0;
         cs.up = 0.0;
         cs.nsetp = 0;
@@ -593,7 +603,7 @@ OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a) {
             cs.pos[k] = 0;
             const unsigned c = gl * CPL + k;
             if (live && c < (unsigned)n) {
-                const double *pc = prob + ((size_t)q * n + c) * m;
+                const double *pc = prob + (size_t)c * m;
 #pragma unroll
                 for (int r = 0; r < m; ++r) col[k][r] = pc[r];
             }
@@ -604,19 +614,16 @@ OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a) {
         }
         int mode, iters;
         double rnorm;
-        // a suspended problem continues in the next trip: new list position in the other
-        // parity's buffers, matrix and state stored from inside the solver
+        // a suspended problem continues in the next trip: matrix and state go to the slot's
+        // carry record (stored from inside the solver) and the slot is listed again
         auto park = [&](const dvec8 (&pcol)[CPL], const CoopCarry<CPL> &st) {
-            const int op = a.parity ^ 1;
-            unsigned q2 = 0;
-            if (gl == 0) q2 = atomicAdd(a.nn_count[op], 1u);
-            q2 = (unsigned)Group<G>::bcast((int)q2, 0);
-            double *cw = a.nn_carry[op] + (size_t)q2 * NN_CARRY;
+            double *cm = a.nn_carry + (size_t)q * NN_CARRY;
+            double *cw = cm + NN_CARRY_STATE;
 #pragma unroll
             for (int k = 0; k < CPL; ++k) {
                 const unsigned c = gl * CPL + k;
                 if (c < (unsigned)n) {
-                    double *pc = a.nn_prob[op] + ((size_t)q2 * n + c) * m;
+                    double *pc = cm + (size_t)c * m;
 #pragma unroll
                     for (int r = 0; r < m; ++r) pc[r] = pcol[k][r];
                 }
@@ -629,10 +636,9 @@ OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a) {
                 cw[8] = st.up;
                 cw[9] = (double)st.nsetp;
                 cw[10] = (double)st.iter;
-                a.nn_meta[op][(size_t)q2 * 2] = (double)(NN_CLASSES - 1);  // scheduled with the long ones
-                a.nn_meta[op][(size_t)q2 * 2 + 1] = -1.0;
+                list_problem<N>(a, a.parity ^ 1, q, NN_CLASSES - 1);  // scheduled with the long ones
                 meta[(size_t)q * 2] = (double)(NNLS_SUSPENDED + 8 * st.iter);
-                meta[(size_t)q * 2 + 1] = (double)q2;
+                meta[(size_t)q * 2 + 1] = -1.0;
             }
         };
         nnls_coop<N, CPL>(live, resume, a.nn_budget, (int)(gl * CPL), col, cs, mode, rnorm, iters, park);
@@ -675,7 +681,7 @@ OPTIK_DEV void eng_bucket_body(const EngArgs &a) {
     const unsigned cnt = *a.nn_count[a.parity];
     unsigned int *cls_cnt = a.nn_count[a.parity] + 1;
     unsigned int *order = a.nn_order[a.parity];
-    const double *meta = a.nn_meta[a.parity];
+    const unsigned int *list = a.nn_list[a.parity], *lcls = a.nn_cls[a.parity];
     const unsigned lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
     const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) / 64u;
@@ -690,7 +696,7 @@ OPTIK_DEV void eng_bucket_body(const EngArgs &a) {
 #pragma unroll
         for (int b = 0; b < BUCKET_SUB; ++b) {
             const unsigned i = i0 + (unsigned)b * 64u + lane;
-            cls[b] = i < cnt ? (int)meta[(size_t)i * 2] : -1;
+            cls[b] = i < cnt ? (int)lcls[i] : -1;
         }
         unsigned mine = 0;  // lane c < NN_CLASSES: problems of class c in this wave's batches
 #pragma unroll
@@ -709,7 +715,7 @@ OPTIK_DEV void eng_bucket_body(const EngArgs &a) {
 #pragma unroll
         for (int b = 0; b < BUCKET_SUB; ++b) {
             const unsigned cb = (unsigned)__shfl((int)base, cls[b] < 0 ? 0 : cls[b], 64);
-            if (cls[b] >= 0) order[(size_t)cls[b] * a.C + cb + rank[b]] = i0 + (unsigned)b * 64u + lane;
+            if (cls[b] >= 0) order[(size_t)cls[b] * a.C + cb + rank[b]] = list[i0 + (unsigned)b * 64u + lane];
         }
     }
 }
@@ -728,6 +734,11 @@ struct CompactArgs {
     int nd, ni;
     unsigned int *counts;   // [0] free slots listed, [1] restarts to move
     unsigned int *free_list, *move_list;
+    // a slot waiting for the next NNLS launch takes its problem record and list entry along
+    double *nn_prob, *nn_meta, *nn_carry;
+    unsigned int *nn_list;  // list of the next trip
+    int rec_len;            // doubles per problem record
+    int nnq_plane;
 };
 
 OPTIK_DEV void compact_scan_body(const CompactArgs &c) {
@@ -757,6 +768,14 @@ OPTIK_DEV void compact_move_body(const CompactArgs &c) {
     for (int p = 0; p < c.nd; ++p) c.d[(size_t)p * c.C + dst] = c.d[(size_t)p * c.C + src];
     for (int p = 0; p < c.ni; ++p) c.i32[(size_t)p * c.C + dst] = c.i32[(size_t)p * c.C + src];
     c.item[dst] = c.item[src];
+    if (c.i32[src] == ST_NNLS) {
+        for (int k = 0; k < c.rec_len; ++k) c.nn_prob[dst * c.rec_len + k] = c.nn_prob[src * c.rec_len + k];
+        c.nn_meta[dst * 2] = c.nn_meta[src * 2];
+        c.nn_meta[dst * 2 + 1] = c.nn_meta[src * 2 + 1];
+        if (c.nn_meta[src * 2 + 1] < 0.0)  // suspended solve: matrix and state live in the carry record
+            for (int k = 0; k < NN_CARRY; ++k) c.nn_carry[dst * NN_CARRY + k] = c.nn_carry[src * NN_CARRY + k];
+        c.nn_list[c.i32[(size_t)c.nnq_plane * c.C + src]] = (unsigned)dst;
+    }
     c.i32[src] = ST_EMPTY;
 }
 
@@ -769,26 +788,20 @@ OPTIK_DEV void eng_finish_body(const EngArgs &a, const ChainDev &ch, size_t slot
     double l[E::NL], g[N], x[N], s[N];
     const double f = ENG_D(E::FC, 0);
     int ireset = ENG_I(E::IRESET), iter = ENG_I(E::ITER);
-    const unsigned q = (unsigned)ENG_I(E::NNQ);
 #pragma unroll
     for (int i = 0; i < E::NL; ++i) l[i] = ENG_D(E::L, i);
 #pragma unroll
     for (int i = 0; i < N; ++i) { x[i] = ENG_D(E::X, i); g[i] = ENG_D(E::G, i); s[i] = 0.0; }
     double h3 = 0.0;
     int32_t status = 0;
-    unsigned q2 = 0;
-    const int code = (int)a.nn_meta[a.parity][(size_t)q * 2];
-    if ((code & 7) == NNLS_SUSPENDED) {  // still being solved: follow it to the next trip's list
-        ENG_I(E::NNQ) = (int32_t)a.nn_meta[a.parity][(size_t)q * 2 + 1];
-        return;
-    }
+    const int code = (int)a.nn_meta[slot * 2];
+    if ((code & 7) == NNLS_SUSPENDED) return;  // still being solved (listed for the next trip)
     const int passes = code >> 3;
     ENG_I(E::NNIT) = passes;
-    const int out = direction_search<N>(a, ch, a.parity ^ 1, a.nn_y[a.parity] + (size_t)q * 2 * N,
-                                        a.nn_meta[a.parity] + (size_t)q * 2, l, g, x, f, ireset, iter, false, s,
-                                        h3, status, q2, passes);
+    const int out = direction_search<N>(a, ch, slot, a.parity ^ 1, a.nn_y + slot * 2 * N, a.nn_meta + slot * 2,
+                                        l, g, x, f, ireset, iter, false, s, h3, status, passes);
     if (out == DIR_OK) store_direction<N>(a, ch, slot, l, g, x, s, f, h3, ireset, iter);
-    else if (out == DIR_DEFER) store_deferred<N>(a, slot, l, g, ireset, iter, q2);
+    else if (out == DIR_DEFER) store_deferred<N>(a, slot, l, g, ireset, iter);
     else { ENG_I(E::STATUS) = status; ENG_I(E::ITER) = iter; ENG_I(E::STATE) = ST_DEAD; }
 }
 

@@ -367,7 +367,8 @@ struct optik_hip_chain {
     EngJob *eng_djobs = nullptr;
     unsigned int *eng_counters = nullptr;  // per trip parity {list length, class sizes}, then n_active
     unsigned int *eng_order = nullptr;     // 2 x [NN_CLASSES][C]
-    double *eng_carry = nullptr;           // 2 x [C][NN_CARRY]
+    double *eng_carry = nullptr;           // [C][NN_CARRY]
+    unsigned int *eng_list = nullptr;      // 2 x {slots [C], classes [C]}
     unsigned long long *nnls_trace = nullptr;  // OPTIK_NNLS_TRACE builds
     unsigned int *eng_trip_log = nullptr;      // OPTIK_ENG_TRIP_LOG diagnostics
     unsigned int *eng_compact = nullptr;       // [2] counters, then free list [C], move list [C]
@@ -584,6 +585,7 @@ void optik_hip_chain_destroy(optik_hip_chain *ch) {
     if (ch->eng_carry) hipFree(ch->eng_carry);
     if (ch->eng_trip_log) hipFree(ch->eng_trip_log);
     if (ch->eng_compact) hipFree(ch->eng_compact);
+    if (ch->eng_list) hipFree(ch->eng_list);
     if (ch->eng_prob) hipFree(ch->eng_prob);
     if (ch->eng_y) hipFree(ch->eng_y);
     if (ch->eng_meta) hipFree(ch->eng_meta);
@@ -910,8 +912,8 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
         default: return fail(OPTIK_HIP_EUNSUPPORTED, OPTIK_N_RANGE_MSG);                         \
         }                                                                                        \
     } while (0)
-        int nd = 0, ni = 0;
-#define M_LAYOUT(NN) nd = EngLayout<NN>::ND; ni = EngLayout<NN>::NI
+        int nd = 0, ni = 0, nnq_plane = 0;
+#define M_LAYOUT(NN) nd = EngLayout<NN>::ND; ni = EngLayout<NN>::NI; nnq_plane = EngLayout<NN>::NNQ
         DISPATCH_N(M_LAYOUT);
 #undef M_LAYOUT
         if (C > ch->eng_C) {
@@ -924,7 +926,8 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             if (ch->eng_order) HIP_TRY(hipFree(ch->eng_order));
             if (ch->eng_carry) HIP_TRY(hipFree(ch->eng_carry));
             if (ch->eng_compact) HIP_TRY(hipFree(ch->eng_compact));
-            ch->eng_compact = nullptr;
+            if (ch->eng_list) HIP_TRY(hipFree(ch->eng_list));
+            ch->eng_compact = nullptr; ch->eng_list = nullptr;
             ch->eng_order = nullptr; ch->eng_carry = nullptr;
             ch->eng_d = nullptr; ch->eng_i32 = nullptr; ch->eng_item = nullptr;
             ch->eng_prob = ch->eng_y = ch->eng_meta = nullptr;
@@ -932,11 +935,12 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             HIP_TRY(hipMalloc(&ch->eng_i32, sizeof(int32_t) * (size_t)ni * C));
             HIP_TRY(hipMalloc(&ch->eng_item, sizeof(unsigned long long) * C));
             const size_t nn = (size_t)ch->n;
-            HIP_TRY(hipMalloc(&ch->eng_prob, sizeof(double) * 2 * C * (2 * nn) * (nn + 1)));
-            HIP_TRY(hipMalloc(&ch->eng_y, sizeof(double) * 2 * C * (2 * nn)));
-            HIP_TRY(hipMalloc(&ch->eng_meta, sizeof(double) * 2 * C * 2));
+            HIP_TRY(hipMalloc(&ch->eng_prob, sizeof(double) * C * (2 * nn) * (nn + 1)));
+            HIP_TRY(hipMalloc(&ch->eng_y, sizeof(double) * C * (2 * nn)));
+            HIP_TRY(hipMalloc(&ch->eng_meta, sizeof(double) * C * 2));
+            HIP_TRY(hipMalloc(&ch->eng_list, sizeof(unsigned int) * 4 * C));
             HIP_TRY(hipMalloc(&ch->eng_order, sizeof(unsigned int) * 2 * NN_CLASSES * C));
-            HIP_TRY(hipMalloc(&ch->eng_carry, sizeof(double) * 2 * NN_CARRY * C));
+            HIP_TRY(hipMalloc(&ch->eng_carry, sizeof(double) * NN_CARRY * C));
             HIP_TRY(hipMalloc(&ch->eng_compact, sizeof(unsigned int) * (2 + 2 * C)));
             ch->eng_C = C;
         }
@@ -970,15 +974,16 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
         a.total_items = total;
         a.next_item = ch->queue;
         {
-            const size_t nn = (size_t)ch->n;
             for (int par = 0; par < 2; ++par) {
                 a.nn_count[par] = ch->eng_counters + par * CB;
                 a.nn_order[par] = ch->eng_order + (size_t)par * NN_CLASSES * ch->eng_C;
-                a.nn_carry[par] = ch->eng_carry + (size_t)par * NN_CARRY * ch->eng_C;
-                a.nn_prob[par] = ch->eng_prob + (size_t)par * ch->eng_C * (2 * nn) * (nn + 1);
-                a.nn_y[par] = ch->eng_y + (size_t)par * ch->eng_C * (2 * nn);
-                a.nn_meta[par] = ch->eng_meta + (size_t)par * ch->eng_C * 2;
+                a.nn_list[par] = ch->eng_list + (size_t)par * 2 * ch->eng_C;
+                a.nn_cls[par] = ch->eng_list + (size_t)par * 2 * ch->eng_C + ch->eng_C;
             }
+            a.nn_carry = ch->eng_carry;
+            a.nn_prob = ch->eng_prob;
+            a.nn_y = ch->eng_y;
+            a.nn_meta = ch->eng_meta;
         }
         a.n_active = ch->eng_counters + 2 * CB;
         a.nn_budget = 6;
@@ -1089,6 +1094,10 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
                     c.counts = ch->eng_compact;
                     c.free_list = ch->eng_compact + 2;
                     c.move_list = ch->eng_compact + 2 + C;
+                    c.nn_prob = ch->eng_prob; c.nn_meta = ch->eng_meta; c.nn_carry = ch->eng_carry;
+                    c.nn_list = a.nn_list[trip & 1];  // the list the next trip consumes
+                    c.rec_len = 2 * ch->n * (ch->n + 1);
+                    c.nnq_plane = nnq_plane;
                     HIP_TRY(hipMemsetAsync(ch->eng_compact, 0, 2 * sizeof(unsigned int), stream));
                     hipLaunchKernelGGL(eng_compact_scan_kernel, dim3((unsigned)((a.n_slots + 255) / 256)), dim3(256), 0, stream, c);
                     hipLaunchKernelGGL(eng_compact_move_kernel, dim3((unsigned)((a.n_slots - n_new + 255) / 256)), dim3(256), 0, stream, c);

@@ -423,31 +423,32 @@ struct LsqPrep {
     bool need_nnls;   // some h_j > 0: the unconstrained step leaves the box
 };
 
-// Returns 1, or 5 when E is numerically singular (Kraft LSI mode 5).
+// E = D^1/2 L', f = -E^-T g, then Kraft's LSI Householder pass.  Returns 1, or 5 when E is
+// numerically singular (Kraft LSI mode 5).
 template <int N>
-OPTIK_DEV int lsq_prepare(const double (&l)[N * (N + 1) / 2], const double (&g)[N], const double (&lo)[N],
-                          const double (&hi)[N], LsqPrep<N> &P) {
+OPTIK_DEV int lsq_factor(const double (&l)[N * (N + 1) / 2], const double (&g)[N], double (&E)[N][N],
+                         double (&f)[N]) {
     // recover E and f from L and g
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const double diag = __builtin_sqrt(l[lidx<N>(i, i)]);
 #pragma unroll
-        for (int j = i + 1; j < N; ++j) P.E[i][j] = l[lidx<N>(i, j)] * diag;
-        P.E[i][i] = diag;
+        for (int j = i + 1; j < N; ++j) E[i][j] = l[lidx<N>(i, j)] * diag;
+        E[i][i] = diag;
         double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < i; ++k) acc += P.E[k][i] * P.f[k];
-        P.f[i] = (g[i] - acc) / diag;
+        for (int k = 0; k < i; ++k) acc += E[k][i] * f[k];
+        f[i] = (g[i] - acc) / diag;
         OPTIK_SCHED_FENCE();
     }
 #pragma unroll
-    for (int i = 0; i < N; ++i) P.f[i] = -P.f[i];
+    for (int i = 0; i < N; ++i) f[i] = -f[i];
 
     // LSI: "QR" of the already-triangular E (a Householder reflection on a column
     // whose sub-diagonal is zero: flips the sign of row i up to roundoff)
 #pragma unroll
     for (int i = 0; i < N - 1; ++i) {
-        const double p = P.E[i][i];
+        const double p = E[i][i];
         double cl = __builtin_fabs(p);
         if (!(cl <= 0.0)) {
             const double clinv = 1.0 / cl;
@@ -456,51 +457,73 @@ OPTIK_DEV int lsq_prepare(const double (&l)[N * (N + 1) / 2], const double (&g)[
             cl *= __builtin_sqrt(sm0);
             if (p > 0.0) cl = -cl;
             const double up = p - cl;
-            P.E[i][i] = cl;
+            E[i][i] = cl;
             double b = up * cl;
             if (!(b >= 0.0)) {
                 b = 1.0 / b;
 #pragma unroll
                 for (int j = i + 1; j < N; ++j) {
-                    double sm = P.E[i][j] * up;
-                    if (sm != 0.0) { sm *= b; P.E[i][j] += sm * up; }
+                    double sm = E[i][j] * up;
+                    if (sm != 0.0) { sm *= b; E[i][j] += sm * up; }
                 }
-                double sm = P.f[i] * up;
-                if (sm != 0.0) { sm *= b; P.f[i] += sm * up; }
+                double sm = f[i] * up;
+                if (sm != 0.0) { sm *= b; f[i] += sm * up; }
             }
         }
         OPTIK_SCHED_FENCE();
     }
-    // transform G = [I; -I] and h = [lo; -hi]: rows of +-E^-1
     bool singular = false;
 #pragma unroll
-    for (int j = 0; j < N; ++j) singular = singular || !(__builtin_fabs(P.E[j][j]) >= EPMACH);
-    P.need_nnls = false;
-    if (singular) return 5;
+    for (int j = 0; j < N; ++j) singular = singular || !(__builtin_fabs(E[j][j]) >= EPMACH);
+    return singular ? 5 : 1;
+}
+
+// Transforms G = [I; -I] and h = [lo; -hi]: row i of E^-1 (entries j >= i) and the two
+// bound rows it gives, handed to sink(i, row, h_lo, h_hi) one row at a time -- a caller
+// that streams the rows out never holds E^-1.  Returns whether some h_j > 0, i.e. the
+// unconstrained step leaves the box.  (NNLS's first dual check is w_j = h_j (b = e_{n+1});
+// when no h_j is positive it returns at once with zero multipliers (y = 0, fac = 1, step
+// 0): skipping it then is bit-identical to running it, every product being an exact zero.)
+template <int N, class RowSink>
+OPTIK_DEV bool lsq_bound_rows(const double (&E)[N][N], const double (&f)[N], const double (&lo)[N],
+                              const double (&hi)[N], RowSink &&sink) {
+    bool need = false;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
+        double row[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) row[j] = 0.0;
 #pragma unroll
         for (int j = i; j < N; ++j) {
             double acc = 0.0;
 #pragma unroll
-            for (int k = i; k < j; ++k) acc += P.Gi[i][k] * P.E[k][j];
-            P.Gi[i][j] = (((j == i) ? 1.0 : 0.0) - acc) / P.E[j][j];
+            for (int k = i; k < j; ++k) acc += row[k] * E[k][j];
+            row[j] = (((j == i) ? 1.0 : 0.0) - acc) / E[j][j];
         }
         double acc = 0.0;
 #pragma unroll
-        for (int j = i; j < N; ++j) acc += P.Gi[i][j] * P.f[j];
-        P.h[i] = lo[i] - acc;
-        P.h[N + i] = (-hi[i]) - (-acc);
+        for (int j = i; j < N; ++j) acc += row[j] * f[j];
+        const double h_lo = lo[i] - acc;
+        const double h_hi = (-hi[i]) - (-acc);
+        need = need || (h_lo > 0.0) || (h_hi > 0.0);
+        sink(i, row, h_lo, h_hi);
         OPTIK_SCHED_FENCE();
     }
-    // NNLS's first dual check is w_j = h_j (b = e_{n+1}); when no h_j is positive it
-    // returns at once with zero multipliers (y = 0, fac = 1, step 0): that case -- the
-    // unconstrained step is feasible -- never touches LDS.  Bit-identical to running
-    // NNLS, whose every product is then an exact zero.
-    bool need = false;
+    return need;
+}
+
+// Returns 1, or 5 when E is numerically singular (Kraft LSI mode 5).
+template <int N>
+OPTIK_DEV int lsq_prepare(const double (&l)[N * (N + 1) / 2], const double (&g)[N], const double (&lo)[N],
+                          const double (&hi)[N], LsqPrep<N> &P) {
+    P.need_nnls = false;
+    if (lsq_factor<N>(l, g, P.E, P.f) != 1) return 5;
+    P.need_nnls = lsq_bound_rows<N>(P.E, P.f, lo, hi, [&](int i, const double (&row)[N], double h_lo, double h_hi) {
 #pragma unroll
-    for (int r = 0; r < 2 * N; ++r) need = need || (P.h[r] > 0.0);
-    P.need_nnls = need;
+        for (int j = 0; j < N; ++j) P.Gi[i][j] = row[j];
+        P.h[i] = h_lo;
+        P.h[N + i] = h_hi;
+    });
     return 1;
 }
 
@@ -564,15 +587,16 @@ OPTIK_DEV int lsq_dual(const NnlsWs<N> &ws, const LsqPrep<N> &P, double (&s)[N],
 // s (transformed space, zero when NNLS was skipped) -> solution of the original
 // problem s = E^-1 (s + f), clipped into [lo, hi] (NLopt).
 template <int N>
-OPTIK_DEV void lsq_finish(const LsqPrep<N> &P, const double (&lo)[N], const double (&hi)[N], double (&s)[N]) {
+OPTIK_DEV void lsq_finish(const double (&E)[N][N], const double (&f)[N], const double (&lo)[N],
+                          const double (&hi)[N], double (&s)[N]) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) s[i] += P.f[i];
+    for (int i = 0; i < N; ++i) s[i] += f[i];
 #pragma unroll
     for (int i = N - 1; i >= 0; --i) {
         double acc = 0.0;
 #pragma unroll
-        for (int j = i + 1; j < N; ++j) acc += P.E[i][j] * s[j];
-        s[i] = (s[i] - acc) / P.E[i][i];
+        for (int j = i + 1; j < N; ++j) acc += E[i][j] * s[j];
+        s[i] = (s[i] - acc) / E[i][i];
         OPTIK_SCHED_FENCE();
     }
 #pragma unroll
@@ -580,6 +604,11 @@ OPTIK_DEV void lsq_finish(const LsqPrep<N> &P, const double (&lo)[N], const doub
         if (s[i] < lo[i]) s[i] = lo[i];
         else if (s[i] > hi[i]) s[i] = hi[i];
     }
+}
+
+template <int N>
+OPTIK_DEV void lsq_finish(const LsqPrep<N> &P, const double (&lo)[N], const double (&hi)[N], double (&s)[N]) {
+    lsq_finish<N>(P.E, P.f, lo, hi, s);
 }
 
 // The whole direction sub-problem.  Returns the LSQ mode (1 ok).
