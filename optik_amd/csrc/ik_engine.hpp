@@ -144,30 +144,18 @@ OPTIK_DEV void list_problem(const EngArgs &a, int parity, size_t slot, int pred)
     a.nn_cls[parity][q] = (unsigned)(pred < 0 ? 0 : (pred >= NN_CLASSES ? NN_CLASSES - 1 : pred));
 }
 
-// Writes the dual problem of a deferred direction (columns of [G E^-1; h]) as one
-// contiguous block for the cooperative NNLS kernel and lists the slot.
+// Problem record of a slot: the rows of E^-1 packed like the factor (row i, entries j >= i,
+// at lidx(i, i) + j - i), then h_lo[N], h_hi[N]; padded to whole 64-byte lines.  The -E^-1
+// block of the dual matrix is the exact negation and is rebuilt by the reader.
 template <int N>
-OPTIK_DEV void emit_problem(const EngArgs &a, int parity, size_t slot, const LsqPrep<N> &P, int pred) {
-    list_problem<N>(a, parity, slot, pred);
-    a.nn_meta[slot * 2 + 1] = 0.0;  // a fresh problem, not a resumed one
-    double *pb = a.nn_prob + slot * (2 * N) * (N + 1);
-#pragma unroll
-    for (int c = 0; c < N; ++c) {
-#pragma unroll
-        for (int r = 0; r < N; ++r) {
-            const double v = (r >= c) ? P.Gi[c][r] : 0.0;
-            pb[c * (N + 1) + r] = v;
-            pb[(N + c) * (N + 1) + r] = (r >= c) ? -v : 0.0;
-        }
-        pb[c * (N + 1) + N] = P.h[c];
-        pb[(N + c) * (N + 1) + N] = P.h[N + c];
-    }
-}
+__host__ __device__ constexpr int rec_stride() { return (N * (N + 1) / 2 + 2 * N + 7) / 8 * 8; }
 
-// LDP tail (Lawson-Hanson ch. 23) from the NNLS answer: transformed-space step.
+// LDP tail (Lawson-Hanson ch. 23) from the NNLS answer: transformed-space step.  The rows
+// of +-E^-1 and h are read back from the slot's problem record (the NNLS kernel leaves it
+// untouched), so the finishing pass does not recompute them.
 template <int N>
-OPTIK_DEV int ldp_from_answer(const LsqPrep<N> &P, const double *y_mem, const double *meta, double (&s)[N]) {
-    constexpr int M = 2 * N;
+OPTIK_DEV int ldp_from_record(const double *rec, const double *y_mem, const double *meta, double (&s)[N]) {
+    constexpr int M = 2 * N, NG = N * (N + 1) / 2;
     int mode = ((int)meta[0]) & 7;
     if (mode == 1 && meta[1] <= 0.0) mode = 4;
     if (mode != 1) return mode;
@@ -176,7 +164,7 @@ OPTIK_DEV int ldp_from_answer(const LsqPrep<N> &P, const double *y_mem, const do
     for (int r = 0; r < M; ++r) y[r] = y_mem[r];
     double hy = 0.0;
 #pragma unroll
-    for (int r = 0; r < M; ++r) hy += P.h[r] * y[r];
+    for (int r = 0; r < M; ++r) hy += rec[NG + r] * y[r];
     double fac = 1.0 - hy;
     const double d1 = 1.0 + fac;
     if (d1 - 1.0 <= 0.0) return 4;
@@ -185,29 +173,32 @@ OPTIK_DEV int ldp_from_answer(const LsqPrep<N> &P, const double *y_mem, const do
     for (int j = 0; j < N; ++j) {
         double acc = 0.0;
 #pragma unroll
-        for (int r = 0; r <= j; ++r) acc += P.Gi[r][j] * y[r];
+        for (int r = 0; r <= j; ++r) acc += rec[lidx<N>(r, j)] * y[r];
 #pragma unroll
-        for (int r = 0; r <= j; ++r) acc += (-P.Gi[r][j]) * y[N + r];
+        for (int r = 0; r <= j; ++r) acc += (-rec[lidx<N>(r, j)]) * y[N + r];
         s[j] = fac * acc;
         OPTIK_SCHED_FENCE();
     }
     return 1;
 }
 
-// Kraft labels 110/130 for one slot: (reset,) LSQ direction, descent test.  A direction
-// whose step leaves the box needs NNLS: its dual problem is emitted for the cooperative
-// kernel and the slot is deferred.  `answer` non-null re-enters at the LSQ call of a
+// Kraft labels 110/130 for one slot: (reset,) LSQ direction, descent test.  The caller has
+// the factor l in the slot planes already (a reset stores the new one here), so l is dead
+// once E is formed.  The rows of the dual problem [G E^-1; h] stream into the slot's record
+// as they are computed; a direction whose step leaves the box needs NNLS: the slot is listed
+// for the cooperative kernel and deferred.  `resume` re-enters at the LSQ call of a
 // deferred pass (its ++iter / reset are done) and completes it with the NNLS answer.
 template <int N>
-OPTIK_DEV int direction_search(const EngArgs &a, const ChainDev &ch, size_t slot, int emit_parity, const double *answer_y,
-                               const double *answer_meta, double (&l)[N * (N + 1) / 2], const double (&g)[N],
-                               const double (&x)[N], double f, int &ireset, int &iter, bool reset,
-                               double (&s)[N], double &h3, int32_t &status, int pred) {
+OPTIK_DEV int direction_search(const EngArgs &a, const ChainDev &ch, size_t slot, int emit_parity, bool resume,
+                               double (&l)[N * (N + 1) / 2], const double (&g)[N], const double (&x)[N],
+                               double f, int &ireset, int &iter, bool reset, double (&s)[N], double &h3,
+                               int32_t &status, int pred) {
+    using EL = EngLayout<N>;
     constexpr int NL = N * (N + 1) / 2;
     const SolveParams &sp = a.sp;
+    double *rec = a.nn_prob + slot * rec_stride<N>();
     double f0 = 0.0;
     bool have0 = false;
-    bool resume = answer_y != nullptr;
     for (;;) {
         if (!resume) {
             if (reset) {
@@ -223,6 +214,8 @@ OPTIK_DEV int direction_search(const EngArgs &a, const ChainDev &ch, size_t slot
                 for (int i = 0; i < NL; ++i) l[i] = 0.0;
 #pragma unroll
                 for (int i = 0; i < N; ++i) l[lidx<N>(i, i)] = 1.0;
+#pragma unroll
+                for (int i = 0; i < NL; ++i) ENG_D(EL::L, i) = l[i];
             }
             ++iter;
         }
@@ -230,17 +223,24 @@ OPTIK_DEV int direction_search(const EngArgs &a, const ChainDev &ch, size_t slot
 #pragma unroll
         for (int i = 0; i < N; ++i) { lo[i] = ch.lb[i] - x[i]; hi[i] = ch.ub[i] - x[i]; }
         OPTIK_SCHED_FENCE();
-        LsqPrep<N> P;
-        int lmode = lsq_prepare<N>(l, g, lo, hi, P);
+        double E[N][N], fv[N];
+        int lmode = lsq_factor<N>(l, g, E, fv);
+        OPTIK_SCHED_FENCE();
         if (lmode == 1) {
-            if (P.need_nnls) {
-                if (resume) {
-                    lmode = ldp_from_answer<N>(P, answer_y, answer_meta, s);
-                } else {
-                    emit_problem<N>(a, emit_parity, slot, P, pred);
+            if (resume) {
+                lmode = ldp_from_record<N>(rec, a.nn_y + slot * 2 * N, a.nn_meta + slot * 2, s);
+            } else {
+                const bool need = lsq_bound_rows<N>(E, fv, lo, hi, [&](int i, const double (&row)[N], double h_lo, double h_hi) {
+#pragma unroll
+                    for (int r = i; r < N; ++r) rec[lidx<N>(i, r)] = row[r];
+                    rec[NL + i] = h_lo;
+                    rec[NL + N + i] = h_hi;
+                });
+                if (need) {
+                    list_problem<N>(a, emit_parity, slot, pred);
+                    a.nn_meta[slot * 2 + 1] = 0.0;  // a fresh problem, not a resumed one
                     return DIR_DEFER;
                 }
-            } else {
 #pragma unroll
                 for (int j = 0; j < N; ++j) s[j] = 0.0;
             }
@@ -251,7 +251,7 @@ OPTIK_DEV int direction_search(const EngArgs &a, const ChainDev &ch, size_t slot
             status = (lmode == 5 || lmode == 6 || lmode == 7) ? RES_ROUNDOFF_LIMITED : RES_FAILURE;
             return DIR_DEAD;
         }
-        lsq_finish<N>(P, lo, hi, s);
+        lsq_finish<N>(E, fv, lo, hi, s);
         OPTIK_SCHED_FENCE();
         f0 = f;
         have0 = true;
@@ -270,8 +270,7 @@ OPTIK_DEV void store_direction(const EngArgs &a, const ChainDev &ch, size_t slot
                                const double (&l)[N * (N + 1) / 2], const double (&g)[N], const double (&x)[N],
                                const double (&s)[N], double f, double h3, int ireset, int iter) {
     using E = EngLayout<N>;
-#pragma unroll
-    for (int i = 0; i < E::NL; ++i) ENG_D(E::L, i) = l[i];
+    (void)l;  // (already in the slot planes)
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         ENG_D(E::G, i) = g[i];
@@ -297,8 +296,7 @@ template <int N>
 OPTIK_DEV void store_deferred(const EngArgs &a, size_t slot, const double (&l)[N * (N + 1) / 2],
                               const double (&g)[N], int ireset, int iter) {
     using E = EngLayout<N>;
-#pragma unroll
-    for (int i = 0; i < E::NL; ++i) ENG_D(E::L, i) = l[i];
+    (void)l;  // (already in the slot planes)
 #pragma unroll
     for (int i = 0; i < N; ++i) ENG_D(E::G, i) = g[i];
     ENG_I(E::IRESET) = ireset;
@@ -524,6 +522,8 @@ OPTIK_DEV void eng_update_body(const EngArgs &a, const ChainDev &ch, size_t slot
             OPTIK_SCHED_FENCE();
             bfgs_update<N>(l, s, u);
             OPTIK_SCHED_FENCE();
+#pragma unroll
+            for (int i = 0; i < E::NL; ++i) ENG_D(E::L, i) = l[i];
         } else {
 #pragma unroll
             for (int i = 0; i < E::NL; ++i) l[i] = 0.0;
@@ -532,7 +532,7 @@ OPTIK_DEV void eng_update_body(const EngArgs &a, const ChainDev &ch, size_t slot
         }
         double h3 = 0.0;
         int32_t status = 0;
-        const int out = direction_search<N>(a, ch, slot, a.parity, nullptr, nullptr, l, g, x, f, ireset, iter,
+        const int out = direction_search<N>(a, ch, slot, a.parity, false, l, g, x, f, ireset, iter,
                                             st == ST_UPDATE_FIRST, s, h3, status, ENG_I(E::NNIT));
         if (out == DIR_OK) store_direction<N>(a, ch, slot, l, g, x, s, f, h3, ireset, iter);
         else if (out == DIR_DEFER) store_deferred<N>(a, slot, l, g, ireset, iter);
@@ -584,7 +584,8 @@ OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a) {
         CoopCarry<CPL> cs;
         const double *cr = a.nn_carry + (size_t)q * NN_CARRY + NN_CARRY_STATE;
         // the matrix: the emitted problem, or the transformed one of a suspended solve
-        const double *prob = resume ? a.nn_carry + (size_t)q * NN_CARRY : a.nn_prob + (size_t)q * n * m;
+        const double *rec = a.nn_prob + (size_t)q * rec_stride<N>();
+        const double *cmat = a.nn_carry + (size_t)q * NN_CARRY;
         cs.b = 0.0;
         cs.up = 0.0;
         cs.nsetp = 0;
@@ -603,9 +604,22 @@ OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a) {
             cs.pos[k] = 0;
             const unsigned c = gl * CPL + k;
             if (live && c < (unsigned)n) {
-                const double *pc = prob + (size_t)c * m;
+                if (resume) {
 #pragma unroll
-                for (int r = 0; r < m; ++r) col[k][r] = pc[r];
+                    for (int r = 0; r < m; ++r) col[k][r] = cmat[(size_t)c * m + r];
+                } else {
+                    // column c < N: row c of E^-1 on rows c .. N-1, h_lo[c] below; column N + c: its
+                    // negation, h_hi[c] below
+                    const bool neg = c >= (unsigned)N;
+                    const int cc = (int)(neg ? c - N : c);
+                    const int off = cc * N - (cc * (cc - 1)) / 2 - cc;  // lidx(cc, cc) - cc
+#pragma unroll
+                    for (int r = 0; r < N; ++r) {
+                        const double v = (r >= cc) ? rec[off + r] : 0.0;
+                        col[k][r] = neg ? ((r >= cc) ? -v : 0.0) : v;
+                    }
+                    col[k][N] = rec[N * (N + 1) / 2 + c];
+                }
             }
             if (resume) {
                 cs.xv[k] = cr[16 + c];
@@ -798,8 +812,8 @@ OPTIK_DEV void eng_finish_body(const EngArgs &a, const ChainDev &ch, size_t slot
     if ((code & 7) == NNLS_SUSPENDED) return;  // still being solved (listed for the next trip)
     const int passes = code >> 3;
     ENG_I(E::NNIT) = passes;
-    const int out = direction_search<N>(a, ch, slot, a.parity ^ 1, a.nn_y + slot * 2 * N, a.nn_meta + slot * 2,
-                                        l, g, x, f, ireset, iter, false, s, h3, status, passes);
+    const int out = direction_search<N>(a, ch, slot, a.parity ^ 1, true, l, g, x, f, ireset, iter, false, s, h3,
+                                        status, passes);
     if (out == DIR_OK) store_direction<N>(a, ch, slot, l, g, x, s, f, h3, ireset, iter);
     else if (out == DIR_DEFER) store_deferred<N>(a, slot, l, g, ireset, iter);
     else { ENG_I(E::STATUS) = status; ENG_I(E::ITER) = iter; ENG_I(E::STATE) = ST_DEAD; }

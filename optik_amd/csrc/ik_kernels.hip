@@ -912,8 +912,8 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
         default: return fail(OPTIK_HIP_EUNSUPPORTED, OPTIK_N_RANGE_MSG);                         \
         }                                                                                        \
     } while (0)
-        int nd = 0, ni = 0, nnq_plane = 0;
-#define M_LAYOUT(NN) nd = EngLayout<NN>::ND; ni = EngLayout<NN>::NI; nnq_plane = EngLayout<NN>::NNQ
+        int nd = 0, ni = 0, nnq_plane = 0, rec_len = 0;
+#define M_LAYOUT(NN) nd = EngLayout<NN>::ND; ni = EngLayout<NN>::NI; nnq_plane = EngLayout<NN>::NNQ; rec_len = rec_stride<NN>()
         DISPATCH_N(M_LAYOUT);
 #undef M_LAYOUT
         if (C > ch->eng_C) {
@@ -935,7 +935,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             HIP_TRY(hipMalloc(&ch->eng_i32, sizeof(int32_t) * (size_t)ni * C));
             HIP_TRY(hipMalloc(&ch->eng_item, sizeof(unsigned long long) * C));
             const size_t nn = (size_t)ch->n;
-            HIP_TRY(hipMalloc(&ch->eng_prob, sizeof(double) * C * (2 * nn) * (nn + 1)));
+            HIP_TRY(hipMalloc(&ch->eng_prob, sizeof(double) * C * rec_len));
             HIP_TRY(hipMalloc(&ch->eng_y, sizeof(double) * C * (2 * nn)));
             HIP_TRY(hipMalloc(&ch->eng_meta, sizeof(double) * C * 2));
             HIP_TRY(hipMalloc(&ch->eng_list, sizeof(unsigned int) * 4 * C));
@@ -1096,7 +1096,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
                     c.move_list = ch->eng_compact + 2 + C;
                     c.nn_prob = ch->eng_prob; c.nn_meta = ch->eng_meta; c.nn_carry = ch->eng_carry;
                     c.nn_list = a.nn_list[trip & 1];  // the list the next trip consumes
-                    c.rec_len = 2 * ch->n * (ch->n + 1);
+                    c.rec_len = rec_len;
                     c.nnq_plane = nnq_plane;
                     HIP_TRY(hipMemsetAsync(ch->eng_compact, 0, 2 * sizeof(unsigned int), stream));
                     hipLaunchKernelGGL(eng_compact_scan_kernel, dim3((unsigned)((a.n_slots + 255) / 256)), dim3(256), 0, stream, c);
