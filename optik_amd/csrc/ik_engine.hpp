@@ -182,85 +182,100 @@ OPTIK_DEV int ldp_from_record(const double *rec, const double *y_mem, const doub
     return 1;
 }
 
-// Kraft labels 110/130 for one slot: (reset,) LSQ direction, descent test.  The caller has
-// the factor l in the slot planes already (a reset stores the new one here), so l is dead
-// once E is formed.  The rows of the dual problem [G E^-1; h] stream into the slot's record
-// as they are computed; a direction whose step leaves the box needs NNLS: the slot is listed
-// for the cooperative kernel and deferred.  `resume` re-enters at the LSQ call of a
-// deferred pass (its ++iter / reset are done) and completes it with the NNLS answer.
+// Outcome of one LSQ pass: the three below, or "not a descent direction: reset and repeat".
+enum : int { DIR_RESET = 3 };
+
+// One pass of Kraft labels 110/130 with the factor l: LSQ direction, descent test.  The rows
+// of the dual problem [G E^-1; h] stream into the slot's record as they are computed; a
+// direction whose step leaves the box needs NNLS: the slot is listed for the cooperative
+// kernel and deferred.  `resume` completes a deferred pass with the NNLS answer instead.
+template <int N>
+OPTIK_DEV int direction_pass(const EngArgs &a, const ChainDev &ch, size_t slot, int emit_parity, bool resume,
+                             const double (&l)[N * (N + 1) / 2], const double (&g)[N], const double (&x)[N],
+                             double (&s)[N], double &h3, int32_t &status, int pred) {
+    constexpr int NL = N * (N + 1) / 2;
+    double *rec = a.nn_prob + slot * rec_stride<N>();
+    double lo[N], hi[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) { lo[i] = ch.lb[i] - x[i]; hi[i] = ch.ub[i] - x[i]; }
+    OPTIK_SCHED_FENCE();
+    double E[N][N], fv[N];
+    int lmode = lsq_factor<N>(l, g, E, fv);
+    OPTIK_SCHED_FENCE();
+    if (lmode == 1) {
+        if (resume) {
+            lmode = ldp_from_record<N>(rec, a.nn_y + slot * 2 * N, a.nn_meta + slot * 2, s);
+        } else {
+            const bool need = lsq_bound_rows<N>(E, fv, lo, hi, [&](int i, const double (&row)[N], double h_lo, double h_hi) {
+#pragma unroll
+                for (int r = i; r < N; ++r) rec[lidx<N>(i, r)] = row[r];
+                rec[NL + i] = h_lo;
+                rec[NL + N + i] = h_hi;
+            });
+            if (need) {
+                list_problem<N>(a, emit_parity, slot, pred);
+                a.nn_meta[slot * 2 + 1] = 0.0;  // a fresh problem, not a resumed one
+                return DIR_DEFER;
+            }
+#pragma unroll
+            for (int j = 0; j < N; ++j) s[j] = 0.0;
+        }
+    }
+    if (lmode != 1) {
+        // NLopt: modes 5,6,7 -> ROUNDOFF_LIMITED; 3,4,9 -> FAILURE
+        status = (lmode == 5 || lmode == 6 || lmode == 7) ? RES_ROUNDOFF_LIMITED : RES_FAILURE;
+        return DIR_DEAD;
+    }
+    lsq_finish<N>(E, fv, lo, hi, s);
+    OPTIK_SCHED_FENCE();
+    double gs = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) gs += g[i] * s[i];
+    h3 = gs;
+    return (h3 >= 0.0) ? DIR_RESET : DIR_OK;
+}
+
+// Kraft labels 110/130 for one slot: (reset,) LSQ direction, descent test, repeated with a
+// reset factor while the direction is not a descent direction.  The caller has l in the
+// slot planes already (a reset stores the identity here); the first pass runs on the
+// caller's l, every reset pass on the constant identity -- l is not carried around the
+// loop, which would pin its 2 x 28 registers for the whole search.  `resume` re-enters at
+// the LSQ call of a deferred pass (its ++iter / reset are done).
 template <int N>
 OPTIK_DEV int direction_search(const EngArgs &a, const ChainDev &ch, size_t slot, int emit_parity, bool resume,
-                               double (&l)[N * (N + 1) / 2], const double (&g)[N], const double (&x)[N],
+                               const double (&l)[N * (N + 1) / 2], const double (&g)[N], const double (&x)[N],
                                double f, int &ireset, int &iter, bool reset, double (&s)[N], double &h3,
                                int32_t &status, int pred) {
     using EL = EngLayout<N>;
     constexpr int NL = N * (N + 1) / 2;
     const SolveParams &sp = a.sp;
-    double *rec = a.nn_prob + slot * rec_stride<N>();
-    double f0 = 0.0;
-    bool have0 = false;
+    bool have0 = false;  // a completed LSQ in this call: Kraft's (f0, x0) = (f, x)
+    if (!reset) {
+        if (!resume) ++iter;
+        const int r = direction_pass<N>(a, ch, slot, emit_parity, resume, l, g, x, s, h3, status, pred);
+        if (r != DIR_RESET) return r;
+        have0 = true;
+    }
+    double ident[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) ident[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) ident[lidx<N>(i, i)] = 1.0;
     for (;;) {
-        if (!resume) {
-            if (reset) {
-                ++ireset;
-                if (ireset > 5) {
-                    // label 255 with acc = 0 -> mode 8; NLopt's relaxed test vs (f0, x0 = x)
-                    status = RES_ROUNDOFF_LIMITED;
-                    if (have0 && __builtin_fabs(f - f0) < sp.ftol_abs && !__builtin_isinf(f0)) status = RES_FTOL_REACHED;
-                    else if (have0 && !(0.0 >= sp.xtol_abs)) status = RES_XTOL_REACHED;  // |x - x0| = 0 everywhere
-                    return DIR_DEAD;
-                }
-#pragma unroll
-                for (int i = 0; i < NL; ++i) l[i] = 0.0;
-#pragma unroll
-                for (int i = 0; i < N; ++i) l[lidx<N>(i, i)] = 1.0;
-#pragma unroll
-                for (int i = 0; i < NL; ++i) ENG_D(EL::L, i) = l[i];
-            }
-            ++iter;
-        }
-        double lo[N], hi[N];
-#pragma unroll
-        for (int i = 0; i < N; ++i) { lo[i] = ch.lb[i] - x[i]; hi[i] = ch.ub[i] - x[i]; }
-        OPTIK_SCHED_FENCE();
-        double E[N][N], fv[N];
-        int lmode = lsq_factor<N>(l, g, E, fv);
-        OPTIK_SCHED_FENCE();
-        if (lmode == 1) {
-            if (resume) {
-                lmode = ldp_from_record<N>(rec, a.nn_y + slot * 2 * N, a.nn_meta + slot * 2, s);
-            } else {
-                const bool need = lsq_bound_rows<N>(E, fv, lo, hi, [&](int i, const double (&row)[N], double h_lo, double h_hi) {
-#pragma unroll
-                    for (int r = i; r < N; ++r) rec[lidx<N>(i, r)] = row[r];
-                    rec[NL + i] = h_lo;
-                    rec[NL + N + i] = h_hi;
-                });
-                if (need) {
-                    list_problem<N>(a, emit_parity, slot, pred);
-                    a.nn_meta[slot * 2 + 1] = 0.0;  // a fresh problem, not a resumed one
-                    return DIR_DEFER;
-                }
-#pragma unroll
-                for (int j = 0; j < N; ++j) s[j] = 0.0;
-            }
-        }
-        resume = false;
-        if (lmode != 1) {
-            // NLopt: modes 5,6,7 -> ROUNDOFF_LIMITED; 3,4,9 -> FAILURE
-            status = (lmode == 5 || lmode == 6 || lmode == 7) ? RES_ROUNDOFF_LIMITED : RES_FAILURE;
+        ++ireset;
+        if (ireset > 5) {
+            // label 255 with acc = 0 -> mode 8; NLopt's relaxed test vs (f0, x0) = (f, x)
+            status = RES_ROUNDOFF_LIMITED;
+            if (have0 && __builtin_fabs(f - f) < sp.ftol_abs && !__builtin_isinf(f)) status = RES_FTOL_REACHED;  // f0 = f
+            else if (have0 && !(0.0 >= sp.xtol_abs)) status = RES_XTOL_REACHED;  // |x - x0| = 0 everywhere
             return DIR_DEAD;
         }
-        lsq_finish<N>(E, fv, lo, hi, s);
-        OPTIK_SCHED_FENCE();
-        f0 = f;
-        have0 = true;
-        double gs = 0.0;
 #pragma unroll
-        for (int i = 0; i < N; ++i) gs += g[i] * s[i];
-        h3 = gs;
-        if (h3 >= 0.0) { reset = true; continue; }
-        return DIR_OK;
+        for (int i = 0; i < NL; ++i) ENG_D(EL::L, i) = ident[i];
+        ++iter;
+        const int r = direction_pass<N>(a, ch, slot, emit_parity, false, ident, g, x, s, h3, status, pred);
+        if (r != DIR_RESET) return r;
+        have0 = true;
     }
 }
 
