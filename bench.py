@@ -35,7 +35,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r1_engine_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r1b_engine_pmc_traffic.json")
 
 
 def pmc_traffic(kernel):
@@ -214,13 +214,16 @@ def main():
             # algorithmic HBM bytes of one launch of the dominant kernel
             if dom == "nnls":
                 units = st["nnls_problems"] / max(trips, 1)              # sub-problems per launch
-                unit_bytes = 8 * (2 * n * m + 2 * n + 2)                   # problem in, multipliers + {mode, rnorm} out
+                # packed record in (rows of E^-1 + h), multipliers + {mode, rnorm} out
+                unit_bytes = 8 * (n * (n + 1) // 2 + 2 * n) + 8 * (2 * n + 2)
             else:
                 slots_per_launch = float(R) * K / max(trips, 1) * mean_evals  # slot-trips per launch (approx.)
                 units = slots_per_launch
                 nl = n * (n + 1) // 2
-                unit_bytes = {"eval": 8 * (2 * n + 6), "update": 8 * (2 * nl + 9 * n + 8),
-                              "finish": 8 * (2 * nl + 7 * n + 2 * n + 10)}[dom]
+                # planes read + written per slot-trip (update also writes the packed problem record,
+                # finish reads it back with the multipliers)
+                unit_bytes = {"eval": 8 * (2 * n + 6), "update": 8 * (3 * nl + 11 * n + 8),
+                              "finish": 8 * (2 * nl + 10 * n + 12)}[dom]
             kernel_ms = per_kernel[dom]
             achieved = unit_bytes * units / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
             kname = {"eval": "eng_eval_kernel", "update": "eng_update_kernel", "nnls": "eng_nnls_coop_kernel",

@@ -82,6 +82,7 @@ constexpr int ENG_MAX_JOBS = 64;
 // the largest down, so a wave's 16 problems take similar numbers of passes and the long
 // ones start first.  Scheduling only -- every problem is solved independently.
 constexpr int NN_CLASSES = 8;
+constexpr int ENG_LIST_COUNTERS = 2 + NN_CLASSES;  // per trip parity: list length, class sizes, spare
 // A problem that needs more than the launch's pass budget is suspended and continues in
 // the next trip's launch (its slot just stays in ST_NNLS): no launch waits for the rare
 // 10+ pass problem.  Carry record: the transformed matrix [112], then b[8], up, nsetp, iter,

@@ -171,6 +171,13 @@ __global__ __launch_bounds__(256, OPTIK_ENG_EVAL_WAVES) void eng_eval_kernel(con
     __shared__ ChainDev sch;
     stage_chain(sch, a.chain);
     const size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x;
+    // first kernel of a trip: reset the other parity's list counters (consumed last trip; this
+    // trip's suspended solves and finishing pass and the next trip's update append to it) and
+    // the in-use count the update kernel accumulates -- no memset launches between trips
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < (unsigned)ENG_LIST_COUNTERS) a.nn_count[a.parity ^ 1][threadIdx.x] = 0u;
+        if (threadIdx.x == 64) *a.n_active = 0u;
+    }
     if (slot < a.n_slots) eng_eval_body<N, TIP>(a, sch, slot);
 }
 
@@ -945,7 +952,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             ch->eng_C = C;
         }
         if (!ch->eng_djobs) HIP_TRY(hipMalloc(&ch->eng_djobs, sizeof(EngJob) * ENG_MAX_JOBS));
-        constexpr int CB = 2 + NN_CLASSES;  // counters per trip parity: list length, class sizes, batch cursor
+        constexpr int CB = ENG_LIST_COUNTERS;  // counters per trip parity
         if (!ch->eng_counters) HIP_TRY(hipMalloc(&ch->eng_counters, (2 * CB + 2) * sizeof(unsigned int)));
         if (!ch->eng_pinned) HIP_TRY(hipHostMalloc(&ch->eng_pinned, 8 * sizeof(unsigned int)));
         if (!ch->queue) HIP_TRY(hipMalloc(&ch->queue, sizeof(unsigned long long)));
@@ -1029,8 +1036,6 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
                 // reset for the finish kernel's re-deferrals and the next trip's update kernel
                 a.parity = trip & 1;
                 a.trip = trip < TRIP_LOG_MAX ? trip : TRIP_LOG_MAX - 1;
-                HIP_TRY(hipMemsetAsync(ch->eng_counters + (a.parity ^ 1) * CB, 0, CB * sizeof(unsigned int), stream));
-                HIP_TRY(hipMemsetAsync(ch->eng_counters + 2 * CB, 0, sizeof(unsigned int), stream));
                 // HIP event pairs around each kernel of every trip (on the launch stream)
                 const bool timed = ch->timing && trip > 0 && ch->eng_tcount < optik_hip_chain::ENG_EV;
                 const int ts = ch->eng_tcount;
