@@ -213,11 +213,11 @@ def main():
             m = n + 1
             # algorithmic HBM bytes of one launch of the dominant kernel
             if dom == "nnls":
-                units = st["nnls_problems"] / max(trips, 1)              # sub-problems per launch
+                units = st["nnls_problems"] / max(st["launches"], 1)     # sub-problems per launch
                 # packed record in (rows of E^-1 + h), multipliers + {mode, rnorm} out
                 unit_bytes = 8 * (n * (n + 1) // 2 + 2 * n) + 8 * (2 * n + 2)
             else:
-                slots_per_launch = float(R) * K / max(trips, 1) * mean_evals  # slot-trips per launch (approx.)
+                slots_per_launch = float(R) * K / max(st["launches"], 1) * mean_evals  # slot-trips per launch (approx.)
                 units = slots_per_launch
                 nl = n * (n + 1) // 2
                 # planes read + written per slot-trip (update also writes the packed problem record,
@@ -235,7 +235,8 @@ def main():
                     "algorithmic_bytes_per_launch": unit_bytes * units,
                     "algorithmic_bytes_per_unit": unit_bytes, "units_per_launch": units,
                     "unit_name": "bounded sub-problem" if dom == "nnls" else "slot-trip",
-                    "all_kernels_ms": per_kernel, "trips": trips, "restart_output_bytes": out_bytes}
+                    "all_kernels_ms": per_kernel, "trips": trips, "sub_pools": st["pools"],
+                    "launches": st["launches"], "restart_output_bytes": out_bytes}
             info = {"grid": None, "block": 256, "lds_bytes": 0}
         else:
             kernel_ms, launches = hc.timing_mean()

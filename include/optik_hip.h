@@ -146,9 +146,15 @@ int optik_hip_engine_submit(optik_hip_chain *chain, const optik_solver_config *c
                             uint32_t flags, const optik_hip_ik_outputs *out);
 int optik_hip_engine_run(optik_hip_chain *chain, void *stream);
 int optik_hip_engine_last_trips(const optik_hip_chain *chain);
+/* The slot pool of a run is split into sub-pools (OPTIK_ENG_POOLS, default 3; at most 4),
+ * each with its own HIP stream, so that kernels of different sub-pools overlap.  Returns
+ * the number of sub-pools of the last run; *launches = launches of each phase kernel,
+ * all sub-pools together (last_trips is the trip count of sub-pool 0). */
+int optik_hip_engine_last_pools(const optik_hip_chain *chain, int32_t *launches);
 /* Last run, when timing is enabled (optik_hip_set_timing): mean duration in ms of the four
- * phase kernels {eval, update, nnls, finish} over the trips of the run (HIP event pairs on
- * the launch stream, first 1024 trips), and the number of bounded sub-problems solved. */
+ * phase kernels {eval, update, nnls, finish} over the trips of sub-pool 0 (HIP event pairs on
+ * its launch stream, first 1024 trips; kernels of the other sub-pools run concurrently), and
+ * the number of bounded sub-problems solved by all sub-pools. */
 int optik_hip_engine_stats(const optik_hip_chain *chain, double *kernel_ms4, int32_t *sampled_trips,
                            uint64_t *nnls_problems);
 

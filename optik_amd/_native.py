@@ -84,6 +84,7 @@ def lib():
                                           C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(IkOutputs)]
     L.optik_hip_engine_run.argtypes = [vp, vp]
     L.optik_hip_engine_last_trips.argtypes = [vp]
+    L.optik_hip_engine_last_pools.argtypes = [vp, C.POINTER(C.c_int32)]
     L.optik_hip_engine_stats.argtypes = [vp, dp, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
     L.optik_hip_probe.argtypes = [C.c_int32, dp, dp, C.c_int64, dp]
     L.optik_hip_set_timing.argtypes = [vp, C.c_int32]

@@ -77,6 +77,10 @@ struct EngJob {
 };
 
 constexpr int ENG_MAX_JOBS = 64;
+// The slot pool runs as a few sub-pools, each with its own stream, lists and trip loop, all
+// pulling work items from the one queue: while one sub-pool is in its (VALU-bound) NNLS
+// kernel the others' latency-bound per-slot kernels fill the idle issue slots.
+constexpr int ENG_MAX_POOLS = 4;
 // Bounded sub-problems are listed by the iteration count their restart's previous
 // sub-problem took (76% repeat it, 92% within one): the NNLS kernel walks the classes from
 // the largest down, so a wave's 16 problems take similar numbers of passes and the long
@@ -100,7 +104,8 @@ struct EngArgs {
     int32_t *i32;                       // NI planes of C ints
     unsigned long long *item;           // [C] local item (t * R + r) of the slot's restart
     unsigned long long C;               // pool capacity = stride of the planes
-    unsigned long long n_slots;         // live prefix [0, n_slots) the per-slot kernels cover (shrinks while the pool drains)
+    unsigned long long slot_base;       // first slot of this sub-pool
+    unsigned long long n_slots;         // live prefix [slot_base, slot_base + n_slots) the per-slot kernels cover (shrinks while the pool drains)
     const EngJob *jobs;                 // [n_jobs] in device memory
     int n_jobs;
     int pad;
@@ -760,7 +765,7 @@ struct CompactArgs {
     double *d;
     int32_t *i32;
     unsigned long long *item;
-    unsigned long long C, n_slots, n_new;
+    unsigned long long C, slot_base, n_slots, n_new;  // live prefix [slot_base, +n_slots) -> [slot_base, +n_new)
     int nd, ni;
     unsigned int *counts;   // [0] free slots listed, [1] restarts to move
     unsigned int *free_list, *move_list;
@@ -772,11 +777,12 @@ struct CompactArgs {
 };
 
 OPTIK_DEV void compact_scan_body(const CompactArgs &c) {
-    const unsigned long long slot = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = slot < c.n_slots;
+    const unsigned long long local = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long slot = c.slot_base + local;
+    const bool in = local < c.n_slots;
     const int st = in ? c.i32[slot] : ST_EMPTY;  // plane 0 = STATE
-    const bool is_free = in && slot < c.n_new && st == ST_EMPTY;
-    const bool is_move = in && slot >= c.n_new && st != ST_EMPTY;
+    const bool is_free = in && local < c.n_new && st == ST_EMPTY;
+    const bool is_move = in && local >= c.n_new && st != ST_EMPTY;
     const unsigned lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
     const unsigned long long mf = __ballot(is_free), mm = __ballot(is_move);

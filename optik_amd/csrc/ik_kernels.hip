@@ -163,30 +163,36 @@ __global__ __launch_bounds__(WAVE) void ik_select_kernel(const SelectLaunch a) {
 #define OPTIK_ENG_EVAL_WAVES 2
 #endif
 #ifndef OPTIK_ENG_UPD_WAVES
-#define OPTIK_ENG_UPD_WAVES 1
+#define OPTIK_ENG_UPD_WAVES 2
+#endif
+// threads per workgroup of the per-slot kernels (eval / update / finish)
+#ifndef OPTIK_ENG_SLOT_BLOCK
+#define OPTIK_ENG_SLOT_BLOCK 256
 #endif
 
 template <int N, bool TIP>
-__global__ __launch_bounds__(256, OPTIK_ENG_EVAL_WAVES) void eng_eval_kernel(const EngArgs a) {
+__global__ __launch_bounds__(OPTIK_ENG_SLOT_BLOCK, OPTIK_ENG_EVAL_WAVES) void eng_eval_kernel(const EngArgs a) {
     __shared__ ChainDev sch;
     stage_chain(sch, a.chain);
-    const size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t local = (size_t)blockIdx.x * OPTIK_ENG_SLOT_BLOCK + threadIdx.x;
+    const size_t slot = (size_t)a.slot_base + local;
     // first kernel of a trip: reset the other parity's list counters (consumed last trip; this
     // trip's suspended solves and finishing pass and the next trip's update append to it) and
     // the in-use count the update kernel accumulates -- no memset launches between trips
     if (blockIdx.x == 0) {
         if (threadIdx.x < (unsigned)ENG_LIST_COUNTERS) a.nn_count[a.parity ^ 1][threadIdx.x] = 0u;
-        if (threadIdx.x == 64) *a.n_active = 0u;
+        if (threadIdx.x == (unsigned)ENG_LIST_COUNTERS) *a.n_active = 0u;
     }
-    if (slot < a.n_slots) eng_eval_body<N, TIP>(a, sch, slot);
+    if (local < a.n_slots) eng_eval_body<N, TIP>(a, sch, slot);
 }
 
 template <int N>
-__global__ __launch_bounds__(256, OPTIK_ENG_UPD_WAVES) void eng_update_kernel(const EngArgs a) {
+__global__ __launch_bounds__(OPTIK_ENG_SLOT_BLOCK, OPTIK_ENG_UPD_WAVES) void eng_update_kernel(const EngArgs a) {
     __shared__ ChainDev sch;
     stage_chain(sch, a.chain);
-    const size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x;
-    eng_update_body<N>(a, sch, slot < a.n_slots ? slot : 0, slot < a.n_slots);
+    const size_t local = (size_t)blockIdx.x * OPTIK_ENG_SLOT_BLOCK + threadIdx.x;
+    const size_t slot = (size_t)a.slot_base + local;
+    eng_update_body<N>(a, sch, local < a.n_slots ? slot : (size_t)a.slot_base, local < a.n_slots);
 }
 
 // columns of a bounded sub-problem held per lane (16 / CPL lanes share a problem)
@@ -209,11 +215,12 @@ __global__ __launch_bounds__(OPTIK_ENG_NNLS_BLOCK, OPTIK_ENG_NNLS_WAVES) void en
 }
 
 template <int N>
-__global__ __launch_bounds__(256, OPTIK_ENG_UPD_WAVES) void eng_finish_kernel(const EngArgs a) {
+__global__ __launch_bounds__(OPTIK_ENG_SLOT_BLOCK, OPTIK_ENG_UPD_WAVES) void eng_finish_kernel(const EngArgs a) {
     __shared__ ChainDev sch;
     stage_chain(sch, a.chain);
-    const size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (slot < a.n_slots) eng_finish_body<N>(a, sch, slot);
+    const size_t local = (size_t)blockIdx.x * OPTIK_ENG_SLOT_BLOCK + threadIdx.x;
+    const size_t slot = (size_t)a.slot_base + local;
+    if (local < a.n_slots) eng_finish_body<N>(a, sch, slot);
 }
 
 __global__ __launch_bounds__(256) void eng_compact_scan_kernel(const CompactArgs c) { compact_scan_body(c); }
@@ -378,7 +385,12 @@ struct optik_hip_chain {
     unsigned int *eng_list = nullptr;      // 2 x {slots [C], classes [C]}
     unsigned long long *nnls_trace = nullptr;  // OPTIK_NNLS_TRACE builds
     unsigned int *eng_trip_log = nullptr;      // OPTIK_ENG_TRIP_LOG diagnostics
-    unsigned int *eng_compact = nullptr;       // [2] counters, then free list [C], move list [C]
+    unsigned int *eng_compact = nullptr;       // [ENG_MAX_POOLS][2] counters, then free list [C], move list [C]
+    hipStream_t eng_streams[ENG_MAX_POOLS] = {};  // streams of sub-pools 1.. (sub-pool 0 runs on the caller's)
+    hipEvent_t eng_pool_ev[ENG_MAX_POOLS][8] = {};
+    hipEvent_t eng_fork_ev = nullptr, eng_join_ev[ENG_MAX_POOLS] = {};
+    int eng_pools = 1;
+    int eng_launches = 0;                      // NNLS launches of the last run, all sub-pools
     int eng_compactions = 0;
     double *eng_prob = nullptr;            // 2 x [C][2n][n+1]
     double *eng_y = nullptr;               // 2 x [C][2n]
@@ -597,6 +609,10 @@ void optik_hip_chain_destroy(optik_hip_chain *ch) {
     if (ch->eng_y) hipFree(ch->eng_y);
     if (ch->eng_meta) hipFree(ch->eng_meta);
     if (ch->eng_pinned) hipHostFree(ch->eng_pinned);
+    for (auto &pe : ch->eng_pool_ev) for (auto &e : pe) if (e) hipEventDestroy(e);
+    if (ch->eng_fork_ev) hipEventDestroy(ch->eng_fork_ev);
+    for (auto &e : ch->eng_join_ev) if (e) hipEventDestroy(e);
+    for (auto &st : ch->eng_streams) if (st) hipStreamDestroy(st);
     for (auto &e : ch->eng_ev) if (e) hipEventDestroy(e);
     for (auto &k : ch->eng_tev) for (auto &p2 : k) for (auto &e : p2) if (e) hipEventDestroy(e);
     if (ch->eng_nn_total) hipFree(ch->eng_nn_total);
@@ -948,17 +964,23 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             HIP_TRY(hipMalloc(&ch->eng_list, sizeof(unsigned int) * 4 * C));
             HIP_TRY(hipMalloc(&ch->eng_order, sizeof(unsigned int) * 2 * NN_CLASSES * C));
             HIP_TRY(hipMalloc(&ch->eng_carry, sizeof(double) * NN_CARRY * C));
-            HIP_TRY(hipMalloc(&ch->eng_compact, sizeof(unsigned int) * (2 + 2 * C)));
+            HIP_TRY(hipMalloc(&ch->eng_compact, sizeof(unsigned int) * (2 * ENG_MAX_POOLS + 2 * C)));
             ch->eng_C = C;
         }
         if (!ch->eng_djobs) HIP_TRY(hipMalloc(&ch->eng_djobs, sizeof(EngJob) * ENG_MAX_JOBS));
         constexpr int CB = ENG_LIST_COUNTERS;  // counters per trip parity
-        if (!ch->eng_counters) HIP_TRY(hipMalloc(&ch->eng_counters, (2 * CB + 2) * sizeof(unsigned int)));
-        if (!ch->eng_pinned) HIP_TRY(hipHostMalloc(&ch->eng_pinned, 8 * sizeof(unsigned int)));
+        constexpr int PCB = 2 * CB + 2;  // counters per sub-pool: two list blocks, slots in use, spare
+        if (!ch->eng_counters) HIP_TRY(hipMalloc(&ch->eng_counters, ENG_MAX_POOLS * PCB * sizeof(unsigned int)));
+        if (!ch->eng_pinned) HIP_TRY(hipHostMalloc(&ch->eng_pinned, ENG_MAX_POOLS * 8 * sizeof(unsigned int)));
         if (!ch->queue) HIP_TRY(hipMalloc(&ch->queue, sizeof(unsigned long long)));
         if (!ch->eng_nn_total) HIP_TRY(hipMalloc(&ch->eng_nn_total, sizeof(unsigned long long)));
         HIP_TRY(hipMemsetAsync(ch->eng_nn_total, 0, sizeof(unsigned long long), stream));
-        for (auto &e : ch->eng_ev) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &pe : ch->eng_pool_ev) for (auto &e : pe) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        if (!ch->eng_fork_ev) HIP_TRY(hipEventCreateWithFlags(&ch->eng_fork_ev, hipEventDisableTiming));
+        for (int p2 = 1; p2 < ENG_MAX_POOLS; ++p2) {
+            if (!ch->eng_streams[p2]) HIP_TRY(hipStreamCreateWithFlags(&ch->eng_streams[p2], hipStreamNonBlocking));
+            if (!ch->eng_join_ev[p2]) HIP_TRY(hipEventCreateWithFlags(&ch->eng_join_ev[p2], hipEventDisableTiming));
+        }
         ch->eng_tcount = 0;
 
         std::vector<EngJob> hj(n_jobs);
@@ -976,23 +998,14 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
         fill_solve_params(&ch->eng_cfg, a.sp);
         std::memcpy(a.key, ch->key, sizeof a.key);
         std::memcpy(a.scale, ch->scale, sizeof a.scale);
-        a.d = ch->eng_d; a.i32 = ch->eng_i32; a.item = ch->eng_item; a.C = C; a.n_slots = C;
+        a.d = ch->eng_d; a.i32 = ch->eng_i32; a.item = ch->eng_item; a.C = C;
         a.jobs = ch->eng_djobs; a.n_jobs = (int)n_jobs;
         a.total_items = total;
         a.next_item = ch->queue;
-        {
-            for (int par = 0; par < 2; ++par) {
-                a.nn_count[par] = ch->eng_counters + par * CB;
-                a.nn_order[par] = ch->eng_order + (size_t)par * NN_CLASSES * ch->eng_C;
-                a.nn_list[par] = ch->eng_list + (size_t)par * 2 * ch->eng_C;
-                a.nn_cls[par] = ch->eng_list + (size_t)par * 2 * ch->eng_C + ch->eng_C;
-            }
-            a.nn_carry = ch->eng_carry;
-            a.nn_prob = ch->eng_prob;
-            a.nn_y = ch->eng_y;
-            a.nn_meta = ch->eng_meta;
-        }
-        a.n_active = ch->eng_counters + 2 * CB;
+        a.nn_carry = ch->eng_carry;
+        a.nn_prob = ch->eng_prob;
+        a.nn_y = ch->eng_y;
+        a.nn_meta = ch->eng_meta;
         a.nn_budget = 6;
         if (const char *e = getenv("OPTIK_ENG_NNLS_BUDGET")) a.nn_budget = atoi(e) > 0 ? atoi(e) : 1;
         a.nn_total = ch->eng_nn_total;
@@ -1014,7 +1027,6 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
         a.prof = ch->prof;
 #endif
 
-        unsigned blocks = (unsigned)((C + 255) / 256);  // per-slot kernels: covers the live prefix
         ch->eng_compactions = 0;
         const bool allow_compact = !getenv("OPTIK_ENG_NO_COMPACT");
         const int cus = ch->num_cus > 0 ? ch->num_cus : 256;
@@ -1022,42 +1034,93 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
         if (const char *e = getenv("OPTIK_ENG_NNLS_WAVES_PER_CU")) nn_waves_per_cu = (unsigned)atoi(e);
         if (nn_waves_per_cu < 1) nn_waves_per_cu = 1;
         const unsigned nn_blocks = (unsigned)cus * nn_waves_per_cu * 64u / OPTIK_ENG_NNLS_BLOCK;
-        HIP_TRY(hipMemsetAsync(ch->eng_counters, 0, (2 * CB + 2) * sizeof(unsigned int), stream));
-        hipLaunchKernelGGL(eng_init_kernel, dim3(blocks), dim3(256), 0, stream, ch->eng_i32, (unsigned long long)C);
+        HIP_TRY(hipMemsetAsync(ch->eng_counters, 0, ENG_MAX_POOLS * PCB * sizeof(unsigned int), stream));
+        hipLaunchKernelGGL(eng_init_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, ch->eng_i32, (unsigned long long)C);
         HIP_TRY(hipGetLastError());
 
+        // sub-pools: equal slot ranges (multiples of 256), each with its own stream and lists
+        int n_pools = 3;  // (measured on MI355X: 1 -> 12.6, 2 -> 14.0, 3 -> 14.6, 4 -> 13.9 M restarts/s)
+        if (const char *e = getenv("OPTIK_ENG_POOLS")) n_pools = atoi(e);
+        if (n_pools < 1) n_pools = 1;
+        if (n_pools > ENG_MAX_POOLS) n_pools = ENG_MAX_POOLS;
+        while (n_pools > 1 && C / (size_t)n_pools < 16384) --n_pools;  // small pools: one trip loop
+        ch->eng_pools = n_pools;
+        struct Pool {
+            EngArgs a;
+            hipStream_t stream;
+            unsigned blocks;
+            int trip, pending, ring;
+            bool done;
+            unsigned int *pinned;
+            hipEvent_t *ev;
+            unsigned int *compact_counts;
+        };
+        Pool pools[ENG_MAX_POOLS];
+        {
+            const size_t per = C / 256 / (size_t)n_pools * 256;
+            for (int p2 = 0; p2 < n_pools; ++p2) {
+                Pool &P = pools[p2];
+                const size_t lo = per * (size_t)p2;
+                const size_t size = (p2 == n_pools - 1) ? C - lo : per;
+                P.a = a;
+                P.a.slot_base = lo;
+                P.a.n_slots = size;
+                unsigned int *cnt = ch->eng_counters + (size_t)p2 * PCB;
+                for (int par = 0; par < 2; ++par) {
+                    P.a.nn_count[par] = cnt + par * CB;
+                    P.a.nn_order[par] = ch->eng_order + (size_t)par * NN_CLASSES * ch->eng_C + lo;  // [class][C] + lo
+                    P.a.nn_list[par] = ch->eng_list + (size_t)par * 2 * ch->eng_C + lo;
+                    P.a.nn_cls[par] = ch->eng_list + (size_t)par * 2 * ch->eng_C + ch->eng_C + lo;
+                }
+                P.a.n_active = cnt + 2 * CB;
+                P.stream = p2 == 0 ? stream : ch->eng_streams[p2];
+                P.blocks = (unsigned)((size + OPTIK_ENG_SLOT_BLOCK - 1) / OPTIK_ENG_SLOT_BLOCK);
+                P.trip = 0; P.pending = 0; P.ring = 0; P.done = false;
+                P.pinned = ch->eng_pinned + 8 * p2;
+                P.ev = ch->eng_pool_ev[p2];
+                P.compact_counts = ch->eng_compact + 2 * p2;
+                if (p2 > 0) { P.a.trip_log = nullptr; P.a.prof = nullptr; }
+            }
+            // the other streams start after the set-up queued on the caller's stream
+            HIP_TRY(hipEventRecord(ch->eng_fork_ev, stream));
+            for (int p2 = 1; p2 < n_pools; ++p2) HIP_TRY(hipStreamWaitEvent(ch->eng_streams[p2], ch->eng_fork_ev, 0));
+        }
+
         const int CHECK = 4;  // trips between termination checks
-        int trip = 0, pending = 0, ring = 0;
-        bool done = false;
         const bool tip = ch->tip;
-        while (!done) {
+        // queues CHECK trips of one sub-pool, then looks at the in-use count of its previous chunk
+        auto advance = [&](Pool &P, bool first_pool) -> int {
+            EngArgs &a = P.a;
+            hipStream_t stream = P.stream;
+            unsigned &blocks = P.blocks;
+            int &trip = P.trip;
             for (int k = 0; k < CHECK; ++k, ++trip) {
                 // this trip consumes list[trip & 1]; the other list (consumed last trip) is
                 // reset for the finish kernel's re-deferrals and the next trip's update kernel
                 a.parity = trip & 1;
                 a.trip = trip < TRIP_LOG_MAX ? trip : TRIP_LOG_MAX - 1;
-                // HIP event pairs around each kernel of every trip (on the launch stream)
-                const bool timed = ch->timing && trip > 0 && ch->eng_tcount < optik_hip_chain::ENG_EV;
+                // HIP event pairs around each kernel of every trip of sub-pool 0 (on its launch stream)
+                const bool timed = first_pool && ch->timing && trip > 0 && ch->eng_tcount < optik_hip_chain::ENG_EV;
                 const int ts = ch->eng_tcount;
                 // (the NNLS kernel -- the longest -- is timed on every trip, the others on every 8th)
                 const bool timed_all = timed && (trip % 8 == 0);
 #define TEV(kind, which) do { if (timed && (kind == 2 || timed_all)) { hipEvent_t &tev_ = ch->eng_tev[kind][ts][which]; if (!tev_) HIP_TRY(hipEventCreate(&tev_)); HIP_TRY(hipEventRecord(tev_, stream)); } } while (0)
                 TEV(0, 0);
                 if (trip > 0) {
-#define M_EVAL_T(NN) hipLaunchKernelGGL((eng_eval_kernel<NN, true>), dim3(blocks), dim3(256), 0, stream, a)
-#define M_EVAL_F(NN) hipLaunchKernelGGL((eng_eval_kernel<NN, false>), dim3(blocks), dim3(256), 0, stream, a)
+#define M_EVAL_T(NN) hipLaunchKernelGGL((eng_eval_kernel<NN, true>), dim3(blocks), dim3(OPTIK_ENG_SLOT_BLOCK), 0, stream, a)
+#define M_EVAL_F(NN) hipLaunchKernelGGL((eng_eval_kernel<NN, false>), dim3(blocks), dim3(OPTIK_ENG_SLOT_BLOCK), 0, stream, a)
                     if (tip) DISPATCH_N(M_EVAL_T);
                     else DISPATCH_N(M_EVAL_F);
 #undef M_EVAL_T
 #undef M_EVAL_F
                 }
                 TEV(0, 1); TEV(1, 0);
-#define M_UPD(NN) hipLaunchKernelGGL((eng_update_kernel<NN>), dim3(blocks), dim3(256), 0, stream, a)
+#define M_UPD(NN) hipLaunchKernelGGL((eng_update_kernel<NN>), dim3(blocks), dim3(OPTIK_ENG_SLOT_BLOCK), 0, stream, a)
                 DISPATCH_N(M_UPD);
 #undef M_UPD
                 TEV(1, 1);
 #ifdef OPTIK_NNLS_TRACE
-                {   // per-wave timeline of one steady-state trip (debug builds only)
+                if (first_pool) {   // per-wave timeline of one steady-state trip (debug builds only)
                     static unsigned long long *tr = nullptr;
                     const int t0 = getenv("OPTIK_NNLS_TRACE_TRIP") ? atoi(getenv("OPTIK_NNLS_TRACE_TRIP")) : 150;
                     if (!tr) { HIP_TRY(hipMalloc(&tr, sizeof(unsigned long long) * 4 * 65536)); HIP_TRY(hipMemset(tr, 0, sizeof(unsigned long long) * 4 * 65536)); }
@@ -1071,50 +1134,67 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
                 DISPATCH_N(M_NNLS);
 #undef M_NNLS
                 TEV(2, 1); TEV(3, 0);
-#define M_FIN(NN) hipLaunchKernelGGL((eng_finish_kernel<NN>), dim3(blocks), dim3(256), 0, stream, a)
+#define M_FIN(NN) hipLaunchKernelGGL((eng_finish_kernel<NN>), dim3(blocks), dim3(OPTIK_ENG_SLOT_BLOCK), 0, stream, a)
                 DISPATCH_N(M_FIN);
 #undef M_FIN
                 TEV(3, 1);
 #undef TEV
                 if (timed) ch->eng_tcount += 1;
+                ch->eng_launches += 1;
             }
             HIP_TRY(hipGetLastError());
-            // read back n_active of the chunk just issued; look at the previous chunk's value
-            HIP_TRY(hipMemcpyAsync(&ch->eng_pinned[ring], ch->eng_counters + 2 * CB, sizeof(unsigned int),
-                                   hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipEventRecord(ch->eng_ev[ring], stream));
-            if (pending) {
-                const int prev = (ring + 7) % 8;
-                HIP_TRY(hipEventSynchronize(ch->eng_ev[prev]));
-                const unsigned long long in_use = ch->eng_pinned[prev];
-                if (in_use == 0) done = true;
+            // read back the in-use count of the chunk just issued; look at the previous chunk's value
+            HIP_TRY(hipMemcpyAsync(&P.pinned[P.ring], a.n_active, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipEventRecord(P.ev[P.ring], stream));
+            if (P.pending) {
+                const int prev = (P.ring + 7) % 8;
+                HIP_TRY(hipEventSynchronize(P.ev[prev]));
+                const unsigned long long in_use = P.pinned[prev];
+                if (in_use == 0) P.done = true;
                 // drain: part of the live prefix no longer holds a restart (the count only
                 // falls once the queue is empty, so the lagging value is an upper bound)
                 unsigned long long n_new = (in_use + 255) / 256 * 256;
                 if (n_new < 1024) n_new = 1024;
-                if (!done && allow_compact && n_new * 5 <= a.n_slots * 4) {  // worth >= 20% of every per-slot launch
+                if (!P.done && allow_compact && n_new * 5 <= a.n_slots * 4) {  // worth >= 20% of every per-slot launch
                     CompactArgs c;
                     c.d = ch->eng_d; c.i32 = ch->eng_i32; c.item = ch->eng_item;
-                    c.C = C; c.n_slots = a.n_slots; c.n_new = n_new; c.nd = nd; c.ni = ni;
-                    c.counts = ch->eng_compact;
-                    c.free_list = ch->eng_compact + 2;
-                    c.move_list = ch->eng_compact + 2 + C;
+                    c.C = C; c.slot_base = a.slot_base; c.n_slots = a.n_slots; c.n_new = n_new; c.nd = nd; c.ni = ni;
+                    c.counts = P.compact_counts;
+                    c.free_list = ch->eng_compact + 2 * ENG_MAX_POOLS + a.slot_base;
+                    c.move_list = ch->eng_compact + 2 * ENG_MAX_POOLS + C + a.slot_base;
                     c.nn_prob = ch->eng_prob; c.nn_meta = ch->eng_meta; c.nn_carry = ch->eng_carry;
                     c.nn_list = a.nn_list[trip & 1];  // the list the next trip consumes
                     c.rec_len = rec_len;
                     c.nnq_plane = nnq_plane;
-                    HIP_TRY(hipMemsetAsync(ch->eng_compact, 0, 2 * sizeof(unsigned int), stream));
+                    HIP_TRY(hipMemsetAsync(P.compact_counts, 0, 2 * sizeof(unsigned int), stream));
                     hipLaunchKernelGGL(eng_compact_scan_kernel, dim3((unsigned)((a.n_slots + 255) / 256)), dim3(256), 0, stream, c);
                     hipLaunchKernelGGL(eng_compact_move_kernel, dim3((unsigned)((a.n_slots - n_new + 255) / 256)), dim3(256), 0, stream, c);
                     HIP_TRY(hipGetLastError());
                     a.n_slots = n_new;
-                    blocks = (unsigned)((n_new + 255) / 256);
+                    blocks = (unsigned)((n_new + OPTIK_ENG_SLOT_BLOCK - 1) / OPTIK_ENG_SLOT_BLOCK);
                     ch->eng_compactions += 1;
                 }
             }
-            pending = 1;
-            ring = (ring + 1) % 8;
+            P.pending = 1;
+            P.ring = (P.ring + 1) % 8;
+            return 0;
+        };
+        ch->eng_launches = 0;
+        for (bool all_done = false; !all_done;) {
+            all_done = true;
+            for (int p2 = 0; p2 < n_pools; ++p2) {
+                if (pools[p2].done) continue;
+                const int prc = advance(pools[p2], p2 == 0);
+                if (prc != 0) return prc;
+                all_done = all_done && pools[p2].done;
+            }
         }
+        // the selection below runs on the caller's stream after every sub-pool
+        for (int p2 = 1; p2 < n_pools; ++p2) {
+            HIP_TRY(hipEventRecord(ch->eng_join_ev[p2], ch->eng_streams[p2]));
+            HIP_TRY(hipStreamWaitEvent(stream, ch->eng_join_ev[p2], 0));
+        }
+        const int trip = pools[0].trip;
         ch->eng_trips = trip;
 
         // selection of every job (lib.rs:397-413)
@@ -1202,6 +1282,12 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
 }
 
 int optik_hip_engine_last_trips(const optik_hip_chain *ch) { return ch ? ch->eng_trips : 0; }
+
+int optik_hip_engine_last_pools(const optik_hip_chain *ch, int32_t *launches) {
+    if (!ch) return 0;
+    if (launches) *launches = ch->eng_launches;
+    return ch->eng_pools;
+}
 
 int optik_hip_engine_stats(const optik_hip_chain *ch, double *kernel_ms4, int32_t *sampled_trips,
                            uint64_t *nnls_problems) {

@@ -159,13 +159,17 @@ class HipChain:
         return int(nat.lib().optik_hip_engine_last_trips(self._h))
 
     def engine_stats(self):
-        """Per-kernel mean ms {eval, update, nnls, finish} over the sampled trips of the last
-        engine_run (needs set_timing(True)), sampled trips, NNLS problems solved."""
+        """Per-kernel mean ms {eval, update, nnls, finish} over the sampled trips of sub-pool 0 of
+        the last engine_run (needs set_timing(True)), sampled trips, NNLS problems solved, the
+        number of sub-pools and the launches of each phase kernel over all of them."""
         ms = (C.c_double * 4)()
         cnt, prob = C.c_int32(0), C.c_uint64(0)
         nat.check(nat.lib().optik_hip_engine_stats(self._h, ms, C.byref(cnt), C.byref(prob)))
+        launches = C.c_int32(0)
+        pools = int(nat.lib().optik_hip_engine_last_pools(self._h, C.byref(launches)))
         return dict(eval_ms=ms[0], update_ms=ms[1], nnls_ms=ms[2], finish_ms=ms[3],
-                    sampled_trips=cnt.value, nnls_problems=prob.value)
+                    sampled_trips=cnt.value, nnls_problems=prob.value, pools=pools,
+                    launches=launches.value)
 
     def set_timing(self, enabled=True):
         nat.lib().optik_hip_set_timing(self._h, 1 if enabled else 0)
