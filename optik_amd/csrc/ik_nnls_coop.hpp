@@ -171,6 +171,8 @@ OPTIK_DEV void nnls_coop(bool live, bool resume, int budget, int cid0, dvec8 (&c
                 park(col, cs);
             }
             const bool cand = run && !none && phase != 5;
+            // (the last trip of most waves: every problem left has just finished)
+            if (wave_any(cand)) {
             // step five: Householder construction on the chosen column j (position bp)
             bool hitk[CPL];
             bool hit_any = false;
@@ -306,6 +308,7 @@ OPTIK_DEV void nnls_coop(bool live, bool resume, int budget, int cid0, dvec8 (&c
             }
             // found: solve (step six); else choose again without recomputing the duals
             phase = cand ? (found ? 2 : 1) : phase;
+            }
         }
         // ---------------- steps six .. ten ---------------------------------------------
         if (wave_any(phase == 2)) {
