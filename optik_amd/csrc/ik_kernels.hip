@@ -11,6 +11,7 @@
 // No CPU fallback exists: every entry point fails loudly without a device.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
 
 #include <cmath>
 #include <cstdio>
@@ -1040,10 +1041,11 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
 
         // sub-pools: equal slot ranges (multiples of 256), each with its own stream and lists
         int n_pools = 3;  // (measured on MI355X: 1 -> 12.6, 2 -> 14.0, 3 -> 14.6, 4 -> 13.9 M restarts/s)
-        if (const char *e = getenv("OPTIK_ENG_POOLS")) n_pools = atoi(e);
+        size_t min_pool = 16384;  // small pools: one trip loop
+        if (const char *e = getenv("OPTIK_ENG_POOLS")) { n_pools = atoi(e); min_pool = 1024; }
         if (n_pools < 1) n_pools = 1;
         if (n_pools > ENG_MAX_POOLS) n_pools = ENG_MAX_POOLS;
-        while (n_pools > 1 && C / (size_t)n_pools < 16384) --n_pools;  // small pools: one trip loop
+        while (n_pools > 1 && C / (size_t)n_pools < min_pool) --n_pools;
         ch->eng_pools = n_pools;
         struct Pool {
             EngArgs a;
@@ -1088,6 +1090,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
 
         const int CHECK = 4;  // trips between termination checks
         const bool tip = ch->tip;
+        double dbg_wait_bulk = 0.0, dbg_wait_drain = 0.0;  // host time blocked on the GPU (OPTIK_ENG_DEBUG)
         // queues CHECK trips of one sub-pool, then looks at the in-use count of its previous chunk
         auto advance = [&](Pool &P, bool first_pool) -> int {
             EngArgs &a = P.a;
@@ -1148,8 +1151,11 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             HIP_TRY(hipEventRecord(P.ev[P.ring], stream));
             if (P.pending) {
                 const int prev = (P.ring + 7) % 8;
+                const auto w0 = std::chrono::steady_clock::now();
                 HIP_TRY(hipEventSynchronize(P.ev[prev]));
+                const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
                 const unsigned long long in_use = P.pinned[prev];
+                (in_use * 2 < a.n_slots || a.n_slots < 16384 ? dbg_wait_drain : dbg_wait_bulk) += waited;
                 if (in_use == 0) P.done = true;
                 // drain: part of the live prefix no longer holds a restart (the count only
                 // falls once the queue is empty, so the lagging value is an upper bound)
@@ -1180,6 +1186,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             return 0;
         };
         ch->eng_launches = 0;
+        const auto dbg_t0 = std::chrono::steady_clock::now();
         for (bool all_done = false; !all_done;) {
             all_done = true;
             for (int p2 = 0; p2 < n_pools; ++p2) {
@@ -1189,6 +1196,10 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
                 all_done = all_done && pools[p2].done;
             }
         }
+        if (getenv("OPTIK_ENG_DEBUG"))
+            fprintf(stderr, "[optik engine] loop %.2f ms, host waited on the GPU %.2f ms (bulk) + %.2f ms (drain), %d launches\n",
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - dbg_t0).count() * 1e3,
+                    dbg_wait_bulk * 1e3, dbg_wait_drain * 1e3, ch->eng_launches);
         // the selection below runs on the caller's stream after every sub-pool
         for (int p2 = 1; p2 < n_pools; ++p2) {
             HIP_TRY(hipEventRecord(ch->eng_join_ev[p2], ch->eng_streams[p2]));

@@ -406,6 +406,10 @@ done: {
 template <int N>
 OPTIK_DEV constexpr int lidx(int i, int j) { return i * N - (i * (i - 1)) / 2 + (j - i); }
 
+#ifndef OPTIK_ROWS_GROUP
+#define OPTIK_ROWS_GROUP 1
+#endif
+
 // ---- Kraft LSQ for m = 0 and finite bounds:  min ||E s - f||, lo <= s <= hi ------
 // Split in three so the streaming engine can run the LDS-free parts at high
 // occupancy and only the lanes whose step hits a bound through NNLS:
@@ -507,7 +511,9 @@ OPTIK_DEV bool lsq_bound_rows(const double (&E)[N][N], const double (&f)[N], con
         const double h_hi = (-hi[i]) - (-acc);
         need = need || (h_lo > 0.0) || (h_hi > 0.0);
         sink(i, row, h_lo, h_hi);
-        OPTIK_SCHED_FENCE();
+        // rows are independent recurrences (each a chain of divisions): letting the scheduler
+        // interleave OPTIK_ROWS_GROUP of them hides the division latency at 2 waves per SIMD
+        if (i % OPTIK_ROWS_GROUP == OPTIK_ROWS_GROUP - 1) OPTIK_SCHED_FENCE();
     }
     return need;
 }

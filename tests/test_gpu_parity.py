@@ -259,6 +259,44 @@ def test_engine_pools_jobs_and_matches_the_single_kernel_path(dev, oracle, chain
             assert torch.equal(r[k].view(torch.int64), o[k].view(torch.int64)), k
 
 
+@pytest.mark.parametrize("knobs", [
+    {"OPTIK_ENG_POOLS": "3", "OPTIK_ENGINE_SLOTS": "3072"},                       # three sub-pools, refilled many times
+    {"OPTIK_ENG_POOLS": "4", "OPTIK_ENGINE_SLOTS": "8192", "OPTIK_ENG_NNLS_BUDGET": "1"},  # every solve suspended each pass
+    {"OPTIK_ENG_POOLS": "2", "OPTIK_ENGINE_SLOTS": "4096", "OPTIK_ENG_NNLS_BUDGET": "2"},
+    {"OPTIK_ENG_POOLS": "1", "OPTIK_ENG_NO_COMPACT": "1"},                         # no drain compaction
+    {"OPTIK_ENG_POOLS": "1", "OPTIK_ENGINE_SLOTS": "2048", "OPTIK_ENG_NNLS_BUDGET": "3"},
+])
+def test_engine_scheduling_does_not_change_results(dev, oracle, chains, hip_chains, knobs):
+    """Sub-pools, the per-launch NNLS pass budget (suspend / resume), pool size (refills) and
+    drain compaction only decide WHERE and WHEN a restart's arithmetic runs: every restart's
+    status, evaluation count, x and f equal the oracle's under any setting."""
+    import os
+    from optik_amd import _native as nat
+    d, ch = chains["panda"]
+    rng = np.random.default_rng(41)
+    tg, x0 = make_targets(oracle, d, ch, rng, 1)
+    kw = dict(solution_mode="quality", tol_f=1e-6)
+    cfg = nat.make_config(**kw)
+    R = 6000
+    old = {k: os.environ.get(k) for k in knobs}
+    os.environ.update(knobs)
+    try:
+        out = _run(hip_chains["panda"], "engine", cfg, torch.tensor(tg, device="cuda"),
+                   torch.tensor(x0, device="cuda"), 0, R)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    ref = _oracle_all(oracle, ch, kw, tg[0], x0[0], 0, R)
+    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    assert np.array_equal(out["evals"].cpu().numpy(), ref["evals"])
+    assert_bit_equal(out["f"].cpu().numpy(), ref["fs"], "per-restart f")
+    assert_bit_equal(out["x"].cpu().numpy(), ref["xs"].T, "per-restart x")
+    assert int(out["win_idx"].cpu()[0]) == ref["winner"]
+
+
 def test_early_exit_keeps_the_winner(dev, oracle, chains, hip_chains):
     """Speed + early exit (lib.rs:382-384): restarts above a known success are
     abandoned, the winner (lowest successful index) does not change."""
