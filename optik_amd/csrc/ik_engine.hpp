@@ -51,7 +51,7 @@ struct EngLayout {
                          L = XP + N, F0 = L + NL, H3 = F0 + 1, AL = H3 + 1, FP = AL + 1, MF = FP + 1,
                          FC = MF + 1, ND = FC + 1;
     // int32 planes
-    static constexpr int STATE = 0, LINE = 1, IRESET = 2, ITER = 3, NEVALS = 4, STATUS = 5, JOB = 6, NNQ = 7, NNIT = 8, NI = 9;
+    static constexpr int STATE = 0, LINE = 1, IRESET = 2, ITER = 3, NEVALS = 4, STATUS = 5, JOB = 6, NNIT = 7, NI = 8;
 };
 
 // One submitted optik_hip_ik_batch call.
@@ -86,7 +86,9 @@ constexpr int ENG_MAX_POOLS = 4;
 // the largest down, so a wave's 16 problems take similar numbers of passes and the long
 // ones start first.  Scheduling only -- every problem is solved independently.
 constexpr int NN_CLASSES = 8;
-constexpr int ENG_LIST_COUNTERS = 2 + NN_CLASSES;  // per trip parity: list length, class sizes, spare
+// counters of a sub-pool: class sizes per trip parity, then slots to refill, slots in use
+constexpr int ENG_POOL_COUNTERS = 2 * NN_CLASSES + 2;
+constexpr unsigned NN_NONE = 0xffffffffu;  // nn_cls entry of a slot without a problem
 // A problem that needs more than the launch's pass budget is suspended and continues in
 // the next trip's launch (its slot just stays in ST_NNLS): no launch waits for the rare
 // 10+ pass problem.  Carry record: the transformed matrix [112], then b[8], up, nsetp, iter,
@@ -114,10 +116,10 @@ struct EngArgs {
     // bounded sub-problems: one record per slot (a slot has at most one outstanding); the
     // lists of a trip are double-buffered by trip parity (the finish kernel of trip s and a
     // suspended solve both defer into the list of trip s+1)
-    unsigned int *nn_count[2];          // list lengths; [1 .. NN_CLASSES] after each: class sizes
-    unsigned int *nn_list[2];           // [C] slots with a problem for the trip, in emission order
-    unsigned int *nn_cls[2];            // [C] predicted class of each list entry
-    unsigned int *nn_order[2];          // [NN_CLASSES][C] the list's slots by predicted class
+    unsigned int *nn_cls[2];            // [sub-pool size] predicted class of the slot's problem for the trip, or NN_NONE
+                                        // (a plain store per emission: no list atomics in the per-slot kernels)
+    unsigned int *nn_class_count[2];    // [NN_CLASSES] class sizes (bucket kernel)
+    unsigned int *nn_order[2];          // [NN_CLASSES][C] the trip's slots by predicted class (bucket kernel)
     double *nn_prob;                    // [C][2n][n+1] dual problem of the slot, one contiguous block
     double *nn_y;                       // [C][2n] multipliers
     double *nn_meta;                    // [C][2] {mode + 8 * passes, rnorm | -1 = suspended, resume from nn_carry}
@@ -126,9 +128,16 @@ struct EngArgs {
     int pad3;
     int parity;                         // list consumed by this trip's NNLS kernel
     int pad2;
-    unsigned int *n_active;             // slots holding a restart after the update kernel (zeroed every trip)
+    unsigned int *n_active;             // slots holding a restart or waiting for one (bucket kernel; reset every trip)
+    // slots whose restart was published this trip (or never started) and want the next work item:
+    // listed by the bucket kernel, handed out one per lane by the finish kernel (a finished
+    // restart per 39 evaluations would otherwise drag 4 of 5 waves through the refill code for
+    // one or two lanes)
+    unsigned int *refill_count;
+    unsigned int *refill_list;          // [sub-pool size]
     unsigned long long *nn_total;       // running count of bounded sub-problems solved
     unsigned long long *prof;           // OPTIK_PROFILE builds: cycle counters, else null
+    unsigned long long *prof2;          // OPTIK_PROFILE builds: direction-search sub-phases
     unsigned int *trip_log;             // diagnostics (OPTIK_ENG_TRIP_LOG): [trip][2] = {slots in use, sub-problems}
     int trip;
     int pad4;
@@ -144,10 +153,7 @@ enum : int { DIR_OK = 0, DIR_DEFER = 1, DIR_DEAD = 2 };
 // Lists the slot for the NNLS launch of trip parity `parity`, with its predicted class.
 template <int N>
 OPTIK_DEV void list_problem(const EngArgs &a, int parity, size_t slot, int pred) {
-    const unsigned q = atomicAdd(a.nn_count[parity], 1u);
-    a.nn_list[parity][q] = (unsigned)slot;
-    ENG_I(EngLayout<N>::NNQ) = (int32_t)q;  // (the pool compaction re-points the entry when it moves the slot)
-    a.nn_cls[parity][q] = (unsigned)(pred < 0 ? 0 : (pred >= NN_CLASSES ? NN_CLASSES - 1 : pred));
+    a.nn_cls[parity][slot - a.slot_base] = (unsigned)(pred < 0 ? 0 : (pred >= NN_CLASSES ? NN_CLASSES - 1 : pred));
 }
 
 // Problem record of a slot: the rows of E^-1 packed like the factor (row i, entries j >= i,
@@ -198,8 +204,18 @@ enum : int { DIR_RESET = 3 };
 template <int N>
 OPTIK_DEV int direction_pass(const EngArgs &a, const ChainDev &ch, size_t slot, int emit_parity, bool resume,
                              const double (&l)[N * (N + 1) / 2], const double (&g)[N], const double (&x)[N],
-                             double (&s)[N], double &h3, int32_t &status, int pred) {
+                             double (&s)[N], double &h3, int32_t &status, int pred
+#ifdef OPTIK_PROFILE
+                             , unsigned long long *dp = nullptr
+#endif
+                             ) {
     constexpr int NL = N * (N + 1) / 2;
+#ifdef OPTIK_PROFILE
+#define DIR_PROBE(k) do { if (dp) { OPTIK_SCHED_FENCE(); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); dp[k] = clock64(); OPTIK_SCHED_FENCE(); } } while (0)
+#else
+#define DIR_PROBE(k)
+#endif
+    DIR_PROBE(0);
     double *rec = a.nn_prob + slot * rec_stride<N>();
     double lo[N], hi[N];
 #pragma unroll
@@ -208,6 +224,7 @@ OPTIK_DEV int direction_pass(const EngArgs &a, const ChainDev &ch, size_t slot, 
     double E[N][N], fv[N];
     int lmode = lsq_factor<N>(l, g, E, fv);
     OPTIK_SCHED_FENCE();
+    DIR_PROBE(1);
     if (lmode == 1) {
         if (resume) {
             lmode = ldp_from_record<N>(rec, a.nn_y + slot * 2 * N, a.nn_meta + slot * 2, s);
@@ -218,6 +235,7 @@ OPTIK_DEV int direction_pass(const EngArgs &a, const ChainDev &ch, size_t slot, 
                 rec[NL + i] = h_lo;
                 rec[NL + N + i] = h_hi;
             });
+            DIR_PROBE(2);
             if (need) {
                 list_problem<N>(a, emit_parity, slot, pred);
                 a.nn_meta[slot * 2 + 1] = 0.0;  // a fresh problem, not a resumed one
@@ -234,6 +252,7 @@ OPTIK_DEV int direction_pass(const EngArgs &a, const ChainDev &ch, size_t slot, 
     }
     lsq_finish<N>(E, fv, lo, hi, s);
     OPTIK_SCHED_FENCE();
+    DIR_PROBE(3);
     double gs = 0.0;
 #pragma unroll
     for (int i = 0; i < N; ++i) gs += g[i] * s[i];
@@ -251,14 +270,22 @@ template <int N>
 OPTIK_DEV int direction_search(const EngArgs &a, const ChainDev &ch, size_t slot, int emit_parity, bool resume,
                                const double (&l)[N * (N + 1) / 2], const double (&g)[N], const double (&x)[N],
                                double f, int &ireset, int &iter, bool reset, double (&s)[N], double &h3,
-                               int32_t &status, int pred) {
+                               int32_t &status, int pred
+#ifdef OPTIK_PROFILE
+                               , unsigned long long *dp = nullptr
+#endif
+                               ) {
     using EL = EngLayout<N>;
     constexpr int NL = N * (N + 1) / 2;
     const SolveParams &sp = a.sp;
     bool have0 = false;  // a completed LSQ in this call: Kraft's (f0, x0) = (f, x)
     if (!reset) {
         if (!resume) ++iter;
+#ifdef OPTIK_PROFILE
+        const int r = direction_pass<N>(a, ch, slot, emit_parity, resume, l, g, x, s, h3, status, pred, dp);
+#else
         const int r = direction_pass<N>(a, ch, slot, emit_parity, resume, l, g, x, s, h3, status, pred);
+#endif
         if (r != DIR_RESET) return r;
         have0 = true;
     }
@@ -468,65 +495,80 @@ OPTIK_DEV void eng_eval_body(const EngArgs &a, const ChainDev &ch, size_t slot) 
     }
 }
 
+// Gives `slot` the work item `it` of the queue (or leaves it empty when the queue is
+// exhausted): restart seed, bookkeeping planes.  Returns the slot's new state.
+template <int N>
+OPTIK_DEV int refill_slot(const EngArgs &a, const ChainDev &ch, size_t slot, unsigned long long it) {
+    using E = EngLayout<N>;
+    int st;
+    if (it < a.total_items) {
+        int job = 0;
+        for (int j = 1; j < a.n_jobs; ++j)
+            if (it >= a.jobs[j].item_base) job = j;
+        const EngJob &J = a.jobs[job];
+        const unsigned long long qi = it - J.item_base;
+        unsigned long long tslot, r;
+        if (J.restart_major) { r = qi / J.n_targets; tslot = qi - r * J.n_targets; }
+        else { tslot = qi / J.n_restarts; r = qi - tslot * J.n_restarts; }
+        const unsigned long long item = tslot * J.n_restarts + r;  // output column
+        const unsigned long long index = J.restart_begin + r;
+        double x[N];
+        restart_seed<N>(a.key, ch.lb, a.scale, index, x);
+        if (index == 0) {  // lib.rs:366-370: restart 0 starts from the caller's seed
+            const double *x0p = J.x0 + (size_t)tslot * N;
+#pragma unroll
+            for (int i = 0; i < N; ++i) x[i] = x0p[i];
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            ENG_D(E::X, i) = x[i];
+            ENG_D(E::XB, i) = x[i];
+            ENG_D(E::XP, i) = x[i];
+        }
+        ENG_D(E::MF, 0) = __builtin_huge_val();
+        ENG_D(E::FP, 0) = __builtin_huge_val();
+        ENG_I(E::NEVALS) = 0;
+        ENG_I(E::ITER) = 0;
+        ENG_I(E::IRESET) = 0;
+        ENG_I(E::LINE) = 0;
+        ENG_I(E::NNIT) = 1;
+        ENG_I(E::JOB) = job;
+        a.item[slot] = item;
+        st = ST_EVAL_FIRST;
+        if (J.first_success) {
+            // lib.rs:308 at the restart's first callback: a lower index already succeeded
+            const unsigned long long fs = __hip_atomic_load(J.first_success + tslot, __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT);
+            if (fs < index) { ENG_I(E::STATUS) = RES_FORCED_STOP; st = ST_DEAD; }
+        }
+    } else {
+        st = ST_EMPTY;
+    }
+    ENG_I(E::STATE) = st;
+    return st;
+}
+
 // ---- kernel 2: update (BFGS + unconstrained direction) and refill ---------------
 
 template <int N>
 OPTIK_DEV void eng_update_body(const EngArgs &a, const ChainDev &ch, size_t slot, bool in_range) {
     using E = EngLayout<N>;
     int st = in_range ? ENG_I(E::STATE) : ST_EMPTY;
+#ifdef OPTIK_PROFILE
+    // phase timers of the update kernel (tools/engine_phase_profile.py): wave cycles between
+    // probes, summed over the waves that ran a direction search
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long prof_factor = 0, prof_rows = 0, prof_tail = 0;
+#define ENG_PROBE(k) do { OPTIK_SCHED_FENCE(); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); pt[k] = clock64(); OPTIK_SCHED_FENCE(); } while (0)
+    ENG_PROBE(0);
+#else
+#define ENG_PROBE(k)
+#endif
 
-    // refill: the next work item of the queue (one atomic per wave)
-    const bool want = st == ST_REFILL;
-    if (wave_any(want)) {
-        const unsigned long long it = fetch_items(a.next_item, want);
-        if (want) {
-            if (it < a.total_items) {
-                int job = 0;
-                for (int j = 1; j < a.n_jobs; ++j)
-                    if (it >= a.jobs[j].item_base) job = j;
-                const EngJob &J = a.jobs[job];
-                const unsigned long long qi = it - J.item_base;
-                unsigned long long tslot, r;
-                if (J.restart_major) { r = qi / J.n_targets; tslot = qi - r * J.n_targets; }
-                else { tslot = qi / J.n_restarts; r = qi - tslot * J.n_restarts; }
-                const unsigned long long item = tslot * J.n_restarts + r;  // output column
-                const unsigned long long index = J.restart_begin + r;
-                double x[N];
-                restart_seed<N>(a.key, ch.lb, a.scale, index, x);
-                if (index == 0) {  // lib.rs:366-370: restart 0 starts from the caller's seed
-                    const double *x0p = J.x0 + (size_t)tslot * N;
-#pragma unroll
-                    for (int i = 0; i < N; ++i) x[i] = x0p[i];
-                }
-#pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    ENG_D(E::X, i) = x[i];
-                    ENG_D(E::XB, i) = x[i];
-                    ENG_D(E::XP, i) = x[i];
-                }
-                ENG_D(E::MF, 0) = __builtin_huge_val();
-                ENG_D(E::FP, 0) = __builtin_huge_val();
-                ENG_I(E::NEVALS) = 0;
-                ENG_I(E::ITER) = 0;
-                ENG_I(E::IRESET) = 0;
-                ENG_I(E::LINE) = 0;
-                ENG_I(E::NNIT) = 1;
-                ENG_I(E::JOB) = job;
-                a.item[slot] = item;
-                st = ST_EVAL_FIRST;
-                if (J.first_success) {
-                    // lib.rs:308 at the restart's first callback: a lower index already succeeded
-                    const unsigned long long fs = __hip_atomic_load(J.first_success + tslot, __ATOMIC_RELAXED,
-                                                                    __HIP_MEMORY_SCOPE_AGENT);
-                    if (fs < index) { ENG_I(E::STATUS) = RES_FORCED_STOP; st = ST_DEAD; }
-                }
-            } else {
-                st = ST_EMPTY;
-            }
-            ENG_I(E::STATE) = st;
-        }
-    }
-
+    ENG_PROBE(1);
+#ifdef OPTIK_PROFILE
+    const bool prof_wave = wave_any(st == ST_UPDATE_FIRST || st == ST_UPDATE_ACCEPT);
+#endif
     if (st == ST_UPDATE_FIRST || st == ST_UPDATE_ACCEPT) {
         double l[E::NL], g[N], x[N], s[N];
         const double f = ENG_D(E::FC, 0);
@@ -541,6 +583,7 @@ OPTIK_DEV void eng_update_body(const EngArgs &a, const ChainDev &ch, size_t slot
 #pragma unroll
             for (int i = 0; i < N; ++i) { s[i] = ENG_D(E::S, i); u[i] = g[i] - ENG_D(E::G, i); }
             OPTIK_SCHED_FENCE();
+            ENG_PROBE(2);
             bfgs_update<N>(l, s, u);
             OPTIK_SCHED_FENCE();
 #pragma unroll
@@ -553,16 +596,53 @@ OPTIK_DEV void eng_update_body(const EngArgs &a, const ChainDev &ch, size_t slot
         }
         double h3 = 0.0;
         int32_t status = 0;
+        ENG_PROBE(3);
+#ifdef OPTIK_PROFILE
+        unsigned long long dpt[4] = {0, 0, 0, 0};
+        const int out = direction_search<N>(a, ch, slot, a.parity, false, l, g, x, f, ireset, iter,
+                                            st == ST_UPDATE_FIRST, s, h3, status, ENG_I(E::NNIT), dpt);
+        ENG_PROBE(5);  // (reused below: end of the search, before the stores)
+        if (dpt[1] && dpt[0]) pt[0] += 0;  // keep dpt live
+        prof_factor = (dpt[1] && dpt[0]) ? dpt[1] - dpt[0] : 0;
+        prof_rows = (dpt[2] && dpt[1]) ? dpt[2] - dpt[1] : 0;
+        prof_tail = dpt[2] ? pt[5] - dpt[2] : 0;
+#else
         const int out = direction_search<N>(a, ch, slot, a.parity, false, l, g, x, f, ireset, iter,
                                             st == ST_UPDATE_FIRST, s, h3, status, ENG_I(E::NNIT));
+#endif
         if (out == DIR_OK) store_direction<N>(a, ch, slot, l, g, x, s, f, h3, ireset, iter);
         else if (out == DIR_DEFER) store_deferred<N>(a, slot, l, g, ireset, iter);
         else { ENG_I(E::STATUS) = status; ENG_I(E::ITER) = iter; ENG_I(E::STATE) = ST_DEAD; }
         st = ST_EVAL_TRIAL;  // (any non-empty value: the slot still holds a restart)
+        ENG_PROBE(4);
     }
+#ifdef OPTIK_PROFILE
+    ENG_PROBE(5);
+    if (a.prof && prof_wave) {
+        // per-lane probes differ only by divergence; lane maxima describe the wave
+        unsigned long long d[5];
+        d[0] = pt[1] - pt[0];                       // refill + entry loads
+        d[1] = pt[2] ? pt[2] - pt[1] : 0;           // plane loads of an accepted step
+        d[2] = (pt[3] && pt[2]) ? pt[3] - pt[2] : 0;  // BFGS
+        d[3] = (pt[4] && pt[3]) ? pt[4] - pt[3] : 0;  // direction search + stores
+        d[4] = pt[5] - pt[0];                       // whole body
+        unsigned long long d2[3] = {prof_factor, prof_rows, prof_tail};
+        if (a.prof2) for (int k = 0; k < 2; ++k) {
+            unsigned long long v = d2[k];
+            for (int off = 32; off >= 1; off >>= 1) { const unsigned long long o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+            if ((threadIdx.x & 63u) == 0) atomicAdd(a.prof2 + k, v);
+        }
+        for (int k = 0; k < 5; ++k) {
+            unsigned long long v = d[k];
+            for (int off = 32; off >= 1; off >>= 1) { const unsigned long long o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+            if ((threadIdx.x & 63u) == 0) atomicAdd(a.prof + k, v);
+        }
+        if ((threadIdx.x & 63u) == 0) atomicAdd(a.prof + 7, 1ull);
+    }
+#endif
+#undef ENG_PROBE
     // count the slots that still hold a restart (termination test on the host)
-    const unsigned long long alive = __ballot(st != ST_EMPTY && st != ST_REFILL);
-    if ((threadIdx.x & 63u) == 0 && alive) atomicAdd(a.n_active, (unsigned)__popcll(alive));
+
 }
 
 // ---- kernel 3: cooperative NNLS over this trip's deferred problems ---------------
@@ -572,15 +652,19 @@ OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a) {
     constexpr int m = N + 1, n = 2 * N;
     constexpr int G = COOP_COLS / CPL;        // lanes per problem
     constexpr unsigned PPW = 64 / G;          // problems per wave
-    const unsigned cnt = *a.nn_count[a.parity];
+    const unsigned int *cls_cnt = a.nn_class_count[a.parity];
+    unsigned cnt = 0;
+    for (int c = 0; c < NN_CLASSES; ++c) cnt += cls_cnt[c];
     double *ybuf = a.nn_y;
     double *meta = a.nn_meta;
     const unsigned lane = threadIdx.x & 63u;
     const unsigned group = lane / G, gl = lane % G;
     const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) / 64u;
     const unsigned n_waves = (gridDim.x * blockDim.x) / 64u;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && a.nn_total) atomicAdd(a.nn_total, (unsigned long long)cnt);
-    const unsigned int *cls_cnt = a.nn_count[a.parity] + 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (a.nn_total) atomicAdd(a.nn_total, (unsigned long long)cnt);
+        if (a.trip_log) { a.trip_log[2 * a.trip] = *a.n_active; a.trip_log[2 * a.trip + 1] = cnt; }
+    }
     const unsigned int *order = a.nn_order[a.parity];
 #ifdef OPTIK_NNLS_TRACE
     const unsigned long long t_begin = wall_clock64();
@@ -710,47 +794,63 @@ OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a) {
 
 // ---- kernel 2b: list the trip's problems by predicted class (counting sort) ---------
 
-constexpr int BUCKET_SUB = 4;  // 64-problem batches per wave (one atomic instruction per wave)
+constexpr int BUCKET_SUB = 4;  // 64-slot batches per wave (one atomic instruction per wave)
 
+// One pass over the sub-pool's slots after the update kernel: the slots with a problem for
+// this trip go to their class list (and their nn_cls entry is cleared for the trip after
+// next), the slots that want a work item to the refill list, and the slots in use are counted.
+// Wave-aggregated: lanes 0 .. 9 of a wave own the ten counters, one atomic instruction per
+// 256 slots.
 OPTIK_DEV void eng_bucket_body(const EngArgs &a) {
-    const unsigned cnt = *a.nn_count[a.parity];
-    unsigned int *cls_cnt = a.nn_count[a.parity] + 1;
+    unsigned int *cls_cnt = a.nn_class_count[a.parity];
     unsigned int *order = a.nn_order[a.parity];
-    const unsigned int *list = a.nn_list[a.parity], *lcls = a.nn_cls[a.parity];
+    unsigned int *lcls = a.nn_cls[a.parity];
+    const int32_t *state = a.i32 + a.slot_base;  // plane 0 = STATE
+    const unsigned n = (unsigned)a.n_slots;
     const unsigned lane = threadIdx.x & 63u;
     const unsigned long long below = (1ull << lane) - 1ull;
     const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) / 64u;
     const unsigned n_waves = (gridDim.x * blockDim.x) / 64u;
-    if (a.trip_log && blockIdx.x == 0 && threadIdx.x == 0) {
-        a.trip_log[2 * a.trip] = *a.n_active;
-        a.trip_log[2 * a.trip + 1] = cnt;
-    }
-    for (unsigned i0 = wave * (64u * BUCKET_SUB); i0 < cnt; i0 += n_waves * (64u * BUCKET_SUB)) {
+    constexpr int K_REFILL = NN_CLASSES, K_USED = NN_CLASSES + 1;
+    for (unsigned i0 = wave * (64u * BUCKET_SUB); i0 < n; i0 += n_waves * (64u * BUCKET_SUB)) {
         int cls[BUCKET_SUB];
-        unsigned rank[BUCKET_SUB];
+        bool refill[BUCKET_SUB];
+        unsigned rank[BUCKET_SUB], rrank[BUCKET_SUB];
+        unsigned mine = 0;  // lane k: members of counter k in this wave's batches
 #pragma unroll
         for (int b = 0; b < BUCKET_SUB; ++b) {
             const unsigned i = i0 + (unsigned)b * 64u + lane;
-            cls[b] = i < cnt ? (int)lcls[i] : -1;
-        }
-        unsigned mine = 0;  // lane c < NN_CLASSES: problems of class c in this wave's batches
+            const unsigned c = i < n ? lcls[i] : NN_NONE;
+            const int st = i < n ? state[i] : ST_EMPTY;
+            cls[b] = (int)c;  // NN_NONE -> -1
+            if (c != NN_NONE) lcls[i] = NN_NONE;
+            refill[b] = st == ST_REFILL;
+            rank[b] = (unsigned)__shfl((int)mine, cls[b] < 0 ? 0 : cls[b], 64);
+            rrank[b] = (unsigned)__shfl((int)mine, K_REFILL, 64);
 #pragma unroll
-        for (int b = 0; b < BUCKET_SUB; ++b) {
-            const unsigned before = (unsigned)__shfl((int)mine, cls[b] < 0 ? 0 : cls[b], 64);
-            rank[b] = before;
-#pragma unroll
-            for (int c = 0; c < NN_CLASSES; ++c) {
-                const unsigned long long mk = __ballot(cls[b] == c);
-                if ((int)lane == c) mine += (unsigned)__popcll(mk);
-                if (cls[b] == c) rank[b] += (unsigned)__popcll(mk & below);
+            for (int k = 0; k < NN_CLASSES; ++k) {
+                const unsigned long long mk = __ballot(cls[b] == k);
+                if ((int)lane == k) mine += (unsigned)__popcll(mk);
+                if (cls[b] == k) rank[b] += (unsigned)__popcll(mk & below);
             }
+            const unsigned long long mr = __ballot(refill[b]);
+            if ((int)lane == K_REFILL) mine += (unsigned)__popcll(mr);
+            rrank[b] += (unsigned)__popcll(mr & below);
+            const unsigned long long mu = __ballot(st != ST_EMPTY);
+            if ((int)lane == K_USED) mine += (unsigned)__popcll(mu);
         }
         unsigned base = 0;
-        if (lane < (unsigned)NN_CLASSES && mine) base = atomicAdd(cls_cnt + lane, mine);
+        if (lane <= (unsigned)K_USED && mine) {
+            unsigned int *ctr = lane < (unsigned)NN_CLASSES ? cls_cnt + lane : ((int)lane == K_REFILL ? a.refill_count : a.n_active);
+            base = atomicAdd(ctr, mine);
+        }
+        const unsigned rbase = (unsigned)__shfl((int)base, K_REFILL, 64);
 #pragma unroll
         for (int b = 0; b < BUCKET_SUB; ++b) {
+            const unsigned slot = (unsigned)a.slot_base + i0 + (unsigned)b * 64u + lane;
             const unsigned cb = (unsigned)__shfl((int)base, cls[b] < 0 ? 0 : cls[b], 64);
-            if (cls[b] >= 0) order[(size_t)cls[b] * a.C + cb + rank[b]] = list[i0 + (unsigned)b * 64u + lane];
+            if (cls[b] >= 0) order[(size_t)cls[b] * a.C + cb + rank[b]] = slot;
+            if (refill[b]) a.refill_list[rbase + rrank[b]] = slot;
         }
     }
 }
@@ -769,11 +869,11 @@ struct CompactArgs {
     int nd, ni;
     unsigned int *counts;   // [0] free slots listed, [1] restarts to move
     unsigned int *free_list, *move_list;
-    // a slot waiting for the next NNLS launch takes its problem record and list entry along
+    // a slot waiting for the next NNLS launch takes its problem record and class entry along
     double *nn_prob, *nn_meta, *nn_carry;
-    unsigned int *nn_list;  // list of the next trip
+    unsigned int *nn_cls;   // class entries of the next trip, by sub-pool slot
     int rec_len;            // doubles per problem record
-    int nnq_plane;
+    int pad;
 };
 
 OPTIK_DEV void compact_scan_body(const CompactArgs &c) {
@@ -810,7 +910,8 @@ OPTIK_DEV void compact_move_body(const CompactArgs &c) {
         c.nn_meta[dst * 2 + 1] = c.nn_meta[src * 2 + 1];
         if (c.nn_meta[src * 2 + 1] < 0.0)  // suspended solve: matrix and state live in the carry record
             for (int k = 0; k < NN_CARRY; ++k) c.nn_carry[dst * NN_CARRY + k] = c.nn_carry[src * NN_CARRY + k];
-        c.nn_list[c.i32[(size_t)c.nnq_plane * c.C + src]] = (unsigned)dst;
+        c.nn_cls[dst - c.slot_base] = c.nn_cls[src - c.slot_base];
+        c.nn_cls[src - c.slot_base] = NN_NONE;
     }
     c.i32[src] = ST_EMPTY;
 }
@@ -818,9 +919,19 @@ OPTIK_DEV void compact_move_body(const CompactArgs &c) {
 // ---- kernel 4: finish the deferred directions with the NNLS answers ----------------
 
 template <int N>
-OPTIK_DEV void eng_finish_body(const EngArgs &a, const ChainDev &ch, size_t slot) {
+OPTIK_DEV void eng_finish_body(const EngArgs &a, const ChainDev &ch, size_t slot, size_t local, bool in_range) {
     using E = EngLayout<N>;
-    if (ENG_I(E::STATE) != ST_NNLS) return;
+    // refill: lane i of the sub-pool takes the i-th listed slot and the next work item of the
+    // queue (one atomic per wave)
+    {
+        const unsigned n_refill = *a.refill_count;
+        const bool want = local < n_refill;
+        if (wave_any(want)) {
+            const unsigned long long it = fetch_items(a.next_item, want);
+            if (want) refill_slot<N>(a, ch, (size_t)a.refill_list[local], it);
+        }
+    }
+    if (!in_range || ENG_I(E::STATE) != ST_NNLS) return;
     double l[E::NL], g[N], x[N], s[N];
     const double f = ENG_D(E::FC, 0);
     int ireset = ENG_I(E::IRESET), iter = ENG_I(E::ITER);

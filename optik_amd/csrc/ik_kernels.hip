@@ -181,8 +181,9 @@ __global__ __launch_bounds__(OPTIK_ENG_SLOT_BLOCK, OPTIK_ENG_EVAL_WAVES) void en
     // trip's suspended solves and finishing pass and the next trip's update append to it) and
     // the in-use count the update kernel accumulates -- no memset launches between trips
     if (blockIdx.x == 0) {
-        if (threadIdx.x < (unsigned)ENG_LIST_COUNTERS) a.nn_count[a.parity ^ 1][threadIdx.x] = 0u;
-        if (threadIdx.x == (unsigned)ENG_LIST_COUNTERS) *a.n_active = 0u;
+        if (threadIdx.x < (unsigned)NN_CLASSES) a.nn_class_count[a.parity ^ 1][threadIdx.x] = 0u;
+        if (threadIdx.x == (unsigned)NN_CLASSES) *a.n_active = 0u;
+        if (threadIdx.x == (unsigned)NN_CLASSES + 1u) *a.refill_count = 0u;
     }
     if (local < a.n_slots) eng_eval_body<N, TIP>(a, sch, slot);
 }
@@ -221,15 +222,15 @@ __global__ __launch_bounds__(OPTIK_ENG_SLOT_BLOCK, OPTIK_ENG_UPD_WAVES) void eng
     stage_chain(sch, a.chain);
     const size_t local = (size_t)blockIdx.x * OPTIK_ENG_SLOT_BLOCK + threadIdx.x;
     const size_t slot = (size_t)a.slot_base + local;
-    if (local < a.n_slots) eng_finish_body<N>(a, sch, slot);
+    eng_finish_body<N>(a, sch, local < a.n_slots ? slot : (size_t)a.slot_base, local, local < a.n_slots);
 }
 
 __global__ __launch_bounds__(256) void eng_compact_scan_kernel(const CompactArgs c) { compact_scan_body(c); }
 __global__ __launch_bounds__(256) void eng_compact_move_kernel(const CompactArgs c) { compact_move_body(c); }
 
-__global__ void eng_init_kernel(int32_t *state, unsigned long long C) {
+__global__ void eng_init_kernel(int32_t *state, unsigned int *cls2, unsigned long long C) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < C) state[i] = ST_REFILL;
+    if (i < C) { state[i] = ST_REFILL; cls2[i] = NN_NONE; cls2[C + i] = NN_NONE; }  // every slot wants a work item
 }
 
 struct EvalLaunch {
@@ -383,7 +384,8 @@ struct optik_hip_chain {
     unsigned int *eng_counters = nullptr;  // per trip parity {list length, class sizes}, then n_active
     unsigned int *eng_order = nullptr;     // 2 x [NN_CLASSES][C]
     double *eng_carry = nullptr;           // [C][NN_CARRY]
-    unsigned int *eng_list = nullptr;      // 2 x {slots [C], classes [C]}
+    unsigned int *eng_list = nullptr;      // 2 x [C] class entries by slot, per trip parity
+    unsigned int *eng_refill = nullptr;    // [C] slots wanting a work item, per sub-pool range
     unsigned long long *nnls_trace = nullptr;  // OPTIK_NNLS_TRACE builds
     unsigned int *eng_trip_log = nullptr;      // OPTIK_ENG_TRIP_LOG diagnostics
     unsigned int *eng_compact = nullptr;       // [ENG_MAX_POOLS][2] counters, then free list [C], move list [C]
@@ -606,6 +608,7 @@ void optik_hip_chain_destroy(optik_hip_chain *ch) {
     if (ch->eng_trip_log) hipFree(ch->eng_trip_log);
     if (ch->eng_compact) hipFree(ch->eng_compact);
     if (ch->eng_list) hipFree(ch->eng_list);
+    if (ch->eng_refill) hipFree(ch->eng_refill);
     if (ch->eng_prob) hipFree(ch->eng_prob);
     if (ch->eng_y) hipFree(ch->eng_y);
     if (ch->eng_meta) hipFree(ch->eng_meta);
@@ -936,8 +939,8 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
         default: return fail(OPTIK_HIP_EUNSUPPORTED, OPTIK_N_RANGE_MSG);                         \
         }                                                                                        \
     } while (0)
-        int nd = 0, ni = 0, nnq_plane = 0, rec_len = 0;
-#define M_LAYOUT(NN) nd = EngLayout<NN>::ND; ni = EngLayout<NN>::NI; nnq_plane = EngLayout<NN>::NNQ; rec_len = rec_stride<NN>()
+        int nd = 0, ni = 0, rec_len = 0;
+#define M_LAYOUT(NN) nd = EngLayout<NN>::ND; ni = EngLayout<NN>::NI; rec_len = rec_stride<NN>()
         DISPATCH_N(M_LAYOUT);
 #undef M_LAYOUT
         if (C > ch->eng_C) {
@@ -951,7 +954,8 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             if (ch->eng_carry) HIP_TRY(hipFree(ch->eng_carry));
             if (ch->eng_compact) HIP_TRY(hipFree(ch->eng_compact));
             if (ch->eng_list) HIP_TRY(hipFree(ch->eng_list));
-            ch->eng_compact = nullptr; ch->eng_list = nullptr;
+            if (ch->eng_refill) HIP_TRY(hipFree(ch->eng_refill));
+            ch->eng_compact = nullptr; ch->eng_list = nullptr; ch->eng_refill = nullptr;
             ch->eng_order = nullptr; ch->eng_carry = nullptr;
             ch->eng_d = nullptr; ch->eng_i32 = nullptr; ch->eng_item = nullptr;
             ch->eng_prob = ch->eng_y = ch->eng_meta = nullptr;
@@ -962,15 +966,15 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             HIP_TRY(hipMalloc(&ch->eng_prob, sizeof(double) * C * rec_len));
             HIP_TRY(hipMalloc(&ch->eng_y, sizeof(double) * C * (2 * nn)));
             HIP_TRY(hipMalloc(&ch->eng_meta, sizeof(double) * C * 2));
-            HIP_TRY(hipMalloc(&ch->eng_list, sizeof(unsigned int) * 4 * C));
+            HIP_TRY(hipMalloc(&ch->eng_list, sizeof(unsigned int) * 2 * C));
+            HIP_TRY(hipMalloc(&ch->eng_refill, sizeof(unsigned int) * C));
             HIP_TRY(hipMalloc(&ch->eng_order, sizeof(unsigned int) * 2 * NN_CLASSES * C));
             HIP_TRY(hipMalloc(&ch->eng_carry, sizeof(double) * NN_CARRY * C));
             HIP_TRY(hipMalloc(&ch->eng_compact, sizeof(unsigned int) * (2 * ENG_MAX_POOLS + 2 * C)));
             ch->eng_C = C;
         }
         if (!ch->eng_djobs) HIP_TRY(hipMalloc(&ch->eng_djobs, sizeof(EngJob) * ENG_MAX_JOBS));
-        constexpr int CB = ENG_LIST_COUNTERS;  // counters per trip parity
-        constexpr int PCB = 2 * CB + 2;  // counters per sub-pool: two list blocks, slots in use, spare
+        constexpr int PCB = ENG_POOL_COUNTERS;
         if (!ch->eng_counters) HIP_TRY(hipMalloc(&ch->eng_counters, ENG_MAX_POOLS * PCB * sizeof(unsigned int)));
         if (!ch->eng_pinned) HIP_TRY(hipHostMalloc(&ch->eng_pinned, ENG_MAX_POOLS * 8 * sizeof(unsigned int)));
         if (!ch->queue) HIP_TRY(hipMalloc(&ch->queue, sizeof(unsigned long long)));
@@ -1012,6 +1016,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
         a.nn_total = ch->eng_nn_total;
         a.parity = 0;
         a.prof = nullptr;
+        a.prof2 = nullptr;
         a.trace = nullptr;
         a.trip_log = nullptr;
         a.trip = 0;
@@ -1026,6 +1031,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
         if (!ch->prof) HIP_TRY(hipMalloc(&ch->prof, 8 * sizeof(unsigned long long)));
         HIP_TRY(hipMemsetAsync(ch->prof, 0, 8 * sizeof(unsigned long long), stream));
         a.prof = ch->prof;
+        a.prof2 = ch->prof + 5;  // slots 5, 6 + (7 is the wave count: sub-phase 2 is derived)
 #endif
 
         ch->eng_compactions = 0;
@@ -1036,7 +1042,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
         if (nn_waves_per_cu < 1) nn_waves_per_cu = 1;
         const unsigned nn_blocks = (unsigned)cus * nn_waves_per_cu * 64u / OPTIK_ENG_NNLS_BLOCK;
         HIP_TRY(hipMemsetAsync(ch->eng_counters, 0, ENG_MAX_POOLS * PCB * sizeof(unsigned int), stream));
-        hipLaunchKernelGGL(eng_init_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, ch->eng_i32, (unsigned long long)C);
+        hipLaunchKernelGGL(eng_init_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, ch->eng_i32, ch->eng_list, (unsigned long long)ch->eng_C);
         HIP_TRY(hipGetLastError());
 
         // sub-pools: equal slot ranges (multiples of 256), each with its own stream and lists
@@ -1069,12 +1075,13 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
                 P.a.n_slots = size;
                 unsigned int *cnt = ch->eng_counters + (size_t)p2 * PCB;
                 for (int par = 0; par < 2; ++par) {
-                    P.a.nn_count[par] = cnt + par * CB;
+                    P.a.nn_class_count[par] = cnt + par * NN_CLASSES;
                     P.a.nn_order[par] = ch->eng_order + (size_t)par * NN_CLASSES * ch->eng_C + lo;  // [class][C] + lo
-                    P.a.nn_list[par] = ch->eng_list + (size_t)par * 2 * ch->eng_C + lo;
-                    P.a.nn_cls[par] = ch->eng_list + (size_t)par * 2 * ch->eng_C + ch->eng_C + lo;
+                    P.a.nn_cls[par] = ch->eng_list + (size_t)par * ch->eng_C + lo;
                 }
-                P.a.n_active = cnt + 2 * CB;
+                P.a.refill_count = cnt + 2 * NN_CLASSES;
+                P.a.n_active = cnt + 2 * NN_CLASSES + 1;
+                P.a.refill_list = ch->eng_refill + lo;
                 P.stream = p2 == 0 ? stream : ch->eng_streams[p2];
                 P.blocks = (unsigned)((size + OPTIK_ENG_SLOT_BLOCK - 1) / OPTIK_ENG_SLOT_BLOCK);
                 P.trip = 0; P.pending = 0; P.ring = 0; P.done = false;
@@ -1169,9 +1176,9 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
                     c.free_list = ch->eng_compact + 2 * ENG_MAX_POOLS + a.slot_base;
                     c.move_list = ch->eng_compact + 2 * ENG_MAX_POOLS + C + a.slot_base;
                     c.nn_prob = ch->eng_prob; c.nn_meta = ch->eng_meta; c.nn_carry = ch->eng_carry;
-                    c.nn_list = a.nn_list[trip & 1];  // the list the next trip consumes
+                    c.nn_cls = a.nn_cls[trip & 1];  // the entries the next trip consumes
                     c.rec_len = rec_len;
-                    c.nnq_plane = nnq_plane;
+                    c.pad = 0;
                     HIP_TRY(hipMemsetAsync(P.compact_counts, 0, 2 * sizeof(unsigned int), stream));
                     hipLaunchKernelGGL(eng_compact_scan_kernel, dim3((unsigned)((a.n_slots + 255) / 256)), dim3(256), 0, stream, c);
                     hipLaunchKernelGGL(eng_compact_move_kernel, dim3((unsigned)((a.n_slots - n_new + 255) / 256)), dim3(256), 0, stream, c);
