@@ -156,18 +156,80 @@ OPTIK_DEV void list_problem(const EngArgs &a, int parity, size_t slot, int pred)
     a.nn_cls[parity][slot - a.slot_base] = (unsigned)(pred < 0 ? 0 : (pred >= NN_CLASSES ? NN_CLASSES - 1 : pred));
 }
 
-// Problem record of a slot: the rows of E^-1 packed like the factor (row i, entries j >= i,
-// at lidx(i, i) + j - i), then h_lo[N], h_hi[N]; padded to whole 64-byte lines.  The -E^-1
-// block of the dual matrix is the exact negation and is rebuilt by the reader.
+// Problem record of a slot, in the order the update kernel produces it: for row i of E^-1
+// its entries j >= i, then h_lo[i], h_hi[i]; padded to whole 64-byte lines.  The -E^-1 block
+// of the dual matrix is the exact negation and is rebuilt by the reader.
 template <int N>
 __host__ __device__ constexpr int rec_stride() { return (N * (N + 1) / 2 + 2 * N + 7) / 8 * 8; }
+template <int N>
+OPTIK_DEV constexpr int rec_row(int i) { return i * (N + 2) - (i * (i - 1)) / 2; }   // offset of row i
+template <int N>
+OPTIK_DEV constexpr int rec_g(int i, int j) { return rec_row<N>(i) + (j - i); }      // E^-1(i, j), j >= i
+template <int N>
+OPTIK_DEV constexpr int rec_hlo(int i) { return rec_row<N>(i) + (N - i); }
+template <int N>
+OPTIK_DEV constexpr int rec_hhi(int i) { return rec_row<N>(i) + (N - i) + 1; }
+
+// The per-slot kernels see 64 consecutive slots per wave, i.e. one contiguous block of
+// records, but each lane touches only its own record: 42 scattered 8-byte accesses per lane
+// (measured: 8.7 M write requests per update launch, L2 82 % busy, the kernel bound by it).
+// Instead the lanes stage their records in an LDS window of the wave and the wave moves the
+// block with whole-line accesses.  The first REC_DIRECT elements of a record bypass the
+// window (it would not fit beside a second workgroup otherwise).
+template <int N>
+struct RecIo {
+    static constexpr int LEN = (N * (N + 1) / 2 + 2 * N + 1) / 2 * 2;  // record length, even
+    static constexpr int STAGED = LEN < 38 ? LEN : 38;                 // elements of a record in the window
+    static constexpr int DIRECT = LEN - STAGED;                        // leading elements accessed in HBM
+    static constexpr int ROW = STAGED + 1;                             // window row stride (odd: no bank conflicts)
+    static constexpr int WINDOW = 64 * ROW;                            // doubles per wave
+    double *rec;   // the lane's record in HBM
+    double *win;   // the lane's row of the wave's window, or null: every element in HBM
+    OPTIK_DEV void put(int e, double v) const {
+        if (e < DIRECT || !win) rec[e] = v;
+        else win[e - DIRECT] = v;
+    }
+    OPTIK_DEV double get(int e) const { return (e < DIRECT || !win) ? rec[e] : win[e - DIRECT]; }
+    // window -> HBM for the records of the lanes in `mask` (all 64 lanes call; slot0 = the wave's first slot)
+    static OPTIK_DEV void flush(double *recs, size_t slot0, const double *window, unsigned long long mask) {
+        const unsigned lane = threadIdx.x & 63u;
+#pragma unroll
+        for (int t = 0; t < STAGED / 2; ++t) {
+            const unsigned p = (unsigned)t * 64u + lane;
+            const unsigned r = p / (STAGED / 2), e = (p % (STAGED / 2)) * 2;
+            if ((mask >> r) & 1ull) {
+                double *dst = recs + (slot0 + r) * rec_stride<N>() + DIRECT + e;
+                dst[0] = window[r * ROW + e];
+                dst[1] = window[r * ROW + e + 1];
+            }
+            if (t % 4 == 3) OPTIK_SCHED_FENCE();  // (a few transfers in flight, not all 19: registers)
+        }
+        OPTIK_SCHED_FENCE();
+    }
+    // HBM -> window, same shape
+    static OPTIK_DEV void fill(const double *recs, size_t slot0, double *window, unsigned long long mask) {
+        const unsigned lane = threadIdx.x & 63u;
+#pragma unroll
+        for (int t = 0; t < STAGED / 2; ++t) {
+            const unsigned p = (unsigned)t * 64u + lane;
+            const unsigned r = p / (STAGED / 2), e = (p % (STAGED / 2)) * 2;
+            if ((mask >> r) & 1ull) {
+                const double *src = recs + (slot0 + r) * rec_stride<N>() + DIRECT + e;
+                window[r * ROW + e] = src[0];
+                window[r * ROW + e + 1] = src[1];
+            }
+            if (t % 4 == 3) OPTIK_SCHED_FENCE();
+        }
+        OPTIK_SCHED_FENCE();
+    }
+};
 
 // LDP tail (Lawson-Hanson ch. 23) from the NNLS answer: transformed-space step.  The rows
 // of +-E^-1 and h are read back from the slot's problem record (the NNLS kernel leaves it
 // untouched), so the finishing pass does not recompute them.
 template <int N>
-OPTIK_DEV int ldp_from_record(const double *rec, const double *y_mem, const double *meta, double (&s)[N]) {
-    constexpr int M = 2 * N, NG = N * (N + 1) / 2;
+OPTIK_DEV int ldp_from_record(const RecIo<N> &rec, const double *y_mem, const double *meta, double (&s)[N]) {
+    constexpr int M = 2 * N;
     int mode = ((int)meta[0]) & 7;
     if (mode == 1 && meta[1] <= 0.0) mode = 4;
     if (mode != 1) return mode;
@@ -176,7 +238,7 @@ OPTIK_DEV int ldp_from_record(const double *rec, const double *y_mem, const doub
     for (int r = 0; r < M; ++r) y[r] = y_mem[r];
     double hy = 0.0;
 #pragma unroll
-    for (int r = 0; r < M; ++r) hy += rec[NG + r] * y[r];
+    for (int r = 0; r < M; ++r) hy += rec.get(r < N ? rec_hlo<N>(r) : rec_hhi<N>(r - N)) * y[r];
     double fac = 1.0 - hy;
     const double d1 = 1.0 + fac;
     if (d1 - 1.0 <= 0.0) return 4;
@@ -185,9 +247,9 @@ OPTIK_DEV int ldp_from_record(const double *rec, const double *y_mem, const doub
     for (int j = 0; j < N; ++j) {
         double acc = 0.0;
 #pragma unroll
-        for (int r = 0; r <= j; ++r) acc += rec[lidx<N>(r, j)] * y[r];
+        for (int r = 0; r <= j; ++r) acc += rec.get(rec_g<N>(r, j)) * y[r];
 #pragma unroll
-        for (int r = 0; r <= j; ++r) acc += (-rec[lidx<N>(r, j)]) * y[N + r];
+        for (int r = 0; r <= j; ++r) acc += (-rec.get(rec_g<N>(r, j))) * y[N + r];
         s[j] = fac * acc;
         OPTIK_SCHED_FENCE();
     }
@@ -204,36 +266,37 @@ enum : int { DIR_RESET = 3 };
 template <int N>
 OPTIK_DEV int direction_pass(const EngArgs &a, const ChainDev &ch, size_t slot, int emit_parity, bool resume,
                              const double (&l)[N * (N + 1) / 2], const double (&g)[N], const double (&x)[N],
-                             double (&s)[N], double &h3, int32_t &status, int pred
+                             double (&s)[N], double &h3, int32_t &status, int pred, const RecIo<N> &rec
 #ifdef OPTIK_PROFILE
                              , unsigned long long *dp = nullptr
 #endif
                              ) {
-    constexpr int NL = N * (N + 1) / 2;
 #ifdef OPTIK_PROFILE
 #define DIR_PROBE(k) do { if (dp) { OPTIK_SCHED_FENCE(); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); dp[k] = clock64(); OPTIK_SCHED_FENCE(); } } while (0)
 #else
 #define DIR_PROBE(k)
 #endif
     DIR_PROBE(0);
-    double *rec = a.nn_prob + slot * rec_stride<N>();
-    double lo[N], hi[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) { lo[i] = ch.lb[i] - x[i]; hi[i] = ch.ub[i] - x[i]; }
-    OPTIK_SCHED_FENCE();
     double E[N][N], fv[N];
     int lmode = lsq_factor<N>(l, g, E, fv);
     OPTIK_SCHED_FENCE();
     DIR_PROBE(1);
+    double lo[N], hi[N];  // the box around x (formed where first needed: 14 registers less across the LDP tail)
     if (lmode == 1) {
         if (resume) {
             lmode = ldp_from_record<N>(rec, a.nn_y + slot * 2 * N, a.nn_meta + slot * 2, s);
+            OPTIK_SCHED_FENCE();
+#pragma unroll
+            for (int i = 0; i < N; ++i) { lo[i] = ch.lb[i] - x[i]; hi[i] = ch.ub[i] - x[i]; }
         } else {
+#pragma unroll
+            for (int i = 0; i < N; ++i) { lo[i] = ch.lb[i] - x[i]; hi[i] = ch.ub[i] - x[i]; }
+            OPTIK_SCHED_FENCE();
             const bool need = lsq_bound_rows<N>(E, fv, lo, hi, [&](int i, const double (&row)[N], double h_lo, double h_hi) {
 #pragma unroll
-                for (int r = i; r < N; ++r) rec[lidx<N>(i, r)] = row[r];
-                rec[NL + i] = h_lo;
-                rec[NL + N + i] = h_hi;
+                for (int r = i; r < N; ++r) rec.put(rec_g<N>(i, r), row[r]);
+                rec.put(rec_hlo<N>(i), h_lo);
+                rec.put(rec_hhi<N>(i), h_hi);
             });
             DIR_PROBE(2);
             if (need) {
@@ -270,7 +333,7 @@ template <int N>
 OPTIK_DEV int direction_search(const EngArgs &a, const ChainDev &ch, size_t slot, int emit_parity, bool resume,
                                const double (&l)[N * (N + 1) / 2], const double (&g)[N], const double (&x)[N],
                                double f, int &ireset, int &iter, bool reset, double (&s)[N], double &h3,
-                               int32_t &status, int pred
+                               int32_t &status, int pred, const RecIo<N> &rec
 #ifdef OPTIK_PROFILE
                                , unsigned long long *dp = nullptr
 #endif
@@ -282,9 +345,9 @@ OPTIK_DEV int direction_search(const EngArgs &a, const ChainDev &ch, size_t slot
     if (!reset) {
         if (!resume) ++iter;
 #ifdef OPTIK_PROFILE
-        const int r = direction_pass<N>(a, ch, slot, emit_parity, resume, l, g, x, s, h3, status, pred, dp);
+        const int r = direction_pass<N>(a, ch, slot, emit_parity, resume, l, g, x, s, h3, status, pred, rec, dp);
 #else
-        const int r = direction_pass<N>(a, ch, slot, emit_parity, resume, l, g, x, s, h3, status, pred);
+        const int r = direction_pass<N>(a, ch, slot, emit_parity, resume, l, g, x, s, h3, status, pred, rec);
 #endif
         if (r != DIR_RESET) return r;
         have0 = true;
@@ -306,7 +369,7 @@ OPTIK_DEV int direction_search(const EngArgs &a, const ChainDev &ch, size_t slot
 #pragma unroll
         for (int i = 0; i < NL; ++i) ENG_D(EL::L, i) = ident[i];
         ++iter;
-        const int r = direction_pass<N>(a, ch, slot, emit_parity, false, ident, g, x, s, h3, status, pred);
+        const int r = direction_pass<N>(a, ch, slot, emit_parity, false, ident, g, x, s, h3, status, pred, rec);
         if (r != DIR_RESET) return r;
         have0 = true;
     }
@@ -551,7 +614,8 @@ OPTIK_DEV int refill_slot(const EngArgs &a, const ChainDev &ch, size_t slot, uns
 // ---- kernel 2: update (BFGS + unconstrained direction) and refill ---------------
 
 template <int N>
-OPTIK_DEV void eng_update_body(const EngArgs &a, const ChainDev &ch, size_t slot, bool in_range) {
+OPTIK_DEV void eng_update_body(const EngArgs &a, const ChainDev &ch, size_t slot, size_t local, bool in_range,
+                                double *window) {
     using E = EngLayout<N>;
     int st = in_range ? ENG_I(E::STATE) : ST_EMPTY;
 #ifdef OPTIK_PROFILE
@@ -569,6 +633,10 @@ OPTIK_DEV void eng_update_body(const EngArgs &a, const ChainDev &ch, size_t slot
 #ifdef OPTIK_PROFILE
     const bool prof_wave = wave_any(st == ST_UPDATE_FIRST || st == ST_UPDATE_ACCEPT);
 #endif
+    // the lane's problem record: staged in the wave's LDS window, moved to HBM at the end
+    const unsigned lane_id = threadIdx.x & 63u;
+    const RecIo<N> rec{a.nn_prob + slot * rec_stride<N>(), window + lane_id * RecIo<N>::ROW};
+    bool emitted = false;
     if (st == ST_UPDATE_FIRST || st == ST_UPDATE_ACCEPT) {
         double l[E::NL], g[N], x[N], s[N];
         const double f = ENG_D(E::FC, 0);
@@ -600,7 +668,7 @@ OPTIK_DEV void eng_update_body(const EngArgs &a, const ChainDev &ch, size_t slot
 #ifdef OPTIK_PROFILE
         unsigned long long dpt[4] = {0, 0, 0, 0};
         const int out = direction_search<N>(a, ch, slot, a.parity, false, l, g, x, f, ireset, iter,
-                                            st == ST_UPDATE_FIRST, s, h3, status, ENG_I(E::NNIT), dpt);
+                                            st == ST_UPDATE_FIRST, s, h3, status, ENG_I(E::NNIT), rec, dpt);
         ENG_PROBE(5);  // (reused below: end of the search, before the stores)
         if (dpt[1] && dpt[0]) pt[0] += 0;  // keep dpt live
         prof_factor = (dpt[1] && dpt[0]) ? dpt[1] - dpt[0] : 0;
@@ -608,14 +676,16 @@ OPTIK_DEV void eng_update_body(const EngArgs &a, const ChainDev &ch, size_t slot
         prof_tail = dpt[2] ? pt[5] - dpt[2] : 0;
 #else
         const int out = direction_search<N>(a, ch, slot, a.parity, false, l, g, x, f, ireset, iter,
-                                            st == ST_UPDATE_FIRST, s, h3, status, ENG_I(E::NNIT));
+                                            st == ST_UPDATE_FIRST, s, h3, status, ENG_I(E::NNIT), rec);
 #endif
+        emitted = out == DIR_DEFER;
         if (out == DIR_OK) store_direction<N>(a, ch, slot, l, g, x, s, f, h3, ireset, iter);
         else if (out == DIR_DEFER) store_deferred<N>(a, slot, l, g, ireset, iter);
         else { ENG_I(E::STATUS) = status; ENG_I(E::ITER) = iter; ENG_I(E::STATE) = ST_DEAD; }
         st = ST_EVAL_TRIAL;  // (any non-empty value: the slot still holds a restart)
         ENG_PROBE(4);
     }
+    RecIo<N>::flush(a.nn_prob, (size_t)a.slot_base + (local - lane_id), window, __ballot(emitted));
 #ifdef OPTIK_PROFILE
     ENG_PROBE(5);
     if (a.prof && prof_wave) {
@@ -717,13 +787,13 @@ OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a) {
                     // negation, h_hi[c] below
                     const bool neg = c >= (unsigned)N;
                     const int cc = (int)(neg ? c - N : c);
-                    const int off = cc * N - (cc * (cc - 1)) / 2 - cc;  // lidx(cc, cc) - cc
+                    const int off = cc * (N + 2) - (cc * (cc - 1)) / 2 - cc;  // rec_row(cc) - cc
 #pragma unroll
                     for (int r = 0; r < N; ++r) {
                         const double v = (r >= cc) ? rec[off + r] : 0.0;
                         col[k][r] = neg ? ((r >= cc) ? -v : 0.0) : v;
                     }
-                    col[k][N] = rec[N * (N + 1) / 2 + c];
+                    col[k][N] = rec[off + N + (neg ? 1 : 0)];  // h_lo / h_hi follow the row
                 }
             }
             if (resume) {
@@ -931,25 +1001,34 @@ OPTIK_DEV void eng_finish_body(const EngArgs &a, const ChainDev &ch, size_t slot
             if (want) refill_slot<N>(a, ch, (size_t)a.refill_list[local], it);
         }
     }
-    if (!in_range || ENG_I(E::STATE) != ST_NNLS) return;
-    double l[E::NL], g[N], x[N], s[N];
-    const double f = ENG_D(E::FC, 0);
-    int ireset = ENG_I(E::IRESET), iter = ENG_I(E::ITER);
+    // the answered problems: each lane reads its record straight from HBM (staging the wave's
+    // block in LDS as the update kernel does costs more here than the scattered reads: measured
+    // 0.067 against 0.039 ms per launch)
+    int code = 0;
+    bool need = in_range && ENG_I(E::STATE) == ST_NNLS;
+    if (need) {
+        code = (int)a.nn_meta[slot * 2];
+        need = (code & 7) != NNLS_SUSPENDED;  // else still being solved (listed for the next trip)
+    }
+    const RecIo<N> rec{a.nn_prob + slot * rec_stride<N>(), nullptr};
+    if (need) {
+        double l[E::NL], g[N], x[N], s[N];
+        const double f = ENG_D(E::FC, 0);
+        int ireset = ENG_I(E::IRESET), iter = ENG_I(E::ITER);
 #pragma unroll
-    for (int i = 0; i < E::NL; ++i) l[i] = ENG_D(E::L, i);
+        for (int i = 0; i < E::NL; ++i) l[i] = ENG_D(E::L, i);
 #pragma unroll
-    for (int i = 0; i < N; ++i) { x[i] = ENG_D(E::X, i); g[i] = ENG_D(E::G, i); s[i] = 0.0; }
-    double h3 = 0.0;
-    int32_t status = 0;
-    const int code = (int)a.nn_meta[slot * 2];
-    if ((code & 7) == NNLS_SUSPENDED) return;  // still being solved (listed for the next trip)
-    const int passes = code >> 3;
-    ENG_I(E::NNIT) = passes;
-    const int out = direction_search<N>(a, ch, slot, a.parity ^ 1, true, l, g, x, f, ireset, iter, false, s, h3,
-                                        status, passes);
-    if (out == DIR_OK) store_direction<N>(a, ch, slot, l, g, x, s, f, h3, ireset, iter);
-    else if (out == DIR_DEFER) store_deferred<N>(a, slot, l, g, ireset, iter);
-    else { ENG_I(E::STATUS) = status; ENG_I(E::ITER) = iter; ENG_I(E::STATE) = ST_DEAD; }
+        for (int i = 0; i < N; ++i) { x[i] = ENG_D(E::X, i); g[i] = ENG_D(E::G, i); s[i] = 0.0; }
+        double h3 = 0.0;
+        int32_t status = 0;
+        const int passes = code >> 3;
+        ENG_I(E::NNIT) = passes;
+        const int out = direction_search<N>(a, ch, slot, a.parity ^ 1, true, l, g, x, f, ireset, iter, false, s, h3,
+                                            status, passes, rec);
+        if (out == DIR_OK) store_direction<N>(a, ch, slot, l, g, x, s, f, h3, ireset, iter);
+        else if (out == DIR_DEFER) store_deferred<N>(a, slot, l, g, ireset, iter);
+        else { ENG_I(E::STATUS) = status; ENG_I(E::ITER) = iter; ENG_I(E::STATE) = ST_DEAD; }
+    }
 }
 
 }  // namespace optik

@@ -194,7 +194,9 @@ __global__ __launch_bounds__(OPTIK_ENG_SLOT_BLOCK, OPTIK_ENG_UPD_WAVES) void eng
     stage_chain(sch, a.chain);
     const size_t local = (size_t)blockIdx.x * OPTIK_ENG_SLOT_BLOCK + threadIdx.x;
     const size_t slot = (size_t)a.slot_base + local;
-    eng_update_body<N>(a, sch, local < a.n_slots ? slot : (size_t)a.slot_base, local < a.n_slots);
+    __shared__ double rec_win[(OPTIK_ENG_SLOT_BLOCK / 64) * RecIo<N>::WINDOW];
+    eng_update_body<N>(a, sch, local < a.n_slots ? slot : (size_t)a.slot_base, local, local < a.n_slots,
+                       rec_win + (threadIdx.x / 64u) * RecIo<N>::WINDOW);
 }
 
 // columns of a bounded sub-problem held per lane (16 / CPL lanes share a problem)
