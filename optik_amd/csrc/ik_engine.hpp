@@ -418,12 +418,12 @@ OPTIK_DEV void store_deferred(const EngArgs &a, size_t slot, const double (&l)[N
 // ---- kernel 1: evaluate + decide ------------------------------------------------
 
 template <int N, bool TIP>
-OPTIK_DEV void eng_eval_body(const EngArgs &a, const ChainDev &ch, size_t slot) {
+OPTIK_DEV void eng_eval_body(const EngArgs &a, const ChainDev &ch, const EngJob *jobs, size_t slot) {
     using E = EngLayout<N>;
     const double alfmin = 0.1;
     const int st = ENG_I(E::STATE);
     if (st != ST_EVAL_FIRST && st != ST_EVAL_TRIAL && st != ST_DEAD) return;
-    const EngJob &J = a.jobs[ENG_I(E::JOB)];
+    const EngJob &J = jobs[ENG_I(E::JOB)];  // (job table staged in LDS: no dependent HBM round trip)
     const unsigned long long item = a.item[slot];
     const unsigned long long tslot = item / J.n_restarts;
     const unsigned long long index = J.restart_begin + (item - tslot * J.n_restarts);

@@ -174,6 +174,14 @@ __global__ __launch_bounds__(WAVE) void ik_select_kernel(const SelectLaunch a) {
 template <int N, bool TIP>
 __global__ __launch_bounds__(OPTIK_ENG_SLOT_BLOCK, OPTIK_ENG_EVAL_WAVES) void eng_eval_kernel(const EngArgs a) {
     __shared__ ChainDev sch;
+    __shared__ EngJob sjobs[ENG_MAX_JOBS];
+    {
+        static_assert(sizeof(EngJob) % sizeof(double) == 0, "EngJob is a whole number of doubles");
+        const double *src = reinterpret_cast<const double *>(a.jobs);
+        double *dst = reinterpret_cast<double *>(sjobs);
+        const int nd = a.n_jobs * (int)(sizeof(EngJob) / sizeof(double));
+        for (int i = threadIdx.x; i < nd; i += blockDim.x) dst[i] = src[i];
+    }
     stage_chain(sch, a.chain);
     const size_t local = (size_t)blockIdx.x * OPTIK_ENG_SLOT_BLOCK + threadIdx.x;
     const size_t slot = (size_t)a.slot_base + local;
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(OPTIK_ENG_SLOT_BLOCK, OPTIK_ENG_EVAL_WAVES) void en
         if (threadIdx.x == (unsigned)NN_CLASSES) *a.n_active = 0u;
         if (threadIdx.x == (unsigned)NN_CLASSES + 1u) *a.refill_count = 0u;
     }
-    if (local < a.n_slots) eng_eval_body<N, TIP>(a, sch, slot);
+    if (local < a.n_slots) eng_eval_body<N, TIP>(a, sch, sjobs, slot);
 }
 
 template <int N>
