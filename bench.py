@@ -102,7 +102,8 @@ def cpu_baseline(robot_name, chain_tables, target7, x0, seconds_budget=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=48,
+                    help="timed steps; on the engine path they are pooled into one run (one drain of the slot pool)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--restarts", type=int, default=65536, help="restarts per GPU per step")
     ap.add_argument("--robot", default="panda", choices=["panda", "ur10"])

@@ -320,8 +320,12 @@ OPTIK_DEV void nnls_coop(bool live, bool resume, int budget, int cid0, dvec8 (&c
                 if (wave_any(run && nsetp >= v)) nmax = v;
             // step six: solve the triangular system on set P (positions nsetp .. 1)
             double zown[CPL];
+            int ppos[CPL];  // position of the lane's columns that are in P (1 .. nsetp), else 0
 #pragma unroll
-            for (int k = 0; k < CPL; ++k) zown[k] = 0.0;
+            for (int k = 0; k < CPL; ++k) {
+                zown[k] = 0.0;
+                ppos[k] = (run && isc[k] && !inZ[k]) ? pos[k] : 0;
+            }
 #pragma unroll
             for (int ip = m; ip >= 1; --ip) {
                 if (ip > nmax) continue;
@@ -331,7 +335,7 @@ OPTIK_DEV void nnls_coop(bool live, bool resume, int budget, int cid0, dvec8 (&c
                 dvec8 mine = 0.0;
 #pragma unroll
                 for (int k = 0; k < CPL; ++k) {
-                    hk[k] = step && isc[k] && !inZ[k] && pos[k] == ip;
+                    hk[k] = ppos[k] == ip;  // (implies step: positions in P are <= nsetp)
                     hit_any = hit_any || hk[k];
 #pragma unroll
                     for (int r = 1; r <= ip; ++r) mine[r - 1] = hk[k] ? col[k][r - 1] : mine[r - 1];
@@ -360,11 +364,13 @@ OPTIK_DEV void nnls_coop(bool live, bool resume, int budget, int cid0, dvec8 (&c
             for (int ip = 1; ip <= m; ++ip) {
                 if (ip > nmax) continue;
                 const bool step = go && ip <= nsetp;
+                // only positions whose z is not positive limit the step: most have none in the whole wave
+                if (!wave_any(step && !(zz[ip - 1] > 0.0))) continue;
                 bool hit_any = false;
                 double hx = 0.0;
 #pragma unroll
                 for (int k = 0; k < CPL; ++k) {
-                    const bool hit = step && isc[k] && !inZ[k] && pos[k] == ip;
+                    const bool hit = go && ppos[k] == ip;
                     hit_any = hit_any || hit;
                     hx = hit ? xv[k] : hx;
                 }
