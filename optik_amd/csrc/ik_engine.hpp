@@ -864,7 +864,10 @@ OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a) {
 
 // ---- kernel 2b: list the trip's problems by predicted class (counting sort) ---------
 
-constexpr int BUCKET_SUB = 4;  // 64-slot batches per wave (one atomic instruction per wave)
+#ifndef OPTIK_BUCKET_SUB
+#define OPTIK_BUCKET_SUB 4
+#endif
+constexpr int BUCKET_SUB = OPTIK_BUCKET_SUB;  // 64-slot batches per wave (one atomic instruction per wave)
 
 // One pass over the sub-pool's slots after the update kernel: the slots with a problem for
 // this trip go to their class list (and their nn_cls entry is cleared for the trip after
