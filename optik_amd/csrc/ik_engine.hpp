@@ -441,26 +441,30 @@ OPTIK_DEV void eng_eval_body(const EngArgs &a, const ChainDev &ch, const EngJob 
         }
     }
     if (ret == 0) {
-        double x[N], gn[N];
+        double f;
+        {
+            double x[N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) x[i] = ENG_D(E::X, i);
-        const Pose target = load_pose(J.targets + (size_t)tslot * 7);
-        const double f = eval_fg<N, TIP>(ch, a.ep, target, x, gn);
+            for (int i = 0; i < N; ++i) x[i] = ENG_D(E::X, i);
+            const Pose target = load_pose(J.targets + (size_t)tslot * 7);
+            // the gradient goes straight to the g_new plane (the update kernel reads it only after
+            // an evaluation that hands the slot over to it, which is the one that wrote it last);
+            // neither it nor x stays in registers across the evaluation
+            f = eval_fg_stream<N, TIP>(ch, a.ep, target, x, [&](int k, double v) { ENG_D(E::GN, k) = v; });
+        }
         ++nevals;
         // NLopt: update best point so far; stopval is tested after every evaluation
         if (f < minf) {
             minf = f;
             ENG_D(E::MF, 0) = f;
 #pragma unroll
-            for (int i = 0; i < N; ++i) ENG_D(E::XB, i) = x[i];
+            for (int i = 0; i < N; ++i) ENG_D(E::XB, i) = ENG_D(E::X, i);
         }
         if (minf < a.sp.stopval) {
             ret = RES_STOPVAL_REACHED;
         } else if (nevals >= MAX_EVALS_CAP) {
             ret = RES_ITER_CAP;
         } else if (st == ST_EVAL_FIRST) {
-#pragma unroll
-            for (int i = 0; i < N; ++i) ENG_D(E::GN, i) = gn[i];
             ENG_D(E::FC, 0) = f;
             ENG_I(E::STATE) = ST_UPDATE_FIRST;
         } else {
@@ -490,19 +494,17 @@ OPTIK_DEV void eng_eval_body(const EngArgs &a, const ChainDev &ch, const EngJob 
                         bool allx = true;
 #pragma unroll
                         for (int i = 0; i < N; ++i)
-                            allx = allx && !(__builtin_fabs(x[i] - ENG_D(E::XP, i)) >= a.sp.xtol_abs);
+                            allx = allx && !(__builtin_fabs(ENG_D(E::X, i) - ENG_D(E::XP, i)) >= a.sp.xtol_abs);
                         if (allx) ret = RES_XTOL_REACHED;
                     }
                 }
                 ENG_D(E::FP, 0) = f;
                 if (a.sp.xtol_abs >= 0.0) {
 #pragma unroll
-                    for (int i = 0; i < N; ++i) ENG_D(E::XP, i) = x[i];
+                    for (int i = 0; i < N; ++i) ENG_D(E::XP, i) = ENG_D(E::X, i);
                 }
                 if (ret == 0 && nevals >= MAX_EVALS_CAP) ret = RES_ITER_CAP;
                 if (ret == 0) {
-#pragma unroll
-                    for (int i = 0; i < N; ++i) ENG_D(E::GN, i) = gn[i];
                     ENG_D(E::FC, 0) = f;
                     ENG_I(E::STATE) = ST_UPDATE_ACCEPT;
                 }

@@ -82,15 +82,38 @@ OPTIK_DEV void forward_kinematics(const ChainDev &ch, const EvalParams &ep, cons
     kin.ee = ep.has_ee_offset ? pose_mul(state, load_pose(ep.ee_offset)) : state;
 }
 
-// Value and gradient at q.  Returns f, writes g[N].
-template <int N, bool TIP>
-OPTIK_DEV double eval_fg(const ChainDev &ch, const EvalParams &ep, const Pose target,
-                         const double (&q)[N], double (&g)[N]) {
-    Kin<N, TIP> kin;
-    forward_kinematics<N, TIP>(ch, ep, q, kin);
+// Value and gradient at q; gradient component k is handed to gsink(k, g_k) as soon as it is
+// known (a caller that stores it right away never holds the gradient).  Returns f.
+//
+// Register diet: only the orientation of every joint frame is kept from the forward pass
+// (4 doubles per joint instead of 7); the Jacobian loop walks the chain again for the
+// positions, t_k = t_(k-1) + R_(k-1) * origin_k.t -- the same operations on the same operands
+// as the forward pass, hence the same bits, for 33 flops per joint.
+template <int N, bool TIP, class GSink>
+OPTIK_DEV double eval_fg_stream(const ChainDev &ch, const EvalParams &ep, const Pose target,
+                                const double (&q)[N], GSink &&gsink) {
+    Q4 tfq[N];  // orientation of T_w_j after joint j's own rotation (kinematics.rs:153-156)
+    Pose ee;    // kinematics.rs:163
+    {
+        Pose state;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            double s, c;
+            sincos_dev(q[j] / 2.0, s, c);  // UnitQuaternion::from_axis_angle
+            const Q4 local{ch.axis[j][0] * s, ch.axis[j][1] * s, ch.axis[j][2] * s, c};
+            Pose jt;  // joint.origin * local_transform(q): the translation part is exact
+            jt.t = V3{ch.origin[j][0], ch.origin[j][1], ch.origin[j][2]};
+            jt.q = qmul(Q4{ch.origin[j][3], ch.origin[j][4], ch.origin[j][5], ch.origin[j][6]}, local);
+            state = (j == 0) ? jt : pose_mul(state, jt);  // identity * jt is exact
+            tfq[j] = state.q;
+            OPTIK_SCHED_FENCE();
+        }
+        if (TIP) state = pose_mul(state, load_pose(ch.origin[N]));
+        ee = ep.has_ee_offset ? pose_mul(state, load_pose(ep.ee_offset)) : state;
+    }
 
     // X = T_target^-1 T_ee  (objective.rs:69-70)
-    const Pose X = pose_inv_mul(target, kin.ee);
+    const Pose X = pose_inv_mul(target, ee);
     const V3 w = so3_log(X.q);
     const RotTerms rt = rot_terms(w);
     const M3 Jr = so3_right_jacobian(rt);          // math.rs:195
@@ -108,16 +131,26 @@ OPTIK_DEV double eval_fg(const ChainDev &ch, const EvalParams &ep, const Pose ta
         if (!ep.skip_ang2) ga = weight_block(target.q, w, ep.w_ang2);
     }
     const double e2[6] = {2.0 * gl.x, 2.0 * gl.y, 2.0 * gl.z, 2.0 * ga.x, 2.0 * ga.y, 2.0 * ga.z};
+    // f = ||e||^2 (objective.rs:56)
+    const double ef[6] = {fl.x, fl.y, fl.z, fa.x, fa.y, fa.z};
+    double f = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) f += ef[i] * ef[i];
+    OPTIK_SCHED_FENCE();
 
     // per joint: body-frame Jacobian column (kinematics.rs:173-184), then
     // Jtask = Jlog6 * J (objective.rs:81) and g = (2 e') Jtask (objective.rs:106-109)
-    const Q4 eeqc = qconj(kin.ee.q);
+    const Q4 eeqc = qconj(ee.q);
+    V3 tk{ch.origin[0][0], ch.origin[0][1], ch.origin[0][2]};  // position of joint frame 0
 #pragma unroll
     for (int k = 0; k < N; ++k) {
+        if (k > 0) {  // pose_mul(state_(k-1), jt_k).t
+            const V3 sft = qrot(tfq[k - 1], V3{ch.origin[k][0], ch.origin[k][1], ch.origin[k][2]});
+            tk = V3{tk.x + sft.x, tk.y + sft.y, tk.z + sft.z};
+        }
         const V3 ax{ch.axis[k][0], ch.axis[k][1], ch.axis[k][2]};
-        const V3 angular = qrot(kin.tf[k].q, ax);
-        const V3 d{kin.ee.t.x - kin.tf[k].t.x, kin.ee.t.y - kin.tf[k].t.y,
-                   kin.ee.t.z - kin.tf[k].t.z};
+        const V3 angular = qrot(tfq[k], ax);
+        const V3 d{ee.t.x - tk.x, ee.t.y - tk.y, ee.t.z - tk.z};
         const V3 linear = cross(angular, d);
         const V3 al = qrot(eeqc, angular);
         const V3 ll = qrot(eeqc, linear);
@@ -140,16 +173,20 @@ OPTIK_DEV double eval_fg(const ChainDev &ch, const EvalParams &ep, const Pose ta
         double acc = 0.0;
 #pragma unroll
         for (int r = 0; r < 6; ++r) acc += e2[r] * jt[r];
-        g[k] = acc;
+        gsink(k, acc);
         OPTIK_SCHED_FENCE();
     }
-
-    // f = ||e||^2 (objective.rs:56)
-    const double ef[6] = {fl.x, fl.y, fl.z, fa.x, fa.y, fa.z};
-    double f = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) f += ef[i] * ef[i];
     return f;
+}
+
+// Value and gradient at q.  Returns f, writes g[N].
+template <int N, bool TIP>
+OPTIK_DEV double eval_fg(const ChainDev &ch, const EvalParams &ep, const Pose target,
+                         const double (&q)[N], double (&g)[N]) {
+    return eval_fg_stream<N, TIP>(ch, ep, target, q, [&](int k, double v) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) g[i] = (i == k) ? v : g[i];
+    });
 }
 
 }  // namespace optik

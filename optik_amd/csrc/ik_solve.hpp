@@ -175,7 +175,7 @@ OPTIK_DEV void solve_wave(const ChainDev &ch, const EvalParams &ep, const SolveP
     double xbest[N], xprev[N];
     double f = 0.0, f0 = 0.0, t0 = 0.0, h3 = 0.0, alpha = 1.0;
     double minf = __builtin_huge_val(), fprev = __builtin_huge_val();
-    int iter = 0, ireset = 0, line = 0, nevals = 0;
+    int ireset = 0, line = 0, nevals = 0;  // (Kraft's iter only feeds maxiter, which NLopt leaves unbounded)
     bool first = true;
     // the work item
     Pose target;
@@ -216,7 +216,7 @@ OPTIK_DEV void solve_wave(const ChainDev &ch, const EvalParams &ep, const SolveP
                     for (int i = 0; i < N; ++i) { xbest[i] = x[i]; xprev[i] = x[i]; x0[i] = x[i]; s[i] = 0.0; g[i] = 0.0; }
                     f = 0.0; f0 = 0.0; t0 = 0.0; h3 = 0.0; alpha = 1.0;
                     minf = __builtin_huge_val(); fprev = __builtin_huge_val();
-                    iter = 0; ireset = 0; line = 0; nevals = 0;
+                    ireset = 0; line = 0; nevals = 0;
                     first = true;
                     active = true;
                 }
@@ -235,7 +235,7 @@ OPTIK_DEV void solve_wave(const ChainDev &ch, const EvalParams &ep, const SolveP
                                                                 __HIP_MEMORY_SCOPE_AGENT);
                 stop = fs < index;
             }
-            if (wq.deadline && wall_clock64() > wq.deadline) stop = true;
+            if (wq.deadline && (unsigned long long)wall_clock64() > wq.deadline) stop = true;
             if (stop) ret = RES_FORCED_STOP;
         }
         double gn[N];
@@ -336,7 +336,6 @@ OPTIK_DEV void solve_wave(const ChainDev &ch, const EvalParams &ep, const SolveP
 #pragma unroll
                     for (int i = 0; i < N; ++i) l[lidx<N>(i, i)] = 1.0;
                 }
-                ++iter;
                 double lo[N], hi[N];
 #pragma unroll
                 for (int i = 0; i < N; ++i) { lo[i] = ch.lb[i] - x[i]; hi[i] = ch.ub[i] - x[i]; }
