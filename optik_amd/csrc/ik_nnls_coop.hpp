@@ -216,14 +216,21 @@ OPTIK_DEV void nnls_coop(bool live, bool resume, int budget, int cid0, dvec8 (&c
                 up = (cand && pivot) ? asave - c2 : up;
                 ulp = pivot ? c2 : ulp;
             }
-            double unorm = 0.0;
-            {
-                double xmax = 0.0;
+            // Lawson-Hanson's independence test diff(unorm + factor |ulp|, unorm) > 0 with unorm the
+            // norm of the column above the pivot.  unorm <= sqrt(m) xmax < 3 xmax, and an addend
+            // above 2^-52 unorm always survives the rounding of the sum: whenever
+            // t > 3 * 2^-52 * xmax the test is true without unorm (also for xmax = 0: t > 0 is the
+            // test itself).  Only if some problem of the wave is not decided that way (t within
+            // 1e-15 of the column norm: a numerically dependent column) is unorm formed.
+            double xmax = 0.0;
 #pragma unroll
-                for (int r = 1; r <= m; ++r) {
-                    const double av = __builtin_fabs(ul[r - 1]);
-                    xmax = (av > xmax) ? av : xmax;
-                }
+            for (int r = 1; r <= m; ++r) {
+                const double av = __builtin_fabs(ul[r - 1]);
+                xmax = (av > xmax) ? av : xmax;
+            }
+            const double t = factor * __builtin_fabs(ulp);
+            bool ok1 = t > 6.7e-16 * xmax;
+            if (wave_any(cand && !ok1)) {
                 const double scale = 1.0 / xmax;
                 double sum = 0.0;
 #pragma unroll
@@ -231,14 +238,13 @@ OPTIK_DEV void nnls_coop(bool live, bool resume, int budget, int cid0, dvec8 (&c
                     const double xs = scale * ul[r - 1];
                     sum += xs * xs;
                 }
-                unorm = (xmax != 0.0) ? xmax * __builtin_sqrt(sum) : 0.0;
+                const double unorm = (xmax != 0.0) ? xmax * __builtin_sqrt(sum) : 0.0;
+                const double d1 = unorm + t;
+                ok1 = d1 - unorm > 0.0;
             }
-            const double t = factor * __builtin_fabs(ulp);
-            const double d1 = unorm + t;
             const double hprod = up * ulp;
             const bool apply_live = cand && h12_live && !(__builtin_fabs(ulp) <= 0.0) && !(hprod >= 0.0);
             const double hb = apply_live ? 1.0 / hprod : 0.0;
-            const bool ok1 = d1 - unorm > 0.0;
             // the transformation as a weight per row: up at the pivot row, u below, 0 above
             dvec8 w = 0.0;
 #pragma unroll
