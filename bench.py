@@ -35,7 +35,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r1c_engine_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r1d_engine_pmc_traffic.json")
 
 
 def pmc_traffic(kernel):
@@ -266,6 +266,7 @@ def main():
                        "path": args.path, "restarts_per_gpu": R, "tol_f": 1e-6,
                        "parallelism": f"restart-range x{world}",
                        "success_rate_last_step": n_success / R, "mean_evals_per_restart": mean_evals,
+                       "objective_gradient_evals_per_s": total / elapsed * mean_evals,
                        "grid": info["grid"], "block": info["block"], "lds_bytes": info["lds_bytes"]},
             "roofline": roof,
         }
