@@ -561,9 +561,13 @@ OPTIK_DEV void eng_eval_body(const EngArgs &a, const ChainDev &ch, const EngJob 
 }
 
 // Gives `slot` the work item `it` of the queue (or leaves it empty when the queue is
-// exhausted): restart seed, bookkeeping planes.  Returns the slot's new state.
+// exhausted): restart seed, bookkeeping planes.  Returns false when the item needs no slot --
+// a lower-index restart of its target has already succeeded (lib.rs:308 at the restart's
+// first callback): its outputs keep their initial "no solution" values and the caller asks
+// for the next item right away (a Speed batch abandons most of its restarts this way; each
+// used to cost its slot a whole trip).
 template <int N>
-OPTIK_DEV int refill_slot(const EngArgs &a, const ChainDev &ch, size_t slot, unsigned long long it) {
+OPTIK_DEV bool refill_slot(const EngArgs &a, const ChainDev &ch, size_t slot, unsigned long long it) {
     using E = EngLayout<N>;
     int st;
     if (it < a.total_items) {
@@ -577,6 +581,15 @@ OPTIK_DEV int refill_slot(const EngArgs &a, const ChainDev &ch, size_t slot, uns
         else { tslot = qi / J.n_restarts; r = qi - tslot * J.n_restarts; }
         const unsigned long long item = tslot * J.n_restarts + r;  // output column
         const unsigned long long index = J.restart_begin + r;
+        if (J.first_success) {
+            const unsigned long long fs = __hip_atomic_load(J.first_success + tslot, __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT);
+            if (fs < index) {  // abandoned before it started (key is +inf from the job's set-up)
+                if (J.out_status) J.out_status[item] = RES_FORCED_STOP;
+                if (J.out_evals) J.out_evals[item] = 0;
+                return false;
+            }
+        }
         double x[N];
         restart_seed<N>(a.key, ch.lb, a.scale, index, x);
         if (index == 0) {  // lib.rs:366-370: restart 0 starts from the caller's seed
@@ -600,17 +613,11 @@ OPTIK_DEV int refill_slot(const EngArgs &a, const ChainDev &ch, size_t slot, uns
         ENG_I(E::JOB) = job;
         a.item[slot] = item;
         st = ST_EVAL_FIRST;
-        if (J.first_success) {
-            // lib.rs:308 at the restart's first callback: a lower index already succeeded
-            const unsigned long long fs = __hip_atomic_load(J.first_success + tslot, __ATOMIC_RELAXED,
-                                                            __HIP_MEMORY_SCOPE_AGENT);
-            if (fs < index) { ENG_I(E::STATUS) = RES_FORCED_STOP; st = ST_DEAD; }
-        }
     } else {
         st = ST_EMPTY;
     }
     ENG_I(E::STATE) = st;
-    return st;
+    return true;
 }
 
 // ---- kernel 2: update (BFGS + unconstrained direction) and refill ---------------
@@ -1000,10 +1007,11 @@ OPTIK_DEV void eng_finish_body(const EngArgs &a, const ChainDev &ch, size_t slot
     // queue (one atomic per wave)
     {
         const unsigned n_refill = *a.refill_count;
-        const bool want = local < n_refill;
-        if (wave_any(want)) {
+        bool want = local < n_refill;
+        const size_t rslot = want ? (size_t)a.refill_list[local] : 0;
+        while (wave_any(want)) {
             const unsigned long long it = fetch_items(a.next_item, want);
-            if (want) refill_slot<N>(a, ch, (size_t)a.refill_list[local], it);
+            if (want) want = !refill_slot<N>(a, ch, rslot, it);
         }
     }
     // the answered problems: each lane reads its record straight from HBM (staging the wave's

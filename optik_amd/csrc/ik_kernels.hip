@@ -238,6 +238,10 @@ __global__ __launch_bounds__(OPTIK_ENG_SLOT_BLOCK, OPTIK_ENG_UPD_WAVES) void eng
 __global__ __launch_bounds__(256) void eng_compact_scan_kernel(const CompactArgs c) { compact_scan_body(c); }
 __global__ __launch_bounds__(256) void eng_compact_move_kernel(const CompactArgs c) { compact_move_body(c); }
 
+__global__ void fill_f64_kernel(double *p, unsigned long long n, double v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
 __global__ void eng_init_kernel(int32_t *state, unsigned int *cls2, unsigned long long C) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < C) { state[i] = ST_REFILL; cls2[i] = NN_NONE; cls2[C + i] = NN_NONE; }  // every slot wants a work item
@@ -1007,7 +1011,13 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
         HIP_TRY(hipStreamSynchronize(stream));  // hj goes out of scope; tiny copy
         HIP_TRY(hipMemsetAsync(ch->queue, 0, sizeof(unsigned long long), stream));
         for (auto &j : ch->eng_jobs)
-            if (j.own_fs) HIP_TRY(hipMemsetAsync(j.own_fs, 0xff, sizeof(unsigned long long) * (size_t)j.T, stream));
+            if (j.own_fs) {
+                HIP_TRY(hipMemsetAsync(j.own_fs, 0xff, sizeof(unsigned long long) * (size_t)j.T, stream));
+                // restarts abandoned before they start never touch their outputs: key = no solution
+                if (j.dev.out_key)
+                    hipLaunchKernelGGL(fill_f64_kernel, dim3(1024), dim3(256), 0, stream, j.dev.out_key,
+                                       (unsigned long long)j.dev.n_items, __builtin_huge_val());
+            }
 
         EngArgs a;
         std::memset(&a, 0, sizeof a);

@@ -34,10 +34,12 @@ def main():
         return m
     targets = np.array([mat(p) for p in pose])
     cfg = SolverConfig(solution_mode="speed", max_time=0.0, max_restarts=R)
-    robot.ik_batch(cfg, targets[:64], x0s[:64])  # warm-up
-    t0 = time.perf_counter()
-    res = robot.ik_batch(cfg, targets, x0s)
-    dt = time.perf_counter() - t0
+    robot.ik_batch(cfg, targets, x0s)  # warm-up at full size (the first call allocates the engine's pool)
+    dt = 1e30
+    for _ in range(3):
+        t0 = time.perf_counter()
+        res = robot.ik_batch(cfg, targets, x0s)
+        dt = min(dt, time.perf_counter() - t0)
     solved = sum(r is not None for r in res)
     print(f"GPU  Robot.ik_batch: {T} targets x <= {R} restarts: {dt*1e3:.1f} ms -> {T/dt:,.0f} ik() calls/s, "
           f"{100.0*solved/T:.1f} % solved")
