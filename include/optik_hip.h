@@ -138,7 +138,11 @@ int optik_hip_ik_batch(optik_hip_chain *chain, const optik_solver_config *cfg,
  * slots in HBM with continuous refill (optik_amd/csrc/ik_engine.hpp).  submit() only
  * records a job (arguments as optik_hip_ik_batch; all jobs of one run must share
  * tolerances, weights and ee_offset; buffers must stay valid until run() returns);
- * run() executes every pending job, runs their selections and blocks until done.
+ * run() executes every pending job, runs their selections and blocks until done (it
+ * uses the given stream and up to three internal ones, joined before it returns).
+ * With OPTIK_HIP_IK_EARLY_EXIT a restart whose target already has a lower-index success
+ * when its turn comes is never started: its status is FORCED_STOP, evals 0, key +inf,
+ * and its x / f entries are left as they were.
  * No deadline support: use optik_hip_ik_batch for max_time. */
 int optik_hip_engine_submit(optik_hip_chain *chain, const optik_solver_config *cfg,
                             const double *d_targets, const double *d_x0, int32_t T,
