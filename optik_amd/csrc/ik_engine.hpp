@@ -135,6 +135,7 @@ struct EngArgs {
     // one or two lanes)
     unsigned int *refill_count;
     unsigned int *refill_list;          // [sub-pool size]
+    unsigned int *host_in_use;          // pinned host word the finish kernel copies the in-use count to (last trip of a chunk), or null
     unsigned long long *nn_total;       // running count of bounded sub-problems solved
     unsigned long long *prof;           // OPTIK_PROFILE builds: cycle counters, else null
     unsigned long long *prof2;          // OPTIK_PROFILE builds: direction-search sub-phases

@@ -232,6 +232,9 @@ __global__ __launch_bounds__(OPTIK_ENG_SLOT_BLOCK, OPTIK_ENG_UPD_WAVES) void eng
     stage_chain(sch, a.chain);
     const size_t local = (size_t)blockIdx.x * OPTIK_ENG_SLOT_BLOCK + threadIdx.x;
     const size_t slot = (size_t)a.slot_base + local;
+    // the host reads the in-use count of a chunk from pinned memory (no copy kernel on the stream)
+    if (a.host_in_use && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(a.host_in_use, *a.n_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     eng_finish_body<N>(a, sch, local < a.n_slots ? slot : (size_t)a.slot_base, local, local < a.n_slots);
 }
 
@@ -1132,6 +1135,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
                 // reset for the finish kernel's re-deferrals and the next trip's update kernel
                 a.parity = trip & 1;
                 a.trip = trip < TRIP_LOG_MAX ? trip : TRIP_LOG_MAX - 1;
+                a.host_in_use = (k == CHECK - 1) ? &P.pinned[P.ring] : nullptr;
                 // HIP event pairs around each kernel of every trip of sub-pool 0 (on its launch stream)
                 const bool timed = first_pool && ch->timing && trip > 0 && ch->eng_tcount < optik_hip_chain::ENG_EV;
                 const int ts = ch->eng_tcount;
@@ -1176,8 +1180,8 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
                 ch->eng_launches += 1;
             }
             HIP_TRY(hipGetLastError());
-            // read back the in-use count of the chunk just issued; look at the previous chunk's value
-            HIP_TRY(hipMemcpyAsync(&P.pinned[P.ring], a.n_active, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+            // the chunk's last finish kernel wrote its in-use count to pinned memory; the host looks
+            // at the previous chunk's value
             HIP_TRY(hipEventRecord(P.ev[P.ring], stream));
             if (P.pending) {
                 const int prev = (P.ring + 7) % 8;
