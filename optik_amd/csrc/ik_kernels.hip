@@ -1124,6 +1124,8 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
         const int CHECK = 4;  // trips between termination checks
         const bool tip = ch->tip;
         double dbg_wait_bulk = 0.0, dbg_wait_drain = 0.0;  // host time blocked on the GPU (OPTIK_ENG_DEBUG)
+        double dbg_drain_t0 = -1.0;  // when the first sub-pool fell under half of its live prefix
+        const auto dbg_t0 = std::chrono::steady_clock::now();
         // queues CHECK trips of one sub-pool, then looks at the in-use count of its previous chunk
         auto advance = [&](Pool &P, bool first_pool) -> int {
             EngArgs &a = P.a;
@@ -1190,6 +1192,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
                 const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
                 const unsigned long long in_use = P.pinned[prev];
                 (in_use * 2 < a.n_slots || a.n_slots < 16384 ? dbg_wait_drain : dbg_wait_bulk) += waited;
+                if (dbg_drain_t0 < 0.0 && in_use * 2 < P.a.n_slots) dbg_drain_t0 = std::chrono::duration<double>(std::chrono::steady_clock::now() - dbg_t0).count();
                 if (in_use == 0) P.done = true;
                 // drain: part of the live prefix no longer holds a restart (the count only
                 // falls once the queue is empty, so the lagging value is an upper bound)
@@ -1220,7 +1223,6 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             return 0;
         };
         ch->eng_launches = 0;
-        const auto dbg_t0 = std::chrono::steady_clock::now();
         for (bool all_done = false; !all_done;) {
             all_done = true;
             for (int p2 = 0; p2 < n_pools; ++p2) {
@@ -1231,8 +1233,8 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             }
         }
         if (getenv("OPTIK_ENG_DEBUG"))
-            fprintf(stderr, "[optik engine] loop %.2f ms, host waited on the GPU %.2f ms (bulk) + %.2f ms (drain), %d launches\n",
-                    std::chrono::duration<double>(std::chrono::steady_clock::now() - dbg_t0).count() * 1e3,
+            fprintf(stderr, "[optik engine] loop %.2f ms (drain from %.2f ms), host waited on the GPU %.2f ms (bulk) + %.2f ms (drain), %d launches\n",
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - dbg_t0).count() * 1e3, dbg_drain_t0 * 1e3,
                     dbg_wait_bulk * 1e3, dbg_wait_drain * 1e3, ch->eng_launches);
         // the selection below runs on the caller's stream after every sub-pool
         for (int p2 = 1; p2 < n_pools; ++p2) {
