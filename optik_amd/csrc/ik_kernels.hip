@@ -403,6 +403,8 @@ struct optik_hip_chain {
     double *eng_carry = nullptr;           // [C][NN_CARRY]
     unsigned int *eng_list = nullptr;      // 2 x [C] class entries by slot, per trip parity
     unsigned int *eng_refill = nullptr;    // [C] slots wanting a work item, per sub-pool range
+    double *hw_dev = nullptr, *hw_pin = nullptr;  // optik_hip_ik_host: device block and pinned staging
+    size_t hw_cap = 0;                            // doubles
     unsigned long long *nnls_trace = nullptr;  // OPTIK_NNLS_TRACE builds
     unsigned int *eng_trip_log = nullptr;      // OPTIK_ENG_TRIP_LOG diagnostics
     unsigned int *eng_compact = nullptr;       // [ENG_MAX_POOLS][2] counters, then free list [C], move list [C]
@@ -626,6 +628,8 @@ void optik_hip_chain_destroy(optik_hip_chain *ch) {
     if (ch->eng_compact) hipFree(ch->eng_compact);
     if (ch->eng_list) hipFree(ch->eng_list);
     if (ch->eng_refill) hipFree(ch->eng_refill);
+    if (ch->hw_dev) hipFree(ch->hw_dev);
+    if (ch->hw_pin) hipHostFree(ch->hw_pin);
     if (ch->eng_prob) hipFree(ch->eng_prob);
     if (ch->eng_y) hipFree(ch->eng_y);
     if (ch->eng_meta) hipFree(ch->eng_meta);
@@ -807,8 +811,13 @@ int optik_hip_ik_batch(optik_hip_chain *ch, const optik_solver_config *cfg, cons
     // Persistent waves: as many 64-lane workgroups as the LDS lets a CU hold (2), times
     // the CU count; each pulls work items until the queue is dry.
     const int cus = ch->num_cus > 0 ? ch->num_cus : 256;
-    long long grid_ll = (long long)((cols + WAVE - 1) / WAVE);
     const long long cap = (long long)cus * ch->waves_per_cu;
+    // fewer work items than lanes on the chip: one restart per wave (or as few as fit)
+    long long lanes = ((long long)cols + cap - 1) / cap;
+    if (lanes < 1) lanes = 1;
+    if (lanes > WAVE) lanes = WAVE;
+    a.wq.lanes = (int)lanes;
+    long long grid_ll = ((long long)cols + lanes - 1) / lanes;
     if (grid_ll > cap) grid_ll = cap;
     const int grid = (int)grid_ll;
 
@@ -1353,46 +1362,37 @@ int optik_hip_ik_host(optik_hip_chain *ch, const optik_solver_config *cfg, const
     // the launch workspace of the chain is in use until the copies below are done
     std::lock_guard<std::mutex> host_lock(ch->host_mu);
     const int n = ch->n;
-    double *d_t = nullptr, *d_x0 = nullptr, *d_wx = nullptr, *d_wf = nullptr, *d_wk = nullptr;
-    uint64_t *d_wi = nullptr;
-    int rc = 0;
-    auto cleanup = [&]() {
-        if (d_t) hipFree(d_t);
-        if (d_x0) hipFree(d_x0);
-        if (d_wx) hipFree(d_wx);
-        if (d_wf) hipFree(d_wf);
-        if (d_wk) hipFree(d_wk);
-        if (d_wi) hipFree(d_wi);
-    };
-#define TRY_CLEAN(expr)                                                                           \
-    do {                                                                                          \
-        hipError_t e_ = (expr);                                                                   \
-        if (e_ != hipSuccess) {                                                                   \
-            cleanup();                                                                            \
-            return fail(OPTIK_HIP_ENODEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-        }                                                                                         \
-    } while (0)
-    TRY_CLEAN(hipMalloc(&d_t, sizeof(double) * 7 * (size_t)T));
-    TRY_CLEAN(hipMalloc(&d_x0, sizeof(double) * (size_t)n * (size_t)T));
-    TRY_CLEAN(hipMalloc(&d_wx, sizeof(double) * (size_t)n * (size_t)T));
-    TRY_CLEAN(hipMalloc(&d_wf, sizeof(double) * (size_t)T));
-    TRY_CLEAN(hipMalloc(&d_wk, sizeof(double) * (size_t)T));
-    TRY_CLEAN(hipMalloc(&d_wi, sizeof(uint64_t) * (size_t)T));
-    TRY_CLEAN(hipMemcpy(d_t, targets, sizeof(double) * 7 * (size_t)T, hipMemcpyHostToDevice));
-    TRY_CLEAN(hipMemcpy(d_x0, x0, sizeof(double) * (size_t)n * (size_t)T, hipMemcpyHostToDevice));
+    // one device block and one pinned staging block, kept with the chain (a call used to pay
+    // six hipMalloc / hipFree pairs and six copies): in = targets [T][7], x0 [T][n];
+    // out = win_x [T][n], win_f [T], win_key [T], win_idx [T]
+    const size_t n_in = (size_t)(7 + n) * (size_t)T, n_out = (size_t)(n + 3) * (size_t)T;
+    if (n_in + n_out > ch->hw_cap) {
+        if (ch->hw_dev) (void)hipFree(ch->hw_dev);
+        if (ch->hw_pin) (void)hipHostFree(ch->hw_pin);
+        ch->hw_dev = nullptr; ch->hw_pin = nullptr; ch->hw_cap = 0;
+        HIP_TRY(hipMalloc(&ch->hw_dev, sizeof(double) * (n_in + n_out)));
+        HIP_TRY(hipHostMalloc(&ch->hw_pin, sizeof(double) * (n_in + n_out)));
+        ch->hw_cap = n_in + n_out;
+    }
+    double *d_t = ch->hw_dev, *d_x0 = d_t + (size_t)7 * T;
+    double *d_wx = ch->hw_dev + n_in, *d_wf = d_wx + (size_t)n * T, *d_wk = d_wf + T;
+    uint64_t *d_wi = reinterpret_cast<uint64_t *>(d_wk + T);
+    std::memcpy(ch->hw_pin, targets, sizeof(double) * 7 * (size_t)T);
+    std::memcpy(ch->hw_pin + (size_t)7 * T, x0, sizeof(double) * (size_t)n * (size_t)T);
+    HIP_TRY(hipMemcpyAsync(ch->hw_dev, ch->hw_pin, sizeof(double) * n_in, hipMemcpyHostToDevice, nullptr));
     optik_hip_ik_outputs o;
     std::memset(&o, 0, sizeof o);
     o.d_win_x = d_wx; o.d_win_f = d_wf; o.d_win_idx = d_wi; o.d_win_key = d_wk;
-    rc = optik_hip_ik_batch(ch, cfg, d_t, d_x0, T, ee_offset7, restart_begin, restart_end, flags, deadline_s,
-                            &o, nullptr);
-    if (rc) { cleanup(); return rc; }
-    TRY_CLEAN(hipDeviceSynchronize());
-    if (win_x) TRY_CLEAN(hipMemcpy(win_x, d_wx, sizeof(double) * (size_t)n * (size_t)T, hipMemcpyDeviceToHost));
-    if (win_f) TRY_CLEAN(hipMemcpy(win_f, d_wf, sizeof(double) * (size_t)T, hipMemcpyDeviceToHost));
-    if (win_idx) TRY_CLEAN(hipMemcpy(win_idx, d_wi, sizeof(uint64_t) * (size_t)T, hipMemcpyDeviceToHost));
-    if (win_key) TRY_CLEAN(hipMemcpy(win_key, d_wk, sizeof(double) * (size_t)T, hipMemcpyDeviceToHost));
-#undef TRY_CLEAN
-    cleanup();
+    const int rc = optik_hip_ik_batch(ch, cfg, d_t, d_x0, T, ee_offset7, restart_begin, restart_end, flags,
+                                      deadline_s, &o, nullptr);
+    if (rc) return rc;
+    double *h_out = ch->hw_pin + n_in;
+    HIP_TRY(hipMemcpyAsync(h_out, d_wx, sizeof(double) * n_out, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    if (win_x) std::memcpy(win_x, h_out, sizeof(double) * (size_t)n * (size_t)T);
+    if (win_f) std::memcpy(win_f, h_out + (size_t)n * T, sizeof(double) * (size_t)T);
+    if (win_key) std::memcpy(win_key, h_out + (size_t)(n + 1) * T, sizeof(double) * (size_t)T);
+    if (win_idx) std::memcpy(win_idx, h_out + (size_t)(n + 2) * T, sizeof(uint64_t) * (size_t)T);
     return 0;
 }
 

@@ -139,7 +139,9 @@ struct WorkQueue {
     unsigned long long *first_success;   // [T] or nullptr
     unsigned long long deadline;         // wall_clock64() ticks, 0 = none
     int quality;                         // selection key: 1 = ||x - x0||_2, 0 = index
-    int pad;
+    int lanes;                           // lanes of a wave that take work items (1 .. 64): a launch too small to
+                                         // fill the chip spreads out, so that a wave does not pay for the phases
+                                         // and NNLS pass counts of 63 other restarts (single-call latency)
     double *out_x;                       // [n][T*R]  best point (NLopt returns best-so-far x)
     double *out_f;                       // [T*R]     minf
     double *out_key;                     // [T*R]     selection key, +inf unless success
@@ -181,7 +183,7 @@ OPTIK_DEV void solve_wave(const ChainDev &ch, const EvalParams &ep, const SolveP
     Pose target;
     unsigned long long item = 0, index = 0;
     unsigned tslot = 0;
-    bool active = false, want = true;
+    bool active = false, want = (int)(threadIdx.x & 63u) < wq.lanes;
 #pragma unroll
     for (int i = 0; i < N; ++i) { x[i] = 0.0; x0[i] = 0.0; g[i] = 0.0; s[i] = 0.0; xbest[i] = 0.0; xprev[i] = 0.0; }
 #pragma unroll
@@ -196,7 +198,7 @@ OPTIK_DEV void solve_wave(const ChainDev &ch, const EvalParams &ep, const SolveP
         // (the seed generation below runs for the whole wave, so wait until several lanes
         // are idle -- or none is busy -- before paying for it)
         const unsigned n_want = (unsigned)__popcll(__ballot(want));
-        if (n_want >= REFILL_BATCH || (n_want > 0 && !wave_any(active))) {
+        if (n_want >= (unsigned)(wq.lanes < REFILL_BATCH ? wq.lanes : REFILL_BATCH) || (n_want > 0 && !wave_any(active))) {
             const unsigned long long it = fetch_items(wq.next_item, want);
             if (want) {
                 want = false;

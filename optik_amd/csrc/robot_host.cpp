@@ -277,9 +277,12 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
     };
     const uint64_t max_restarts = config->max_restarts > 0 ? config->max_restarts : UINT64_MAX;  // lib.rs:273-277
     const bool quality = config->solution_mode == 1;
-    // One launch covers `batch` restart indices: enough 64-lane tiles to fill every CU
-    // a few times over, so a single launch is also the latency-optimal first attempt.
-    const uint64_t batch = (uint64_t)(r->num_cus > 0 ? r->num_cus : 256) * 2 * 64 * 2;
+    // The first launch covers as many restart indices as the chip holds resident waves (one
+    // restart per wave: no wave pays for the phases of 63 other restarts, and a third to a
+    // half of the restarts succeed, so it almost always contains the answer); later launches
+    // cover enough 64-lane tiles to fill every CU a few times over.
+    const uint64_t cus = (uint64_t)(r->num_cus > 0 ? r->num_cus : 256);
+    const uint64_t first_batch = cus * 2, later_batch = cus * 2 * 64 * 2;
     bool have = false;
     double best_key = 0.0, best_f = 0.0;
     uint64_t best_idx = UINT64_MAX;
@@ -291,6 +294,7 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
             deadline = config->max_time - elapsed();
             if (deadline <= 0.0) break;
         }
+        const uint64_t batch = begin == 0 ? first_batch : later_batch;
         const uint64_t end = (max_restarts - begin > batch) ? begin + batch : max_restarts;
         double wf = 0.0, wkey = 0.0;
         uint64_t widx = UINT64_MAX;
