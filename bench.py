@@ -107,12 +107,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--restarts", type=int, default=65536, help="restarts per GPU per step")
     ap.add_argument("--robot", default="panda", choices=["panda", "ur10"])
-    ap.add_argument("--path", default="engine", choices=["engine", "kernel"],
+    ap.add_argument("--path", default="auto", choices=["auto", "engine", "kernel"],
                     help="engine: streaming phase kernels with continuous batching (steps submitted "
-                         "together share the slot pool); kernel: one persistent solve kernel per step")
+                         "together share the slot pool); kernel: one persistent solve kernel per step; "
+                         "auto (default): engine from 3 steps on -- a run of the engine has a latency "
+                         "floor of ~35 ms (the longest restart's ~330 sequential trips) whatever its "
+                         "size, a solve-kernel launch takes ~15 ms per step; results are identical")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
+    if args.path == "auto":
+        args.path = "engine" if args.steps >= 3 else "kernel"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
