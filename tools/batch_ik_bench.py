@@ -1,10 +1,9 @@
 #!/usr/bin/env python3
 """Config 5 of BASELINE.json as the user sees it: T independent ik() calls (reachable random
-targets, random seeds, SolutionMode::Speed, up to 256 restarts each) -- GPU Robot.ik_batch vs
-the CPU oracle's restart loop with early exit on the host's usable cores.  Prints ik() calls/s."""
+targets, random seeds, SolutionMode::Speed, up to 256 restarts each) through Robot.ik_batch.
+Prints ik() calls/s.  (The CPU oracle's figure for the same workload: tests/perf/cpu_ik_batch_rate.py.)"""
 import os
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,7 +15,6 @@ def main():
     T = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     R = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     from optik_amd import Robot, SolverConfig
-    from bench import usable_cores
     robot = Robot.from_urdf_file(os.path.join(ROOT, "optik_amd", "robots", "panda.urdf"), "panda_link0", "panda_link8")
     rng = np.random.default_rng(0)
     lb, ub = (np.array(v) for v in robot.joint_limits())
@@ -43,25 +41,6 @@ def main():
     solved = sum(r is not None for r in res)
     print(f"GPU  Robot.ik_batch: {T} targets x <= {R} restarts: {dt*1e3:.1f} ms -> {T/dt:,.0f} ik() calls/s, "
           f"{100.0*solved/T:.1f} % solved")
-
-    from oracle import binding as ob, urdf_chain
-    d = urdf_chain.chain_from_urdf(open(os.path.join(ROOT, "optik_amd", "robots", "panda.urdf")).read(),
-                                   "panda_link0", "panda_link8")
-    ch = ob.make_chain(**d)
-    ocfg = ob.make_config(solution_mode="speed", max_restarts=R)
-    cores = usable_cores()
-    Tc = min(T, 2048)
-    out = [None] * Tc
-
-    def work(lo, hi):
-        for t in range(lo, hi):
-            out[t] = ob.ik(ch, ocfg, pose[t], x0s[t], 0, R, n_threads=1, early_exit=True)["found"]
-    th = [threading.Thread(target=work, args=(k * Tc // cores, (k + 1) * Tc // cores)) for k in range(cores)]
-    t0 = time.perf_counter()
-    [x.start() for x in th]; [x.join() for x in th]
-    dtc = time.perf_counter() - t0
-    print(f"CPU  oracle, {cores} threads (one target per call, early exit): {Tc} targets: {dtc*1e3:.1f} ms -> "
-          f"{Tc/dtc:,.0f} ik() calls/s, {100.0*sum(out)/Tc:.1f} % solved")
 
 
 if __name__ == "__main__":
