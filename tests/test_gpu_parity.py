@@ -297,6 +297,35 @@ def test_engine_scheduling_does_not_change_results(dev, oracle, chains, hip_chai
     assert int(out["win_idx"].cpu()[0]) == ref["winner"]
 
 
+@pytest.mark.parametrize("robot,tol_f", [("panda", 1e-6), ("ur10", 1e-8), ("ur3e", 1e-6), ("panda_hand", 1e-6)])
+def test_engine_many_targets_pooled_bit_exact(dev, oracle, chains, hip_chains, robot, tol_f):
+    """Eight targets submitted as eight jobs of one engine run (restart ranges that do not start
+    at 0, weights other than the default): every restart of every job equals the oracle's."""
+    from optik_amd import _native as nat
+    d, ch = chains[robot]
+    rng = np.random.default_rng(97)
+    kw = dict(solution_mode="quality", tol_f=tol_f, linear_weight=(1.0, 2.0, 0.5), angular_weight=(0.7, 1.0, 1.3))
+    cfg = nat.make_config(**kw)
+    jobs = []
+    for j in range(8):
+        tg, x0 = make_targets(oracle, d, ch, rng, 1)
+        begin = int(rng.integers(0, 5000))
+        end = begin + int(rng.integers(300, 900))
+        out = hip_chains[robot].engine_submit(cfg, torch.tensor(tg, device="cuda"), torch.tensor(x0, device="cuda"),
+                                              begin, end)
+        jobs.append((tg, x0, begin, end, out))
+    hip_chains[robot].engine_run()
+    torch.cuda.synchronize()
+    for tg, x0, begin, end, out in jobs:
+        ref = _oracle_all(oracle, ch, kw, tg[0], x0[0], begin, end)
+        assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+        assert np.array_equal(out["evals"].cpu().numpy(), ref["evals"])
+        assert_bit_equal(out["f"].cpu().numpy(), ref["fs"], "per-restart f")
+        assert_bit_equal(out["x"].cpu().numpy(), ref["xs"].T, "per-restart x")
+        want = ref["winner"] if ref["found"] else -1
+        assert int(out["win_idx"].cpu()[0]) == want
+
+
 def test_early_exit_keeps_the_winner(dev, oracle, chains, hip_chains):
     """Speed + early exit (lib.rs:382-384): restarts above a known success are
     abandoned, the winner (lowest successful index) does not change."""
