@@ -39,9 +39,10 @@ const double *optik_robot_fk(const optik_robot *robot, const double *x);      /*
 const double *optik_robot_random_configuration(const optik_robot *robot);     /* lib.rs:119-125 */
 const double *optik_robot_ik(const optik_robot *robot, const CSolverConfig *config,
                              const double *target, const double *x0);         /* lib.rs:128-162 */
-/* Differential IK (lib.rs:165-183) is outside the accelerated hot path (SURVEY 8f
- * rank 4).  The symbol exists so existing binaries link; it reports the fact on
- * stderr and returns NULL ("no solution"). */
+/* Differential IK (optik-cpp lib.rs:165-183; Robot::diff_ik, lib.rs:123-239): the joint
+ * velocities v_n[n] realising alpha * V_WE for the largest feasible 0 <= alpha <= 1 under
+ * |v_i| <= v_max_i.  The LP (<= 8 unknowns) is solved exactly on the host; FK and the Jacobian
+ * come from the HIP kernels.  NULL = no solution. */
 const double *optik_robot_diff_ik(const optik_robot *robot, const double *x0, const double *V_WE,
                                   const double *v_max);
 
@@ -64,6 +65,10 @@ int optik_robot_ik_ex(const optik_robot *robot, const CSolverConfig *config, con
 int optik_robot_ik_batch_ex(const optik_robot *robot, const CSolverConfig *config, int32_t T,
                             const double *targets16, const double *x0, const double *ee_offset16,
                             double *x_out, double *f_out, int32_t *found_out);
+/* Robot::diff_ik with its full signature: ee_offset and alpha.  rc 0 = solved, 1 = none. */
+int optik_robot_diff_ik_ex(const optik_robot *robot, const double *x0, const double *V_WE6,
+                           const double *v_max, const double *ee_offset16, double *alpha_out,
+                           double *v_out);
 int optik_robot_fk_ex(const optik_robot *robot, const double *x, const double *ee_offset16,
                       double *pose16_out);
 int optik_robot_joint_jacobian_ex(const optik_robot *robot, const double *x,

@@ -426,11 +426,167 @@ const double *optik_robot_ik(const optik_robot *r, const CSolverConfig *config, 
     return malloc_copy(x.data(), x.size());
 }
 
-const double *optik_robot_diff_ik(const optik_robot *, const double *, const double *, const double *) {
-    std::fprintf(stderr,
-                 "optik_amd: diff_ik (lib.rs:123-239) is outside the accelerated random-restart IK path "
-                 "and is not provided by this library\n");
-    return nullptr;
+// Robot::diff_ik, lib.rs:123-239: the largest 0 <= alpha <= 1 for which joint velocities v with
+// |v_i| <= v_max_i realise the end-effector twist alpha * V_WE (world frame):
+//     max alpha   s.t.   J_W(q) v = alpha V,   -v_max <= v <= v_max,   0 <= alpha <= 1.
+// The reference hands this LP to Clarabel (an interior-point solver; un-vendored).  It has at
+// most 8 unknowns, so it is solved exactly here: the equality constraints are eliminated
+// (null space of [J_W | -V] by Gauss-Jordan with full pivoting) and the vertices of the
+// remaining polytope (dimension <= 3) are enumerated.  The optimal alpha is unique; when the
+// optimal v is not (a redundant arm with alpha = 1), the minimum-norm optimal v is returned,
+// where Clarabel returns the analytic centre of the optimal face -- both pass the reference's
+// test (tests/test_ik.rs:185-209).  FK and the Jacobian come from the HIP kernels.
+int optik_robot_diff_ik_ex(const optik_robot *r, const double *x0, const double *V_WE, const double *v_max,
+                           const double *ee16, double *alpha_out, double *v_out) {
+    if (!r || !x0 || !V_WE || !v_max) return set_err(-1, "null argument");
+    const int n = r->n, nz = n + 1;
+    double p7[7];
+    std::vector<double> jac(6 * (size_t)n);
+    if (fk_on_device(r, x0, ee16, p7, jac.data())) return -1;
+    for (int i = 0; i < n; ++i)
+        if (!(v_max[i] >= 0.0)) return 1;  // infeasible box
+    // body-frame Jacobian -> world frame: both 3-row blocks rotated by R_WE (lib.rs:190-197)
+    const double qi = p7[3], qj = p7[4], qk = p7[5], qw = p7[6];
+    const double R[3][3] = {{qw * qw + qi * qi - qj * qj - qk * qk, 2 * (qi * qj - qw * qk), 2 * (qw * qj + qi * qk)},
+                            {2 * (qw * qk + qi * qj), qw * qw - qi * qi + qj * qj - qk * qk, 2 * (qj * qk - qw * qi)},
+                            {2 * (qi * qk - qw * qj), 2 * (qw * qi + qj * qk), qw * qw - qi * qi - qj * qj + qk * qk}};
+    double M[6][9];  // [J_W | -V], 6 x (n + 1)
+    for (int c = 0; c < n; ++c)
+        for (int blk = 0; blk < 2; ++blk)
+            for (int a = 0; a < 3; ++a) {
+                double acc = 0.0;
+                for (int b = 0; b < 3; ++b) acc += R[a][b] * jac[(size_t)c * 6 + blk * 3 + b];
+                M[blk * 3 + a][c] = acc;
+            }
+    double scale = 0.0;
+    for (int a = 0; a < 6; ++a) {
+        M[a][n] = -V_WE[a];
+        for (int c = 0; c < nz; ++c) scale = std::max(scale, std::fabs(M[a][c]));
+    }
+    // Gauss-Jordan with full pivoting: pivot columns pc[0..rank), the others are free
+    int pc[6], rank = 0;
+    bool is_pivot[9] = {false};
+    for (int step = 0; step < 6; ++step) {
+        int br = -1, bc = -1;
+        double best = 1e-12 * (scale > 0.0 ? scale : 1.0);
+        for (int a = step; a < 6; ++a)
+            for (int c = 0; c < nz; ++c)
+                if (!is_pivot[c] && std::fabs(M[a][c]) > best) { best = std::fabs(M[a][c]); br = a; bc = c; }
+        if (br < 0) break;
+        for (int c = 0; c < nz; ++c) std::swap(M[step][c], M[br][c]);
+        const double piv = M[step][bc];
+        for (int c = 0; c < nz; ++c) M[step][c] /= piv;
+        for (int a = 0; a < 6; ++a)
+            if (a != step) {
+                const double f = M[a][bc];
+                if (f != 0.0) for (int c = 0; c < nz; ++c) M[a][c] -= f * M[step][c];
+            }
+        is_pivot[bc] = true;
+        pc[rank++] = bc;
+    }
+    const int d = nz - rank;  // dimension of {z = (v, alpha) : [J_W | -V] z = 0}
+    std::vector<double> best_z((size_t)nz, 0.0);  // z = 0 (alpha = 0, v = 0) is always feasible
+    double best_alpha = 0.0, best_norm = 0.0;
+    if (d >= 1 && d <= 3) {
+        // basis B (nz x d): free variable k = 1, pivot variables from the reduced rows
+        int freec[3], nf = 0;
+        for (int c = 0; c < nz; ++c) if (!is_pivot[c]) freec[nf++] = c;
+        double B[9][3];
+        for (int k = 0; k < d; ++k) {
+            for (int c = 0; c < nz; ++c) B[c][k] = 0.0;
+            B[freec[k]][k] = 1.0;
+            for (int rr = 0; rr < rank; ++rr) B[pc[rr]][k] = -M[rr][freec[k]];
+        }
+        // half-spaces lo_c <= (B t)_c <= hi_c; vertices = d of them tight
+        const int nh = 2 * nz;
+        auto bound = [&](int h, double &sgn) -> double {  // constraint h: sgn * (B t)_c <= value
+            const int c = h / 2;
+            const bool upper = (h % 2) == 0;
+            sgn = upper ? 1.0 : -1.0;
+            if (c == n) return upper ? 1.0 : 0.0;
+            return v_max[c];
+        };
+        const double tol = 1e-9;
+        auto consider = [&](const double *t) {
+            double z[9];
+            for (int c = 0; c < nz; ++c) { z[c] = 0.0; for (int k = 0; k < d; ++k) z[c] += B[c][k] * t[k]; }
+            for (int h = 0; h < nh; ++h) {
+                double sgn; const double val = bound(h, sgn);
+                if (sgn * z[h / 2] > val + tol * (1.0 + val)) return;
+            }
+            double nrm = 0.0;
+            for (int c = 0; c < n; ++c) nrm += z[c] * z[c];
+            if (z[n] > best_alpha + 1e-12 || (std::fabs(z[n] - best_alpha) <= 1e-12 && nrm < best_norm)) {
+                best_alpha = z[n]; best_norm = nrm;
+                for (int c = 0; c < nz; ++c) best_z[(size_t)c] = z[c];
+            }
+        };
+        auto vertex = [&](const int *idx) {  // the point where the d constraints idx[] are tight
+            double A[3][4];
+            for (int q = 0; q < d; ++q) {
+                double sgn; const double val = bound(idx[q], sgn);
+                for (int k = 0; k < d; ++k) A[q][k] = sgn * B[idx[q] / 2][k];
+                A[q][d] = val;
+            }
+            for (int q = 0; q < d; ++q) {  // Gauss-Jordan, partial pivoting
+                int pr = q;
+                for (int a = q + 1; a < d; ++a) if (std::fabs(A[a][q]) > std::fabs(A[pr][q])) pr = a;
+                if (std::fabs(A[pr][q]) < 1e-13) return;  // the constraints are parallel: no vertex
+                for (int k = 0; k <= d; ++k) std::swap(A[q][k], A[pr][k]);
+                for (int a = 0; a < d; ++a)
+                    if (a != q) {
+                        const double f = A[a][q] / A[q][q];
+                        for (int k = q; k <= d; ++k) A[a][k] -= f * A[q][k];
+                    }
+            }
+            double t[3];
+            for (int q = 0; q < d; ++q) t[q] = A[q][d] / A[q][q];
+            consider(t);
+        };
+        int idx[3];
+        for (idx[0] = 0; idx[0] < nh; ++idx[0]) {
+            if (d == 1) { vertex(idx); continue; }
+            for (idx[1] = idx[0] + 1; idx[1] < nh; ++idx[1]) {
+                if (d == 2) { vertex(idx); continue; }
+                for (idx[2] = idx[1] + 1; idx[2] < nh; ++idx[2]) vertex(idx);
+            }
+        }
+        // a redundant arm at the optimum: slide along the optimal face to the minimum-norm v
+        if (d == 2) {
+            // direction inside the face: alpha fixed -> B[n] . dt = 0
+            const double dt[2] = {-B[n][1], B[n][0]};
+            double dz[9], dd = 0.0, zd = 0.0;
+            for (int c = 0; c < nz; ++c) dz[c] = B[c][0] * dt[0] + B[c][1] * dt[1];
+            for (int c = 0; c < n; ++c) { dd += dz[c] * dz[c]; zd += best_z[(size_t)c] * dz[c]; }
+            if (dd > 0.0) {
+                double lo = -1e300, hi = 1e300;  // feasible range of the step along dz
+                for (int c = 0; c < n; ++c) {
+                    if (std::fabs(dz[c]) < 1e-14) continue;
+                    double a1 = (-v_max[c] - best_z[(size_t)c]) / dz[c], a2 = (v_max[c] - best_z[(size_t)c]) / dz[c];
+                    if (a1 > a2) std::swap(a1, a2);
+                    lo = std::max(lo, a1); hi = std::min(hi, a2);
+                }
+                double step = -zd / dd;
+                step = std::min(std::max(step, lo), hi);
+                if (lo <= hi && std::isfinite(step))
+                    for (int c = 0; c < n; ++c) best_z[(size_t)c] += step * dz[c];
+            }
+        }
+    }
+    if (alpha_out) *alpha_out = std::min(std::max(best_z[(size_t)n], 0.0), 1.0);
+    if (v_out) for (int c = 0; c < n; ++c) v_out[c] = best_z[(size_t)c];
+    return 0;
+}
+
+// lib.rs:165-183 of optik-cpp: the joint velocities only, malloc'ed; NULL = no solution.
+const double *optik_robot_diff_ik(const optik_robot *r, const double *x0, const double *V_WE, const double *v_max) {
+    if (!r) panic("null robot");
+    std::vector<double> v((size_t)r->n);
+    double alpha = 0.0;
+    const int rc = optik_robot_diff_ik_ex(r, x0, V_WE, v_max, nullptr, &alpha, v.data());
+    if (rc < 0) panic(g_robot_err);
+    if (rc != 0) return nullptr;
+    return malloc_copy(v.data(), v.size());
 }
 
 int optik_robot_chain_tables(const optik_robot *r, int32_t *n_joints, double *origins7, double *axes3,

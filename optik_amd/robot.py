@@ -4,7 +4,7 @@ bound with ctypes to the `optik_robot_*` C ABI of liboptik_amd.so (include/optik
 
 Poses are 4x4 homogeneous matrices given as nested lists / arrays in row-major
 order (optik-py/src/lib.rs:8-15); results come back as Python lists, as in the
-reference.  `diff_ik` is outside the accelerated path and raises.
+reference (`diff_ik` included: a small LP solved exactly on the host).
 """
 from __future__ import annotations
 
@@ -32,6 +32,7 @@ def _bind(L):
     L.optik_robot_ik_batch_ex.argtypes = [vp, C.POINTER(nat.SolverConfigC), C.c_int32, dp, dp, dp, dp, dp,
                                           C.POINTER(C.c_int32)]
     L.optik_robot_fk_ex.argtypes = [vp, dp, dp, dp]
+    L.optik_robot_diff_ik_ex.argtypes = [vp, dp, dp, dp, dp, C.POINTER(C.c_double), dp]
     L.optik_robot_joint_jacobian_ex.argtypes = [vp, dp, dp, dp]
     L.optik_robot_chain_tables.argtypes = [vp, C.POINTER(C.c_int32), dp, dp, C.POINTER(C.c_int32)]
     L.optik_robot_hip_chain.argtypes = [vp]
@@ -198,8 +199,21 @@ class Robot:
         return [(x[t].tolist(), float(f[t])) if found[t] else None for t in range(T)]
 
     def diff_ik(self, x0, V_WE, v_max, ee_offset=None):
-        raise NotImplementedError(
-            "diff_ik (lib.rs:123-239) is outside the accelerated random-restart IK path")
+        """Returns (alpha, v) or None (optik.pyi:43-49; lib.rs:123-239): the joint velocities
+        realising alpha * V_WE for the largest feasible 0 <= alpha <= 1 under |v_i| <= v_max_i."""
+        x0 = self._check_x(x0)
+        n = self.num_positions()
+        V = np.ascontiguousarray(V_WE, dtype=np.float64).reshape(6)
+        vm = np.ascontiguousarray(v_max, dtype=np.float64).reshape(n)
+        ee = _pose16(ee_offset) if ee_offset is not None else None
+        alpha, v = C.c_double(0.0), np.zeros(n)
+        rc = self._L.optik_robot_diff_ik_ex(self._h, _dp(x0), _dp(V), _dp(vm),
+                                            _dp(ee) if ee is not None else None, C.byref(alpha), _dp(v))
+        if rc < 0:
+            raise RuntimeError(_err(self._L))
+        if rc == 1:
+            return None
+        return alpha.value, v.tolist()
 
     # -- extensions ---------------------------------------------------------------
     def chain_tables(self):

@@ -229,3 +229,57 @@ def test_ik_batch_equals_individual_calls(panda, oracle, chains):
     far[:3, 3] = 50.0
     res = panda.ik_batch(SolverConfig(max_time=0.0, max_restarts=16), [targets[0], far], x0s[:2])
     assert res[1] is None and res[0] is not None
+
+
+def _world_jacobian(robot, x):
+    fk = np.array(robot.fk(x))
+    J = np.array(robot.joint_jacobian(x))
+    R = fk[:3, :3]
+    return np.vstack([R @ J[:3], R @ J[3:]])
+
+
+@pytest.mark.parametrize("name", ["ur3e", "panda"])
+def test_diff_ik(name, ur3e, panda):
+    """tests/test_ik.rs:185-209 (alpha in [0, 1], |v| <= v_max), plus what its TODO leaves out:
+    the Cartesian velocity is tracked (J_W v = alpha V) and alpha is the LP optimum (checked
+    against scipy's HiGHS on the same LP)."""
+    from scipy.optimize import linprog
+    robot = {"ur3e": ur3e, "panda": panda}[name]
+    n = robot.num_positions()
+    rng = np.random.default_rng(42)
+    lb, ub = (np.array(v) for v in robot.joint_limits())
+    eps = 1e-6
+    for trial in range(20):
+        x0 = rng.uniform(lb, ub)
+        v_max = np.ones(n) if trial % 2 == 0 else rng.uniform(0.2, 2.0, size=n)
+        V = rng.random(6) * (1.0 if trial % 3 else 0.05)  # small twists reach alpha = 1
+        out = robot.diff_ik(x0.tolist(), V.tolist(), v_max.tolist())
+        assert out is not None
+        alpha, v = out[0], np.array(out[1])
+        assert -eps <= alpha <= 1.0 + eps
+        assert np.all(v >= -v_max - eps) and np.all(v <= v_max + eps)
+        JW = _world_jacobian(robot, x0.tolist())
+        assert np.allclose(JW @ v, alpha * V, atol=1e-8)
+        # the same LP on the CPU: max alpha s.t. JW v - alpha V = 0, |v| <= v_max, 0 <= alpha <= 1
+        c = np.zeros(n + 1); c[n] = -1.0
+        res = linprog(c, A_eq=np.hstack([JW, -V[:, None]]), b_eq=np.zeros(6),
+                      bounds=[(-m, m) for m in v_max] + [(0.0, 1.0)], method="highs")
+        assert res.status == 0
+        assert abs(alpha - res.x[n]) < 1e-7, (alpha, res.x[n])
+        if name == "panda" and alpha > 1.0 - 1e-9:
+            # redundant arm, full twist reachable: the minimum-norm optimal v is returned
+            assert np.dot(v, v) <= np.dot(res.x[:n], res.x[:n]) + 1e-9
+
+
+def test_diff_ik_with_ee_offset(ur3e):
+    rng = np.random.default_rng(5)
+    lb, ub = (np.array(v) for v in ur3e.joint_limits())
+    x0 = rng.uniform(lb, ub)
+    off = np.eye(4); off[:3, 3] = [0.05, -0.02, 0.1]
+    V = rng.random(6)
+    alpha, v = ur3e.diff_ik(x0.tolist(), V.tolist(), [1.0] * 6, off.tolist())
+    fk = np.array(ur3e.fk(x0.tolist(), off.tolist()))
+    J = np.array(ur3e.joint_jacobian(x0.tolist(), off.tolist()))
+    JW = np.vstack([fk[:3, :3] @ J[:3], fk[:3, :3] @ J[3:]])
+    assert np.allclose(JW @ np.array(v), alpha * V, atol=1e-8)
+    assert 0.0 <= alpha <= 1.0
