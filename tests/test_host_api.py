@@ -158,3 +158,42 @@ def test_no_gpu_means_loud_failure(built):
         device.HipChain(**r.chain_tables())
     with pytest.raises(OptikHipError):
         device.probe(0, np.ones(4), np.ones(4))
+
+
+def test_headers_compile_as_c_and_link(built, tmp_path):
+    """include/optik.h and include/optik_hip.h are plain C (what a cgo / FFI binding consumes): a
+    C11 translation unit that uses the reference's 11 symbols compiles with gcc and links against
+    the shared library (no GPU call is made: it only loads a URDF and reads the joint limits)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "optik_amd", "csrc")
+    src = tmp_path / "abi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <stdlib.h>
+#include "optik.h"
+int main(int argc, char **argv) {
+    optik_robot *r = optik_robot_from_urdf_file(argv[1], argv[2], argv[3]);
+    unsigned n = optik_robot_num_positions(r);
+    const double *lim = optik_robot_joint_limits(r);
+    printf("%u %.17g %.17g\n", n, lim[0], lim[n]);
+    free((void *)lim);
+    optik_robot_set_parallelism(r, 4);
+    CSolverConfig cfg;
+    (void)cfg; (void)sizeof(optik_hip_ik_outputs);
+    /* referenced, not called (they need a GPU) */
+    void *fns[] = {(void *)optik_robot_ik, (void *)optik_robot_fk, (void *)optik_robot_joint_jacobian,
+                   (void *)optik_robot_diff_ik, (void *)optik_robot_random_configuration,
+                   (void *)optik_robot_from_urdf_str, (void *)optik_hip_ik_batch, (void *)optik_hip_engine_run};
+    printf("%d\n", (int)(sizeof fns / sizeof fns[0]));
+    optik_robot_free(r);
+    return 0;
+}
+''')
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src),
+                           "-L", libdir, "-loptik_amd", "-Wl,-rpath," + libdir, "-o", str(exe)])
+    path, base, ee = ROBOT_SPECS["panda"]
+    out = subprocess.check_output([str(exe), path, base, ee], text=True).split()
+    assert out[0] == "7" and out[3] == "8"
+    assert abs(float(out[1]) + 2.8973) < 1e-12 and abs(float(out[2]) - 2.8973) < 1e-12
