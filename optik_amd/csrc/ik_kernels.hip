@@ -22,6 +22,7 @@
 
 #include "../../include/optik_hip.h"
 #include "ik_engine.hpp"
+#include "ik_tail.hpp"
 
 using namespace optik;
 
@@ -238,6 +239,21 @@ __global__ __launch_bounds__(OPTIK_ENG_SLOT_BLOCK, OPTIK_ENG_UPD_WAVES) void eng
     eng_finish_body<N>(a, sch, local < a.n_slots ? slot : (size_t)a.slot_base, local, local < a.n_slots);
 }
 
+// the last restarts of a run, one per lane, to the end without kernel boundaries (ik_tail.hpp)
+template <int N, bool TIP>
+__global__ __launch_bounds__(WAVE) void eng_tail_kernel(const EngArgs a, const unsigned int *list,
+                                                        const unsigned int *count, int lanes) {
+    __shared__ ChainDev sch;
+    __shared__ double nnls_lds[NnlsLayout<N>::SLOTS * WAVE];
+    stage_chain(sch, a.chain);
+    const NnlsWs<N> ws{nnls_lds + threadIdx.x};
+    tail_wave<N, TIP>(a, sch, a.jobs, list, *count, lanes, ws);
+}
+__global__ __launch_bounds__(256) void eng_tail_list_kernel(const int32_t *state, unsigned long long n_slots,
+                                                            unsigned int *count, unsigned int *list) {
+    tail_list_body(state, n_slots, count, list);
+}
+
 __global__ __launch_bounds__(256) void eng_compact_scan_kernel(const CompactArgs c) { compact_scan_body(c); }
 __global__ __launch_bounds__(256) void eng_compact_move_kernel(const CompactArgs c) { compact_move_body(c); }
 
@@ -413,6 +429,7 @@ struct optik_hip_chain {
     hipEvent_t eng_fork_ev = nullptr, eng_join_ev[ENG_MAX_POOLS] = {};
     int eng_pools = 1;
     int eng_launches = 0;                      // NNLS launches of the last run, all sub-pools
+    int eng_tail_restarts = 0;                 // restarts (upper bound) the tail kernel took over in the last run
     int eng_compactions = 0;
     double *eng_prob = nullptr;            // 2 x [C][2n][n+1]
     double *eng_y = nullptr;               // 2 x [C][2n]
@@ -1097,6 +1114,9 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             unsigned int *pinned;
             hipEvent_t *ev;
             unsigned int *compact_counts;
+            unsigned long long last_in_use;  // latest in-use count the host has seen
+            unsigned long long initial_size;
+            bool drained;                    // a count below the sub-pool's size was seen: the queue is empty
         };
         Pool pools[ENG_MAX_POOLS];
         {
@@ -1120,6 +1140,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
                 P.stream = p2 == 0 ? stream : ch->eng_streams[p2];
                 P.blocks = (unsigned)((size + OPTIK_ENG_SLOT_BLOCK - 1) / OPTIK_ENG_SLOT_BLOCK);
                 P.trip = 0; P.pending = 0; P.ring = 0; P.done = false;
+                P.last_in_use = size; P.drained = false; P.initial_size = size;
                 P.pinned = ch->eng_pinned + 8 * p2;
                 P.ev = ch->eng_pool_ev[p2];
                 P.compact_counts = ch->eng_compact + 2 * p2;
@@ -1202,6 +1223,8 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
                 const unsigned long long in_use = P.pinned[prev];
                 (in_use * 2 < a.n_slots || a.n_slots < 16384 ? dbg_wait_drain : dbg_wait_bulk) += waited;
                 if (dbg_drain_t0 < 0.0 && in_use * 2 < P.a.n_slots) dbg_drain_t0 = std::chrono::duration<double>(std::chrono::steady_clock::now() - dbg_t0).count();
+                P.last_in_use = in_use;
+                if (in_use < P.initial_size) P.drained = true;
                 if (in_use == 0) P.done = true;
                 // drain: part of the live prefix no longer holds a restart (the count only
                 // falls once the queue is empty, so the lagging value is an upper bound)
@@ -1232,6 +1255,13 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             return 0;
         };
         ch->eng_launches = 0;
+        // hand-over to the tail kernel once this few restarts are left in all sub-pools together
+        unsigned long long tail_max = total / 16;
+        if (tail_max > 4096) tail_max = 4096;
+        if (tail_max < 64) tail_max = 64;
+        if (getenv("OPTIK_ENG_NO_TAIL")) tail_max = 0;
+        if (const char *e = getenv("OPTIK_ENG_TAIL_MAX")) tail_max = (unsigned long long)atoll(e);
+        ch->eng_tail_restarts = 0;
         for (bool all_done = false; !all_done;) {
             all_done = true;
             for (int p2 = 0; p2 < n_pools; ++p2) {
@@ -1240,6 +1270,47 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
                 if (prc != 0) return prc;
                 all_done = all_done && pools[p2].done;
             }
+            if (all_done || tail_max == 0) continue;
+            // every sub-pool still running has reported a count since the queue ran dry?
+            unsigned long long left = 0;
+            bool known = true;
+            for (int p2 = 0; p2 < n_pools; ++p2) {
+                const Pool &P = pools[p2];
+                if (P.done) continue;
+                known = known && P.drained;
+                left += P.last_in_use;
+            }
+            if (!known || left > tail_max) continue;
+            // the trip loops stop here; everything they queued precedes the tail on the caller's stream
+            for (int p2 = 1; p2 < n_pools; ++p2) {
+                if (pools[p2].done) continue;
+                HIP_TRY(hipEventRecord(ch->eng_join_ev[p2], pools[p2].stream));
+                HIP_TRY(hipStreamWaitEvent(stream, ch->eng_join_ev[p2], 0));
+            }
+            unsigned int *t_count = ch->eng_compact;          // (the compaction scratch is free from here on)
+            unsigned int *t_list = ch->eng_refill;            // [C]
+            HIP_TRY(hipMemsetAsync(t_count, 0, sizeof(unsigned int), stream));
+            hipLaunchKernelGGL(eng_tail_list_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream,
+                               ch->eng_i32, (unsigned long long)C, t_count, t_list);
+            const unsigned long long cap_waves = (unsigned long long)cus * (unsigned long long)ch->waves_per_cu;
+            unsigned long long lanes = (left + cap_waves - 1) / cap_waves;
+            if (lanes < 1) lanes = 1;
+            if (lanes > WAVE) lanes = WAVE;
+            const unsigned t_grid = (unsigned)((left + lanes - 1) / lanes);
+            const int lanes_i = (int)lanes;
+            EngArgs ta = pools[0].a;
+            ta.slot_base = 0;
+            ta.n_slots = C;
+#define M_TAIL_T(NN) hipLaunchKernelGGL((eng_tail_kernel<NN, true>), dim3(t_grid), dim3(WAVE), 0, stream, ta, t_list, t_count, lanes_i)
+#define M_TAIL_F(NN) hipLaunchKernelGGL((eng_tail_kernel<NN, false>), dim3(t_grid), dim3(WAVE), 0, stream, ta, t_list, t_count, lanes_i)
+            if (tip) DISPATCH_N(M_TAIL_T);
+            else DISPATCH_N(M_TAIL_F);
+#undef M_TAIL_T
+#undef M_TAIL_F
+            HIP_TRY(hipGetLastError());
+            ch->eng_tail_restarts = (int)left;
+            for (int p2 = 0; p2 < n_pools; ++p2) pools[p2].done = true;
+            all_done = true;
         }
         if (getenv("OPTIK_ENG_DEBUG"))
             fprintf(stderr, "[optik engine] loop %.2f ms (drain from %.2f ms), host waited on the GPU %.2f ms (bulk) + %.2f ms (drain), %d launches\n",
@@ -1285,6 +1356,9 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipStreamSynchronize(stream));
+        if (getenv("OPTIK_ENG_DEBUG"))
+            fprintf(stderr, "[optik engine] run complete %.2f ms after the loop started (tail kernel took over <= %d restarts)\n",
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - dbg_t0).count() * 1e3, ch->eng_tail_restarts);
         for (int k = 0; k < 4; ++k) {
             double sum = 0.0;
             int cnt = 0;
