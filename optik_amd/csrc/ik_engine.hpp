@@ -728,7 +728,7 @@ OPTIK_DEV void eng_update_body(const EngArgs &a, const ChainDev &ch, size_t slot
 // ---- kernel 3: cooperative NNLS over this trip's deferred problems ---------------
 
 template <int N, int CPL>
-OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a) {
+OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a, double *wave_lds) {
     constexpr int m = N + 1, n = 2 * N;
     constexpr int G = COOP_COLS / CPL;        // lanes per problem
     constexpr unsigned PPW = 64 / G;          // problems per wave
@@ -840,7 +840,8 @@ OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a) {
                 meta[(size_t)q * 2 + 1] = -1.0;
             }
         };
-        nnls_coop<N, CPL>(live, resume, a.nn_budget, (int)(gl * CPL), col, cs, mode, rnorm, iters, park);
+        nnls_coop<N, CPL>(live, resume, a.nn_budget, (int)(gl * CPL), col, cs, mode, rnorm, iters,
+                          wave_lds + group * COOP_WIN, wave_lds + PPW * COOP_WIN, park);
         if (live && mode != NNLS_SUSPENDED) {
 #pragma unroll
             for (int k = 0; k < CPL; ++k) {

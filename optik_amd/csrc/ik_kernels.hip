@@ -169,7 +169,15 @@ __global__ __launch_bounds__(WAVE) void ik_select_kernel(const SelectLaunch a) {
 #endif
 // threads per workgroup of the per-slot kernels (eval / update / finish)
 #ifndef OPTIK_ENG_SLOT_BLOCK
-#define OPTIK_ENG_SLOT_BLOCK 256
+#define OPTIK_ENG_SLOT_BLOCK 128
+#endif
+
+// ... of the update and finish kernels: one wave.  A workgroup keeps its LDS (the update
+// kernel's record window: 20 KB per wave) and its CU slots until its slowest wave is done;
+// with single-wave workgroups every wave gives them back as soon as it ends (measured
+// +7 % restarts/s against 256-thread workgroups).
+#ifndef OPTIK_ENG_UPD_BLOCK
+#define OPTIK_ENG_UPD_BLOCK 64
 #endif
 
 template <int N, bool TIP>
@@ -198,12 +206,12 @@ __global__ __launch_bounds__(OPTIK_ENG_SLOT_BLOCK, OPTIK_ENG_EVAL_WAVES) void en
 }
 
 template <int N>
-__global__ __launch_bounds__(OPTIK_ENG_SLOT_BLOCK, OPTIK_ENG_UPD_WAVES) void eng_update_kernel(const EngArgs a) {
+__global__ __launch_bounds__(OPTIK_ENG_UPD_BLOCK, OPTIK_ENG_UPD_WAVES) void eng_update_kernel(const EngArgs a) {
     __shared__ ChainDev sch;
     stage_chain(sch, a.chain);
-    const size_t local = (size_t)blockIdx.x * OPTIK_ENG_SLOT_BLOCK + threadIdx.x;
+    const size_t local = (size_t)blockIdx.x * OPTIK_ENG_UPD_BLOCK + threadIdx.x;
     const size_t slot = (size_t)a.slot_base + local;
-    __shared__ double rec_win[(OPTIK_ENG_SLOT_BLOCK / 64) * RecIo<N>::WINDOW];
+    __shared__ double rec_win[(OPTIK_ENG_UPD_BLOCK / 64) * RecIo<N>::WINDOW];
     eng_update_body<N>(a, sch, local < a.n_slots ? slot : (size_t)a.slot_base, local, local < a.n_slots,
                        rec_win + (threadIdx.x / 64u) * RecIo<N>::WINDOW);
 }
@@ -224,14 +232,18 @@ __global__ __launch_bounds__(256) void eng_bucket_kernel(const EngArgs a) { eng_
 
 template <int N>
 __global__ __launch_bounds__(OPTIK_ENG_NNLS_BLOCK, OPTIK_ENG_NNLS_WAVES) void eng_nnls_coop_kernel(const EngArgs a) {
-    eng_nnls_coop_body<N, OPTIK_ENG_CPL>(a);
+    constexpr int WL = coop_wave_lds<OPTIK_ENG_CPL>();
+    __shared__ __attribute__((aligned(16))) double win[(OPTIK_ENG_NNLS_BLOCK / 64) * WL];
+    double *wave_lds = win + (threadIdx.x / 64u) * WL;
+    if ((threadIdx.x & 63u) < 8) wave_lds[WL - 8 + (threadIdx.x & 63u)] = 0.0;
+    eng_nnls_coop_body<N, OPTIK_ENG_CPL>(a, wave_lds);
 }
 
 template <int N>
-__global__ __launch_bounds__(OPTIK_ENG_SLOT_BLOCK, OPTIK_ENG_UPD_WAVES) void eng_finish_kernel(const EngArgs a) {
+__global__ __launch_bounds__(OPTIK_ENG_UPD_BLOCK, OPTIK_ENG_UPD_WAVES) void eng_finish_kernel(const EngArgs a) {
     __shared__ ChainDev sch;
     stage_chain(sch, a.chain);
-    const size_t local = (size_t)blockIdx.x * OPTIK_ENG_SLOT_BLOCK + threadIdx.x;
+    const size_t local = (size_t)blockIdx.x * OPTIK_ENG_UPD_BLOCK + threadIdx.x;
     const size_t slot = (size_t)a.slot_base + local;
     // the host reads the in-use count of a chunk from pinned memory (no copy kernel on the stream)
     if (a.host_in_use && blockIdx.x == 0 && threadIdx.x == 0)
@@ -955,7 +967,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
     const unsigned long long total = ch->eng_jobs.back().dev.item_base + ch->eng_jobs.back().dev.n_items;
 
     // pool size: enough slots for every CU to hold several waves of each phase kernel
-    size_t cap = 393216;  // (3 x 131072: +2 % over 262144, 524288 is slower; measured at 48 pooled steps)
+    size_t cap = 344064;  // (3 x 114688; measured at 48 pooled steps: 294912 -> 22.8, 327680 .. 360448 -> 23.2, 393216 -> 21.9 M restarts/s)
     if (const char *e = std::getenv("OPTIK_ENGINE_SLOTS")) { const long v = std::atol(e); if (v >= 256) cap = (size_t)v; }
     size_t C = (size_t)((total + 255ull) / 256ull * 256ull);
     if (C > cap) C = cap;
@@ -1184,7 +1196,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
 #undef M_EVAL_F
                 }
                 TEV(0, 1); TEV(1, 0);
-#define M_UPD(NN) hipLaunchKernelGGL((eng_update_kernel<NN>), dim3(blocks), dim3(OPTIK_ENG_SLOT_BLOCK), 0, stream, a)
+#define M_UPD(NN) hipLaunchKernelGGL((eng_update_kernel<NN>), dim3(blocks * (OPTIK_ENG_SLOT_BLOCK / OPTIK_ENG_UPD_BLOCK)), dim3(OPTIK_ENG_UPD_BLOCK), 0, stream, a)
                 DISPATCH_N(M_UPD);
 #undef M_UPD
                 TEV(1, 1);
@@ -1203,7 +1215,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
                 DISPATCH_N(M_NNLS);
 #undef M_NNLS
                 TEV(2, 1); TEV(3, 0);
-#define M_FIN(NN) hipLaunchKernelGGL((eng_finish_kernel<NN>), dim3(blocks), dim3(OPTIK_ENG_SLOT_BLOCK), 0, stream, a)
+#define M_FIN(NN) hipLaunchKernelGGL((eng_finish_kernel<NN>), dim3(blocks * (OPTIK_ENG_SLOT_BLOCK / OPTIK_ENG_UPD_BLOCK)), dim3(OPTIK_ENG_UPD_BLOCK), 0, stream, a)
                 DISPATCH_N(M_FIN);
 #undef M_FIN
                 TEV(3, 1);

@@ -22,6 +22,18 @@ namespace optik {
 
 constexpr int COOP_COLS = 16;  // columns a group covers (2n <= 16)
 
+// LDS window of one group: the columns of set P by position (column p at doubles
+// [8 (p-1), 8 p): the triangular factor the solve of step six walks), then the solution z.
+// The registers stay the master copy; the window only serves reads whose index differs
+// from problem to problem (a register file cannot be indexed per lane, and selecting among
+// eight registers costs 14 instructions per value).  Stride 74: 16-byte aligned, and the 16
+// groups of a wave fall on disjoint banks for 16-byte reads.
+constexpr int COOP_WIN_Z = 64;
+constexpr int COOP_WIN = 74;
+// doubles of LDS per wave: the windows of its groups, then one column of zeros
+template <int CPL>
+constexpr int coop_wave_lds() { return (64 / (COOP_COLS / CPL)) * COOP_WIN + 8; }
+
 template <int G>
 struct Group {
     static OPTIK_DEV int base() { return (int)(threadIdx.x & 63u) & ~(G - 1); }
@@ -76,9 +88,12 @@ constexpr int NNLS_SUSPENDED = 7;  // mode: pass budget of this launch used up, 
 // `park(col, cs)` is called by the lanes of a group at the moment it is suspended, with cs
 // filled in (the caller stores matrix and state there and then: keeping the matrix live
 // past the loop just to store it costs ~280 B of scratch per lane).
+//
+// `win` = the group's LDS window, `zeros` = eight doubles of +0.0 in LDS (read only).
 template <int N, int CPL, class Park>
 OPTIK_DEV void nnls_coop(bool live, bool resume, int budget, int cid0, dvec8 (&col)[CPL], CoopCarry<CPL> &cs,
-                         int &mode_out, double &rnorm_out, int &iters_out, Park &&park) {
+                         int &mode_out, double &rnorm_out, int &iters_out, double *win, const double *zeros,
+                         Park &&park) {
     constexpr int m = N + 1, n = 2 * N;
     constexpr int G = COOP_COLS / CPL;
     static_assert(m <= 8, "a column is one dvec8");
@@ -108,6 +123,18 @@ OPTIK_DEV void nnls_coop(bool live, bool resume, int budget, int cid0, dvec8 (&c
         xv[k] = resume ? xv[k] : 0.0;
     }
     int rem_jj = 0;  // step eleven: position being removed
+    // copies the lane's columns that are in set P to the window, each at its position
+    auto mirror = [&](bool on) {
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            if (on && isc[k] && !inZ[k]) {
+                double *d = win + (pos[k] - 1) * 8;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) d[r] = col[k][r];
+            }
+        }
+    };
+    mirror(live && resume);
     // phases: 0 = step two (recompute duals, then choose), 1 = step three (choose again),
     // 2 = step six (solve), 3 = step eleven (remove), 4 = done, 5 = suspended at step two
     int phase = live ? 0 : 4;
@@ -282,6 +309,14 @@ OPTIK_DEV void nnls_coop(bool live, bool resume, int budget, int cid0, dvec8 (&c
             }
             nsetp = found ? npp1 : nsetp;
             npp1 = nsetp + 1;
+            // the column that entered P: untouched above the pivot row, ulp on it (the rows below
+            // are never read from the window)
+            if (found && Gr::lane() == 0) {
+                double *d = win + (nsetp - 1) * 8;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) d[r] = u[r];
+                d[nsetp - 1] = ulp;
+            }
             // rows the transformation leaves alone get -0.0 added (sign bit forced on a zero)
             unsigned rowkeep[8];
             dvec8 newv = 0.0;  // the chosen column after the transformation
@@ -324,40 +359,38 @@ OPTIK_DEV void nnls_coop(bool live, bool resume, int budget, int cid0, dvec8 (&c
 #pragma unroll
             for (int v = 1; v <= m; ++v)
                 if (wave_any(run && nsetp >= v)) nmax = v;
-            // step six: solve the triangular system on set P (positions nsetp .. 1)
-            double zown[CPL];
+            // step six: solve the triangular system on set P (positions nsetp .. 1); column ip of the
+            // factor comes from the window.  A group whose set P ends below ip reads the zeros
+            // instead and subtracts 0 * 0 = +0, which changes nothing (x - (+0) == x bit for bit).
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             int ppos[CPL];  // position of the lane's columns that are in P (1 .. nsetp), else 0
 #pragma unroll
-            for (int k = 0; k < CPL; ++k) {
-                zown[k] = 0.0;
-                ppos[k] = (run && isc[k] && !inZ[k]) ? pos[k] : 0;
-            }
+            for (int k = 0; k < CPL; ++k) ppos[k] = (run && isc[k] && !inZ[k]) ? pos[k] : 0;
 #pragma unroll
             for (int ip = m; ip >= 1; --ip) {
                 if (ip > nmax) continue;
                 const bool step = run && ip <= nsetp;
-                bool hk[CPL];
-                bool hit_any = false;
-                dvec8 mine = 0.0;
-#pragma unroll
-                for (int k = 0; k < CPL; ++k) {
-                    hk[k] = ppos[k] == ip;  // (implies step: positions in P are <= nsetp)
-                    hit_any = hit_any || hk[k];
-#pragma unroll
-                    for (int r = 1; r <= ip; ++r) mine[r - 1] = hk[k] ? col[k][r - 1] : mine[r - 1];
-                }
-                const int ol = Gr::find(hit_any);
-                const int src = Gr::base() + (ol < 0 ? 0 : ol);
+                const double *cp = step ? win + (ip - 1) * 8 : zeros;
                 dvec8 cv = 0.0;
 #pragma unroll
-                for (int r = 1; r <= ip; ++r) cv[r - 1] = __shfl(mine[r - 1], src, 64);
+                for (int r = 1; r <= ip; ++r) cv[r - 1] = cp[r - 1];
                 const double zi = zz[ip - 1] / cv[ip - 1];
+                const double zie = step ? zi : 0.0;
                 zz[ip - 1] = step ? zi : zz[ip - 1];
 #pragma unroll
-                for (int r = 1; r < ip; ++r) zz[r - 1] = step ? zz[r - 1] - zi * cv[r - 1] : zz[r - 1];
-#pragma unroll
-                for (int k = 0; k < CPL; ++k) zown[k] = hk[k] ? zi : zown[k];
+                for (int r = 1; r < ip; ++r) zz[r - 1] = zz[r - 1] - zie * cv[r - 1];
             }
+            // z of the lane's own columns, by position
+            if (run && Gr::lane() == 0) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) win[COOP_WIN_Z + r] = zz[r];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            double zown[CPL];
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) zown[k] = win[COOP_WIN_Z + (ppos[k] > 1 ? ppos[k] : 1) - 1];
             if (run) {
                 ++iter;
                 if (iter > itmax) { mode = 3; phase = 4; }
@@ -461,6 +494,7 @@ OPTIK_DEV void nnls_coop(bool live, bool resume, int budget, int cid0, dvec8 (&c
                     if (leaving[k]) { pos[k] = nsetp + 1; inZ[k] = true; }  // --iz1; indx[iz1] = i
                 if (nsetp <= 0) { mode = 3; phase = 4; }
             }
+            mirror(run);  // the columns left in P moved and were rotated
             if (phase == 3) {
                 // is every coefficient left in P feasible?  first offending position, in order
                 int bad = 0x7fffffff;
