@@ -6,19 +6,23 @@
 // For throughput the same arithmetic is re-cut along the phases instead:
 //
 //   * a pool of C restart *slots* lives in HBM as struct-of-arrays planes
-//     (plane k of slot s at [k*C + s]): thread s of every kernel owns slot s, so all
-//     state traffic is perfectly coalesced and no compaction lists are needed;
-//   * one *trip* = three kernels over the pool, each doing one phase for the slots
-//     that are in it:
-//       eng_eval_kernel    objective + gradient at x, NLopt bookkeeping / stop tests,
-//                          line-search accept/reject (rejected: next trial point)
-//       eng_update_kernel  accepted: BFGS update + LSQ direction when the step stays
-//                          inside the box (no LDS); finished: refill the slot with the
-//                          next (job, target, restart) work item from the queue
-//       eng_nnls_kernel    only the slots whose step hits a bound: Kraft's
-//                          LSQ -> LDP -> NNLS with the active set in LDS
-//     so the evaluation and update kernels run without LDS at several waves per SIMD
-//     and only the NNLS kernel is LDS-bound -- on a compacted list of slots;
+//     (plane k of slot s at [k*C + s]): thread s of every per-slot kernel owns slot s, so
+//     all state traffic is coalesced;
+//   * one *trip* = five kernels over a sub-pool, each doing one phase for the slots that
+//     are in it:
+//       eng_eval_kernel     objective + gradient at x, NLopt bookkeeping / stop tests,
+//                           line-search accept/reject (rejected: next trial point)
+//       eng_update_kernel   accepted: BFGS update, LSQ factor, the rows of the bounded
+//                           dual problem streamed into the slot's record; direction when
+//                           the step stays inside the box
+//       eng_bucket_kernel   this trip's problems ordered by predicted pass count, slots
+//                           to refill, in-use count
+//       eng_nnls_coop_kernel  Lawson-Hanson NNLS, one problem per four lanes
+//                           (ik_nnls_coop.hpp)
+//       eng_finish_kernel   refill of finished slots from the work queue; LDP tail,
+//                           descent test and next trial point from the NNLS answers
+//     (the last few thousand restarts of a run are finished by eng_tail_kernel,
+//     ik_tail.hpp, without kernel boundaries);
 //   * jobs (one optik_hip_ik_batch call each) submitted before a run share the pool:
 //     a slot that finishes a restart of one job may continue with another job's.
 //
@@ -177,10 +181,13 @@ OPTIK_DEV constexpr int rec_hhi(int i) { return rec_row<N>(i) + (N - i) + 1; }
 // Instead the lanes stage their records in an LDS window of the wave and the wave moves the
 // block with whole-line accesses.  The first REC_DIRECT elements of a record bypass the
 // window (it would not fit beside a second workgroup otherwise).
+#ifndef OPTIK_REC_STAGED
+#define OPTIK_REC_STAGED 38
+#endif
 template <int N>
 struct RecIo {
     static constexpr int LEN = (N * (N + 1) / 2 + 2 * N + 1) / 2 * 2;  // record length, even
-    static constexpr int STAGED = LEN < 38 ? LEN : 38;                 // elements of a record in the window
+    static constexpr int STAGED = LEN < OPTIK_REC_STAGED ? LEN : OPTIK_REC_STAGED;  // elements of a record in the window
     static constexpr int DIRECT = LEN - STAGED;                        // leading elements accessed in HBM
     static constexpr int ROW = STAGED + 1;                             // window row stride (odd: no bank conflicts)
     static constexpr int WINDOW = 64 * ROW;                            // doubles per wave
