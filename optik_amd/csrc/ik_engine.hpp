@@ -149,7 +149,16 @@ struct EngArgs {
     unsigned long long *trace;          // OPTIK_NNLS_TRACE builds: per-wave {start, end, hw id, passes} of one trip
 };
 
+// double planes: tiled by 64 slots -- the planes of slots [64 t, 64 t + 64) are contiguous
+// ([t][plane][64]): a wave still reads 512 contiguous bytes per plane, and its ~80 planes
+// sit in one 42 KB block instead of 80 places C * 8 bytes apart (DRAM pages, TLB reach)
+#ifndef OPTIK_ENG_PLANE_MAJOR
+#define ENG_D(plane, k) a.d[((size_t)(slot) >> 6) * (size_t)(EngLayout<N>::ND * 64) + (size_t)((plane) + (k)) * 64u + ((size_t)(slot) & 63u)]
+#define ENG_D_AT(base, nd, C, p, s) (base)[((size_t)(s) >> 6) * (size_t)((nd) * 64) + (size_t)(p) * 64u + ((size_t)(s) & 63u)]
+#else
 #define ENG_D(plane, k) a.d[(size_t)((plane) + (k)) * a.C + slot]
+#define ENG_D_AT(base, nd, C, p, s) (base)[(size_t)(p) * (C) + (s)]
+#endif
 #define ENG_I(plane) a.i32[(size_t)(plane) * a.C + slot]
 
 // Outcome of the direction search for one slot.
@@ -992,7 +1001,7 @@ OPTIK_DEV void compact_move_body(const CompactArgs &c) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= c.counts[1]) return;
     const size_t src = c.move_list[i], dst = c.free_list[i];
-    for (int p = 0; p < c.nd; ++p) c.d[(size_t)p * c.C + dst] = c.d[(size_t)p * c.C + src];
+    for (int p = 0; p < c.nd; ++p) ENG_D_AT(c.d, c.nd, c.C, p, dst) = ENG_D_AT(c.d, c.nd, c.C, p, src);
     for (int p = 0; p < c.ni; ++p) c.i32[(size_t)p * c.C + dst] = c.i32[(size_t)p * c.C + src];
     c.item[dst] = c.item[src];
     if (c.i32[src] == ST_NNLS) {
