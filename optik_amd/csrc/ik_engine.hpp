@@ -393,7 +393,8 @@ OPTIK_DEV int direction_search(const EngArgs &a, const ChainDev &ch, size_t slot
 }
 
 // Stores the result of a successful direction search: label 190 with alpha = 1.
-template <int N>
+// (STORE_G = false: the caller read g from the slot's plane and did not change it)
+template <int N, bool STORE_G = true>
 OPTIK_DEV void store_direction(const EngArgs &a, const ChainDev &ch, size_t slot,
                                const double (&l)[N * (N + 1) / 2], const double (&g)[N], const double (&x)[N],
                                const double (&s)[N], double f, double h3, int ireset, int iter) {
@@ -401,7 +402,7 @@ OPTIK_DEV void store_direction(const EngArgs &a, const ChainDev &ch, size_t slot
     (void)l;  // (already in the slot planes)
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        ENG_D(E::G, i) = g[i];
+        if (STORE_G) ENG_D(E::G, i) = g[i];
         const double si = s[i] * 1.0;  // s *= alpha (alpha = 1)
         ENG_D(E::S, i) = si;
         ENG_D(E::X0, i) = x[i];
@@ -420,13 +421,15 @@ OPTIK_DEV void store_direction(const EngArgs &a, const ChainDev &ch, size_t slot
     ENG_I(E::STATE) = ST_EVAL_TRIAL;
 }
 
-template <int N>
+template <int N, bool STORE_G = true>
 OPTIK_DEV void store_deferred(const EngArgs &a, size_t slot, const double (&l)[N * (N + 1) / 2],
                               const double (&g)[N], int ireset, int iter) {
     using E = EngLayout<N>;
     (void)l;  // (already in the slot planes)
+    if (STORE_G) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) ENG_D(E::G, i) = g[i];
+        for (int i = 0; i < N; ++i) ENG_D(E::G, i) = g[i];
+    }
     ENG_I(E::IRESET) = ireset;
     ENG_I(E::ITER) = iter;
     ENG_I(E::STATE) = ST_NNLS;
@@ -1056,8 +1059,8 @@ OPTIK_DEV void eng_finish_body(const EngArgs &a, const ChainDev &ch, size_t slot
         ENG_I(E::NNIT) = passes;
         const int out = direction_search<N>(a, ch, slot, a.parity ^ 1, true, l, g, x, f, ireset, iter, false, s, h3,
                                             status, passes, rec);
-        if (out == DIR_OK) store_direction<N>(a, ch, slot, l, g, x, s, f, h3, ireset, iter);
-        else if (out == DIR_DEFER) store_deferred<N>(a, slot, l, g, ireset, iter);
+        if (out == DIR_OK) store_direction<N, false>(a, ch, slot, l, g, x, s, f, h3, ireset, iter);
+        else if (out == DIR_DEFER) store_deferred<N, false>(a, slot, l, g, ireset, iter);
         else { ENG_I(E::STATUS) = status; ENG_I(E::ITER) = iter; ENG_I(E::STATE) = ST_DEAD; }
     }
 }
