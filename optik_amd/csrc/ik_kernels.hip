@@ -1017,7 +1017,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             ch->eng_order = nullptr; ch->eng_carry = nullptr;
             ch->eng_d = nullptr; ch->eng_i32 = nullptr; ch->eng_item = nullptr;
             ch->eng_prob = ch->eng_y = ch->eng_meta = nullptr;
-            HIP_TRY(hipMalloc(&ch->eng_d, sizeof(double) * (size_t)nd * ((AC + 63) / 64 * 64)));  // whole 64-slot tiles
+            HIP_TRY(hipMalloc(&ch->eng_d, sizeof(double) * (size_t)((nd + 1) / 2 * 2) * ((AC + 63) / 64 * 64)));  // whole 64-slot tiles of plane pairs
             HIP_TRY(hipMalloc(&ch->eng_i32, sizeof(int32_t) * (size_t)ni * AC));
             HIP_TRY(hipMalloc(&ch->eng_item, sizeof(unsigned long long) * AC));
             const size_t nn = (size_t)ch->n;
