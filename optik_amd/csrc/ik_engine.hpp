@@ -129,7 +129,7 @@ struct EngArgs {
     double *nn_meta;                    // [C][2] {mode + 8 * passes, rnorm | -1 = suspended, resume from nn_carry}
     double *nn_carry;                   // [C][NN_CARRY] matrix and state of a suspended solve
     int nn_budget;                      // solve passes per problem per launch (stragglers continue next trip)
-    int pad3;
+    int nn_slack;                       // ... and per problem: at most its predicted count + nn_slack
     int parity;                         // list consumed by this trip's NNLS kernel
     int pad2;
     unsigned int *n_active;             // slots holding a restart or waiting for one (bucket kernel; reset every trip)
@@ -772,21 +772,27 @@ OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a, double *wave_lds) {
 #ifdef OPTIK_NNLS_TRACE
     const unsigned long long t_begin = wall_clock64();
     const unsigned long long c_begin = clock64();
-    int max_passes = -1;
+    int max_passes = -1, sum_max = 0, sum_passes = 0, n_problems = 0;
 #endif
     for (unsigned q0 = wave * PPW; q0 < cnt; q0 += n_waves * PPW) {
         const bool live = q0 + group < cnt;
         // the slot of the (q0 + group)-th problem in class order, largest predicted pass count first
         unsigned q = 0;
+        int cls = NN_CLASSES - 1;
         {
             unsigned i = q0 + group;
             bool placed = !live;
             for (int c = NN_CLASSES - 1; c >= 0; --c) {
                 const unsigned cc = cls_cnt[c];
-                if (!placed && i < cc) { q = order[(size_t)c * a.C + i]; placed = true; }
+                if (!placed && i < cc) { q = order[(size_t)c * a.C + i]; placed = true; cls = c; }
                 if (!placed) i -= cc;
             }
         }
+        // pass budget of the problem in this launch: a little more than its predicted count (a
+        // wave runs as many passes as its slowest problem: the ~8 % that need more than
+        // predicted + slack continue next trip among the long ones instead of holding 15 others)
+        const int want = cls + a.nn_slack < 1 ? 1 : cls + a.nn_slack;
+        const int budget = (cls == NN_CLASSES - 1 || want > a.nn_budget) ? a.nn_budget : want;
         const bool resume = live && meta[(size_t)q * 2 + 1] < 0.0;
         dvec8 col[CPL];
         CoopCarry<CPL> cs;
@@ -863,7 +869,7 @@ OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a, double *wave_lds) {
                 meta[(size_t)q * 2 + 1] = -1.0;
             }
         };
-        nnls_coop<N, CPL>(live, resume, a.nn_budget, (int)(gl * CPL), col, cs, mode, rnorm, iters,
+        nnls_coop<N, CPL>(live, resume, budget, (int)(gl * CPL), col, cs, mode, rnorm, iters,
                           wave_lds + group * COOP_WIN, wave_lds + PPW * COOP_WIN, park);
         if (live && mode != NNLS_SUSPENDED) {
 #pragma unroll
@@ -876,9 +882,15 @@ OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a, double *wave_lds) {
 #ifdef OPTIK_NNLS_TRACE
         {
             int mp = live ? iters : -1;
+            int sp = (live && gl == 0) ? iters : 0, np = (live && gl == 0) ? 1 : 0;
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(mp, off, 64); mp = o > mp ? o : mp; }
+            for (int off = 32; off >= 1; off >>= 1) {
+                const int o = __shfl_xor(mp, off, 64); mp = o > mp ? o : mp;
+                sp += __shfl_xor(sp, off, 64); np += __shfl_xor(np, off, 64);
+            }
             max_passes = mp > max_passes ? mp : max_passes;
+            if (mp > 0) sum_max += mp;
+            sum_passes += sp; n_problems += np;
         }
 #endif
     }
@@ -890,8 +902,9 @@ OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a, double *wave_lds) {
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         a.trace[(size_t)wave * 4 + 0] = t_begin;
         a.trace[(size_t)wave * 4 + 1] = wall_clock64();
-        a.trace[(size_t)wave * 4 + 2] = ((unsigned long long)xcc << 32) | hw;
-        a.trace[(size_t)wave * 4 + 3] = ((unsigned long long)(clock64() - c_begin) << 16) | (unsigned long long)(max_passes & 0xffff);
+        a.trace[(size_t)wave * 4 + 2] = ((unsigned long long)(n_problems & 0xff) << 56) | ((unsigned long long)(sum_passes & 0xffff) << 40) |
+                                        ((unsigned long long)(xcc & 0xff) << 32) | hw;
+        a.trace[(size_t)wave * 4 + 3] = ((unsigned long long)(clock64() - c_begin) << 16) | (unsigned long long)(sum_max & 0xffff);  // (passes the wave ran: sum over its batches of the largest count)
     }
 #endif
 }

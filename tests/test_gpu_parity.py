@@ -267,6 +267,8 @@ def test_engine_pools_jobs_and_matches_the_single_kernel_path(dev, oracle, chain
     {"OPTIK_ENG_POOLS": "1", "OPTIK_ENGINE_SLOTS": "2048", "OPTIK_ENG_NNLS_BUDGET": "3"},
     {"OPTIK_ENGINE_SLOTS": "1000", "OPTIK_ENG_POOLS": "1"},                        # pool that is not a whole number of 64-slot tiles
     {"OPTIK_ENGINE_SLOTS": "1900", "OPTIK_ENG_POOLS": "3"},
+    {"OPTIK_ENG_NNLS_SLACK": "0", "OPTIK_ENGINE_SLOTS": "4096"},                   # every solve capped at its predicted pass count
+    {"OPTIK_ENG_NNLS_SLACK": "100"},                                               # ... or only by the launch budget
     {"OPTIK_ENG_NO_TAIL": "1"},                                                    # the engine finishes every restart itself
     {"OPTIK_ENG_TAIL_MAX": "100000", "OPTIK_ENGINE_SLOTS": "4096"},                # tail kernel takes over as soon as the queue is empty
     {"OPTIK_ENG_TAIL_MAX": "7", "OPTIK_ENG_POOLS": "2"},                           # ... or only for the last handful

@@ -10,7 +10,7 @@ t0 = a[:, 0].min()
 st = (a[:, 0] - t0).astype(np.float64) / 100.0  # us
 en = (a[:, 1] - t0).astype(np.float64) / 100.0
 hw = a[:, 2] & 0xFFFFFFFF
-xcc = (a[:, 2] >> 32).astype(np.int64)
+xcc = ((a[:, 2] >> 32) & 0xFF).astype(np.int64)
 passes = (a[:, 3] & 0xFFFF).astype(np.int16).astype(np.int64)
 cyc = (a[:, 3] >> 16).astype(np.float64)
 work = passes >= 0
