@@ -130,6 +130,8 @@ struct EngArgs {
     double *nn_carry;                   // [C][NN_CARRY] matrix and state of a suspended solve
     int nn_budget;                      // solve passes per problem per launch (stragglers continue next trip)
     int nn_slack;                       // ... and per problem: at most its predicted count + nn_slack
+    int nn_pred_viol;                   // prediction also from the number of violated bounds
+    int pad5;
     int parity;                         // list consumed by this trip's NNLS kernel
     int pad2;
     unsigned int *n_active;             // slots holding a restart or waiting for one (bucket kernel; reset every trip)
@@ -313,15 +315,19 @@ OPTIK_DEV int direction_pass(const EngArgs &a, const ChainDev &ch, size_t slot, 
 #pragma unroll
             for (int i = 0; i < N; ++i) { lo[i] = ch.lb[i] - x[i]; hi[i] = ch.ub[i] - x[i]; }
             OPTIK_SCHED_FENCE();
+            int nviol = 0;  // bounds the unconstrained step violates (the positive duals NNLS starts from)
             const bool need = lsq_bound_rows<N>(E, fv, lo, hi, [&](int i, const double (&row)[N], double h_lo, double h_hi) {
 #pragma unroll
                 for (int r = i; r < N; ++r) rec.put(rec_g<N>(i, r), row[r]);
                 rec.put(rec_hlo<N>(i), h_lo);
                 rec.put(rec_hhi<N>(i), h_hi);
+                nviol += (h_lo > 0.0 ? 1 : 0) + (h_hi > 0.0 ? 1 : 0);
             });
             DIR_PROBE(2);
             if (need) {
-                list_problem<N>(a, emit_parity, slot, pred);
+                // predicted solve passes: what the restart's previous problem took, or the number
+                // of violated bounds if that is larger (each enters the active set in its own pass)
+                list_problem<N>(a, emit_parity, slot, (a.nn_pred_viol && nviol > pred) ? nviol : pred);
                 a.nn_meta[slot * 2 + 1] = 0.0;  // a fresh problem, not a resumed one
                 return DIR_DEFER;
             }

@@ -1077,6 +1077,8 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
         a.nn_meta = ch->eng_meta;
         a.nn_budget = 6;
         if (const char *e = getenv("OPTIK_ENG_NNLS_BUDGET")) a.nn_budget = atoi(e) > 0 ? atoi(e) : 1;
+        a.nn_pred_viol = 1;
+        if (const char *e = getenv("OPTIK_ENG_NNLS_PRED_VIOL")) a.nn_pred_viol = atoi(e);
         a.nn_slack = 1;  // (measured: no per-problem cap 23.9, slack 1 -> 24.6, slack 0 -> 23.2 M restarts/s)
         if (const char *e = getenv("OPTIK_ENG_NNLS_SLACK")) a.nn_slack = atoi(e) > 0 ? atoi(e) : 0;
         a.nn_total = ch->eng_nn_total;
