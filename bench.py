@@ -35,7 +35,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r1g_engine_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r1h_engine_pmc_traffic.json")
 
 
 def pmc_traffic(kernel):
@@ -242,8 +242,13 @@ def main():
                     "algorithmic_bytes_per_unit": unit_bytes, "units_per_launch": units,
                     "unit_name": "bounded sub-problem" if dom == "nnls" else "slot-trip",
                     "all_kernels_ms": per_kernel, "trips": trips, "sub_pools": st["pools"],
-                    "launches": st["launches"], "restart_output_bytes": out_bytes}
-            info = {"grid": None, "block": 256, "lds_bytes": 0}
+                    "launches": st["launches"], "restart_output_bytes": out_bytes,
+                    # the whole path at its boundary: SURVEY 8d's per-restart figure with in-kernel
+                    # seeds (outputs only) and with the seeds counted as read (16n + 16)
+                    "path_boundary": {"bytes_per_restart": out_bytes, "bytes_per_restart_survey": 16 * n + 16,
+                                      "GBps": total / elapsed * out_bytes / 1e9,
+                                      "frac": total / elapsed * out_bytes / 1e9 / HBM_PEAK_GBS}}
+            info = {"grid": None, "block": 128, "lds_bytes": 0}
         else:
             kernel_ms, launches = hc.timing_mean()
             info = hc.last_launch()
