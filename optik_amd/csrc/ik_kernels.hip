@@ -967,7 +967,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
     const unsigned long long total = ch->eng_jobs.back().dev.item_base + ch->eng_jobs.back().dev.n_items;
 
     // pool size: enough slots for every CU to hold several waves of each phase kernel
-    size_t cap = 344064;  // (3 x 114688; measured at 48 pooled steps: 294912 -> 22.8, 327680 .. 360448 -> 23.2, 393216 -> 21.9 M restarts/s)
+    size_t cap = 393216;  // 3 sub-pools x 131072 slots = 2048 waves: one full round of the chip (2 waves per SIMD) per kernel; 417792 is 6 % slower
     if (const char *e = std::getenv("OPTIK_ENGINE_SLOTS")) { const long v = std::atol(e); if (v >= 256) cap = (size_t)v; }
     size_t C = (size_t)((total + 255ull) / 256ull * 256ull);
     if (C > cap) C = cap;
