@@ -277,6 +277,9 @@ def main():
                        "parallelism": f"restart-range x{world}",
                        "success_rate_last_step": n_success / R, "mean_evals_per_restart": mean_evals,
                        "objective_gradient_evals_per_s": total / elapsed * mean_evals,
+                       # global winner (lowest successful restart index) of every timed step: the
+                       # same for any number of ranks covering the same restart range
+                       "winner_index_per_step": [int(v) for v in winners.cpu().tolist()][:64],
                        "grid": info["grid"], "block": info["block"], "lds_bytes": info["lds_bytes"]},
             "roofline": roof,
         }
