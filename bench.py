@@ -35,7 +35,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r1i_engine_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r1j_engine_pmc_traffic.json")
 
 
 def pmc_traffic(kernel):

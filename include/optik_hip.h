@@ -156,8 +156,9 @@ int optik_hip_engine_last_trips(const optik_hip_chain *chain);
  * all sub-pools together (last_trips is the trip count of sub-pool 0). */
 int optik_hip_engine_last_pools(const optik_hip_chain *chain, int32_t *launches);
 /* Last run, when timing is enabled (optik_hip_set_timing): mean duration in ms of the four
- * phase kernels {eval, update, nnls, finish} over the trips of sub-pool 0 (HIP event pairs on
- * its launch stream, first 1024 trips; kernels of the other sub-pools run concurrently), and
+ * phase kernels {eval, update, nnls, finish} over the trips of sub-pool 0 (HIP start / stop events
+ * attached to the dispatches on its launch stream, first 1024 trips; kernels of the other
+ * sub-pools run concurrently), and
  * the number of bounded sub-problems solved by all sub-pools. */
 int optik_hip_engine_stats(const optik_hip_chain *chain, double *kernel_ms4, int32_t *sampled_trips,
                            uint64_t *nnls_problems);

@@ -10,6 +10,7 @@
 //   probe_kernel      elementary functions (test hook)
 // No CPU fallback exists: every entry point fails loudly without a device.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <algorithm>
 #include <chrono>
 
@@ -1189,21 +1190,28 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
                 const int ts = ch->eng_tcount;
                 // (the NNLS kernel -- the longest -- is timed on every trip, the others on every 8th)
                 const bool timed_all = timed && (trip % 8 == 0);
-#define TEV(kind, which) do { if (timed && (kind == 2 || timed_all)) { hipEvent_t &tev_ = ch->eng_tev[kind][ts][which]; if (!tev_) HIP_TRY(hipEventCreate(&tev_)); HIP_TRY(hipEventRecord(tev_, stream)); } } while (0)
-                TEV(0, 0);
+                // The events are attached to the kernel dispatch itself (hipExtLaunchKernelGGL): they
+                // carry the dispatch's own start and end timestamps -- what rocprofv3's kernel trace
+                // reports -- not the time the launch waits for CUs behind the other sub-pools' kernels.
+                hipEvent_t tev0 = nullptr, tev1 = nullptr;
+#define TEV(kind) do { tev0 = tev1 = nullptr; if (timed && (kind == 2 || timed_all)) {                                   \
+                        for (int w_ = 0; w_ < 2; ++w_) { hipEvent_t &tev_slot_ = ch->eng_tev[kind][ts][w_]; if (!tev_slot_) HIP_TRY(hipEventCreate(&tev_slot_)); } \
+                        tev0 = ch->eng_tev[kind][ts][0]; tev1 = ch->eng_tev[kind][ts][1]; } } while (0)
+#define ENG_LAUNCH(kernel, grid, block) do { if (tev0) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, tev0, tev1, 0, a); \
+                                             else hipLaunchKernelGGL(kernel, grid, block, 0, stream, a); } while (0)
+                TEV(0);
                 if (trip > 0) {
-#define M_EVAL_T(NN) hipLaunchKernelGGL((eng_eval_kernel<NN, true>), dim3(blocks), dim3(OPTIK_ENG_SLOT_BLOCK), 0, stream, a)
-#define M_EVAL_F(NN) hipLaunchKernelGGL((eng_eval_kernel<NN, false>), dim3(blocks), dim3(OPTIK_ENG_SLOT_BLOCK), 0, stream, a)
+#define M_EVAL_T(NN) ENG_LAUNCH((eng_eval_kernel<NN, true>), dim3(blocks), dim3(OPTIK_ENG_SLOT_BLOCK))
+#define M_EVAL_F(NN) ENG_LAUNCH((eng_eval_kernel<NN, false>), dim3(blocks), dim3(OPTIK_ENG_SLOT_BLOCK))
                     if (tip) DISPATCH_N(M_EVAL_T);
                     else DISPATCH_N(M_EVAL_F);
 #undef M_EVAL_T
 #undef M_EVAL_F
                 }
-                TEV(0, 1); TEV(1, 0);
-#define M_UPD(NN) hipLaunchKernelGGL((eng_update_kernel<NN>), dim3(blocks * (OPTIK_ENG_SLOT_BLOCK / OPTIK_ENG_UPD_BLOCK)), dim3(OPTIK_ENG_UPD_BLOCK), 0, stream, a)
+                TEV(1);
+#define M_UPD(NN) ENG_LAUNCH((eng_update_kernel<NN>), dim3(blocks * (OPTIK_ENG_SLOT_BLOCK / OPTIK_ENG_UPD_BLOCK)), dim3(OPTIK_ENG_UPD_BLOCK))
                 DISPATCH_N(M_UPD);
 #undef M_UPD
-                TEV(1, 1);
 #ifdef OPTIK_NNLS_TRACE
                 if (first_pool) {   // per-wave timeline of one steady-state trip (debug builds only)
                     static unsigned long long *tr = nullptr;
@@ -1214,16 +1222,16 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
                 }
 #endif
                 hipLaunchKernelGGL(eng_bucket_kernel, dim3((unsigned)cus), dim3(256), 0, stream, a);
-                TEV(2, 0);
-#define M_NNLS(NN) hipLaunchKernelGGL((eng_nnls_coop_kernel<NN>), dim3(nn_blocks), dim3(OPTIK_ENG_NNLS_BLOCK), 0, stream, a)
+                TEV(2);
+#define M_NNLS(NN) ENG_LAUNCH((eng_nnls_coop_kernel<NN>), dim3(nn_blocks), dim3(OPTIK_ENG_NNLS_BLOCK))
                 DISPATCH_N(M_NNLS);
 #undef M_NNLS
-                TEV(2, 1); TEV(3, 0);
-#define M_FIN(NN) hipLaunchKernelGGL((eng_finish_kernel<NN>), dim3(blocks * (OPTIK_ENG_SLOT_BLOCK / OPTIK_ENG_UPD_BLOCK)), dim3(OPTIK_ENG_UPD_BLOCK), 0, stream, a)
+                TEV(3);
+#define M_FIN(NN) ENG_LAUNCH((eng_finish_kernel<NN>), dim3(blocks * (OPTIK_ENG_SLOT_BLOCK / OPTIK_ENG_UPD_BLOCK)), dim3(OPTIK_ENG_UPD_BLOCK))
                 DISPATCH_N(M_FIN);
 #undef M_FIN
-                TEV(3, 1);
 #undef TEV
+#undef ENG_LAUNCH
                 if (timed) ch->eng_tcount += 1;
                 ch->eng_launches += 1;
             }
