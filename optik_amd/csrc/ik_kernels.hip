@@ -1185,11 +1185,12 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
                 a.parity = trip & 1;
                 a.trip = trip < TRIP_LOG_MAX ? trip : TRIP_LOG_MAX - 1;
                 a.host_in_use = (k == CHECK - 1) ? &P.pinned[P.ring] : nullptr;
-                // HIP event pairs around each kernel of every trip of sub-pool 0 (on its launch stream)
+                // start / stop events on the kernels of sub-pool 0 (on its launch stream)
                 const bool timed = first_pool && ch->timing && trip > 0 && ch->eng_tcount < optik_hip_chain::ENG_EV;
                 const int ts = ch->eng_tcount;
-                // (the NNLS kernel -- the longest -- is timed on every trip, the others on every 8th)
-                const bool timed_all = timed && (trip % 8 == 0);
+                // (the NNLS kernel -- the longest -- is timed on every trip, the others on every 8th: a
+                // trip in the middle of a chunk, not the one the host queues right after its wait)
+                const bool timed_all = timed && (trip % 8 == 2);
                 // The events are attached to the kernel dispatch itself (hipExtLaunchKernelGGL): they
                 // carry the dispatch's own start and end timestamps -- what rocprofv3's kernel trace
                 // reports -- not the time the launch waits for CUs behind the other sub-pools' kernels.
@@ -1388,7 +1389,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             int cnt = 0;
             for (int i = 0; i < ch->eng_tcount; ++i) {
                 const int trip_i = i + 1;  // sample i was taken on trip i + 1
-                if (k != 2 && trip_i % 8 != 0) continue;
+                if (k != 2 && trip_i % 8 != 2) continue;
                 float ms = 0.0f;
                 HIP_TRY(hipEventElapsedTime(&ms, ch->eng_tev[k][i][0], ch->eng_tev[k][i][1]));
                 sum += ms;
@@ -1407,7 +1408,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
                     const int i = t - 1;
                     if (i >= 0 && i < ch->eng_tcount)
                         for (int k = 0; k < 4; ++k)
-                            if (k == 2 || t % 8 == 0) hipEventElapsedTime(&ms[k], ch->eng_tev[k][i][0], ch->eng_tev[k][i][1]);
+                            if (k == 2 || t % 8 == 2) hipEventElapsedTime(&ms[k], ch->eng_tev[k][i][0], ch->eng_tev[k][i][1]);
                     fprintf(fp, "%d,%u,%u,%.4f,%.4f,%.4f,%.4f\n", t, h[2 * t], h[2 * t + 1], ms[0], ms[1], ms[2], ms[3]);
                 }
                 fclose(fp);
