@@ -161,6 +161,15 @@ def main():
     begin, end = shard_range(0, R * world, rank, world)
     n_buf = max(K, W) if args.path == "engine" else 1
     bufs = [hc.alloc_ik_buffers(1, R, per_restart=True) for _ in range(n_buf)]
+    # the per-step winner records are rows of two tensors, so that the winners of a whole run are
+    # selected (and, with several ranks, reduced) in one piece without gathering them first
+    win_idx_all = torch.zeros(n_buf, dtype=torch.int64, device=dev)
+    win_key_all = torch.zeros(n_buf, dtype=torch.float64, device=dev)
+    for k, b in enumerate(bufs):
+        b["win_idx"] = win_idx_all[k:k + 1]
+        b["win_key"] = win_key_all[k:k + 1]
+    if args.path == "engine":
+        hc.engine_reserve()  # the slot pool: allocated with the other buffers, not inside a run
     torch.cuda.synchronize()
 
     def run_steps(first, count):
@@ -174,8 +183,7 @@ def main():
                     i = first + k
                     hc.engine_submit(cfg, targets[i:i + 1], x0[i:i + 1], begin, end, bufs=bufs[k])
                 hc.engine_run()
-            stacked = {"win_idx": torch.cat([bufs[k]["win_idx"] for k in range(count)]),
-                       "win_key": torch.cat([bufs[k]["win_key"] for k in range(count)])}
+            stacked = {"win_idx": win_idx_all[:count], "win_key": win_key_all[:count]}
             return select_winner(stacked, "speed", distributed)  # one collective for all steps
         winners = []
         for k in range(count):

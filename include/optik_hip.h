@@ -149,6 +149,10 @@ int optik_hip_engine_submit(optik_hip_chain *chain, const optik_solver_config *c
                             const double *ee_offset7, uint64_t restart_begin, uint64_t restart_end,
                             uint32_t flags, const optik_hip_ik_outputs *out);
 int optik_hip_engine_run(optik_hip_chain *chain, void *stream);
+/* Allocates the engine's slot pool and work buffers for up to `slots` slots (0 = the default
+ * capacity, 393 216) ahead of the first run -- set-up a caller does once; runs allocate on
+ * demand otherwise. */
+int optik_hip_engine_reserve(optik_hip_chain *chain, uint64_t slots, void *stream);
 int optik_hip_engine_last_trips(const optik_hip_chain *chain);
 /* The slot pool of a run is split into sub-pools (OPTIK_ENG_POOLS, default 3; at most 4),
  * each with its own HIP stream, so that kernels of different sub-pools overlap.  Returns

@@ -959,6 +959,65 @@ int optik_hip_engine_submit(optik_hip_chain *ch, const optik_solver_config *cfg,
     return 0;
 }
 
+// Device memory and streams of the streaming engine for a pool of AC slots (no-op when the
+// chain already holds that much).  nd / ni / rec_len: planes and record length of the chain's n.
+static int engine_reserve(optik_hip_chain *ch, size_t AC, int nd, int ni, int rec_len, hipStream_t stream) {
+    if (AC > ch->eng_C) {
+        if (ch->eng_d) HIP_TRY(hipFree(ch->eng_d));
+        if (ch->eng_i32) HIP_TRY(hipFree(ch->eng_i32));
+        if (ch->eng_item) HIP_TRY(hipFree(ch->eng_item));
+        if (ch->eng_prob) HIP_TRY(hipFree(ch->eng_prob));
+        if (ch->eng_y) HIP_TRY(hipFree(ch->eng_y));
+        if (ch->eng_meta) HIP_TRY(hipFree(ch->eng_meta));
+        if (ch->eng_order) HIP_TRY(hipFree(ch->eng_order));
+        if (ch->eng_carry) HIP_TRY(hipFree(ch->eng_carry));
+        if (ch->eng_compact) HIP_TRY(hipFree(ch->eng_compact));
+        if (ch->eng_list) HIP_TRY(hipFree(ch->eng_list));
+        if (ch->eng_refill) HIP_TRY(hipFree(ch->eng_refill));
+        ch->eng_compact = nullptr; ch->eng_list = nullptr; ch->eng_refill = nullptr;
+        ch->eng_order = nullptr; ch->eng_carry = nullptr;
+        ch->eng_d = nullptr; ch->eng_i32 = nullptr; ch->eng_item = nullptr;
+        ch->eng_prob = ch->eng_y = ch->eng_meta = nullptr;
+        HIP_TRY(hipMalloc(&ch->eng_d, sizeof(double) * (size_t)((nd + 1) / 2 * 2) * ((AC + 63) / 64 * 64)));  // whole 64-slot tiles of plane pairs
+        HIP_TRY(hipMalloc(&ch->eng_i32, sizeof(int32_t) * (size_t)ni * AC));
+        HIP_TRY(hipMalloc(&ch->eng_item, sizeof(unsigned long long) * AC));
+        const size_t nn = (size_t)ch->n;
+        HIP_TRY(hipMalloc(&ch->eng_prob, sizeof(double) * AC * rec_len));
+        HIP_TRY(hipMalloc(&ch->eng_y, sizeof(double) * AC * (2 * nn)));
+        HIP_TRY(hipMalloc(&ch->eng_meta, sizeof(double) * AC * 2));
+        HIP_TRY(hipMalloc(&ch->eng_list, sizeof(unsigned int) * 2 * AC));
+        HIP_TRY(hipMalloc(&ch->eng_refill, sizeof(unsigned int) * AC));
+        HIP_TRY(hipMalloc(&ch->eng_order, sizeof(unsigned int) * 2 * NN_CLASSES * AC));
+        HIP_TRY(hipMalloc(&ch->eng_carry, sizeof(double) * NN_CARRY * AC));
+        HIP_TRY(hipMalloc(&ch->eng_compact, sizeof(unsigned int) * (2 * ENG_MAX_POOLS + 2 * AC)));
+        ch->eng_C = AC;
+        // first touch of the big buffers here, not in the first run that uses the slots (a
+        // warm-up of one step followed by a 5-step run paid ~10 ms for it inside the timed run)
+        HIP_TRY(hipMemsetAsync(ch->eng_d, 0, sizeof(double) * (size_t)((nd + 1) / 2 * 2) * ((AC + 63) / 64 * 64), stream));
+        HIP_TRY(hipMemsetAsync(ch->eng_i32, 0, sizeof(int32_t) * (size_t)ni * AC, stream));
+        HIP_TRY(hipMemsetAsync(ch->eng_item, 0, sizeof(unsigned long long) * AC, stream));
+        HIP_TRY(hipMemsetAsync(ch->eng_prob, 0, sizeof(double) * AC * rec_len, stream));
+        HIP_TRY(hipMemsetAsync(ch->eng_y, 0, sizeof(double) * AC * (2 * nn), stream));
+        HIP_TRY(hipMemsetAsync(ch->eng_meta, 0, sizeof(double) * AC * 2, stream));
+        HIP_TRY(hipMemsetAsync(ch->eng_order, 0, sizeof(unsigned int) * 2 * NN_CLASSES * AC, stream));
+        HIP_TRY(hipMemsetAsync(ch->eng_carry, 0, sizeof(double) * NN_CARRY * AC, stream));
+    }
+    if (!ch->eng_djobs) HIP_TRY(hipMalloc(&ch->eng_djobs, sizeof(EngJob) * ENG_MAX_JOBS));
+    constexpr int PCB = ENG_POOL_COUNTERS;
+    if (!ch->eng_counters) HIP_TRY(hipMalloc(&ch->eng_counters, ENG_MAX_POOLS * PCB * sizeof(unsigned int)));
+    if (!ch->eng_pinned) HIP_TRY(hipHostMalloc(&ch->eng_pinned, ENG_MAX_POOLS * 8 * sizeof(unsigned int)));
+    if (!ch->queue) HIP_TRY(hipMalloc(&ch->queue, sizeof(unsigned long long)));
+    if (!ch->eng_nn_total) HIP_TRY(hipMalloc(&ch->eng_nn_total, sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(ch->eng_nn_total, 0, sizeof(unsigned long long), stream));
+    for (auto &pe : ch->eng_pool_ev) for (auto &e : pe) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (!ch->eng_fork_ev) HIP_TRY(hipEventCreateWithFlags(&ch->eng_fork_ev, hipEventDisableTiming));
+    for (int p2 = 1; p2 < ENG_MAX_POOLS; ++p2) {
+        if (!ch->eng_streams[p2]) HIP_TRY(hipStreamCreateWithFlags(&ch->eng_streams[p2], hipStreamNonBlocking));
+        if (!ch->eng_join_ev[p2]) HIP_TRY(hipEventCreateWithFlags(&ch->eng_join_ev[p2], hipEventDisableTiming));
+    }
+    return 0;
+}
+
 int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
     if (!ch) return fail(OPTIK_HIP_EINVAL, "bad argument");
     hipStream_t stream = (hipStream_t)stream_v;
@@ -985,6 +1044,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
         }
     }
     int rc = 0;
+    const auto dbg_entry = std::chrono::steady_clock::now();
     auto run = [&]() -> int {
         // M(NN) is a statement macro instantiated for the chain's n
 #define DISPATCH_N(M)                                                                            \
@@ -999,52 +1059,13 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
 #define M_LAYOUT(NN) nd = EngLayout<NN>::ND; ni = EngLayout<NN>::NI; rec_len = rec_stride<NN>()
         DISPATCH_N(M_LAYOUT);
 #undef M_LAYOUT
-        if (C > ch->eng_C) {
+        {
             // a run of bench size reserves the full capacity at once: the next, larger run (a
             // warm-up followed by the timed run) does not reallocate ~1 GB inside its timed region
-            const size_t AC = (C >= 65536 && cap > C) ? cap : C;
-            if (ch->eng_d) HIP_TRY(hipFree(ch->eng_d));
-            if (ch->eng_i32) HIP_TRY(hipFree(ch->eng_i32));
-            if (ch->eng_item) HIP_TRY(hipFree(ch->eng_item));
-            if (ch->eng_prob) HIP_TRY(hipFree(ch->eng_prob));
-            if (ch->eng_y) HIP_TRY(hipFree(ch->eng_y));
-            if (ch->eng_meta) HIP_TRY(hipFree(ch->eng_meta));
-            if (ch->eng_order) HIP_TRY(hipFree(ch->eng_order));
-            if (ch->eng_carry) HIP_TRY(hipFree(ch->eng_carry));
-            if (ch->eng_compact) HIP_TRY(hipFree(ch->eng_compact));
-            if (ch->eng_list) HIP_TRY(hipFree(ch->eng_list));
-            if (ch->eng_refill) HIP_TRY(hipFree(ch->eng_refill));
-            ch->eng_compact = nullptr; ch->eng_list = nullptr; ch->eng_refill = nullptr;
-            ch->eng_order = nullptr; ch->eng_carry = nullptr;
-            ch->eng_d = nullptr; ch->eng_i32 = nullptr; ch->eng_item = nullptr;
-            ch->eng_prob = ch->eng_y = ch->eng_meta = nullptr;
-            HIP_TRY(hipMalloc(&ch->eng_d, sizeof(double) * (size_t)((nd + 1) / 2 * 2) * ((AC + 63) / 64 * 64)));  // whole 64-slot tiles of plane pairs
-            HIP_TRY(hipMalloc(&ch->eng_i32, sizeof(int32_t) * (size_t)ni * AC));
-            HIP_TRY(hipMalloc(&ch->eng_item, sizeof(unsigned long long) * AC));
-            const size_t nn = (size_t)ch->n;
-            HIP_TRY(hipMalloc(&ch->eng_prob, sizeof(double) * AC * rec_len));
-            HIP_TRY(hipMalloc(&ch->eng_y, sizeof(double) * AC * (2 * nn)));
-            HIP_TRY(hipMalloc(&ch->eng_meta, sizeof(double) * AC * 2));
-            HIP_TRY(hipMalloc(&ch->eng_list, sizeof(unsigned int) * 2 * AC));
-            HIP_TRY(hipMalloc(&ch->eng_refill, sizeof(unsigned int) * AC));
-            HIP_TRY(hipMalloc(&ch->eng_order, sizeof(unsigned int) * 2 * NN_CLASSES * AC));
-            HIP_TRY(hipMalloc(&ch->eng_carry, sizeof(double) * NN_CARRY * AC));
-            HIP_TRY(hipMalloc(&ch->eng_compact, sizeof(unsigned int) * (2 * ENG_MAX_POOLS + 2 * AC)));
-            ch->eng_C = AC;
+            const int arc = engine_reserve(ch, (C >= 65536 && cap > C) ? cap : C, nd, ni, rec_len, stream);
+            if (arc) return arc;
         }
-        if (!ch->eng_djobs) HIP_TRY(hipMalloc(&ch->eng_djobs, sizeof(EngJob) * ENG_MAX_JOBS));
         constexpr int PCB = ENG_POOL_COUNTERS;
-        if (!ch->eng_counters) HIP_TRY(hipMalloc(&ch->eng_counters, ENG_MAX_POOLS * PCB * sizeof(unsigned int)));
-        if (!ch->eng_pinned) HIP_TRY(hipHostMalloc(&ch->eng_pinned, ENG_MAX_POOLS * 8 * sizeof(unsigned int)));
-        if (!ch->queue) HIP_TRY(hipMalloc(&ch->queue, sizeof(unsigned long long)));
-        if (!ch->eng_nn_total) HIP_TRY(hipMalloc(&ch->eng_nn_total, sizeof(unsigned long long)));
-        HIP_TRY(hipMemsetAsync(ch->eng_nn_total, 0, sizeof(unsigned long long), stream));
-        for (auto &pe : ch->eng_pool_ev) for (auto &e : pe) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        if (!ch->eng_fork_ev) HIP_TRY(hipEventCreateWithFlags(&ch->eng_fork_ev, hipEventDisableTiming));
-        for (int p2 = 1; p2 < ENG_MAX_POOLS; ++p2) {
-            if (!ch->eng_streams[p2]) HIP_TRY(hipStreamCreateWithFlags(&ch->eng_streams[p2], hipStreamNonBlocking));
-            if (!ch->eng_join_ev[p2]) HIP_TRY(hipEventCreateWithFlags(&ch->eng_join_ev[p2], hipEventDisableTiming));
-        }
         ch->eng_tcount = 0;
 
         std::vector<EngJob> hj(n_jobs);
@@ -1173,6 +1194,8 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
         double dbg_wait_bulk = 0.0, dbg_wait_drain = 0.0;  // host time blocked on the GPU (OPTIK_ENG_DEBUG)
         double dbg_drain_t0 = -1.0;  // when the first sub-pool fell under half of its live prefix
         const auto dbg_t0 = std::chrono::steady_clock::now();
+        if (getenv("OPTIK_ENG_DEBUG"))
+            fprintf(stderr, "[optik engine] set-up %.2f ms (C = %zu)\n", std::chrono::duration<double>(dbg_t0 - dbg_entry).count() * 1e3, (size_t)C);
         // queues CHECK trips of one sub-pool, then looks at the in-use count of its previous chunk
         auto advance = [&](Pool &P, bool first_pool) -> int {
             EngArgs &a = P.a;
@@ -1436,6 +1459,28 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
     return rc;
 }
 
+/* Allocates the engine's slot pool and work buffers for up to `slots` slots (0 = the default
+ * capacity) ahead of the first run: set-up, not part of a timed region. */
+int optik_hip_engine_reserve(optik_hip_chain *ch, uint64_t slots, void *stream_v) {
+    if (!ch) return fail(OPTIK_HIP_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> lock(ch->mu);
+    size_t cap = 393216;
+    if (const char *e = std::getenv("OPTIK_ENGINE_SLOTS")) { const long v = std::atol(e); if (v >= 256) cap = (size_t)v; }
+    const size_t AC = slots ? (size_t)((slots + 255) / 256 * 256) : cap;
+    int nd = 0, ni = 0, rec_len = 0;
+    switch (ch->n) {
+#define M_LAYOUT(NN) case NN: nd = EngLayout<NN>::ND; ni = EngLayout<NN>::NI; rec_len = rec_stride<NN>(); break
+    M_LAYOUT(2); M_LAYOUT(3); M_LAYOUT(4); M_LAYOUT(5); M_LAYOUT(6); M_LAYOUT(7);
+#undef M_LAYOUT
+    default: return fail(OPTIK_HIP_EUNSUPPORTED, OPTIK_N_RANGE_MSG);
+    }
+    hipStream_t stream = (hipStream_t)stream_v;
+    const int rc = engine_reserve(ch, AC, nd, ni, rec_len, stream);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+}
+
 int optik_hip_engine_last_trips(const optik_hip_chain *ch) { return ch ? ch->eng_trips : 0; }
 
 int optik_hip_engine_last_pools(const optik_hip_chain *ch, int32_t *launches) {
@@ -1518,6 +1563,14 @@ void optik_hip_set_timing(optik_hip_chain *ch, int32_t enabled) {
     std::lock_guard<std::mutex> lock(ch->mu);
     ch->timing = enabled;
     ch->ev_count = 0;
+    if (enabled) {
+        // the engine's per-trip events are created here, not lazily inside a timed run
+        for (int k = 0; k < 4; ++k)
+            for (int i = 0; i < optik_hip_chain::ENG_EV; ++i)
+                for (int w = 0; w < 2; ++w)
+                    if (!ch->eng_tev[k][i][w] && (k == 2 || (i + 1) % 8 == 2))
+                        (void)hipEventCreate(&ch->eng_tev[k][i][w]);
+    }
 }
 
 /* OPTIK_PROFILE builds: phase cycle totals of the last solve launch (8 words:

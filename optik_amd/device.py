@@ -152,6 +152,10 @@ class HipChain:
         self._pending.append((targets, x0, bufs))  # keep the buffers alive
         return bufs
 
+    def engine_reserve(self, slots=0):
+        """Allocate the engine's slot pool ahead of the first run (0 = default capacity)."""
+        nat.check(nat.lib().optik_hip_engine_reserve(self._h, int(slots), _stream_ptr()))
+
     def engine_run(self):
         """Run every submitted job to completion (blocking) and their selections."""
         nat.check(nat.lib().optik_hip_engine_run(self._h, _stream_ptr()))
