@@ -119,6 +119,38 @@ def test_config3_ur10_one_million_tight_tolerance(robots):
     assert h == _checksum(out)
 
 
+def test_config4_panda_four_million_sharded_quality(robots):
+    """Panda, 2^22 restarts as 8 shards of 524 288 (one per GPU), SolutionMode::Quality: the
+    winner the two min-all-reduces of optik_amd.parallel would pick from the shards' winner
+    records is the winner of the unsharded run, and every shard's records are the matching
+    slice of it (here the eight ranges run one after the other on the one GPU of the box)."""
+    from optik_amd import _native as nat
+    from optik_amd.parallel import I64_MAX, local_key
+    robot = robots["panda"]
+    hc = robot.hip_chain("cuda:0")
+    tg, x0, lb, ub = _targets(robot, hc, 1, 4)
+    cfg = nat.make_config("quality", tol_f=1e-6)
+    R, G = 1 << 22, 8
+    whole = hc.engine_submit(cfg, tg, x0, 0, R, per_restart=False)
+    hc.engine_run()
+    torch.cuda.synchronize()
+    shards = [hc.engine_submit(cfg, tg, x0, g * (R // G), (g + 1) * (R // G), per_restart=False) for g in range(G)]
+    hc.engine_run()
+    torch.cuda.synchronize()
+    keys, idxs = zip(*(local_key(sh, "quality") for sh in shards))
+    key = torch.stack(keys).min(0).values                      # all-reduce MIN of the keys
+    cand = [torch.where(k == key, i, torch.full_like(i, I64_MAX)) for k, i in zip(keys, idxs)]
+    win = torch.stack(cand).min(0).values                      # all-reduce MIN of the indices
+    assert int(win[0]) == int(whole["win_idx"][0]) >= 0
+    owner = int(win[0]) // (R // G)
+    assert torch.equal(shards[owner]["win_x"], whole["win_x"]) and torch.equal(shards[owner]["win_key"], whole["win_key"])
+    # the winner is a solution: FK(x) == target to the tolerance tol_f implies, inside the limits
+    x = whole["win_x"][0]
+    assert _pose_error(hc, x.view(-1, 1), tg[0]).max().item() < 2e-3
+    assert (x >= torch.tensor(lb, device="cuda")).all() and (x <= torch.tensor(ub, device="cuda")).all()
+    assert abs(float(whole["win_key"][0]) - float((x - x0[0]).norm())) < 1e-9
+
+
 def test_config5_motion_planning_batch(robots):
     """4096 independent targets x 256 restarts each (512 targets is one GPU's share), Speed."""
     from optik_amd import _native as nat
