@@ -85,6 +85,18 @@ int optik_hip_chain_create(const double *origins, const double *axes, const int3
 void optik_hip_chain_destroy(optik_hip_chain *chain);
 int32_t optik_hip_chain_num_positions(const optik_hip_chain *chain);
 
+/* Which rand 0.9.2 code path the restart seeds restate for `rng.random_range(lb..=ub)`
+ * (lib.rs:89).  SINGLE_INCLUSIVE (default): UniformFloat::sample_single_inclusive, which is
+ * what Rng::random_range dispatches to for a RangeInclusive<f64> -- scale = ub - lb.
+ * NEW_INCLUSIVE: Uniform::new_inclusive(lb, ub).sample(rng) -- scale = (ub - lb) / (1 - eps),
+ * decreased by ulps until scale * (1 - eps) + lb <= ub.  The two differ in the last bits
+ * of every seed; the kernels only see the precomputed scale.  The environment variable
+ * OPTIK_RANDOM_RANGE_RULE=new_inclusive selects the second rule for chains created after
+ * it is set.  Not to be called while a launch on the chain is in flight. */
+enum { OPTIK_HIP_RANGE_SINGLE_INCLUSIVE = 0, OPTIK_HIP_RANGE_NEW_INCLUSIVE = 1 };
+int optik_hip_chain_set_range_rule(optik_hip_chain *chain, int32_t rule);
+int32_t optik_hip_chain_range_rule(const optik_hip_chain *chain);
+
 /* objective + objective_grad (objective.rs:40-110) for B configurations.
  * d_q [n][B] -> d_f [B], d_g [n][B] (d_g may be NULL).  Only the weights of
  * `cfg` are read.  ee_offset7 may be NULL (identity). */

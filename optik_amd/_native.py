@@ -18,6 +18,8 @@ UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 
 RES_FAILURE, RES_ROUNDOFF, RES_FORCED_STOP, RES_ITER_CAP = -1, -4, -5, -100
 RES_STOPVAL, RES_FTOL, RES_XTOL = 2, 3, 4
+# rand 0.9.2 random_range(lb..=ub) reading (include/optik_hip.h: OPTIK_HIP_RANGE_*)
+RANGE_SINGLE_INCLUSIVE, RANGE_NEW_INCLUSIVE = 0, 1
 
 
 class OptikHipError(RuntimeError):
@@ -71,6 +73,8 @@ def lib():
     L.optik_hip_chain_create.argtypes = [dp, dp, ip, C.c_int32, dp, dp, C.c_int32, C.POINTER(vp)]
     L.optik_hip_chain_destroy.argtypes = [vp]
     L.optik_hip_chain_num_positions.argtypes = [vp]
+    L.optik_hip_chain_set_range_rule.argtypes = [vp, C.c_int32]
+    L.optik_hip_chain_range_rule.argtypes = [vp]
     L.optik_hip_eval_batch.argtypes = [vp, C.POINTER(SolverConfigC), dp, dp, vp, C.c_int64, vp, vp, vp]
     L.optik_hip_fk_batch.argtypes = [vp, dp, vp, C.c_int64, vp, vp, vp]
     L.optik_hip_seed_batch.argtypes = [vp, C.c_uint64, C.c_int64, vp, vp]

@@ -398,6 +398,7 @@ struct optik_hip_chain {
     bool tip = false;
     uint32_t key[8];
     double scale[MAX_DOF];
+    int range_rule = 0;  // OPTIK_HIP_RANGE_*: how `scale` was formed
     // launch workspace (grown on demand; one in-flight ik call per chain handle)
     std::mutex mu;
     std::mutex host_mu;  // serialises optik_hip_ik_host calls (they share the workspace below)
@@ -495,8 +496,14 @@ void seed_from_u64(uint64_t state, uint32_t key[8]) {
     }
 }
 
-// rand 0.9 UniformFloat<f64>::new_inclusive: scale with the 1-ulp decrease loop.
-double uniform_scale(double low, double high) {
+// Scale of `rng.random_range(lb..=ub)` (lib.rs:89; rand 0.9.2, not vendored).  The call chain
+// Rng::random_range -> SampleRange for RangeInclusive<f64> -> UniformFloat::sample_single_inclusive
+// ends in `scale = high - low` (rule OPTIK_HIP_RANGE_SINGLE_INCLUSIVE, the default).  The other
+// reading -- Uniform::new_inclusive(lo, hi).sample(rng): (high - low) / (1 - eps) with the 1-ulp
+// decrease loop -- stays selectable (optik_hip_chain_set_range_rule / OPTIK_RANDOM_RANGE_RULE):
+// the kernels only ever see the precomputed scale, so the choice is host-side data.
+double uniform_scale(double low, double high, int rule) {
+    if (rule == OPTIK_HIP_RANGE_SINGLE_INCLUSIVE) return high - low;
     const double max_rand = 1.0 - 2.220446049250313e-16;
     double scale = (high - low) / max_rand;
     while (scale * max_rand + low > high) {
@@ -506,6 +513,22 @@ double uniform_scale(double low, double high) {
         std::memcpy(&scale, &u, 8);
     }
     return scale;
+}
+
+int default_range_rule() {
+    if (const char *e = std::getenv("OPTIK_RANDOM_RANGE_RULE"))
+        if (std::strcmp(e, "new_inclusive") == 0 || std::strcmp(e, "1") == 0) return OPTIK_HIP_RANGE_NEW_INCLUSIVE;
+    return OPTIK_HIP_RANGE_SINGLE_INCLUSIVE;
+}
+
+void set_chain_scales(optik_hip_chain *ch, int rule) {
+    ch->range_rule = rule;
+    for (int k = 0; k < ch->n; ++k) {
+        const double lb = ch->host.lb[k], ub = ch->host.ub[k];
+        // infinite limits (continuous joints) make random_range panic in the
+        // reference (quirk Q5); restarts > 0 are refused at launch time instead.
+        ch->scale[k] = (std::isfinite(lb) && std::isfinite(ub)) ? uniform_scale(lb, ub, rule) : NAN;
+    }
 }
 
 // approx::relative_eq!(a, b, epsilon = eps), default max_relative = f64::EPSILON.
@@ -619,10 +642,8 @@ int optik_hip_chain_create(const double *origins, const double *axes, const int3
     for (int k = 0; k < n; ++k) {
         ch->host.lb[k] = lb[k];
         ch->host.ub[k] = ub[k];
-        // infinite limits (continuous joints) make random_range panic in the
-        // reference (quirk Q5); restarts > 0 are refused at launch time instead.
-        ch->scale[k] = (std::isfinite(lb[k]) && std::isfinite(ub[k])) ? uniform_scale(lb[k], ub[k]) : NAN;
     }
+    set_chain_scales(ch, default_range_rule());
     seed_from_u64(42, ch->key);  // RNG_SEED, lib.rs:360
     hipError_t e = hipMalloc(&ch->dev, sizeof(ChainDev));
     if (e == hipSuccess) e = hipMemcpy(ch->dev, &ch->host, sizeof(ChainDev), hipMemcpyHostToDevice);
@@ -679,6 +700,16 @@ void optik_hip_chain_destroy(optik_hip_chain *ch) {
 }
 
 int32_t optik_hip_chain_num_positions(const optik_hip_chain *ch) { return ch ? ch->n : 0; }
+
+int optik_hip_chain_set_range_rule(optik_hip_chain *ch, int32_t rule) {
+    if (!ch || (rule != OPTIK_HIP_RANGE_SINGLE_INCLUSIVE && rule != OPTIK_HIP_RANGE_NEW_INCLUSIVE))
+        return fail(OPTIK_HIP_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> lock(ch->mu);
+    set_chain_scales(ch, rule);
+    return 0;
+}
+
+int32_t optik_hip_chain_range_rule(const optik_hip_chain *ch) { return ch ? ch->range_rule : -1; }
 
 int optik_hip_eval_batch(const optik_hip_chain *ch, const optik_solver_config *cfg, const double *target7,
                          const double *ee_offset7, const double *d_q, int64_t B, double *d_f, double *d_g,

@@ -57,6 +57,10 @@ class HipChain:
         except Exception:
             pass
 
+    def set_range_rule(self, rule):
+        """Which rand 0.9.2 code path the restart seeds follow (nat.RANGE_*; optik_hip.h)."""
+        nat.check(nat.lib().optik_hip_chain_set_range_rule(self._h, int(rule)))
+
     # -- batched primitives ----------------------------------------------------
     def eval_batch(self, q, target7, cfg=None, ee_offset7=None, grad=True):
         """q: [n, B] float64 cuda tensor -> (f [B], g [n, B])."""

@@ -19,6 +19,8 @@ MAX_DOF = 16
 
 RES_STOPVAL, RES_FTOL, RES_XTOL = 2, 3, 4
 RES_FAILURE, RES_ROUNDOFF, RES_FORCED, RES_ITER_CAP = -1, -4, -5, -100
+# how rand 0.9.2's random_range(lb..=ub) is restated (optik_oracle.c:ok_uniform_scale)
+RANGE_SINGLE_INCLUSIVE, RANGE_NEW_INCLUSIVE = 0, 1
 
 
 class Pose(C.Structure):
@@ -110,6 +112,10 @@ def lib():
         L.ok_seed_from_u64.argtypes = [C.c_uint64, C.POINTER(C.c_uint32)]
         L.ok_uniform_inclusive.argtypes = [C.c_double, C.c_double, C.c_uint64]
         L.ok_uniform_inclusive.restype = C.c_double
+        L.ok_uniform_scale.argtypes = [C.c_double, C.c_double, C.c_int]
+        L.ok_uniform_scale.restype = C.c_double
+        L.ok_set_range_rule.argtypes = [C.c_int]
+        L.ok_get_range_rule.restype = C.c_int
         L.ok_restart_seed.argtypes = [C.POINTER(Chain), C.c_uint64, dp]
         L.ok_solve_restart.argtypes = [C.POINTER(Chain), C.POINTER(Config), C.POINTER(Pose),
                                        C.POINTER(Pose), dp, C.c_uint64,
@@ -226,6 +232,22 @@ def eval_fg(chain: Chain, target7, q, w_lin=(1, 1, 1), w_ang=(1, 1, 1), ee_offse
     f = lib().ok_eval(C.byref(chain), C.byref(tgt), C.byref(ee_off), _dp(wl), _dp(wa), _dp(q),
                       _dp(g) if grad else None)
     return (f, g) if grad else f
+
+
+class range_rule:
+    """``with range_rule(RANGE_NEW_INCLUSIVE): ...`` -- process-wide rule switch, restored on exit."""
+
+    def __init__(self, rule):
+        self.rule = rule
+
+    def __enter__(self):
+        self.prev = lib().ok_get_range_rule()
+        lib().ok_set_range_rule(self.rule)
+        return self
+
+    def __exit__(self, *exc):
+        lib().ok_set_range_rule(self.prev)
+        return False
 
 
 def restart_seed(chain: Chain, index: int):

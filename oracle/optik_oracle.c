@@ -537,8 +537,24 @@ void ok_seed_from_u64(uint64_t state, uint32_t key[8]) {
     }
 }
 
-/* rand 0.9 UniformFloat<f64>::new_inclusive + sample. */
-double ok_uniform_inclusive(double low, double high, uint64_t bits) {
+/* rand 0.9.2 `Rng::random_range(lb..=ub)` for f64 (lib.rs:89).  Call chain in the
+ * crate (src/rng.rs, src/distr/uniform.rs, src/distr/uniform_float.rs):
+ *   Rng::random_range(range)            -> range.sample_single(self).unwrap()
+ *   SampleRange for RangeInclusive<f64> -> UniformFloat::<f64>::sample_single_inclusive(lo, hi, rng)
+ *   sample_single_inclusive             -> scale = high - low;  (no division, no decrease loop)
+ *                                          value1_2 = (next_u64 >> 12) with exponent 0;
+ *                                          value0_1 = value1_2 - 1.0;  value0_1 * scale + low
+ * Rule 0 (OK_RANGE_SINGLE_INCLUSIVE, the default) is that chain.  Rule 1
+ * (OK_RANGE_NEW_INCLUSIVE) is `Uniform::new_inclusive(lo, hi).sample(rng)` -- what rand
+ * 0.8.5's default `sample_single_inclusive` did: scale = (high - low) / (1 - eps) with the
+ * 1-ulp decrease loop -- kept so that either reading can be checked against a real
+ * `cargo run`.  The crate is not vendored: see the header. */
+static int g_range_rule = OK_RANGE_SINGLE_INCLUSIVE;
+void ok_set_range_rule(int rule) { g_range_rule = rule; }
+int ok_get_range_rule(void) { return g_range_rule; }
+
+double ok_uniform_scale(double low, double high, int rule) {
+    if (rule == OK_RANGE_SINGLE_INCLUSIVE) return high - low;
     const double max_rand = 1.0 - 2.220446049250313e-16;
     double scale = (high - low) / max_rand;
     while (scale * max_rand + low > high) {
@@ -547,6 +563,11 @@ double ok_uniform_inclusive(double low, double high, uint64_t bits) {
         u -= 1;
         memcpy(&scale, &u, 8);
     }
+    return scale;
+}
+
+double ok_uniform_inclusive(double low, double high, uint64_t bits) {
+    const double scale = ok_uniform_scale(low, high, g_range_rule);
     uint64_t m = (bits >> 12) | 0x3ff0000000000000ull; /* into_float_with_exponent(0) */
     double value1_2;
     memcpy(&value1_2, &m, 8);

@@ -12,7 +12,9 @@
  *     files of /root/reference/crates/optik/tests/data).
  *   - NLopt SLSQP (nlopt 0.8.1 @ kylc/rust-nlopt 8e731e3, not vendored in the
  *     reference tree), rand_chacha 0.9.0 / rand 0.9.2 (not vendored): restated
- *     from the published algorithms.  PARITY UNPINNED against the reference; the
+ *     from the published algorithms.  PARITY UNPINNED against the reference (the
+ *     generated fixtures under tests/golden/generated/ and the Rust program of
+ *     INTEGRATION.md section 5 are what a maintainer with cargo runs to pin it); the
  *     SLSQP restatement is cross-checked iterate-by-iterate against scipy
  *     1.15.3's Fortran build of the same Kraft code, the ChaCha core against the
  *     published 8-round known-answer and libsodium at 20 rounds.
@@ -116,7 +118,14 @@ double ok_eval(const ok_chain *c, const ok_pose *target, const ok_pose *ee_offse
 void ok_chacha_block(const uint32_t key[8], uint64_t counter, uint64_t stream, int rounds,
                      uint32_t out[16]);
 void ok_seed_from_u64(uint64_t seed, uint32_t key[8]);           /* rand_core PCG32 expansion */
-double ok_uniform_inclusive(double lo, double hi, uint64_t bits);/* rand UniformFloat<f64> */
+/* which rand 0.9.2 code path `random_range(lb..=ub)` (lib.rs:89) is restated; process-wide,
+ * set before solving.  See the comment at ok_uniform_scale in optik_oracle.c. */
+enum { OK_RANGE_SINGLE_INCLUSIVE = 0, /* UniformFloat::sample_single_inclusive: scale = hi - lo (default) */
+       OK_RANGE_NEW_INCLUSIVE = 1 };  /* Uniform::new_inclusive(..).sample(..): scale = (hi - lo)/(1 - eps), decreased */
+void ok_set_range_rule(int rule);
+int ok_get_range_rule(void);
+double ok_uniform_scale(double lo, double hi, int rule);
+double ok_uniform_inclusive(double lo, double hi, uint64_t bits);/* rand UniformFloat<f64>, current rule */
 /* lib.rs:358-370 + 86-91: seed of restart i (i >= 1); restart 0 uses the caller's x0. */
 void ok_restart_seed(const ok_chain *c, uint64_t restart_index, double *q0);
 
