@@ -73,8 +73,10 @@ int optik_robot_fk_ex(const optik_robot *robot, const double *x, const double *e
                       double *pose16_out);
 int optik_robot_joint_jacobian_ex(const optik_robot *robot, const double *x,
                                   const double *ee_offset16, double *jac6n_out);
-/* Flat chain table (what KinematicChain::from_urdf produced): n_joints poses, axes,
- * types; buffers sized for OPTIK_HIP_MAX_DOF + 1 joints. */
+/* Flat chain table (what KinematicChain::from_urdf produced): n_joints poses, axes, types.
+ * Call once with NULL buffers to learn *n_joints, then with buffers of n_joints x 7 / x 3 /
+ * x 1 elements; on entry of the second call *n_joints holds the caller's capacity in joints
+ * (fewer than the chain has: error, nothing is written). */
 int optik_robot_chain_tables(const optik_robot *robot, int32_t *n_joints, double *origins7,
                              double *axes3, int32_t *types);
 /* The device-side chain of this robot on the current HIP device (created on first

@@ -390,7 +390,7 @@ OPTIK_DEV int direction_search(const EngArgs &a, const ChainDev &ch, size_t slot
             // label 255 with acc = 0 -> mode 8; NLopt's relaxed test vs (f0, x0) = (f, x)
             status = RES_ROUNDOFF_LIMITED;
             if (have0 && __builtin_fabs(f - f) < sp.ftol_abs && !__builtin_isinf(f)) status = RES_FTOL_REACHED;  // f0 = f
-            else if (have0 && !(0.0 >= sp.xtol_abs)) status = RES_XTOL_REACHED;  // |x - x0| = 0 everywhere
+            else if (have0 && (sp.stop_x_zero || !(0.0 >= sp.xtol_abs))) status = RES_XTOL_REACHED;  // |x - x0| = 0 everywhere
             return DIR_DEAD;
         }
 #pragma unroll
@@ -520,16 +520,15 @@ OPTIK_DEV void eng_eval_body(const EngArgs &a, const ChainDev &ch, const EngJob 
                 const double fprev = ENG_D(E::FP, 0);
                 if (!__builtin_isinf(fprev)) {
                     if (__builtin_fabs(f - fprev) < a.sp.ftol_abs) ret = RES_FTOL_REACHED;
-                    else if (a.sp.xtol_abs >= 0.0) {
-                        bool allx = true;
+                    else if (xprev_live(a.sp)) {
+                        double xc[N], xp[N];
 #pragma unroll
-                        for (int i = 0; i < N; ++i)
-                            allx = allx && !(__builtin_fabs(ENG_D(E::X, i) - ENG_D(E::XP, i)) >= a.sp.xtol_abs);
-                        if (allx) ret = RES_XTOL_REACHED;
+                        for (int i = 0; i < N; ++i) { xc[i] = ENG_D(E::X, i); xp[i] = ENG_D(E::XP, i); }
+                        if (stop_x<N>(a.sp, xc, xp)) ret = RES_XTOL_REACHED;
                     }
                 }
                 ENG_D(E::FP, 0) = f;
-                if (a.sp.xtol_abs >= 0.0) {
+                if (xprev_live(a.sp)) {
 #pragma unroll
                     for (int i = 0; i < N; ++i) ENG_D(E::XP, i) = ENG_D(E::X, i);
                 }

@@ -105,8 +105,9 @@ struct SelectLaunch {
 __global__ __launch_bounds__(256) void ik_tile_argmin_kernel(const SelectLaunch a) {
     __shared__ double s_key[4];
     __shared__ unsigned long long s_idx[4];
-    const int t = blockIdx.y;
-    const int tile = blockIdx.x;
+    // (one-dimensional grid over target-major tiles: grid.y would cap T at 65 535)
+    const int t = (int)(blockIdx.x / (unsigned)a.tiles_per_target);
+    const int tile = (int)(blockIdx.x % (unsigned)a.tiles_per_target);
     const unsigned long long lo = (unsigned long long)tile * (unsigned long long)a.tile;
     unsigned long long hi = lo + (unsigned long long)a.tile;
     if (hi > a.n_restarts) hi = a.n_restarts;
@@ -594,6 +595,19 @@ int ensure_device() {
         if (!done_) return fail(OPTIK_HIP_EUNSUPPORTED, OPTIK_N_RANGE_MSG);            \
     } while (0)
 
+void fill_solve_params(const optik_solver_config *cfg, SolveParams &sp) {
+    sp.stopval = cfg->tol_f;
+    sp.ftol_abs = (cfg->tol_df > 0.0) ? cfg->tol_df : 1e-3 * cfg->tol_f;  // lib.rs:283-293
+    sp.xtol_abs = cfg->tol_dx;
+    sp.ok_stopval = cfg->tol_f >= 0.0;
+    sp.ok_ftol = cfg->tol_df >= 0.0;
+    sp.ok_xtol = cfg->tol_dx >= 0.0;
+    // nlopt_stop_x of the bundled NLopt (2.7.1): a zero step counts as x-converged; the 2.5
+    // behaviour (per-coordinate test only) for anyone pinning against an older build
+    sp.stop_x_zero = std::getenv("OPTIK_NLOPT_STOP_X_LEGACY") ? 0 : 1;
+}
+
+
 int grid_for(const optik_hip_chain *ch, long long work, int block, int per_cu) {
     long long blocks = (work + block - 1) / block;
     const long long cap = (long long)(ch->num_cus > 0 ? ch->num_cus : 256) * per_cu;
@@ -785,8 +799,8 @@ int optik_hip_ik_batch(optik_hip_chain *ch, const optik_solver_config *cfg, cons
     constexpr int SEL_TILE = 4096;
     const uint64_t tiles_per_target = (R + SEL_TILE - 1) / SEL_TILE;
     const uint64_t n_tiles64 = tiles_per_target * (uint64_t)T;
-    if (n_tiles64 > 0x7fffffffull || tiles_per_target > 65535ull * 64ull || (uint64_t)T > 65535ull)
-        return fail(OPTIK_HIP_EINVAL, "too many restarts / targets in one launch");
+    if (n_tiles64 > 0x7fffffffull)
+        return fail(OPTIK_HIP_EINVAL, "too many restarts / targets in one launch (more than 2^31 selection tiles)");
     const int n_tiles = (int)n_tiles64;
     const size_t cols = (size_t)T * (size_t)R;
 
@@ -834,12 +848,7 @@ int optik_hip_ik_batch(optik_hip_chain *ch, const optik_solver_config *cfg, cons
     std::memset(&a, 0, sizeof a);
     a.chain = ch->dev;
     make_eval_params(cfg->linear_weight, cfg->angular_weight, ee_offset7, a.ep);
-    a.sp.stopval = cfg->tol_f;
-    a.sp.ftol_abs = (cfg->tol_df > 0.0) ? cfg->tol_df : 1e-3 * cfg->tol_f;  // lib.rs:283-293
-    a.sp.xtol_abs = cfg->tol_dx;
-    a.sp.ok_stopval = cfg->tol_f >= 0.0;
-    a.sp.ok_ftol = cfg->tol_df >= 0.0;
-    a.sp.ok_xtol = cfg->tol_dx >= 0.0;
+    fill_solve_params(cfg, a.sp);
     std::memcpy(a.key, ch->key, sizeof a.key);
     std::memcpy(a.scale, ch->scale, sizeof a.scale);
     a.wq.next_item = ch->queue;
@@ -910,8 +919,7 @@ int optik_hip_ik_batch(optik_hip_chain *ch, const optik_solver_config *cfg, cons
         s.ld = cols;
         s.win_x = out->d_win_x; s.win_f = out->d_win_f;
         s.win_idx = (unsigned long long *)out->d_win_idx; s.win_key = out->d_win_key;
-        hipLaunchKernelGGL(ik_tile_argmin_kernel, dim3((unsigned)tiles_per_target, (unsigned)T), dim3(256), 0,
-                           stream, s);
+        hipLaunchKernelGGL(ik_tile_argmin_kernel, dim3((unsigned)n_tiles), dim3(256), 0, stream, s);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(ik_select_kernel, dim3(T), dim3(WAVE), 0, stream, s);
         HIP_TRY(hipGetLastError());
@@ -921,15 +929,6 @@ int optik_hip_ik_batch(optik_hip_chain *ch, const optik_solver_config *cfg, cons
 
 // ---- streaming engine: submit jobs, then run them through the shared slot pool ----
 
-static void fill_solve_params(const optik_solver_config *cfg, SolveParams &sp) {
-    sp.stopval = cfg->tol_f;
-    sp.ftol_abs = (cfg->tol_df > 0.0) ? cfg->tol_df : 1e-3 * cfg->tol_f;  // lib.rs:283-293
-    sp.xtol_abs = cfg->tol_dx;
-    sp.ok_stopval = cfg->tol_f >= 0.0;
-    sp.ok_ftol = cfg->tol_df >= 0.0;
-    sp.ok_xtol = cfg->tol_dx >= 0.0;
-    sp.pad = 0;
-}
 
 int optik_hip_engine_submit(optik_hip_chain *ch, const optik_solver_config *cfg, const double *d_targets,
                             const double *d_x0, int32_t T, const double *ee_offset7, uint64_t restart_begin,
@@ -959,6 +958,8 @@ int optik_hip_engine_submit(optik_hip_chain *ch, const optik_solver_config *cfg,
         if (!same) return fail(OPTIK_HIP_EINVAL, "jobs pooled in one engine run must share tolerances, weights and ee_offset");
     }
     const uint64_t R = restart_end - restart_begin;
+    if (((R + 4095) / 4096) * (uint64_t)T > 0x7fffffffull)
+        return fail(OPTIK_HIP_EINVAL, "too many restarts / targets in one job (more than 2^31 selection tiles)");
     optik_hip_chain::EngineJobHost j;
     std::memset(&j.dev, 0, sizeof j.dev);
     j.T = T;
@@ -966,14 +967,27 @@ int optik_hip_engine_submit(optik_hip_chain *ch, const optik_solver_config *cfg,
     const size_t cols = (size_t)T * (size_t)R;
     const bool want_win = out->d_win_x || out->d_win_f || out->d_win_idx || out->d_win_key;
     double *px = out->d_x, *pf = out->d_f, *pk = nullptr;
+    // (a failed allocation releases what this job already holds)
+#define JOB_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            if (j.own_x) (void)hipFree(j.own_x);                                             \
+            if (j.own_f) (void)hipFree(j.own_f);                                             \
+            if (j.own_key) (void)hipFree(j.own_key);                                         \
+            if (j.own_fs) (void)hipFree(j.own_fs);                                           \
+            return fail(OPTIK_HIP_ENOMEM, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+        }                                                                                    \
+    } while (0)
     if (want_win) {
-        HIP_TRY(hipMalloc(&j.own_key, sizeof(double) * cols));
+        JOB_TRY(hipMalloc(&j.own_key, sizeof(double) * cols));
         pk = j.own_key;
-        if (!px && out->d_win_x) { HIP_TRY(hipMalloc(&j.own_x, sizeof(double) * cols * (size_t)ch->n)); px = j.own_x; }
-        if (!pf && out->d_win_f) { HIP_TRY(hipMalloc(&j.own_f, sizeof(double) * cols)); pf = j.own_f; }
+        if (!px && out->d_win_x) { JOB_TRY(hipMalloc(&j.own_x, sizeof(double) * cols * (size_t)ch->n)); px = j.own_x; }
+        if (!pf && out->d_win_f) { JOB_TRY(hipMalloc(&j.own_f, sizeof(double) * cols)); pf = j.own_f; }
     }
     const bool early = (flags & OPTIK_HIP_IK_EARLY_EXIT) && cfg->solution_mode == 2;
-    if (early) HIP_TRY(hipMalloc(&j.own_fs, sizeof(unsigned long long) * (size_t)T));
+    if (early) JOB_TRY(hipMalloc(&j.own_fs, sizeof(unsigned long long) * (size_t)T));
+#undef JOB_TRY
     j.dev.targets = d_targets;
     j.dev.x0 = d_x0;
     j.dev.item_base = ch->eng_jobs.empty() ? 0ull : ch->eng_jobs.back().dev.item_base + ch->eng_jobs.back().dev.n_items;
@@ -1430,7 +1444,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             s.ld = (size_t)j.dev.n_items;
             s.win_x = o.d_win_x; s.win_f = o.d_win_f;
             s.win_idx = (unsigned long long *)o.d_win_idx; s.win_key = o.d_win_key;
-            hipLaunchKernelGGL(ik_tile_argmin_kernel, dim3((unsigned)tiles_per_target, (unsigned)j.T), dim3(256), 0, stream, s);
+            hipLaunchKernelGGL(ik_tile_argmin_kernel, dim3((unsigned)n_tiles), dim3(256), 0, stream, s);
             hipLaunchKernelGGL(ik_select_kernel, dim3(j.T), dim3(WAVE), 0, stream, s);
             HIP_TRY(hipGetLastError());
         }

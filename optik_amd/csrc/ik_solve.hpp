@@ -60,8 +60,27 @@ struct SolveParams {
     double ftol_abs;  // tol_df heuristic (set_ftol_abs, lib.rs:283-293, 346)
     double xtol_abs;  // tol_dx           (set_xtol_abs1, lib.rs:347)
     int32_t ok_stopval, ok_ftol, ok_xtol;  // lib.rs:376-379: tol_* >= 0
-    int32_t pad;
+    // nlopt_stop_x of NLopt >= 2.6.2 (what rust-nlopt 0.8 bundles: 2.7.1) returns 1 first of all
+    // when ||x - oldx|| <= xtol_rel * ||x||, i.e. with xtol_rel = 0 when the step is exactly
+    // zero; NLopt 2.5 only has the per-coordinate xtol_abs test.  1 = the newer rule (default).
+    // It can only matter when ftol_abs <= 0: a zero step leaves f unchanged and the ftol
+    // test, which comes first, fires on |f - fprev| = 0 < ftol_abs.
+    int32_t stop_x_zero;
 };
+
+// nlopt_stop_x(x, oldx) with xtol_rel = 0 and xtol_abs[i] = tol_dx (nlopt/src/util/stop.c).
+template <int N>
+OPTIK_DEV bool stop_x(const SolveParams &sp, const double (&x)[N], const double (&oldx)[N]) {
+    bool zero = sp.stop_x_zero != 0, allx = true;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        zero = zero && (x[i] == oldx[i]);
+        allx = allx && !(__builtin_fabs(x[i] - oldx[i]) >= sp.xtol_abs);
+    }
+    return zero || allx;
+}
+// the previous iterate is only needed when one of the two tests can fire after the ftol test
+OPTIK_DEV bool xprev_live(const SolveParams &sp) { return sp.xtol_abs >= 0.0 || (sp.stop_x_zero && !(sp.ftol_abs > 0.0)); }
 
 // ---- RNG: ChaCha8Rng::seed_from_u64(42), set_stream(i)  (lib.rs:358-362) -----
 
@@ -290,13 +309,7 @@ OPTIK_DEV void solve_wave(const ChainDev &ch, const EvalParams &ep, const SolveP
                     if (line > 1) ++nevals;
                     if (!__builtin_isinf(fprev)) {
                         if (__builtin_fabs(f - fprev) < sp.ftol_abs) ret = RES_FTOL_REACHED;
-                        else {
-                            bool allx = true;
-#pragma unroll
-                            for (int i = 0; i < N; ++i)
-                                allx = allx && !(__builtin_fabs(x[i] - xprev[i]) >= sp.xtol_abs);
-                            if (allx) ret = RES_XTOL_REACHED;
-                        }
+                        else if (stop_x<N>(sp, x, xprev)) ret = RES_XTOL_REACHED;
                     }
                     fprev = f;
 #pragma unroll
@@ -324,13 +337,7 @@ OPTIK_DEV void solve_wave(const ChainDev &ch, const EvalParams &ep, const SolveP
                         // label 255 with acc = 0 -> mode 8; NLopt's relaxed test vs (f0, x0)
                         ret = RES_ROUNDOFF_LIMITED;
                         if (__builtin_fabs(f - f0) < sp.ftol_abs && !__builtin_isinf(f0)) ret = RES_FTOL_REACHED;
-                        else {
-                            bool allx = true;
-#pragma unroll
-                            for (int i = 0; i < N; ++i)
-                                allx = allx && !(__builtin_fabs(x[i] - x0[i]) >= sp.xtol_abs);
-                            if (allx) ret = RES_XTOL_REACHED;
-                        }
+                        else if (stop_x<N>(sp, x, x0)) ret = RES_XTOL_REACHED;
                         break;
                     }
 #pragma unroll

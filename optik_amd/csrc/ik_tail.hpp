@@ -151,16 +151,10 @@ OPTIK_DEV void tail_wave(const EngArgs &a, const ChainDev &ch, const EngJob *job
                         if (line > 1) ++nevals;  // NLopt re-evaluates the accepted point unless it was trial 1
                         if (!__builtin_isinf(fprev)) {
                             if (__builtin_fabs(f - fprev) < sp.ftol_abs) ret = RES_FTOL_REACHED;
-                            else if (sp.xtol_abs >= 0.0) {
-                                bool allx = true;
-#pragma unroll
-                                for (int i = 0; i < N; ++i)
-                                    allx = allx && !(__builtin_fabs(x[i] - xprev[i]) >= sp.xtol_abs);
-                                if (allx) ret = RES_XTOL_REACHED;
-                            }
+                            else if (xprev_live(sp) && stop_x<N>(sp, x, xprev)) ret = RES_XTOL_REACHED;
                         }
                         fprev = f;
-                        if (sp.xtol_abs >= 0.0) {
+                        if (xprev_live(sp)) {
 #pragma unroll
                             for (int i = 0; i < N; ++i) xprev[i] = x[i];
                         }
@@ -187,7 +181,7 @@ OPTIK_DEV void tail_wave(const EngArgs &a, const ChainDev &ch, const EngJob *job
                         // label 255 with acc = 0 -> mode 8; NLopt's relaxed test vs (f0, x0) = (f, x)
                         ret = RES_ROUNDOFF_LIMITED;
                         if (have0 && __builtin_fabs(f - f0) < sp.ftol_abs && !__builtin_isinf(f0)) ret = RES_FTOL_REACHED;
-                        else if (have0 && !(0.0 >= sp.xtol_abs)) ret = RES_XTOL_REACHED;  // |x - x0| = 0 everywhere
+                        else if (have0 && (sp.stop_x_zero || !(0.0 >= sp.xtol_abs))) ret = RES_XTOL_REACHED;  // |x - x0| = 0 everywhere
                         break;
                     }
 #pragma unroll

@@ -592,7 +592,10 @@ const double *optik_robot_diff_ik(const optik_robot *r, const double *x0, const 
 int optik_robot_chain_tables(const optik_robot *r, int32_t *n_joints, double *origins7, double *axes3,
                              int32_t *types) {
     if (!r || !n_joints) return set_err(-1, "null argument");
+    const int32_t cap = *n_joints;
     *n_joints = (int32_t)r->types.size();
+    if ((origins7 || axes3 || types) && cap < *n_joints)
+        return set_err(-1, "chain_tables: buffers too small for the chain's joints");
     if (origins7) std::memcpy(origins7, r->origins.data(), sizeof(double) * r->origins.size());
     if (axes3) std::memcpy(axes3, r->axes.data(), sizeof(double) * r->axes.size());
     if (types) std::memcpy(types, r->types.data(), sizeof(int32_t) * r->types.size());

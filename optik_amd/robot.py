@@ -219,10 +219,14 @@ class Robot:
     def chain_tables(self):
         """Flat chain (types, origins[J,7], axes[J,3], lb, ub) as loaded by the C++ URDF loader."""
         nj = C.c_int32(0)
-        origins, axes = np.zeros(9 * 7), np.zeros(9 * 3)
-        types = np.zeros(9, dtype=np.int32)
-        self._L.optik_robot_chain_tables(self._h, C.byref(nj), _dp(origins), _dp(axes),
-                                         types.ctypes.data_as(C.POINTER(C.c_int32)))
+        # first call: joint count only (NULL buffers), then buffers of exactly that size
+        if self._L.optik_robot_chain_tables(self._h, C.byref(nj), None, None, None):
+            raise RuntimeError(_err(self._L))
+        origins, axes = np.zeros(nj.value * 7), np.zeros(nj.value * 3)
+        types = np.zeros(nj.value, dtype=np.int32)
+        if self._L.optik_robot_chain_tables(self._h, C.byref(nj), _dp(origins), _dp(axes),
+                                            types.ctypes.data_as(C.POINTER(C.c_int32))):
+            raise RuntimeError(_err(self._L))
         J = nj.value
         lb, ub = self.joint_limits()
         return dict(types=types[:J].copy(), origins=origins[:J * 7].reshape(J, 7).copy(),

@@ -115,6 +115,7 @@ def lib():
         L.ok_uniform_scale.argtypes = [C.c_double, C.c_double, C.c_int]
         L.ok_uniform_scale.restype = C.c_double
         L.ok_set_range_rule.argtypes = [C.c_int]
+        L.ok_set_stop_x_zero.argtypes = [C.c_int]
         L.ok_get_range_rule.restype = C.c_int
         L.ok_restart_seed.argtypes = [C.POINTER(Chain), C.c_uint64, dp]
         L.ok_solve_restart.argtypes = [C.POINTER(Chain), C.POINTER(Config), C.POINTER(Pose),

@@ -1128,8 +1128,19 @@ static int relstop(double vold, double vnew, double reltol, double abstol) {
            || (reltol > 0 && vnew == vold);
 }
 
-/* nlopt_stop_x with xtol_rel = 0 and xtol_abs[i] = tol_dx. */
+/* nlopt_stop_x with xtol_rel = 0 and xtol_abs[i] = tol_dx.  NLopt >= 2.6.2 (rust-nlopt 0.8
+ * bundles 2.7.1) first returns 1 when ||x - oldx|| <= xtol_rel * ||x||, i.e. here when the step
+ * is exactly zero; NLopt 2.5 has only the per-coordinate test (ok_set_stop_x_zero(0)).  The
+ * rule can only change a result when ftol_abs <= 0: a zero step leaves f unchanged and the
+ * ftol test, which comes first in slsqp.c, fires on 0 < ftol_abs. */
+static int g_stop_x_zero = 1;
+void ok_set_stop_x_zero(int on) { g_stop_x_zero = on; }
 static int stop_x(int n, const double *x, const double *oldx, double xtol_abs) {
+    if (g_stop_x_zero) {
+        int zero = 1;
+        for (int i = 0; i < n; ++i) zero = zero && (x[i] == oldx[i]);
+        if (zero) return 1;
+    }
     for (int i = 0; i < n; ++i)
         if (fabs(x[i] - oldx[i]) >= xtol_abs) return 0;
     return 1;

@@ -130,6 +130,8 @@ double ok_uniform_inclusive(double lo, double hi, uint64_t bits);/* rand Uniform
 void ok_restart_seed(const ok_chain *c, uint64_t restart_index, double *q0);
 
 /* ---- NLopt SLSQP restatement + lib.rs:301-391 ------------------------- */
+/* nlopt_stop_x rule: 1 (default) = NLopt >= 2.6.2, a zero step is x-converged; 0 = NLopt 2.5. */
+void ok_set_stop_x_zero(int on);
 /* One restart: builds the seed (x0 if index==0), runs SLSQP with NLopt's
  * stopping rules, classifies.  trace (optional, may be NULL) receives one row
  * of n+1 doubles [x..., f] per objective evaluation, up to trace_cap rows. */

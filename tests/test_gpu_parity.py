@@ -372,3 +372,27 @@ def test_ftol_and_xtol_count_as_success_when_enabled(dev, oracle, chains, hip_ch
     assert (st == nat.RES_FTOL).any() and (st == nat.RES_XTOL).any()
     assert_bit_equal(out["x"].cpu().numpy(), ref["xs"].T, "x")
     assert int(out["win_idx"].cpu()[0]) == ref["winner"]
+
+
+@pytest.mark.parametrize("path", ["kernel", "engine"])
+@pytest.mark.parametrize("tol_dx", [-1.0, 0.0])
+def test_zero_step_counts_as_xtol(dev, oracle, chains, hip_chains, path, tol_dx):
+    """ftol_abs = 0 (tol_f = tol_df = 0): neither stopval nor ftol can fire, and restarts end
+    through nlopt_stop_x's zero-step rule (NLopt >= 2.6.2: ||x - oldx|| <= xtol_rel ||x|| with
+    xtol_rel = 0) -- XTOL_REACHED, a success only when tol_dx >= 0 (lib.rs:376-379)."""
+    from optik_amd import _native as nat
+    d, ch = chains["panda"]
+    rng = np.random.default_rng(3)
+    tg, x0 = make_targets(oracle, d, ch, rng, 1)
+    kw = dict(solution_mode="speed", tol_f=0.0, tol_df=0.0, tol_dx=tol_dx)
+    R = 256
+    out = _run(hip_chains["panda"], path, nat.make_config(**kw), torch.tensor(tg, device="cuda"),
+               torch.tensor(x0, device="cuda"), 0, R)
+    ref = _oracle_all(oracle, ch, kw, tg[0], x0[0], 0, R)
+    status = out["status"].cpu().numpy()
+    assert np.array_equal(status, ref["status"])
+    assert (status == nat.RES_XTOL).mean() > 0.9
+    assert np.array_equal(out["evals"].cpu().numpy(), ref["evals"])
+    assert_bit_equal(out["x"].cpu().numpy(), ref["xs"].T, "per-restart x")
+    assert int(out["win_idx"].cpu()[0]) == (ref["winner"] if ref["found"] else -1)
+    assert ref["found"] == (tol_dx >= 0.0)
