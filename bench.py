@@ -10,17 +10,27 @@ the winner selection.  Targets, seeds x0 and all output buffers are resident in
 HBM before the timed region.  With --path engine (default) the K timed steps are
 submitted as K jobs and executed by one run of the streaming engine, which keeps
 its slot pool full across step boundaries (continuous batching); --path kernel
-launches one persistent solve kernel per step, back to back.  With N > 1 (one process per GPU under
-torch.distributed.run) every rank solves its own contiguous restart range
-[rank*R, (rank+1)*R) of the same target -- weak scaling, no data-path
-collective -- and the per-step winner is chosen with one 8-byte RCCL
-min-all-reduce of the selection key over xGMI.
+launches one persistent solve kernel per step, back to back.
+
+Multi-GPU (one process per GPU under torch.distributed.run, RCCL over xGMI):
+  --scaling weak    (default) every rank solves its own contiguous restart range
+                    [rank*R, (rank+1)*R) of the step's target: R restarts per GPU per step
+  --scaling strong  the step's R restarts are cut into one contiguous range per rank
+                    (BASELINE.json config 4: 4 M restarts sharded 8-way)
+  --mode speed|quality   SolutionMode: the per-step winner is the lowest successful index
+                    (one 8-byte min-all-reduce) or the success closest to the seed (min-all-reduce
+                    of ||x - x0||, then of the index among the ranks holding the minimum)
+  --targets T       BASELINE.json config 5: a step is T independent targets x --restarts
+                    restart indices each (Speed with early exit, as Robot::ik), the targets cut
+                    into one contiguous part per rank, no collective; value = ik() calls/s
 
 The JSON line carries:
-  roofline      algorithmic HBM bytes of the solve kernel / its mean duration
-                (HIP events on the launch stream, recorded inside the C ABI)
-  cpu_baseline  the CPU oracle (a port of the reference algorithm, NOT the
-                reference binary) timed on this host's cores on a bounded sample
+  roofline      algorithmic HBM bytes of the dominant kernel / its mean duration (HIP events
+                attached to that kernel's dispatches inside the C ABI); `traffic` = PMC bytes per
+                launch when profiles/ holds a PMC pass of this exact command, else null;
+                `secondary` = the f64 vector-ALU view (HBM is not what binds this path)
+  cpu_baseline  the CPU oracle (a port of the reference algorithm, NOT the reference binary)
+                timed on this host's cores (1 thread, half, all) on a bounded sample
 """
 import argparse
 import json
@@ -34,25 +44,25 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r1j_engine_pmc_traffic.json")
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F64_VALU_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 16 f64 lanes/clk x 2 (FMA) x 2.4 GHz
+PMC_FILE = os.path.join(ROOT, "profiles", "r2_pmc_by_command.json")
+
+ENGINE_POOL = 240  # steps whose restarts share one engine run (the engine pools up to 256 jobs)
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same
-    command (tools/profile_round.sh; FETCH_SIZE and WRITE_SIZE collected in separate runs).
-    gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts half the bytes of a wide
-    coalesced read, so it is doubled; both counters are in KB."""
+def command_key(args, world):
+    """Identifies the workload a PMC pass was taken on (tools/profile_round.sh writes the same key)."""
+    return (f"robot={args.robot},restarts={args.restarts},steps={args.steps},warmup={args.warmup},"
+            f"mode={args.mode},scaling={args.scaling},targets={args.targets},path={args.path},gpus={world}")
+
+
+def pmc_for(key):
     try:
-        with open(PMC_TRAFFIC_FILE) as fh:
-            k = json.load(fh)["kernels"][kernel]
-        return (2.0 * k["FETCH_SIZE"]["mean_kb_per_launch"] + k["WRITE_SIZE"]["mean_kb_per_launch"]) * 1024.0
+        with open(PMC_FILE) as fh:
+            return json.load(fh)["commands"].get(key)
     except (OSError, KeyError, ValueError):
         return None
-
-
-
-ENGINE_POOL = 48  # steps whose restarts share one engine run
 
 
 def load_chain(robot):
@@ -78,25 +88,35 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(robot_name, chain_tables, target7, x0, seconds_budget=15.0):
-    """Times the CPU oracle (checker code, used here only as the reported baseline)."""
+def cpu_baseline(robot_name, chain_tables, target7, x0, mode, seconds_budget=15.0):
+    """Times the CPU oracle (checker code, used here only as the reported baseline) at 1 thread,
+    half the usable cores (the reference's advice, README.md:90-91) and all of them."""
     from oracle import binding as ob
-    ob.build()
+    flags = ob.use_native_build()  # -O3 -march=native of THIS host (SURVEY 8d), same arithmetic
     ch = ob.make_chain(**chain_tables)
-    cfg = ob.make_config(solution_mode="speed", tol_f=1e-6)
+    cfg = ob.make_config(solution_mode=mode, tol_f=1e-6)
     cores = usable_cores()
-    # calibrate on a small sample, then size the timed sample to ~seconds_budget
-    t0 = time.perf_counter()
-    ob.ik(ch, cfg, target7, x0, 1, 1 + 64 * cores, n_threads=cores, early_exit=False)
-    rate = 64 * cores / max(time.perf_counter() - t0, 1e-6)
-    n = int(min(max(rate * seconds_budget, 256 * cores), 4_000_000))
-    t0 = time.perf_counter()
-    res = ob.ik(ch, cfg, target7, x0, 0, n, n_threads=cores, early_exit=False)
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "restarts/s", "cores": cores, "kind": "port",
-            "sample": f"{robot_name}: restarts 0..{n - 1} of the bench target, all run to termination, "
-                      f"{cores} threads pulling indices from a shared counter, {dt:.1f} s",
-            "winner": int(res["winner"]) if res["found"] else -1}
+    points = sorted({1, max(1, cores // 2), cores})
+    share = {1: 0.25, max(1, cores // 2): 0.3, cores: 0.45}
+    by_threads, winner, sample = {}, -1, []
+    for th in points:
+        budget = seconds_budget * share.get(th, 0.3) if len(points) > 1 else seconds_budget
+        t0 = time.perf_counter()
+        ob.ik(ch, cfg, target7, x0, 1, 1 + 32 * th, n_threads=th, early_exit=False)
+        rate = 32 * th / max(time.perf_counter() - t0, 1e-6)
+        n = int(min(max(rate * budget, 64 * th), 4_000_000))
+        t0 = time.perf_counter()
+        res = ob.ik(ch, cfg, target7, x0, 0, n, n_threads=th, early_exit=False)
+        dt = time.perf_counter() - t0
+        by_threads[str(th)] = n / dt
+        sample.append(f"{th} thread(s): restarts 0..{n - 1} in {dt:.1f} s")
+        if th == cores:
+            winner = int(res["winner"]) if res["found"] else -1
+    return {"value": by_threads[str(cores)], "unit": "restarts/s", "cores": cores, "kind": "port",
+            "by_threads": by_threads, "build": flags,
+            "sample": f"{robot_name}: the bench target, SolutionMode {mode}, every restart run to termination, threads "
+                      f"pulling indices from a shared counter; " + "; ".join(sample),
+            "winner": winner}
 
 
 def main():
@@ -105,19 +125,27 @@ def main():
     ap.add_argument("--steps", type=int, default=48,
                     help="timed steps; on the engine path they are pooled into one run (one drain of the slot pool)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--restarts", type=int, default=65536, help="restarts per GPU per step")
+    ap.add_argument("--restarts", type=int, default=None,
+                    help="restarts per step: per GPU (weak) or in total (strong); per target with --targets; "
+                         "default 65536 (256 with --targets)")
     ap.add_argument("--robot", default="panda", choices=["panda", "ur10"])
+    ap.add_argument("--mode", default="speed", choices=["speed", "quality"], help="SolutionMode (config.rs:3-8)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--targets", type=int, default=0,
+                    help="config 5: targets per step (cut into one part per rank), each an independent ik() call")
     ap.add_argument("--path", default="auto", choices=["auto", "engine", "kernel"],
                     help="engine: streaming phase kernels with continuous batching (steps submitted "
                          "together share the slot pool); kernel: one persistent solve kernel per step; "
-                         "auto (default) = engine: one 65 536-restart step takes 12 ms in an engine run "
-                         "(the tail kernel finishes the longest restarts) against 14 ms for a solve-kernel "
-                         "launch, and 2.4 ms per step from there on; results are identical")
+                         "auto (default) = engine; results are identical")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
     if args.path == "auto":
         args.path = "engine"
+    if args.restarts is None:
+        args.restarts = 256 if args.targets else 65536
+    if args.targets and args.path != "engine":
+        raise SystemExit("--targets runs on the engine path")
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -147,54 +175,69 @@ def main():
     n = robot.num_positions()
     R = args.restarts
     K, W = args.steps, args.warmup
+    T = args.targets
+    mode = args.mode
 
     # synthetic workload: reachable targets FK(q*), q* and x0 uniform in the limits
     rng = np.random.default_rng(0)
     lb, ub = (np.array(v) for v in robot.joint_limits())
-    n_tgt = K + W
+    per_step = max(T, 1)
+    n_tgt = (K + W) * per_step
     q_star = rng.uniform(lb, ub, size=(n_tgt, n))
     x0_host = rng.uniform(lb, ub, size=(n_tgt, n))
     pose = hc.fk_batch(torch.tensor(q_star.T.copy(), device=dev))  # [7, n_tgt] on the GPU
     targets = pose.T.contiguous()
     x0 = torch.tensor(x0_host, device=dev)
-    cfg = nat.make_config(solution_mode="speed", tol_f=1e-6)
-    begin, end = shard_range(0, R * world, rank, world)
+    cfg = nat.make_config(solution_mode=mode, tol_f=1e-6)
+    if T:
+        t_lo, t_hi = shard_range(0, T, rank, world)    # this rank's targets of every step
+        begin, end = 0, R                              # every target runs restart indices 0..R-1
+        T_loc = t_hi - t_lo
+        cols = R
+    else:
+        t_lo, t_hi, T_loc = 0, 1, 1
+        begin, end = shard_range(0, R * world if args.scaling == "weak" else R, rank, world)
+        cols = end - begin
+    if T_loc < 1 or cols < 1:
+        raise SystemExit("more ranks than work items: nothing to do on this rank")
     n_buf = max(K, W) if args.path == "engine" else 1
-    bufs = [hc.alloc_ik_buffers(1, R, per_restart=True) for _ in range(n_buf)]
+    bufs = [hc.alloc_ik_buffers(T_loc, cols, per_restart=not T) for _ in range(n_buf)]
     # the per-step winner records are rows of two tensors, so that the winners of a whole run are
     # selected (and, with several ranks, reduced) in one piece without gathering them first
-    win_idx_all = torch.zeros(n_buf, dtype=torch.int64, device=dev)
-    win_key_all = torch.zeros(n_buf, dtype=torch.float64, device=dev)
+    win_idx_all = torch.zeros((n_buf, T_loc), dtype=torch.int64, device=dev)
+    win_key_all = torch.zeros((n_buf, T_loc), dtype=torch.float64, device=dev)
     for k, b in enumerate(bufs):
-        b["win_idx"] = win_idx_all[k:k + 1]
-        b["win_key"] = win_key_all[k:k + 1]
+        b["win_idx"] = win_idx_all[k]
+        b["win_key"] = win_key_all[k]
     if args.path == "engine":
         hc.engine_reserve()  # the slot pool: allocated with the other buffers, not inside a run
     # plumbing first-use costs (torch's lazily loaded elementwise kernels, the communicator of the
     # first collective) are paid here on dummy records, not inside the timed region when W = 0
     select_winner({"win_idx": torch.zeros(1, dtype=torch.int64, device=dev),
-                   "win_key": torch.zeros(1, dtype=torch.float64, device=dev)}, "speed", distributed)
+                   "win_key": torch.zeros(1, dtype=torch.float64, device=dev)}, mode, distributed and not T)
     torch.cuda.synchronize()
+    flags = nat.IK_EARLY_EXIT if T else 0
 
     def run_steps(first, count):
-        """`count` steps starting at target `first`; returns the per-step global winners."""
+        """`count` steps starting at step `first`; returns the per-step winners ([count, T_loc])."""
         if args.path == "engine":
-            # every step is its own job (own target, own outputs); jobs submitted together
+            # every step is its own job (own targets, own outputs); jobs submitted together
             # share the engine's slot pool, then one blocking run executes them all
-            # (at most ENGINE_POOL jobs per run: the engine's job table holds 64)
             for g0 in range(0, count, ENGINE_POOL):
                 for k in range(g0, min(g0 + ENGINE_POOL, count)):
-                    i = first + k
-                    hc.engine_submit(cfg, targets[i:i + 1], x0[i:i + 1], begin, end, bufs=bufs[k])
+                    i = (first + k) * per_step + t_lo
+                    hc.engine_submit(cfg, targets[i:i + T_loc], x0[i:i + T_loc], begin, end, flags=flags,
+                                     bufs=bufs[k])
                 hc.engine_run()
-            stacked = {"win_idx": win_idx_all[:count], "win_key": win_key_all[:count]}
-            return select_winner(stacked, "speed", distributed)  # one collective for all steps
+            stacked = {"win_idx": win_idx_all[:count].reshape(-1), "win_key": win_key_all[:count].reshape(-1)}
+            # config 5: every rank owns its targets outright -- no collective
+            return select_winner(stacked, mode, distributed and not T).reshape(count, T_loc)
         winners = []
         for k in range(count):
-            i = first + k
-            hc.ik_batch(cfg, targets[i:i + 1], x0[i:i + 1], begin, end, bufs=bufs[0])
-            winners.append(select_winner(bufs[0], "speed", distributed))
-        return torch.cat(winners)
+            i = (first + k) * per_step + t_lo
+            hc.ik_batch(cfg, targets[i:i + T_loc], x0[i:i + T_loc], begin, end, bufs=bufs[0])
+            winners.append(select_winner(bufs[0], mode, distributed))
+        return torch.stack(winners)
 
     if W:
         run_steps(0, W)
@@ -217,26 +260,37 @@ def main():
         elapsed = float(tmax.item())
 
     last = bufs[K - 1] if args.path == "engine" else bufs[0]
-    n_success = int((last["status"] == nat.RES_STOPVAL).sum().item())
-    mean_evals = float(last["evals"].double().mean().item())
+    solved_targets = int((winners >= 0).logical_and(winners < torch.iinfo(torch.int64).max).sum().item())
+    if T:
+        n_success, mean_evals, mean_exec = None, None, None
+    else:
+        n_success = int((last["status"] == nat.RES_STOPVAL).sum().item())
+        # NLopt's count over every restart of the timed steps (the population the executed count covers)
+        timed = bufs[:K] if args.path == "engine" else bufs
+        mean_evals = float(sum(b["evals"].double().sum().item() for b in timed) / (len(timed) * cols))
+        mean_exec = None
 
     if rank == 0:
-        total = float(R) * world * K
+        units_per_step = float(T) if T else float(cols) * world      # ik() calls or restarts, all ranks
+        total = units_per_step * K
         out_bytes = 8 * n + 8 + 8 + 4 + 4  # x[n] + f + key + status + evals written per restart
+        key = command_key(args, world)
+        pmc = pmc_for(key)
         if args.path == "engine":
             st = hc.engine_stats()
             trips = int(nat.lib().optik_hip_engine_last_trips(hc._h))
             per_kernel = {k: st[k + "_ms"] for k in ("eval", "update", "nnls", "finish")}
             dom = max(per_kernel, key=per_kernel.get)
-            m = n + 1
+            if st.get("evals_executed") and not T:
+                mean_exec = st["evals_executed"] / (float(cols) * K)
             # algorithmic HBM bytes of one launch of the dominant kernel
             if dom == "nnls":
                 units = st["nnls_problems"] / max(st["launches"], 1)     # sub-problems per launch
                 # packed record in (rows of E^-1 + h), multipliers + {mode, rnorm} out
                 unit_bytes = 8 * (n * (n + 1) // 2 + 2 * n) + 8 * (2 * n + 2)
             else:
-                slots_per_launch = float(R) * K / max(st["launches"], 1) * mean_evals  # slot-trips per launch (approx.)
-                units = slots_per_launch
+                slot_trips = st.get("slot_trips") or float(cols) * K * (mean_evals or 39.0)
+                units = slot_trips / max(st["launches"], 1)              # slot-trips per launch
                 nl = n * (n + 1) // 2
                 # planes read + written per slot-trip (update also writes the packed problem record,
                 # finish reads it back with the multipliers)
@@ -246,10 +300,17 @@ def main():
             achieved = unit_bytes * units / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
             kname = {"eval": "eng_eval_kernel", "update": "eng_update_kernel", "nnls": "eng_nnls_coop_kernel",
                      "finish": "eng_finish_kernel"}[dom]
+            traffic, traffic_note = None, f"no PMC pass of this command in {os.path.relpath(PMC_FILE, ROOT)} (key: {key})"
+            if pmc and kname in pmc.get("kernels", {}):
+                kp = pmc["kernels"][kname]
+                # gfx950 (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts half the bytes of a wide
+                # coalesced read, so it is doubled; both counters are in KB; per launch of the timed run
+                traffic = (2.0 * kp["FETCH_SIZE_kb_per_launch"] + kp["WRITE_SIZE_kb_per_launch"]) * 1024.0
+                traffic_note = (f"{os.path.relpath(PMC_FILE, ROOT)}: separate FETCH_SIZE / WRITE_SIZE passes of this "
+                                f"command, the {kp['launches']} launches of the timed run")
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kname),
-                    "traffic_source": os.path.relpath(PMC_TRAFFIC_FILE, ROOT), "kernel": kname,
-                    "kernel_ms": kernel_ms, "launches_timed": st["sampled_trips"],
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                    "kernel": kname, "kernel_ms": kernel_ms, "launches_timed": st["sampled_trips"],
                     "algorithmic_bytes_per_launch": unit_bytes * units,
                     "algorithmic_bytes_per_unit": unit_bytes, "units_per_launch": units,
                     "unit_name": "bounded sub-problem" if dom == "nnls" else "slot-trip",
@@ -257,49 +318,80 @@ def main():
                     "launches": st["launches"], "restart_output_bytes": out_bytes,
                     # the whole path at its boundary: SURVEY 8d's per-restart figure with in-kernel
                     # seeds (outputs only) and with the seeds counted as read (16n + 16)
-                    "path_boundary": {"bytes_per_restart": out_bytes, "bytes_per_restart_survey": 16 * n + 16,
-                                      "GBps": total / elapsed * out_bytes / 1e9,
-                                      "frac": total / elapsed * out_bytes / 1e9 / HBM_PEAK_GBS}}
+                    "path_boundary": None if T else {
+                        "bytes_per_restart": out_bytes, "bytes_per_restart_survey": 16 * n + 16,
+                        "GBps": total / elapsed * out_bytes / 1e9,
+                        "frac": total / elapsed * out_bytes / 1e9 / HBM_PEAK_GBS}}
+            # HBM is the roofline the north star names, but this path is bound by f64 vector
+            # arithmetic and its latency: the secondary view prices it against the f64 VALU peak
+            if pmc and pmc.get("f64_flops_per_restart") and not T:
+                fl = pmc["f64_flops_per_restart"]
+                tf = total / elapsed * fl / 1e12
+                roof["secondary"] = {"bound": "valu_f64", "achieved": tf, "peak": F64_VALU_PEAK_TFLOPS,
+                                     "unit": "TFLOP/s", "frac": tf / F64_VALU_PEAK_TFLOPS,
+                                     "f64_flops_per_restart": fl, "valu_busy": pmc.get("valu_busy"),
+                                     "source": os.path.relpath(PMC_FILE, ROOT) + ": SQ_INSTS_VALU_*_F64 x 64 lanes "
+                                     "per restart and SQ_ACTIVE_INST_VALU per kernel of this command"}
+            else:
+                roof["secondary"] = None
             info = {"grid": None, "block": 128, "lds_bytes": 0}
         else:
             kernel_ms, launches = hc.timing_mean()
             info = hc.last_launch()
-            achieved = out_bytes * R / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+            achieved = out_bytes * cols / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "ik_solve_kernel",
                     "kernel_ms": kernel_ms, "launches_timed": launches,
-                    "algorithmic_bytes_per_unit": out_bytes, "units_per_launch": R}
+                    "algorithmic_bytes_per_unit": out_bytes, "units_per_launch": cols, "secondary": None}
+        if T:
+            metric = f"ik() calls/sec ({args.robot}, {T} targets x {R} restarts per step, 1e-6 tol; BASELINE.json config 5)"
+            unit = "ik calls/s"
+            workload = (f"{args.robot} {n}-DoF, {T} independent targets per step cut into one part per GPU, restart "
+                        f"indices 0..{R - 1} each, SolutionMode::Speed with early exit (Robot::ik semantics), no collective")
+        else:
+            metric = ("random-restart IK solves/sec (Panda 7-DoF, 1e-6 tol)" if args.robot == "panda"
+                      else f"random-restart IK solves/sec ({args.robot}, 1e-6 tol)")
+            unit = "restarts/s"
+            per = f"{R} random restarts per GPU per step" if args.scaling == "weak" else \
+                f"{R} random restarts per step cut into one contiguous range per GPU"
+            workload = (f"{args.robot} {n}-DoF, {per}, one target per step, SolutionMode::{mode.capitalize()}, "
+                        "every restart run to termination")
         line = {
-            "metric": "random-restart IK solves/sec (Panda 7-DoF, 1e-6 tol)" if args.robot == "panda"
-                      else f"random-restart IK solves/sec ({args.robot}, 1e-6 tol)",
+            "metric": metric,
             "value": total / elapsed,
-            "unit": "restarts/s",
+            "unit": unit,
             "n_gpus": world,
             "steps": K,
             "warmup": W,
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.robot} {n}-DoF, {R} random restarts per GPU per step, one target "
-                                   "per step, SolutionMode::Speed, every restart run to termination",
-                       "path": args.path, "restarts_per_gpu": R, "tol_f": 1e-6,
-                       "parallelism": f"restart-range x{world}",
-                       "success_rate_last_step": n_success / R, "mean_evals_per_restart": mean_evals,
-                       "objective_gradient_evals_per_s": total / elapsed * mean_evals,
-                       # global winner (lowest successful restart index) of every timed step: the
-                       # same for any number of ranks covering the same restart range
-                       "winner_index_per_step": [int(v) for v in winners.cpu().tolist()][:64],
+            "config": {"workload": workload,
+                       "path": args.path, "restarts_per_gpu": cols, "tol_f": 1e-6, "solution_mode": mode,
+                       "parallelism": (f"targets x{world}" if T else f"restart-range x{world}"),
+                       "success_rate_last_step": (n_success / cols) if n_success is not None else None,
+                       "solved_targets": solved_targets, "targets_per_step": per_step,
+                       # NLopt's evaluation count per restart (what the reference's callback would be
+                       # called), and the evaluations the kernels actually execute: NLopt re-evaluates an
+                       # accepted line-search point that was not the first trial, the kernels do not
+                       "mean_nlopt_evals_per_restart": mean_evals,
+                       "mean_executed_evals_per_restart": mean_exec,
+                       "executed_objective_gradient_evals_per_s":
+                           (total / elapsed * mean_exec) if mean_exec else None,
+                       # global winner of every timed step (first target of the step): the same for
+                       # any number of ranks covering the same restart range
+                       "winner_index_per_step": [int(v) for v in winners[:, 0].cpu().tolist()][:64],
                        "grid": info["grid"], "block": info["block"], "lds_bytes": info["lds_bytes"]},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not T:
             tables = robot.chain_tables()
             line["cpu_baseline"] = cpu_baseline(args.robot, tables, targets[W].cpu().numpy(),
-                                                x0_host[W], args.cpu_seconds)
-            line["cpu_baseline"]["gpu_winner_same_target"] = int(winners[0].item())
+                                                x0_host[W], mode, args.cpu_seconds)
+            line["cpu_baseline"]["gpu_winner_same_target"] = int(winners[0, 0].item())
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)

@@ -65,6 +65,17 @@ int optik_robot_ik_ex(const optik_robot *robot, const CSolverConfig *config, con
 int optik_robot_ik_batch_ex(const optik_robot *robot, const CSolverConfig *config, int32_t T,
                             const double *targets16, const double *x0, const double *ee_offset16,
                             double *x_out, double *f_out, int32_t *found_out);
+/* GPUs of this node the robot spreads its work over (restarts shard trivially: lib.rs:297-300
+ * hands the same index range to rayon workers).  optik_robot_ik / _ik_ex: after the
+ * latency-sized first launch every round's restart range is cut into one contiguous part per
+ * GPU and the host keeps the minimum of the per-GPU (key, index) records -- the 16-byte
+ * reduction SURVEY 8e calls for; _ik_batch_ex: the targets are cut into one contiguous part
+ * per GPU, no reduction.  Results do not depend on the device list.  Must be called before
+ * the robot's first GPU call; count = 0 restores the default (the HIP device current at first
+ * use); the environment variable OPTIK_DEVICES ("all", a count, or "0,1,...") sets the list
+ * for robots created after it.  A device may be listed more than once. */
+int optik_robot_set_devices(optik_robot *robot, const int32_t *device_ids, int32_t count);
+int32_t optik_robot_num_devices(const optik_robot *robot);
 /* Robot::diff_ik with its full signature: ee_offset and alpha.  rc 0 = solved, 1 = none. */
 int optik_robot_diff_ik_ex(const optik_robot *robot, const double *x0, const double *V_WE6,
                            const double *v_max, const double *ee_offset16, double *alpha_out,

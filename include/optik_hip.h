@@ -155,12 +155,19 @@ int optik_hip_ik_batch(optik_hip_chain *chain, const optik_solver_config *cfg,
  * With OPTIK_HIP_IK_EARLY_EXIT a restart whose target already has a lower-index success
  * when its turn comes is never started: its status is FORCED_STOP, evals 0, key +inf,
  * and its x / f entries are left as they were.
- * No deadline support: use optik_hip_ik_batch for max_time. */
+ * Any number of jobs may be submitted; at most 256 of them share one run of the slot pool
+ * (more are executed as consecutive runs inside engine_run). */
 int optik_hip_engine_submit(optik_hip_chain *chain, const optik_solver_config *cfg,
                             const double *d_targets, const double *d_x0, int32_t T,
                             const double *ee_offset7, uint64_t restart_begin, uint64_t restart_end,
                             uint32_t flags, const optik_hip_ik_outputs *out);
 int optik_hip_engine_run(optik_hip_chain *chain, void *stream);
+/* The same with max_time (lib.rs:260-264, 308, 393): `deadline_s` > 0 seconds after the call
+ * starts, restarts still in flight are abandoned at their next evaluation (status FORCED_STOP,
+ * x / f = their best point so far, never a success) and restarts not yet started are not
+ * started (FORCED_STOP, 0 evaluations); solutions published before the deadline stay and are
+ * selected as usual.  The host checks the clock between chunks of four trips. */
+int optik_hip_engine_run_ex(optik_hip_chain *chain, void *stream, double deadline_s);
 /* Allocates the engine's slot pool and work buffers for up to `slots` slots (0 = the default
  * capacity, 393 216) ahead of the first run -- set-up a caller does once; runs allocate on
  * demand otherwise. */
@@ -178,6 +185,11 @@ int optik_hip_engine_last_pools(const optik_hip_chain *chain, int32_t *launches)
  * the number of bounded sub-problems solved by all sub-pools. */
 int optik_hip_engine_stats(const optik_hip_chain *chain, double *kernel_ms4, int32_t *sampled_trips,
                            uint64_t *nnls_problems);
+
+/* Objective + gradient evaluations the last engine run executed (all sub-pools, tail kernel
+ * included).  d_evals reports NLopt's count per restart, which also includes the re-evaluation
+ * of an accepted line-search point that was not the first trial; the kernels skip that one. */
+uint64_t optik_hip_engine_executed_evals(const optik_hip_chain *chain);
 
 /* Host-buffer convenience over optik_hip_ik_batch (what Robot::ik calls): copies
  * targets/x0 in, runs, synchronises, copies the per-target winners out.

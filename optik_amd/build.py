@@ -19,8 +19,13 @@ HEADERS = ["ik_math.hpp", "ik_eval.hpp", "ik_slsqp.hpp", "ik_solve.hpp", "ik_nnl
            "urdf_chain.hpp",
            os.path.join("..", "..", "include", "optik_hip.h"),
            os.path.join("..", "..", "include", "optik.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
          "-Wno-unused-value", "-pthread"]
+# headers each translation unit depends on (a source is recompiled when one of them is newer than
+# its object file; the objects are build artefacts, git-ignored like the library)
+DEPS = {"ik_kernels.hip": HEADERS,
+        "robot_host.cpp": ["urdf_chain.hpp", os.path.join("..", "..", "include", "optik_hip.h"),
+                           os.path.join("..", "..", "include", "optik.h")]}
 
 
 def _hipcc():
@@ -38,11 +43,29 @@ def is_stale() -> bool:
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
+def _newer(path, than):
+    return os.path.exists(path) and os.path.getmtime(path) > than
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [_hipcc(), *FLAGS, "-x", "hip", *srcs, "-o", LIB]
+    hipcc = _hipcc()
+    objs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        if not os.path.exists(sp):
+            continue
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        t = os.path.getmtime(obj) if os.path.exists(obj) else -1.0
+        deps = [sp] + [os.path.join(CSRC, d) for d in DEPS.get(src, HEADERS)]
+        if force or t < 0 or any(_newer(d, t) for d in deps):
+            cmd = [hipcc, *FLAGS, "-x", "hip", "-c", sp, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd, cwd=CSRC)
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", *objs, "-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
@@ -50,4 +73,5 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -80,7 +80,9 @@ struct EngJob {
     unsigned long long n_targets;      // T
 };
 
-constexpr int ENG_MAX_JOBS = 64;
+// jobs pooled in one run (the table is staged in the eval kernel's LDS, 120 bytes a job); more
+// submissions than this are executed as consecutive runs by optik_hip_engine_run
+constexpr int ENG_MAX_JOBS = 256;
 // The slot pool runs as a few sub-pools, each with its own stream, lists and trip loop, all
 // pulling work items from the one queue: while one sub-pool is in its (VALU-bound) NNLS
 // kernel the others' latency-bound per-slot kernels fill the idle issue slots.
@@ -114,7 +116,9 @@ struct EngArgs {
     unsigned long long n_slots;         // live prefix [slot_base, slot_base + n_slots) the per-slot kernels cover (shrinks while the pool drains)
     const EngJob *jobs;                 // [n_jobs] in device memory
     int n_jobs;
-    int pad;
+    // max_time expired (lib.rs:308: every callback of every restart then returns None): restarts
+    // in flight are published as FORCED_STOP at their next evaluation, queued ones are never started
+    int abort;
     unsigned long long total_items;
     unsigned long long *next_item;      // global queue head
     // bounded sub-problems: one record per slot (a slot has at most one outstanding); the
@@ -149,7 +153,13 @@ struct EngArgs {
     int trip;
     int pad4;
     unsigned long long *trace;          // OPTIK_NNLS_TRACE builds: per-wave {start, end, hw id, passes} of one trip
+    unsigned long long tail_deadline_ticks;  // tail kernel: wall-clock ticks after its start at which max_time expires (0 = none)
+    // objective + gradient evaluations actually executed (NLopt's per-restart count, out_evals, also
+    // counts the re-evaluation of an accepted trial point that the kernels skip): 64 counters, one
+    // per workgroup index mod 64, so that the per-wave additions do not queue on one L2 word
+    unsigned long long *exec_evals;
 };
+constexpr int ENG_EXEC_SHARDS = 64;
 
 // double planes: tiled by 64 slots, two planes interleaved per lane -- the planes of slots
 // [64 t, 64 t + 64) are contiguous ([t][plane / 2][64][2]).  A wave's ~80 planes sit in one
@@ -447,12 +457,13 @@ OPTIK_DEV void store_deferred(const EngArgs &a, size_t slot, const double (&l)[N
 
 // ---- kernel 1: evaluate + decide ------------------------------------------------
 
+// Returns whether the objective was evaluated.
 template <int N, bool TIP>
-OPTIK_DEV void eng_eval_body(const EngArgs &a, const ChainDev &ch, const EngJob *jobs, size_t slot) {
+OPTIK_DEV bool eng_eval_body(const EngArgs &a, const ChainDev &ch, const EngJob *jobs, size_t slot) {
     using E = EngLayout<N>;
     const double alfmin = 0.1;
     const int st = ENG_I(E::STATE);
-    if (st != ST_EVAL_FIRST && st != ST_EVAL_TRIAL && st != ST_DEAD) return;
+    if (st != ST_EVAL_FIRST && st != ST_EVAL_TRIAL && st != ST_DEAD) return false;
     const EngJob &J = jobs[ENG_I(E::JOB)];  // (job table staged in LDS: no dependent HBM round trip)
     const unsigned long long item = a.item[slot];
     const unsigned long long tslot = item / J.n_restarts;
@@ -469,7 +480,9 @@ OPTIK_DEV void eng_eval_body(const EngArgs &a, const ChainDev &ch, const EngJob 
                                                             __HIP_MEMORY_SCOPE_AGENT);
             if (fs < index) ret = RES_FORCED_STOP;
         }
+        if (a.abort) ret = RES_FORCED_STOP;  // lib.rs:308: timed out
     }
+    const bool evaluated = ret == 0;
     if (ret == 0) {
         double f;
         {
@@ -587,6 +600,7 @@ OPTIK_DEV void eng_eval_body(const EngArgs &a, const ChainDev &ch, const EngJob 
         if (J.out_key) J.out_key[item] = k;
         ENG_I(E::STATE) = ST_REFILL;
     }
+    return evaluated;
 }
 
 // Gives `slot` the work item `it` of the queue (or leaves it empty when the queue is
@@ -600,9 +614,12 @@ OPTIK_DEV bool refill_slot(const EngArgs &a, const ChainDev &ch, size_t slot, un
     using E = EngLayout<N>;
     int st;
     if (it < a.total_items) {
+        // the job of work item `it`: the last one whose first item is <= it (binary search)
         int job = 0;
-        for (int j = 1; j < a.n_jobs; ++j)
-            if (it >= a.jobs[j].item_base) job = j;
+        for (int lo = 1, hi = a.n_jobs; lo < hi;) {
+            const int mid = (lo + hi) >> 1;
+            if (it >= a.jobs[mid].item_base) { job = mid; lo = mid + 1; } else hi = mid;
+        }
         const EngJob &J = a.jobs[job];
         const unsigned long long qi = it - J.item_base;
         unsigned long long tslot, r;
@@ -610,14 +627,17 @@ OPTIK_DEV bool refill_slot(const EngArgs &a, const ChainDev &ch, size_t slot, un
         else { tslot = qi / J.n_restarts; r = qi - tslot * J.n_restarts; }
         const unsigned long long item = tslot * J.n_restarts + r;  // output column
         const unsigned long long index = J.restart_begin + r;
-        if (J.first_success) {
+        bool skip = a.abort != 0;  // timed out before the restart was issued (lib.rs:393)
+        if (!skip && J.first_success) {
             const unsigned long long fs = __hip_atomic_load(J.first_success + tslot, __ATOMIC_RELAXED,
                                                             __HIP_MEMORY_SCOPE_AGENT);
-            if (fs < index) {  // abandoned before it started (key is +inf from the job's set-up)
-                if (J.out_status) J.out_status[item] = RES_FORCED_STOP;
-                if (J.out_evals) J.out_evals[item] = 0;
-                return false;
-            }
+            skip = fs < index;  // abandoned before it started (key is +inf from the job's set-up)
+        }
+        if (skip) {
+            if (J.out_status) J.out_status[item] = RES_FORCED_STOP;
+            if (J.out_evals) J.out_evals[item] = 0;
+            if (a.abort && J.out_key) J.out_key[item] = __builtin_huge_val();
+            return false;
         }
         double x[N];
         restart_seed<N>(a.key, ch.lb, a.scale, index, x);

@@ -185,7 +185,8 @@ __global__ __launch_bounds__(WAVE) void ik_select_kernel(const SelectLaunch a) {
 template <int N, bool TIP>
 __global__ __launch_bounds__(OPTIK_ENG_SLOT_BLOCK, OPTIK_ENG_EVAL_WAVES) void eng_eval_kernel(const EngArgs a) {
     __shared__ ChainDev sch;
-    __shared__ EngJob sjobs[ENG_MAX_JOBS];
+    extern __shared__ __attribute__((aligned(16))) unsigned char eval_dyn_lds[];  // n_jobs job records
+    EngJob *sjobs = reinterpret_cast<EngJob *>(eval_dyn_lds);
     {
         static_assert(sizeof(EngJob) % sizeof(double) == 0, "EngJob is a whole number of doubles");
         const double *src = reinterpret_cast<const double *>(a.jobs);
@@ -204,7 +205,10 @@ __global__ __launch_bounds__(OPTIK_ENG_SLOT_BLOCK, OPTIK_ENG_EVAL_WAVES) void en
         if (threadIdx.x == (unsigned)NN_CLASSES) *a.n_active = 0u;
         if (threadIdx.x == (unsigned)NN_CLASSES + 1u) *a.refill_count = 0u;
     }
-    if (local < a.n_slots) eng_eval_body<N, TIP>(a, sch, sjobs, slot);
+    const bool evaluated = local < a.n_slots && eng_eval_body<N, TIP>(a, sch, sjobs, slot);
+    const unsigned long long em = __ballot(evaluated);
+    if (a.exec_evals && em && (threadIdx.x & 63u) == 0)
+        atomicAdd(a.exec_evals + (blockIdx.x % ENG_EXEC_SHARDS), (unsigned long long)__popcll(em));
 }
 
 template <int N>
@@ -400,6 +404,7 @@ struct optik_hip_chain {
     uint32_t key[8];
     double scale[MAX_DOF];
     int range_rule = 0;  // OPTIK_HIP_RANGE_*: how `scale` was formed
+    int device_id = 0;   // the HIP device the chain lives on (the current device at creation)
     // launch workspace (grown on demand; one in-flight ik call per chain handle)
     std::mutex mu;
     std::mutex host_mu;  // serialises optik_hip_ik_host calls (they share the workspace below)
@@ -457,8 +462,9 @@ struct optik_hip_chain {
     hipEvent_t eng_tev[4][ENG_EV][2] = {};
     int eng_tcount = 0;                    // sampled trips of the last run
     double eng_kernel_ms[4] = {0, 0, 0, 0};
-    unsigned long long *eng_nn_total = nullptr;  // problems solved by the NNLS kernel (device counter)
+    unsigned long long *eng_nn_total = nullptr;  // [0] problems solved by the NNLS kernel; [1 .. 64] executed evaluations (sharded)
     unsigned long long eng_nn_problems = 0;
+    unsigned long long eng_exec_evals = 0;       // objective + gradient evaluations executed by the last run
     int waves_per_cu = 2;                 // resident 64-lane workgroups per CU (LDS-bound)
     // timing
     int timing = 0;
@@ -576,6 +582,11 @@ int ensure_device() {
     return 0;
 }
 
+// A chain lives on the device that was current when it was created; its entry points make that
+// device current for the calling thread (a host that drives several GPUs from one process
+// calls them from one thread per device, or in turn).
+#define BIND_DEVICE(CH) HIP_TRY(hipSetDevice((CH)->device_id))
+
 // Dispatch on (n, trailing fixed joint).
 // Kernels are instantiated for 2 <= n <= 7 revolute joints (n + 1 <= 8 rows fit the
 // register-resident NNLS of the engine), each with and without a trailing fixed joint.
@@ -667,6 +678,7 @@ int optik_hip_chain_create(const double *origins, const double *axes, const int3
     }
     int dev = 0;
     hipGetDevice(&dev);
+    ch->device_id = dev;
     hipDeviceGetAttribute(&ch->num_cus, hipDeviceAttributeMultiprocessorCount, dev);
     hipDeviceGetAttribute(&ch->wall_clock_khz, hipDeviceAttributeWallClockRate, dev);
     *out = ch;
@@ -730,6 +742,7 @@ int optik_hip_eval_batch(const optik_hip_chain *ch, const optik_solver_config *c
                          void *stream) {
     if (!ch || !cfg || !target7 || !d_q || !d_f || B < 0) return fail(OPTIK_HIP_EINVAL, "bad argument");
     if (B == 0) return 0;
+    BIND_DEVICE(ch);
     EvalLaunch a;
     a.chain = ch->dev;
     make_eval_params(cfg->linear_weight, cfg->angular_weight, ee_offset7, a.ep);
@@ -747,6 +760,7 @@ int optik_hip_fk_batch(const optik_hip_chain *ch, const double *ee_offset7, cons
                        double *d_pose, double *d_jac, void *stream) {
     if (!ch || !d_q || !d_pose || B < 0) return fail(OPTIK_HIP_EINVAL, "bad argument");
     if (B == 0) return 0;
+    BIND_DEVICE(ch);
     FkLaunch a;
     a.chain = ch->dev;
     const double one[3] = {1, 1, 1};
@@ -766,6 +780,7 @@ int optik_hip_seed_batch(const optik_hip_chain *ch, uint64_t first, int64_t coun
     for (int k = 0; k < ch->n; ++k)
         if (std::isnan(ch->scale[k]))
             return fail(OPTIK_HIP_EINVAL, "random restarts need finite joint limits (reference: random_range panics)");
+    BIND_DEVICE(ch);
     SeedLaunch a;
     std::memcpy(a.key, ch->key, sizeof a.key);
     std::memcpy(a.lb, ch->host.lb, sizeof a.lb);
@@ -794,6 +809,7 @@ int optik_hip_ik_batch(optik_hip_chain *ch, const optik_solver_config *cfg, cons
                 return fail(OPTIK_HIP_EINVAL, "random restarts need finite joint limits (reference: random_range panics)");
     hipStream_t stream = (hipStream_t)stream_v;
     std::lock_guard<std::mutex> lock(ch->mu);
+    BIND_DEVICE(ch);
 
     // selection tiles: 4096 restarts per 256-thread block
     constexpr int SEL_TILE = 4096;
@@ -942,7 +958,7 @@ int optik_hip_engine_submit(optik_hip_chain *ch, const optik_solver_config *cfg,
             if (std::isnan(ch->scale[k]))
                 return fail(OPTIK_HIP_EINVAL, "random restarts need finite joint limits (reference: random_range panics)");
     std::lock_guard<std::mutex> lock(ch->mu);
-    if ((int)ch->eng_jobs.size() >= ENG_MAX_JOBS) return fail(OPTIK_HIP_EINVAL, "too many pending engine jobs");
+    BIND_DEVICE(ch);
     const double ident[7] = {0, 0, 0, 0, 0, 0, 1};
     const double *ee = ee_offset7 ? ee_offset7 : ident;
     if (ch->eng_jobs.empty()) {
@@ -1052,8 +1068,8 @@ static int engine_reserve(optik_hip_chain *ch, size_t AC, int nd, int ni, int re
     if (!ch->eng_counters) HIP_TRY(hipMalloc(&ch->eng_counters, ENG_MAX_POOLS * PCB * sizeof(unsigned int)));
     if (!ch->eng_pinned) HIP_TRY(hipHostMalloc(&ch->eng_pinned, ENG_MAX_POOLS * 8 * sizeof(unsigned int)));
     if (!ch->queue) HIP_TRY(hipMalloc(&ch->queue, sizeof(unsigned long long)));
-    if (!ch->eng_nn_total) HIP_TRY(hipMalloc(&ch->eng_nn_total, sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(ch->eng_nn_total, 0, sizeof(unsigned long long), stream));
+    if (!ch->eng_nn_total) HIP_TRY(hipMalloc(&ch->eng_nn_total, sizeof(unsigned long long) * (1 + ENG_EXEC_SHARDS)));
+    HIP_TRY(hipMemsetAsync(ch->eng_nn_total, 0, sizeof(unsigned long long) * (1 + ENG_EXEC_SHARDS), stream));
     for (auto &pe : ch->eng_pool_ev) for (auto &e : pe) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (!ch->eng_fork_ev) HIP_TRY(hipEventCreateWithFlags(&ch->eng_fork_ev, hipEventDisableTiming));
     for (int p2 = 1; p2 < ENG_MAX_POOLS; ++p2) {
@@ -1063,13 +1079,23 @@ static int engine_reserve(optik_hip_chain *ch, size_t AC, int nd, int ni, int re
     return 0;
 }
 
-int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
+int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) { return optik_hip_engine_run_ex(ch, stream_v, 0.0); }
+
+int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline_s) {
     if (!ch) return fail(OPTIK_HIP_EINVAL, "bad argument");
     hipStream_t stream = (hipStream_t)stream_v;
     std::lock_guard<std::mutex> lock(ch->mu);
+    BIND_DEVICE(ch);
     if (ch->eng_jobs.empty()) return 0;
-    const size_t n_jobs = ch->eng_jobs.size();
-    const unsigned long long total = ch->eng_jobs.back().dev.item_base + ch->eng_jobs.back().dev.n_items;
+    const auto t_call = std::chrono::steady_clock::now();
+    auto since_call = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call).count(); };
+    int rc = 0;
+    // at most ENG_MAX_JOBS jobs share one run of the pool; more are executed as consecutive runs
+    for (size_t g0 = 0; g0 < ch->eng_jobs.size() && rc == 0; g0 += ENG_MAX_JOBS) {
+    const size_t g1 = std::min(ch->eng_jobs.size(), g0 + (size_t)ENG_MAX_JOBS);
+    const size_t n_jobs = g1 - g0;
+    const unsigned long long base0 = ch->eng_jobs[g0].dev.item_base;
+    const unsigned long long total = ch->eng_jobs[g1 - 1].dev.item_base + ch->eng_jobs[g1 - 1].dev.n_items - base0;
 
     // pool size: enough slots for every CU to hold several waves of each phase kernel
     size_t cap = 393216;  // 3 sub-pools x 131072 slots = 2048 waves: one full round of the chip (2 waves per SIMD) per kernel; 417792 is 6 % slower
@@ -1081,14 +1107,17 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
         // few restarts per target keeps the phase kernels small (their cost is per slot scanned)
         bool all_early = true;
         unsigned long long targets = 0;
-        for (const auto &j : ch->eng_jobs) { all_early = all_early && j.own_fs != nullptr; targets += (unsigned long long)j.T; }
+        for (size_t ji = g0; ji < g1; ++ji) {
+            const auto &j = ch->eng_jobs[ji];
+            all_early = all_early && j.own_fs != nullptr;
+            targets += (unsigned long long)j.T;
+        }
         if (all_early && !std::getenv("OPTIK_ENGINE_SLOTS")) {
             size_t want = (size_t)((targets * 8ull + 255ull) / 256ull * 256ull);
             if (want < 16384) want = 16384;
             if (want < C) C = want;
         }
     }
-    int rc = 0;
     const auto dbg_entry = std::chrono::steady_clock::now();
     auto run = [&]() -> int {
         // M(NN) is a statement macro instantiated for the chain's n
@@ -1114,11 +1143,12 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
         ch->eng_tcount = 0;
 
         std::vector<EngJob> hj(n_jobs);
-        for (size_t i = 0; i < n_jobs; ++i) hj[i] = ch->eng_jobs[i].dev;
+        for (size_t i = 0; i < n_jobs; ++i) { hj[i] = ch->eng_jobs[g0 + i].dev; hj[i].item_base -= base0; }
         HIP_TRY(hipMemcpyAsync(ch->eng_djobs, hj.data(), sizeof(EngJob) * n_jobs, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));  // hj goes out of scope; tiny copy
         HIP_TRY(hipMemsetAsync(ch->queue, 0, sizeof(unsigned long long), stream));
-        for (auto &j : ch->eng_jobs)
+        for (size_t ji = g0; ji < g1; ++ji) {
+            auto &j = ch->eng_jobs[ji];
             if (j.own_fs) {
                 HIP_TRY(hipMemsetAsync(j.own_fs, 0xff, sizeof(unsigned long long) * (size_t)j.T, stream));
                 // restarts abandoned before they start never touch their outputs: key = no solution
@@ -1126,6 +1156,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
                     hipLaunchKernelGGL(fill_f64_kernel, dim3(1024), dim3(256), 0, stream, j.dev.out_key,
                                        (unsigned long long)j.dev.n_items, __builtin_huge_val());
             }
+        }
 
         EngArgs a;
         std::memset(&a, 0, sizeof a);
@@ -1149,6 +1180,9 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
         a.nn_slack = 1;  // (measured: no per-problem cap 23.9, slack 1 -> 24.6, slack 0 -> 23.2 M restarts/s)
         if (const char *e = getenv("OPTIK_ENG_NNLS_SLACK")) a.nn_slack = atoi(e) > 0 ? atoi(e) : 0;
         a.nn_total = ch->eng_nn_total;
+        a.exec_evals = ch->eng_nn_total + 1;
+        a.tail_deadline_ticks = 0;
+        a.abort = 0;
         a.parity = 0;
         a.prof = nullptr;
         a.prof2 = nullptr;
@@ -1242,11 +1276,17 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
         if (getenv("OPTIK_ENG_DEBUG"))
             fprintf(stderr, "[optik engine] set-up %.2f ms (C = %zu)\n", std::chrono::duration<double>(dbg_t0 - dbg_entry).count() * 1e3, (size_t)C);
         // queues CHECK trips of one sub-pool, then looks at the in-use count of its previous chunk
+        const size_t eval_lds = sizeof(EngJob) * n_jobs;  // the eval kernel's copy of the job table
+        bool aborted = false;
         auto advance = [&](Pool &P, bool first_pool) -> int {
             EngArgs &a = P.a;
             hipStream_t stream = P.stream;
             unsigned &blocks = P.blocks;
             int &trip = P.trip;
+            // max_time (lib.rs:260-264, 308): once it has expired every trip queued from here on
+            // abandons what is in flight and drains the queue without starting anything
+            if (deadline_s > 0.0 && !aborted && since_call() > deadline_s) aborted = true;
+            a.abort = aborted ? 1 : 0;
             for (int k = 0; k < CHECK; ++k, ++trip) {
                 // this trip consumes list[trip & 1]; the other list (consumed last trip) is
                 // reset for the finish kernel's re-deferrals and the next trip's update kernel
@@ -1266,12 +1306,13 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
 #define TEV(kind) do { tev0 = tev1 = nullptr; if (timed && (kind == 2 || timed_all)) {                                   \
                         for (int w_ = 0; w_ < 2; ++w_) { hipEvent_t &tev_slot_ = ch->eng_tev[kind][ts][w_]; if (!tev_slot_) HIP_TRY(hipEventCreate(&tev_slot_)); } \
                         tev0 = ch->eng_tev[kind][ts][0]; tev1 = ch->eng_tev[kind][ts][1]; } } while (0)
-#define ENG_LAUNCH(kernel, grid, block) do { if (tev0) hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, tev0, tev1, 0, a); \
-                                             else hipLaunchKernelGGL(kernel, grid, block, 0, stream, a); } while (0)
+#define ENG_LAUNCH_LDS(kernel, grid, block, lds) do { if (tev0) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, tev0, tev1, 0, a); \
+                                                       else hipLaunchKernelGGL(kernel, grid, block, lds, stream, a); } while (0)
+#define ENG_LAUNCH(kernel, grid, block) ENG_LAUNCH_LDS(kernel, grid, block, 0)
                 TEV(0);
                 if (trip > 0) {
-#define M_EVAL_T(NN) ENG_LAUNCH((eng_eval_kernel<NN, true>), dim3(blocks), dim3(OPTIK_ENG_SLOT_BLOCK))
-#define M_EVAL_F(NN) ENG_LAUNCH((eng_eval_kernel<NN, false>), dim3(blocks), dim3(OPTIK_ENG_SLOT_BLOCK))
+#define M_EVAL_T(NN) ENG_LAUNCH_LDS((eng_eval_kernel<NN, true>), dim3(blocks), dim3(OPTIK_ENG_SLOT_BLOCK), eval_lds)
+#define M_EVAL_F(NN) ENG_LAUNCH_LDS((eng_eval_kernel<NN, false>), dim3(blocks), dim3(OPTIK_ENG_SLOT_BLOCK), eval_lds)
                     if (tip) DISPATCH_N(M_EVAL_T);
                     else DISPATCH_N(M_EVAL_F);
 #undef M_EVAL_T
@@ -1301,6 +1342,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
 #undef M_FIN
 #undef TEV
 #undef ENG_LAUNCH
+#undef ENG_LAUNCH_LDS
                 if (timed) ch->eng_tcount += 1;
                 ch->eng_launches += 1;
             }
@@ -1363,7 +1405,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
                 if (prc != 0) return prc;
                 all_done = all_done && pools[p2].done;
             }
-            if (all_done || tail_max == 0) continue;
+            if (all_done || tail_max == 0 || aborted) continue;
             // every sub-pool still running has reported a count since the queue ran dry?
             unsigned long long left = 0;
             bool known = true;
@@ -1394,6 +1436,12 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             EngArgs ta = pools[0].a;
             ta.slot_base = 0;
             ta.n_slots = C;
+            ta.tail_deadline_ticks = 0;
+            if (deadline_s > 0.0) {
+                const double left_s = deadline_s - since_call();
+                const double khz = ch->wall_clock_khz > 0 ? (double)ch->wall_clock_khz : 100000.0;
+                ta.tail_deadline_ticks = left_s > 0.0 ? (unsigned long long)(left_s * khz * 1e3) + 1ull : 1ull;
+            }
 #define M_TAIL_T(NN) hipLaunchKernelGGL((eng_tail_kernel<NN, true>), dim3(t_grid), dim3(WAVE), 0, stream, ta, t_list, t_count, lanes_i)
 #define M_TAIL_F(NN) hipLaunchKernelGGL((eng_tail_kernel<NN, false>), dim3(t_grid), dim3(WAVE), 0, stream, ta, t_list, t_count, lanes_i)
             if (tip) DISPATCH_N(M_TAIL_T);
@@ -1419,7 +1467,8 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
 
         // selection of every job (lib.rs:397-413)
         constexpr int SEL_TILE = 4096;
-        for (auto &j : ch->eng_jobs) {
+        for (size_t ji = g0; ji < g1; ++ji) {
+            auto &j = ch->eng_jobs[ji];
             const optik_hip_ik_outputs &o = j.out;
             if (!(o.d_win_x || o.d_win_f || o.d_win_idx || o.d_win_key)) continue;
             const uint64_t R = j.dev.n_restarts;
@@ -1489,11 +1538,18 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
             if (FILE *fp = fopen(tf, "wb")) { fwrite(h.data(), sizeof(unsigned long long), h.size(), fp); fclose(fp); }
         }
 #endif
-        HIP_TRY(hipMemcpy(&ch->eng_nn_problems, ch->eng_nn_total, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        {
+            unsigned long long h[1 + ENG_EXEC_SHARDS];
+            HIP_TRY(hipMemcpy(h, ch->eng_nn_total, sizeof h, hipMemcpyDeviceToHost));
+            ch->eng_nn_problems = h[0];
+            ch->eng_exec_evals = 0;
+            for (int k = 0; k < ENG_EXEC_SHARDS; ++k) ch->eng_exec_evals += h[1 + k];
+        }
         return 0;
 #undef DISPATCH_N
     };
     rc = run();
+    }  // job groups
     for (auto &j : ch->eng_jobs) {
         if (j.own_x) (void)hipFree(j.own_x);
         if (j.own_f) (void)hipFree(j.own_f);
@@ -1509,6 +1565,7 @@ int optik_hip_engine_run(optik_hip_chain *ch, void *stream_v) {
 int optik_hip_engine_reserve(optik_hip_chain *ch, uint64_t slots, void *stream_v) {
     if (!ch) return fail(OPTIK_HIP_EINVAL, "bad argument");
     std::lock_guard<std::mutex> lock(ch->mu);
+    BIND_DEVICE(ch);
     size_t cap = 393216;
     if (const char *e = std::getenv("OPTIK_ENGINE_SLOTS")) { const long v = std::atol(e); if (v >= 256) cap = (size_t)v; }
     const size_t AC = slots ? (size_t)((slots + 255) / 256 * 256) : cap;
@@ -1543,6 +1600,8 @@ int optik_hip_engine_stats(const optik_hip_chain *ch, double *kernel_ms4, int32_
     return 0;
 }
 
+uint64_t optik_hip_engine_executed_evals(const optik_hip_chain *ch) { return ch ? ch->eng_exec_evals : 0; }
+
 int optik_hip_ik_host(optik_hip_chain *ch, const optik_solver_config *cfg, const double *targets,
                       const double *x0, int32_t T, const double *ee_offset7, uint64_t restart_begin,
                       uint64_t restart_end, uint32_t flags, double deadline_s, double *win_x, double *win_f,
@@ -1550,6 +1609,7 @@ int optik_hip_ik_host(optik_hip_chain *ch, const optik_solver_config *cfg, const
     if (!ch || !targets || !x0 || T < 1) return fail(OPTIK_HIP_EINVAL, "bad argument");
     // the launch workspace of the chain is in use until the copies below are done
     std::lock_guard<std::mutex> host_lock(ch->host_mu);
+    BIND_DEVICE(ch);
     const int n = ch->n;
     // one device block and one pinned staging block, kept with the chain (a call used to pay
     // six hipMalloc / hipFree pairs and six copies): in = targets [T][7], x0 [T][n];

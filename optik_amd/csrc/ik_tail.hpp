@@ -94,8 +94,12 @@ OPTIK_DEV void tail_wave(const EngArgs &a, const ChainDev &ch, const EngJob *job
         }
     }
     const EngJob &J = jobs[job];
+    // max_time (lib.rs:308): restarts still running at the deadline are abandoned
+    const unsigned long long deadline = a.tail_deadline_ticks ? (unsigned long long)wall_clock64() + a.tail_deadline_ticks : 0ull;
 
+    unsigned n_exec = 0;  // evaluations this lane executed
     while (wave_any(active)) {
+        if (active && ret == 0 && deadline && (unsigned long long)wall_clock64() > deadline) ret = RES_FORCED_STOP;
         if (active && ret == 0 && J.first_success) {
             // lib.rs:308: abandon when a lower-index restart of the same target succeeded
             const unsigned long long fs = __hip_atomic_load(J.first_success + tslot, __ATOMIC_RELAXED,
@@ -106,7 +110,7 @@ OPTIK_DEV void tail_wave(const EngArgs &a, const ChainDev &ch, const EngJob *job
         double fn = 0.0;
         const bool do_eval = active && ret == 0 && !pending_dir;
         OPTIK_SCHED_FENCE();
-        if (do_eval) fn = eval_fg<N, TIP>(ch, a.ep, target, x, gn);
+        if (do_eval) { fn = eval_fg<N, TIP>(ch, a.ep, target, x, gn); ++n_exec; }
         OPTIK_SCHED_FENCE();
         if (active && ret == 0) {
             bool need_dir = false, reset = false;
@@ -259,6 +263,12 @@ OPTIK_DEV void tail_wave(const EngArgs &a, const ChainDev &ch, const EngJob *job
             ENG_I(E::STATE) = ST_EMPTY;
             active = false;
         }
+    }
+    if (a.exec_evals) {
+        unsigned tot = n_exec;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) tot += (unsigned)__shfl_xor((int)tot, off, 64);
+        if (lane == 0 && tot) atomicAdd(a.exec_evals + (blockIdx.x % ENG_EXEC_SHARDS), (unsigned long long)tot);
     }
 }
 

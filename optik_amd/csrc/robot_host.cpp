@@ -14,10 +14,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <memory>
 #include <mutex>
 #include <random>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/optik.h"
@@ -26,6 +28,20 @@
 using optik_host::Chain;
 using optik_host::HPose;
 
+// What the robot keeps on one GPU: the uploaded chain and reusable staging for the host API.
+struct DeviceCtx {
+    int device = 0;
+    optik_hip_chain *chain = nullptr;
+    double *d_scratch = nullptr;  // q[n] | pose[7] | jac[6n]
+    int num_cus = 0;
+    // optik_robot_ik_batch_ex workspace, grown on demand and kept across calls:
+    // device block = targets [T][7] | x0 [T][n] | win_x [T][n] | win_f [T] | win_key [T] | win_idx [T]
+    double *d_batch = nullptr;
+    double *h_batch = nullptr;  // pinned mirror
+    size_t batch_cap = 0;       // doubles
+    std::mutex batch_mu;        // one batch at a time per device
+};
+
 struct optik_robot {
     Chain chain;
     int n = 0;
@@ -33,10 +49,12 @@ struct optik_robot {
     std::vector<double> origins, axes;  // n_joints x 7, n_joints x 3
     std::vector<int32_t> types;
     unsigned parallelism = 0;  // accepted for API compatibility (lib.rs:66-72); unused
-    mutable std::mutex mu;     // guards the lazily created device chain and the scratch
-    mutable optik_hip_chain *dev = nullptr;
-    mutable double *d_scratch = nullptr;  // q[n] | pose[7] | jac[6n]
-    mutable int num_cus = 0;
+    mutable std::mutex mu;     // guards the lazily created device contexts and the FK scratch
+    // GPUs this robot spreads restart ranges / targets over (optik_robot_set_devices,
+    // OPTIK_DEVICES); empty = the HIP device current at first use.  The same id may be listed
+    // more than once (two contexts on one GPU: how the sharding is tested on a 1-GPU box).
+    std::vector<int> device_ids;
+    mutable std::vector<std::unique_ptr<DeviceCtx>> devs;
 };
 
 namespace {
@@ -54,6 +72,8 @@ int set_err(int code, const std::string &msg) {
     g_robot_err = msg;
     return code;
 }
+
+std::vector<int> devices_from_env();
 
 optik_robot *make_robot(const std::string &urdf, const char *base, const char *ee) {
     auto *r = new optik_robot();
@@ -74,14 +94,28 @@ optik_robot *make_robot(const std::string &urdf, const char *base, const char *e
             r->ub.push_back(j.upper);
         }
     }
+    r->device_ids = devices_from_env();
     return r;
 }
 
-// Device chain of the robot, created on first use.  Returns nullptr and sets the
-// error string on failure.
-optik_hip_chain *device_chain(const optik_robot *r) {
+// Context k of the robot (its k-th listed GPU), created on first use.  Returns nullptr and sets
+// the error string on failure.
+DeviceCtx *device_ctx(const optik_robot *r, size_t k = 0) {
     std::lock_guard<std::mutex> lock(r->mu);
-    if (r->dev) return r->dev;
+    if (r->devs.empty()) {
+        const size_t count = r->device_ids.empty() ? 1 : r->device_ids.size();
+        for (size_t i = 0; i < count; ++i) r->devs.emplace_back(new DeviceCtx());
+    }
+    if (k >= r->devs.size()) { g_robot_err = "no such device context"; return nullptr; }
+    DeviceCtx *c = r->devs[k].get();
+    if (c->chain) return c;
+    int devid = 0;
+    if (r->device_ids.empty()) (void)hipGetDevice(&devid);
+    else devid = r->device_ids[k];
+    if (hipSetDevice(devid) != hipSuccess) {
+        g_robot_err = "hipSetDevice(" + std::to_string(devid) + ") failed";
+        return nullptr;
+    }
     optik_hip_chain *h = nullptr;
     const int rc = optik_hip_chain_create(r->origins.data(), r->axes.data(), r->types.data(),
                                           (int32_t)r->types.size(), r->lb.data(), r->ub.data(), r->n, &h);
@@ -89,16 +123,37 @@ optik_hip_chain *device_chain(const optik_robot *r) {
         g_robot_err = std::string("GPU chain creation failed: ") + optik_hip_last_error();
         return nullptr;
     }
-    if (hipMalloc(&r->d_scratch, sizeof(double) * (size_t)(r->n + 7 + 6 * r->n)) != hipSuccess) {
+    if (hipMalloc(&c->d_scratch, sizeof(double) * (size_t)(r->n + 7 + 6 * r->n)) != hipSuccess) {
         optik_hip_chain_destroy(h);
         g_robot_err = "GPU scratch allocation failed";
         return nullptr;
     }
-    int devid = 0;
-    (void)hipGetDevice(&devid);
-    (void)hipDeviceGetAttribute(&r->num_cus, hipDeviceAttributeMultiprocessorCount, devid);
-    r->dev = h;
-    return h;
+    (void)hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, devid);
+    c->device = devid;
+    c->chain = h;
+    return c;
+}
+
+size_t device_count(const optik_robot *r) { return r->device_ids.empty() ? 1 : r->device_ids.size(); }
+
+// OPTIK_DEVICES = "all" | "N" (the first N devices) | "0,2,3": GPUs a robot spreads work over
+std::vector<int> devices_from_env() {
+    std::vector<int> ids;
+    const char *e = std::getenv("OPTIK_DEVICES");
+    if (!e || !*e) return ids;
+    int have = 0;
+    (void)hipGetDeviceCount(&have);
+    const std::string v(e);
+    if (v == "all") { for (int i = 0; i < have; ++i) ids.push_back(i); return ids; }
+    if (v.find(',') == std::string::npos) {
+        const int cnt = std::atoi(v.c_str());
+        for (int i = 0; i < cnt && i < have; ++i) ids.push_back(i);
+        return ids;
+    }
+    std::stringstream ss(v);
+    for (std::string tok; std::getline(ss, tok, ',');)
+        if (!tok.empty()) ids.push_back(std::atoi(tok.c_str()));
+    return ids;
 }
 
 // 4x4 column-major homogeneous matrix -> pose7, with nalgebra's
@@ -144,12 +199,14 @@ void mat16_from_pose7(const double *p, double *m) {
 }
 
 int fk_on_device(const optik_robot *r, const double *x, const double *ee16, double *pose7, double *jac) {
-    optik_hip_chain *h = device_chain(r);
-    if (!h) return -1;
+    DeviceCtx *c = device_ctx(r);
+    if (!c) return -1;
+    optik_hip_chain *h = c->chain;
     double ee7[7];
     if (ee16) pose7_from_mat16(ee16, ee7);
     std::lock_guard<std::mutex> lock(r->mu);
-    double *d_q = r->d_scratch, *d_pose = d_q + r->n, *d_jac = d_pose + 7;
+    if (hipSetDevice(c->device) != hipSuccess) return set_err(-1, "hipSetDevice failed");
+    double *d_q = c->d_scratch, *d_pose = d_q + r->n, *d_jac = d_pose + 7;
     if (hipMemcpy(d_q, x, sizeof(double) * (size_t)r->n, hipMemcpyHostToDevice) != hipSuccess)
         return set_err(-1, "hipMemcpy failed");
     if (optik_hip_fk_batch(h, ee16 ? ee7 : nullptr, d_q, 1, d_pose, jac ? d_jac : nullptr, nullptr))
@@ -202,10 +259,30 @@ optik_robot *optik_robot_from_urdf_file(const char *path, const char *base_link,
 
 void optik_robot_free(optik_robot *r) {
     if (!r) return;
-    if (r->dev) optik_hip_chain_destroy(r->dev);
-    if (r->d_scratch) (void)hipFree(r->d_scratch);
+    for (auto &c : r->devs) {
+        if (!c->chain) continue;
+        (void)hipSetDevice(c->device);
+        optik_hip_chain_destroy(c->chain);
+        if (c->d_scratch) (void)hipFree(c->d_scratch);
+        if (c->d_batch) (void)hipFree(c->d_batch);
+        if (c->h_batch) (void)hipHostFree(c->h_batch);
+    }
     delete r;
 }
+
+int optik_robot_set_devices(optik_robot *r, const int32_t *device_ids, int32_t count) {
+    if (!r || count < 0 || (count > 0 && !device_ids)) return set_err(-1, "bad argument");
+    std::lock_guard<std::mutex> lock(r->mu);
+    if (!r->devs.empty()) return set_err(-1, "set_devices must be called before the robot's first GPU call");
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess) have = 0;
+    for (int i = 0; i < count; ++i)
+        if (device_ids[i] < 0 || device_ids[i] >= have) return set_err(-1, "no such HIP device");
+    r->device_ids.assign(device_ids, device_ids + count);
+    return 0;
+}
+
+int32_t optik_robot_num_devices(const optik_robot *r) { return r ? (int32_t)device_count(r) : 0; }
 
 void optik_robot_set_parallelism(optik_robot *r, unsigned int n) {
     // The rayon pool size has no counterpart: the GPU grid is sized from the device.
@@ -265,8 +342,8 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
     for (int i = 0; i < r->n; ++i)
         if (x0[i] < r->lb[i] || x0[i] > r->ub[i])
             return set_err(-2, "seed joint position outside of joint limits");
-    optik_hip_chain *h = device_chain(r);
-    if (!h) return -1;
+    DeviceCtx *c0 = device_ctx(r);
+    if (!c0) return -1;
     double tgt7[7], ee7[7];
     pose7_from_mat16(target16, tgt7);
     if (ee16) pose7_from_mat16(ee16, ee7);
@@ -280,13 +357,25 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
     // The first launch covers as many restart indices as the chip holds resident waves (one
     // restart per wave: no wave pays for the phases of 63 other restarts, and a third to a
     // half of the restarts succeed, so it almost always contains the answer); later launches
-    // cover enough 64-lane tiles to fill every CU a few times over.
-    const uint64_t cus = (uint64_t)(r->num_cus > 0 ? r->num_cus : 256);
+    // cover enough 64-lane tiles to fill every CU a few times over -- on every GPU of the robot
+    // at once: device g of G takes the g-th contiguous part of the round's index range
+    // (lib.rs:297-300 shards the same range over rayon workers) and the host keeps the
+    // minimum of the G (key, index) records.
+    const uint64_t cus = (uint64_t)(c0->num_cus > 0 ? c0->num_cus : 256);
     const uint64_t first_batch = cus * 2, later_batch = cus * 2 * 64 * 2;
+    const size_t G = device_count(r);
+    struct Part {
+        DeviceCtx *ctx = nullptr;
+        uint64_t begin = 0, end = 0, widx = UINT64_MAX;
+        double wf = 0.0, wkey = 0.0;
+        std::vector<double> wx;
+        int rc = 0;
+        std::string err;
+    };
     bool have = false;
     double best_key = 0.0, best_f = 0.0;
     uint64_t best_idx = UINT64_MAX;
-    std::vector<double> best_x((size_t)r->n), wx((size_t)r->n);
+    std::vector<double> best_x((size_t)r->n);
     for (uint64_t begin = 0; begin < max_restarts;) {
         // lib.rs:393: stop issuing restarts once out of time
         double deadline = 0.0;
@@ -294,22 +383,44 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
             deadline = config->max_time - elapsed();
             if (deadline <= 0.0) break;
         }
+        const size_t g_round = begin == 0 ? 1 : G;  // (the latency-sized first launch stays on one GPU)
         const uint64_t batch = begin == 0 ? first_batch : later_batch;
-        const uint64_t end = (max_restarts - begin > batch) ? begin + batch : max_restarts;
-        double wf = 0.0, wkey = 0.0;
-        uint64_t widx = UINT64_MAX;
-        const int rc = optik_hip_ik_host(h, config, tgt7, x0, 1, ee16 ? ee7 : nullptr, begin, end,
-                                         quality ? 0u : OPTIK_HIP_IK_EARLY_EXIT, deadline, wx.data(), &wf,
-                                         &widx, &wkey);
-        if (rc) return set_err(-1, optik_hip_last_error());
-        if (widx != UINT64_MAX) {
-            // lib.rs:397-413: Quality keeps the solution closest to the seed, Speed the first one
-            if (!have || wkey < best_key || (wkey == best_key && widx < best_idx)) {
-                have = true; best_key = wkey; best_idx = widx; best_f = wf; best_x = wx;
-            }
-            if (!quality) break;
+        std::vector<Part> parts;
+        for (size_t g = 0; g < g_round && begin < max_restarts; ++g) {
+            Part p;
+            p.ctx = g == 0 ? c0 : device_ctx(r, g);
+            if (!p.ctx) return -1;
+            p.begin = begin;
+            p.end = (max_restarts - begin > batch) ? begin + batch : max_restarts;
+            p.wx.resize((size_t)r->n);
+            begin = p.end;
+            parts.push_back(std::move(p));
         }
-        begin = end;
+        auto run_part = [&](Part &p) {
+            p.rc = optik_hip_ik_host(p.ctx->chain, config, tgt7, x0, 1, ee16 ? ee7 : nullptr, p.begin, p.end,
+                                     quality ? 0u : OPTIK_HIP_IK_EARLY_EXIT, deadline, p.wx.data(), &p.wf, &p.widx,
+                                     &p.wkey);
+            if (p.rc) p.err = optik_hip_last_error();
+        };
+        if (parts.size() == 1) {
+            run_part(parts[0]);
+        } else {
+            std::vector<std::thread> th;
+            for (size_t g = 1; g < parts.size(); ++g) th.emplace_back(run_part, std::ref(parts[g]));
+            run_part(parts[0]);
+            for (auto &t : th) t.join();
+        }
+        bool found_round = false;
+        for (const Part &p : parts) {
+            if (p.rc) return set_err(-1, p.err);
+            if (p.widx == UINT64_MAX) continue;
+            found_round = true;
+            // lib.rs:397-413: Quality keeps the solution closest to the seed, Speed the first one
+            if (!have || p.wkey < best_key || (p.wkey == best_key && p.widx < best_idx)) {
+                have = true; best_key = p.wkey; best_idx = p.widx; best_f = p.wf; best_x = p.wx;
+            }
+        }
+        if (found_round && !quality) break;
     }
     if (!have) return 1;
     if (x_out) std::memcpy(x_out, best_x.data(), sizeof(double) * (size_t)r->n);
@@ -318,31 +429,24 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
     return 0;
 }
 
-// Many independent ik() calls at once (the motion-planning workload of examples/example.rs:
-// a stream of targets, each with its own seed): every target gets the semantics of Robot::ik
-// with the same SolverConfig.  Runs on the streaming engine in rounds of `round` restart
-// indices per target; targets already solved (Speed) drop out of later rounds; max_time is
-// checked between rounds.
-int optik_robot_ik_batch_ex(const optik_robot *r, const CSolverConfig *config, int32_t T,
-                            const double *targets16, const double *x0, const double *ee16, double *x_out,
-                            double *f_out, int32_t *found_out) {
-    if (!r || !config || !targets16 || !x0 || T < 1) return set_err(-1, "bad argument");
+namespace {
+
+// optik_robot_ik_batch_ex for the targets of one GPU: rounds of `round` restart indices per
+// target on the streaming engine; targets already solved (Speed) drop out of later rounds;
+// max_time is enforced inside a run (optik_hip_engine_run_ex) and between rounds.
+int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *config, int32_t T,
+                       const double *targets16, const double *x0, const double *ee7,
+                       std::chrono::steady_clock::time_point start, double *x_out, double *f_out,
+                       int32_t *found_out, std::string &err) {
     const int n = r->n;
-    for (int t = 0; t < T; ++t)
-        for (int i = 0; i < n; ++i)
-            if (x0[(size_t)t * n + i] < r->lb[i] || x0[(size_t)t * n + i] > r->ub[i])
-                return set_err(-2, "seed joint position outside of joint limits");
-    optik_hip_chain *h = device_chain(r);
-    if (!h) return -1;
-    double ee7[7];
-    if (ee16) pose7_from_mat16(ee16, ee7);
-    const auto start = std::chrono::steady_clock::now();
     auto elapsed = [&]() {
         return std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
     };
     const uint64_t max_restarts = config->max_restarts > 0 ? config->max_restarts : UINT64_MAX;
     const bool quality = config->solution_mode == 1;
     const uint64_t round = 256;  // restart indices per target per engine run
+    std::lock_guard<std::mutex> lock(c->batch_mu);
+    if (hipSetDevice(c->device) != hipSuccess) { err = "hipSetDevice failed"; return -1; }
 
     std::vector<double> tgt7((size_t)T * 7), best_key((size_t)T, 0.0);
     std::vector<uint64_t> best_idx((size_t)T, UINT64_MAX);
@@ -351,57 +455,62 @@ int optik_robot_ik_batch_ex(const optik_robot *r, const CSolverConfig *config, i
     for (int t = 0; t < T; ++t) live[t] = t;
     for (int t = 0; t < T; ++t) if (found_out) found_out[t] = 0;
 
-    double *d_t = nullptr, *d_x0 = nullptr, *d_wx = nullptr, *d_wf = nullptr, *d_wk = nullptr;
-    uint64_t *d_wi = nullptr;
-    auto cleanup = [&]() {
-        if (d_t) (void)hipFree(d_t);
-        if (d_x0) (void)hipFree(d_x0);
-        if (d_wx) (void)hipFree(d_wx);
-        if (d_wf) (void)hipFree(d_wf);
-        if (d_wk) (void)hipFree(d_wk);
-        if (d_wi) (void)hipFree(d_wi);
-    };
-#define TRYH(expr) do { if ((expr) != hipSuccess) { cleanup(); return set_err(-1, #expr " failed"); } } while (0)
-    TRYH(hipMalloc(&d_t, sizeof(double) * 7 * (size_t)T));
-    TRYH(hipMalloc(&d_x0, sizeof(double) * (size_t)n * (size_t)T));
-    TRYH(hipMalloc(&d_wx, sizeof(double) * (size_t)n * (size_t)T));
-    TRYH(hipMalloc(&d_wf, sizeof(double) * (size_t)T));
-    TRYH(hipMalloc(&d_wk, sizeof(double) * (size_t)T));
-    TRYH(hipMalloc(&d_wi, sizeof(uint64_t) * (size_t)T));
-    std::vector<double> ht, hx, wx, wf, wk;
-    std::vector<uint64_t> wi;
-    for (uint64_t begin = 0; begin < max_restarts && !live.empty();) {
-        if (config->max_time > 0.0 && elapsed() > config->max_time) break;  // lib.rs:393
-        const uint64_t end = (max_restarts - begin > round) ? begin + round : max_restarts;
-        const int L = (int)live.size();
-        ht.resize((size_t)L * 7); hx.resize((size_t)L * n);
-        for (int k = 0; k < L; ++k) {
-            std::memcpy(&ht[(size_t)k * 7], &tgt7[(size_t)live[k] * 7], sizeof(double) * 7);
-            std::memcpy(&hx[(size_t)k * n], &x0[(size_t)live[k] * n], sizeof(double) * (size_t)n);
+    // one device block and its pinned mirror, kept with the context across calls
+    const size_t n_in = (size_t)(7 + n) * (size_t)T, n_out = (size_t)(n + 3) * (size_t)T;
+    if (n_in + n_out > c->batch_cap) {
+        if (c->d_batch) (void)hipFree(c->d_batch);
+        if (c->h_batch) (void)hipHostFree(c->h_batch);
+        c->d_batch = nullptr; c->h_batch = nullptr; c->batch_cap = 0;
+        if (hipMalloc(&c->d_batch, sizeof(double) * (n_in + n_out)) != hipSuccess
+            || hipHostMalloc(&c->h_batch, sizeof(double) * (n_in + n_out)) != hipSuccess) {
+            err = "batch workspace allocation failed";
+            return -1;
         }
-        TRYH(hipMemcpy(d_t, ht.data(), sizeof(double) * ht.size(), hipMemcpyHostToDevice));
-        TRYH(hipMemcpy(d_x0, hx.data(), sizeof(double) * hx.size(), hipMemcpyHostToDevice));
+        c->batch_cap = n_in + n_out;
+    }
+    for (uint64_t begin = 0; begin < max_restarts && !live.empty();) {
+        double deadline = 0.0;
+        if (config->max_time > 0.0) {
+            deadline = config->max_time - elapsed();
+            if (deadline <= 0.0) break;  // lib.rs:393
+        }
+        const uint64_t end = (max_restarts - begin > round) ? begin + round : max_restarts;
+        const size_t L = live.size();
+        double *h_t = c->h_batch, *h_x0 = h_t + 7 * L, *h_out = h_x0 + (size_t)n * L;
+        double *d_t = c->d_batch, *d_x0 = d_t + 7 * L, *d_wx = d_x0 + (size_t)n * L, *d_wf = d_wx + (size_t)n * L,
+               *d_wk = d_wf + L;
+        uint64_t *d_wi = reinterpret_cast<uint64_t *>(d_wk + L);
+        for (size_t k = 0; k < L; ++k) {
+            std::memcpy(&h_t[k * 7], &tgt7[(size_t)live[k] * 7], sizeof(double) * 7);
+            std::memcpy(&h_x0[k * n], &x0[(size_t)live[k] * n], sizeof(double) * (size_t)n);
+        }
+        if (hipMemcpyAsync(d_t, h_t, sizeof(double) * (size_t)(7 + n) * L, hipMemcpyHostToDevice, nullptr) != hipSuccess) {
+            err = "upload failed";
+            return -1;
+        }
         optik_hip_ik_outputs o;
         std::memset(&o, 0, sizeof o);
         o.d_win_x = d_wx; o.d_win_f = d_wf; o.d_win_idx = d_wi; o.d_win_key = d_wk;
-        int rc = optik_hip_engine_submit(h, config, d_t, d_x0, L, ee16 ? ee7 : nullptr, begin, end,
+        int rc = optik_hip_engine_submit(c->chain, config, d_t, d_x0, (int32_t)L, ee7, begin, end,
                                          quality ? 0u : OPTIK_HIP_IK_EARLY_EXIT, &o);
-        if (!rc) rc = optik_hip_engine_run(h, nullptr);
-        if (rc) { cleanup(); return set_err(-1, optik_hip_last_error()); }
-        wx.resize((size_t)L * n); wf.resize((size_t)L); wk.resize((size_t)L); wi.resize((size_t)L);
-        TRYH(hipMemcpy(wx.data(), d_wx, sizeof(double) * wx.size(), hipMemcpyDeviceToHost));
-        TRYH(hipMemcpy(wf.data(), d_wf, sizeof(double) * wf.size(), hipMemcpyDeviceToHost));
-        TRYH(hipMemcpy(wk.data(), d_wk, sizeof(double) * wk.size(), hipMemcpyDeviceToHost));
-        TRYH(hipMemcpy(wi.data(), d_wi, sizeof(uint64_t) * wi.size(), hipMemcpyDeviceToHost));
+        if (!rc) rc = optik_hip_engine_run_ex(c->chain, nullptr, deadline);
+        if (rc) { err = optik_hip_last_error(); return -1; }
+        if (hipMemcpyAsync(h_out, d_wx, sizeof(double) * (size_t)(n + 3) * L, hipMemcpyDeviceToHost, nullptr) != hipSuccess
+            || hipStreamSynchronize(nullptr) != hipSuccess) {
+            err = "download failed";
+            return -1;
+        }
+        const double *wx = h_out, *wf = wx + (size_t)n * L, *wk = wf + L;
+        const uint64_t *wi = reinterpret_cast<const uint64_t *>(wk + L);
         std::vector<int> still;
-        for (int k = 0; k < L; ++k) {
+        for (size_t k = 0; k < L; ++k) {
             const int t = live[k];
             if (wi[k] != UINT64_MAX) {
                 const bool better = best_idx[t] == UINT64_MAX || wk[k] < best_key[t]
                                     || (wk[k] == best_key[t] && wi[k] < best_idx[t]);
                 if (better) {
                     best_idx[t] = wi[k]; best_key[t] = wk[k];
-                    if (x_out) std::memcpy(&x_out[(size_t)t * n], &wx[(size_t)k * n], sizeof(double) * (size_t)n);
+                    if (x_out) std::memcpy(&x_out[(size_t)t * n], &wx[k * n], sizeof(double) * (size_t)n);
                     if (f_out) f_out[t] = wf[k];
                     if (found_out) found_out[t] = 1;
                 }
@@ -412,8 +521,54 @@ int optik_robot_ik_batch_ex(const optik_robot *r, const CSolverConfig *config, i
         live.swap(still);
         begin = end;
     }
-#undef TRYH
-    cleanup();
+    return 0;
+}
+
+}  // namespace
+
+// Many independent ik() calls at once (the motion-planning workload of examples/example.rs:
+// a stream of targets, each with its own seed): every target gets the semantics of Robot::ik
+// with the same SolverConfig.  The targets are split into contiguous parts over the robot's
+// GPUs (BASELINE.json config 5: no collective, the host gathers), each part runs on its GPU's
+// streaming engine from its own host thread.
+int optik_robot_ik_batch_ex(const optik_robot *r, const CSolverConfig *config, int32_t T,
+                            const double *targets16, const double *x0, const double *ee16, double *x_out,
+                            double *f_out, int32_t *found_out) {
+    if (!r || !config || !targets16 || !x0 || T < 1) return set_err(-1, "bad argument");
+    const int n = r->n;
+    for (int t = 0; t < T; ++t)
+        for (int i = 0; i < n; ++i)
+            if (x0[(size_t)t * n + i] < r->lb[i] || x0[(size_t)t * n + i] > r->ub[i])
+                return set_err(-2, "seed joint position outside of joint limits");
+    double ee7[7];
+    if (ee16) pose7_from_mat16(ee16, ee7);
+    const auto start = std::chrono::steady_clock::now();
+    size_t G = device_count(r);
+    if (G > (size_t)T) G = (size_t)T;
+    struct Part { DeviceCtx *ctx; int32_t t0, t1; int rc; std::string err; };
+    std::vector<Part> parts;
+    for (size_t g = 0; g < G; ++g) {
+        Part p{device_ctx(r, g), (int32_t)((int64_t)T * (int64_t)g / (int64_t)G),
+               (int32_t)((int64_t)T * (int64_t)(g + 1) / (int64_t)G), 0, {}};
+        if (!p.ctx) return -1;
+        parts.push_back(p);
+    }
+    auto run_part = [&](Part &p) {
+        p.rc = ik_batch_on_device(r, p.ctx, config, p.t1 - p.t0, targets16 + (size_t)p.t0 * 16,
+                                  x0 + (size_t)p.t0 * n, ee16 ? ee7 : nullptr, start,
+                                  x_out ? x_out + (size_t)p.t0 * n : nullptr, f_out ? f_out + p.t0 : nullptr,
+                                  found_out ? found_out + p.t0 : nullptr, p.err);
+    };
+    if (parts.size() == 1) {
+        run_part(parts[0]);
+    } else {
+        std::vector<std::thread> th;
+        for (size_t g = 1; g < parts.size(); ++g) th.emplace_back(run_part, std::ref(parts[g]));
+        run_part(parts[0]);
+        for (auto &t : th) t.join();
+    }
+    for (const Part &p : parts)
+        if (p.rc) return set_err(-1, p.err);
     return 0;
 }
 
@@ -602,6 +757,10 @@ int optik_robot_chain_tables(const optik_robot *r, int32_t *n_joints, double *or
     return 0;
 }
 
-optik_hip_chain *optik_robot_hip_chain(const optik_robot *r) { return r ? device_chain(r) : nullptr; }
+optik_hip_chain *optik_robot_hip_chain(const optik_robot *r) {
+    if (!r) return nullptr;
+    DeviceCtx *c = device_ctx(r);
+    return c ? c->chain : nullptr;
+}
 
 }  // extern "C"

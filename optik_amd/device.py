@@ -160,9 +160,10 @@ class HipChain:
         """Allocate the engine's slot pool ahead of the first run (0 = default capacity)."""
         nat.check(nat.lib().optik_hip_engine_reserve(self._h, int(slots), _stream_ptr()))
 
-    def engine_run(self):
-        """Run every submitted job to completion (blocking) and their selections."""
-        nat.check(nat.lib().optik_hip_engine_run(self._h, _stream_ptr()))
+    def engine_run(self, deadline_s=0.0):
+        """Run every submitted job to completion (blocking) and their selections.  deadline_s > 0:
+        max_time -- restarts still running that long after the call started are abandoned."""
+        nat.check(nat.lib().optik_hip_engine_run_ex(self._h, _stream_ptr(), float(deadline_s)))
         self._pending = []
         return int(nat.lib().optik_hip_engine_last_trips(self._h))
 
@@ -175,9 +176,10 @@ class HipChain:
         nat.check(nat.lib().optik_hip_engine_stats(self._h, ms, C.byref(cnt), C.byref(prob)))
         launches = C.c_int32(0)
         pools = int(nat.lib().optik_hip_engine_last_pools(self._h, C.byref(launches)))
+        executed = int(nat.lib().optik_hip_engine_executed_evals(self._h))
         return dict(eval_ms=ms[0], update_ms=ms[1], nnls_ms=ms[2], finish_ms=ms[3],
                     sampled_trips=cnt.value, nnls_problems=prob.value, pools=pools,
-                    launches=launches.value)
+                    launches=launches.value, evals_executed=executed, slot_trips=executed)
 
     def set_timing(self, enabled=True):
         nat.lib().optik_hip_set_timing(self._h, 1 if enabled else 0)

@@ -34,6 +34,8 @@ def _bind(L):
     L.optik_robot_fk_ex.argtypes = [vp, dp, dp, dp]
     L.optik_robot_diff_ik_ex.argtypes = [vp, dp, dp, dp, dp, C.POINTER(C.c_double), dp]
     L.optik_robot_joint_jacobian_ex.argtypes = [vp, dp, dp, dp]
+    L.optik_robot_set_devices.argtypes = [vp, C.POINTER(C.c_int32), C.c_int32]
+    L.optik_robot_num_devices.argtypes = [vp]
     L.optik_robot_chain_tables.argtypes = [vp, C.POINTER(C.c_int32), dp, dp, C.POINTER(C.c_int32)]
     L.optik_robot_hip_chain.argtypes = [vp]
     L.optik_robot_hip_chain.restype = vp
@@ -53,10 +55,22 @@ def _dp(a):
 
 
 def _pose16(m):
-    """Row-major nested 4x4 -> column-major flat (parse_pose, optik-py/src/lib.rs:8-15)."""
+    """Row-major nested 4x4 -> column-major flat (parse_pose, optik-py/src/lib.rs:8-15).
+
+    parse_pose converts with nalgebra's ``try_convert::<Matrix4, Isometry3>`` and panics with
+    "invalid target transform specified" unless the matrix is an isometry: bottom row exactly
+    (0, 0, 0, 1) and the 3x3 block special-orthogonal -- R^T R equal to the identity within
+    100 * f64::EPSILON per entry (``is_special_orthogonal``) and det R > 0.  Host-side input
+    validation, the same message."""
     a = np.asarray(m, dtype=np.float64)
     if a.shape != (4, 4):
         raise ValueError("pose must be a 4x4 homogeneous matrix")
+    R = a[:3, :3]
+    eps = 100.0 * np.finfo(np.float64).eps
+    ok = (a[3, 0] == 0.0 and a[3, 1] == 0.0 and a[3, 2] == 0.0 and a[3, 3] == 1.0
+          and np.all(np.abs(R.T @ R - np.eye(3)) <= eps) and np.linalg.det(R) > 0.0)
+    if not ok:
+        raise ValueError("invalid target transform specified")
     return np.ascontiguousarray(a.T).ravel()
 
 
@@ -122,6 +136,16 @@ class Robot:
 
     def set_parallelism(self, n: int) -> None:
         self._L.optik_robot_set_parallelism(self._h, int(n))
+
+    def set_devices(self, device_ids) -> None:
+        """GPUs of this node the robot spreads restart ranges (ik) and targets (ik_batch) over
+        (extension; include/optik.h: optik_robot_set_devices).  Before the first GPU call."""
+        ids = (C.c_int32 * len(device_ids))(*[int(d) for d in device_ids])
+        if self._L.optik_robot_set_devices(self._h, ids, len(device_ids)):
+            raise RuntimeError(_err(self._L))
+
+    def num_devices(self) -> int:
+        return int(self._L.optik_robot_num_devices(self._h))
 
     def num_positions(self) -> int:
         return int(self._L.optik_robot_num_positions(self._h))

@@ -89,14 +89,41 @@ def build(force: bool = False) -> str:
 
 
 _lib = None
+_lib_path = _LIB_PATH  # which build lib() loads (use_native_build() switches it)
+
+NATIVE_FLAGS = ["-O3", "-march=native", "-flto", "-fPIC", "-std=c11", "-ffp-contract=off", "-fno-fast-math", "-pthread"]
+
+
+def use_native_build() -> str:
+    """Compile the oracle for THIS host (-O3 -march=native -flto: the stand-in for the reference's
+    release profile, Cargo.toml:36-39 / SURVEY 8d) into liboptik_oracle_native.so and make lib()
+    load it.  Same arithmetic (-ffp-contract=off, no fast-math): bit-identical results, checked by
+    tests/test_oracle_native_build.py.  Used by bench.py's cpu_baseline leg only: the portable
+    build is what travels to the GPU box with the repository, an -march=native build cannot.
+    Falls back to the portable build when the compiler is missing; returns the flags in use."""
+    global _lib, _lib_path
+    out = os.path.join(_HERE, "liboptik_oracle_native.so")
+    src = os.path.join(_HERE, "optik_oracle.c")
+    try:
+        subprocess.check_call(["gcc", *NATIVE_FLAGS, "-shared", "-o", out, src, "-lm", "-lpthread"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except (OSError, subprocess.CalledProcessError):
+        return "portable: -O3 -ffp-contract=off (native build failed)"
+    _lib, _lib_path = None, out
+    return "gcc " + " ".join(NATIVE_FLAGS)
+
+
+def use_portable_build():
+    global _lib, _lib_path
+    _lib, _lib_path = None, _LIB_PATH
 
 
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
+        if not os.path.exists(_lib_path):
             build()
-        L = C.CDLL(_LIB_PATH)
+        L = C.CDLL(_lib_path)
         dp = C.POINTER(C.c_double)
         L.ok_so3_log.argtypes = [dp, dp]
         L.ok_so3_right_jacobian.argtypes = [dp, dp]

@@ -40,3 +40,49 @@ def test_two_ranks_report_the_single_rank_winners():
     assert a["n_gpus"] == 1 and b["n_gpus"] == 2 and b["scaling"] == "weak"
     assert b["config"]["winner_index_per_step"] == a["config"]["winner_index_per_step"]
     assert b["value"] > 0 and b["roofline"]["frac"] > 0
+
+
+def _bench(extra, ranks, port=None):
+    common = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", *extra]
+    if ranks == 1:
+        r = subprocess.run([sys.executable, "bench.py", *common], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    else:
+        env = dict(os.environ, OPTIK_BENCH_BACKEND="gloo", OPTIK_BENCH_ONE_DEVICE="1")
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+                            "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", str(ranks),
+                            *common], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return _line(r.stdout)
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.gpu
+def test_config4_quality_strong_scaling_two_ranks():
+    """BASELINE.json config 4 in small: SolutionMode::Quality, one restart range cut into a
+    contiguous part per rank, min-all-reduce of ||x - x0|| then of the index."""
+    extra = ["--mode", "quality", "--scaling", "strong", "--restarts", "8192"]
+    a, b = _bench(extra, 1), _bench(extra, 2, _port())
+    assert b["n_gpus"] == 2 and b["scaling"] == "strong" and b["config"]["solution_mode"] == "quality"
+    assert b["config"]["restarts_per_gpu"] == 4096 and a["config"]["restarts_per_gpu"] == 8192
+    assert b["config"]["winner_index_per_step"] == a["config"]["winner_index_per_step"]
+    assert all(w > 0 for w in a["config"]["winner_index_per_step"])
+
+
+@pytest.mark.gpu
+def test_config5_targets_sharded_two_ranks():
+    """BASELINE.json config 5 in small: independent targets cut into one part per rank, no
+    collective; every target is solved by its own rank exactly as by a single rank."""
+    extra = ["--targets", "64", "--restarts", "128"]
+    a, b = _bench(extra, 1), _bench(extra, 2, _port())
+    assert a["unit"] == b["unit"] == "ik calls/s"
+    assert b["config"]["parallelism"] == "targets x2"
+    # rank 0 reports its own targets: the first 32 of every step
+    assert b["config"]["winner_index_per_step"] == a["config"]["winner_index_per_step"]
+    assert a["config"]["solved_targets"] >= 3 * 60 and b["config"]["solved_targets"] >= 3 * 30

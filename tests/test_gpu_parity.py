@@ -396,3 +396,58 @@ def test_zero_step_counts_as_xtol(dev, oracle, chains, hip_chains, path, tol_dx)
     assert_bit_equal(out["x"].cpu().numpy(), ref["xs"].T, "per-restart x")
     assert int(out["win_idx"].cpu()[0]) == (ref["winner"] if ref["found"] else -1)
     assert ref["found"] == (tol_dx >= 0.0)
+
+
+def test_more_jobs_than_the_pool_table_holds(dev, oracle, chains, hip_chains):
+    """Any number of jobs may be submitted before a run: more than ENG_MAX_JOBS (256) are executed
+    as consecutive runs inside engine_run, each job's result what it is alone."""
+    from optik_amd import _native as nat
+    d, ch = chains["ur3e"]
+    rng = np.random.default_rng(23)
+    J, R = 300, 24
+    tg, x0 = make_targets(oracle, d, ch, rng, J)
+    cfg = nat.make_config(solution_mode="speed")
+    hc = hip_chains["ur3e"]
+    tgd, x0d = torch.tensor(tg, device="cuda"), torch.tensor(x0, device="cuda")
+    outs = [hc.engine_submit(cfg, tgd[j:j + 1], x0d[j:j + 1], 0, R) for j in range(J)]
+    hc.engine_run()
+    torch.cuda.synchronize()
+    for j in (0, 1, 128, 255, 256, 257, 299):
+        ref = _oracle_all(oracle, ch, dict(solution_mode="speed"), tg[j], x0[j], 0, R)
+        assert np.array_equal(outs[j]["status"].cpu().numpy(), ref["status"]), j
+        assert_bit_equal(outs[j]["x"].cpu().numpy(), ref["xs"].T, f"job {j}")
+        assert int(outs[j]["win_idx"].cpu()[0]) == (ref["winner"] if ref["found"] else -1)
+
+
+def test_engine_deadline_abandons_and_keeps_what_was_found(dev, oracle, chains, hip_chains):
+    """optik_hip_engine_run_ex(deadline): restarts in flight at the deadline end FORCED_STOP with
+    their best point so far, queued ones never start (0 evaluations); whatever finished before
+    is what the oracle computes for that restart, and the selection sees only those."""
+    from optik_amd import _native as nat
+    d, ch = chains["panda"]
+    rng = np.random.default_rng(29)
+    tg, x0 = make_targets(oracle, d, ch, rng, 1)
+    cfg = nat.make_config(solution_mode="speed")
+    hc = hip_chains["panda"]
+    R = 1 << 20
+    tgd, x0d = torch.tensor(tg, device="cuda"), torch.tensor(x0, device="cuda")
+    out = hc.engine_submit(cfg, tgd, x0d, 0, R)
+    import time
+    t0 = time.perf_counter()
+    hc.engine_run(deadline_s=0.010)
+    took = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    status = out["status"].cpu().numpy()
+    evals = out["evals"].cpu().numpy()
+    forced = status == nat.RES_FORCED_STOP
+    assert forced.any() and (~forced).any(), "the deadline should fall inside the run"
+    assert took < 0.035, took                      # a full run of 2^20 restarts takes ~45 ms
+    assert (evals[forced & (evals == 0)] == 0).all() and (forced & (evals == 0)).sum() > R // 4  # never started
+    done = np.flatnonzero(~forced)[:200]
+    xs = out["x"].cpu().numpy()
+    for i in done[::10]:
+        r = oracle.solve_restart(ch, oracle.make_config("speed"), tg[0], x0[0], int(i))
+        assert r.result == status[i] and r.n_evals == evals[i]
+        assert_bit_equal(xs[:, i], np.array(r.x[:7]), f"restart {i}")
+    ok = np.flatnonzero(status == nat.RES_STOPVAL)
+    assert int(out["win_idx"].cpu()[0]) == (ok.min() if len(ok) else -1)

@@ -283,3 +283,76 @@ def test_diff_ik_with_ee_offset(ur3e):
     JW = np.vstack([fk[:3, :3] @ J[:3], fk[:3, :3] @ J[3:]])
     assert np.allclose(JW @ np.array(v), alpha * V, atol=1e-8)
     assert 0.0 <= alpha <= 1.0
+
+
+def test_multi_device_sharding_gives_the_single_device_answers():
+    """optik_robot_set_devices: restart ranges (ik) and targets (ik_batch) spread over several
+    device contexts -- here the one GPU listed twice, which runs the same sharding, threads and
+    host-side min as two GPUs would -- return exactly what one device returns."""
+    from optik_amd import Robot, SolverConfig
+    path = os.path.join(ROBOTS, "panda.urdf")
+    one = Robot.from_urdf_file(path, "panda_link0", "panda_link8")
+    two = Robot.from_urdf_file(path, "panda_link0", "panda_link8")
+    two.set_devices([0, 0])
+    assert one.num_devices() == 1 and two.num_devices() == 2
+    rng = np.random.default_rng(21)
+    lb, ub = (np.array(v) for v in one.joint_limits())
+    targets = [np.array(one.fk(rng.uniform(lb, ub))) for _ in range(9)]
+    x0s = rng.uniform(lb, ub, size=(9, 7))
+    # Quality over 100 000 restarts: first launch on one context, then rounds cut in two parts
+    cfg = SolverConfig(solution_mode="quality", max_time=0.0, max_restarts=100_000)
+    a = one.ik(cfg, targets[0], x0s[0].tolist(), return_index=True)
+    b = two.ik(cfg, targets[0], x0s[0].tolist(), return_index=True)
+    assert a is not None and a == b
+    # Speed on an unreachable-then-reachable pair: the winner index is the lowest success
+    cfg = SolverConfig(solution_mode="speed", max_time=0.0, max_restarts=5000)
+    for t in range(3):
+        assert one.ik(cfg, targets[t], x0s[t].tolist(), return_index=True) == \
+            two.ik(cfg, targets[t], x0s[t].tolist(), return_index=True)
+    # ik_batch: 9 targets -> parts of 4 and 5
+    for mode in ("speed", "quality"):
+        cfg = SolverConfig(solution_mode=mode, max_time=0.0, max_restarts=300)
+        assert one.ik_batch(cfg, targets, x0s) == two.ik_batch(cfg, targets, x0s)
+    with pytest.raises(RuntimeError):
+        two.set_devices([0])  # only before the first GPU call
+
+
+def test_ik_batch_honours_max_time_inside_an_engine_run(panda):
+    """lib.rs:308: the time-out is checked at every evaluation, so a batch whose round would
+    run for tens of ms returns close to max_time (the engine abandons what is in flight)."""
+    from optik_amd import SolverConfig
+    far = np.eye(4)
+    far[:3, 3] = 50.0  # unreachable: every restart runs until it stalls
+    T = 4096
+    rng = np.random.default_rng(4)
+    lb, ub = (np.array(v) for v in panda.joint_limits())
+    x0s = rng.uniform(lb, ub, size=(T, 7))
+    cfg_free = SolverConfig(max_time=0.0, max_restarts=256)
+    panda.ik_batch(cfg_free, [far] * 64, x0s[:64])  # warm-up: pool allocation, module load
+    t0 = time.perf_counter()
+    res = panda.ik_batch(cfg_free, [far] * T, x0s)
+    full = time.perf_counter() - t0
+    assert all(r is None for r in res)
+    budget = max(full / 8.0, 0.004)
+    t0 = time.perf_counter()
+    res = panda.ik_batch(SolverConfig(max_time=budget, max_restarts=256), [far] * T, x0s)
+    took = time.perf_counter() - t0
+    assert all(r is None for r in res)
+    assert took < budget + max(0.25 * full, 0.01), (took, budget, full)
+
+
+def test_pose_validation_matches_parse_pose(ur3e):
+    """optik-py parse_pose: a matrix that is not an isometry is rejected with the reference's
+    message; its own fk output round-trips."""
+    from optik_amd import SolverConfig
+    x = [0.1, -0.4, 0.3, 0.2, -0.1, 0.5]
+    good = np.array(ur3e.fk(x))
+    cfg = SolverConfig(max_time=0.0, max_restarts=50)
+    assert ur3e.ik(cfg, good.tolist(), x) is not None
+    for bad in (good * np.array([[1.0 + 1e-9] * 4] * 3 + [[1.0] * 4]),      # scaled rotation block
+                np.vstack([good[:3], [0.0, 0.0, 1e-3, 1.0]]),              # bottom row
+                np.diag([1.0, 1.0, -1.0, 1.0])):                           # reflection
+        with pytest.raises(ValueError, match="invalid target transform specified"):
+            ur3e.ik(cfg, bad.tolist(), x)
+    with pytest.raises(ValueError, match="invalid target transform specified"):
+        ur3e.fk(x, ee_offset=(good * 2.0).tolist())
