@@ -355,6 +355,52 @@ __global__ __launch_bounds__(256) void fk_batch_kernel(const FkLaunch a) {
     }
 }
 
+// Chains with prismatic joints: the reference's FK handles them (kinematics.rs:243-255), its
+// Jacobian -- and with it ik() -- does not (kinematics.rs:185: todo!()).  One generic kernel walks
+// the joint table at run time: state = state * (origin_j * local_transform_j(q_j)).
+struct FkGeneralLaunch {
+    int32_t n_joints, n_pos;
+    int32_t types[MAX_JOINTS];
+    int32_t pad;
+    double origin[MAX_JOINTS][7];
+    double axis[MAX_JOINTS][3];
+    double ee_offset[7];
+    const double *q;  // [n][B]
+    long long B;
+    double *pose;     // [7][B]
+};
+
+__global__ __launch_bounds__(256) void fk_general_kernel(const FkGeneralLaunch a) {
+    for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < a.B;
+         b += (long long)gridDim.x * blockDim.x) {
+        Pose state;
+        state.t = V3{0.0, 0.0, 0.0};
+        state.q = Q4{0.0, 0.0, 0.0, 1.0};
+        int qi = 0;
+        for (int j = 0; j < a.n_joints; ++j) {
+            Pose local;
+            local.t = V3{0.0, 0.0, 0.0};
+            local.q = Q4{0.0, 0.0, 0.0, 1.0};
+            if (a.types[j] == OPTIK_JOINT_REVOLUTE) {
+                double s, c;
+                sincos_dev(a.q[(size_t)qi * a.B + b] / 2.0, s, c);  // UnitQuaternion::from_axis_angle
+                local.q = Q4{a.axis[j][0] * s, a.axis[j][1] * s, a.axis[j][2] * s, c};
+                ++qi;
+            } else if (a.types[j] == OPTIK_JOINT_PRISMATIC) {
+                const double d = a.q[(size_t)qi * a.B + b];
+                local.t = V3{a.axis[j][0] * d, a.axis[j][1] * d, a.axis[j][2] * d};
+                ++qi;
+            }
+            const Pose jt = pose_mul(load_pose(a.origin[j]), local);
+            state = pose_mul(state, jt);
+        }
+        const Pose ee = pose_mul(state, load_pose(a.ee_offset));
+        const double p[7] = {ee.t.x, ee.t.y, ee.t.z, ee.q.i, ee.q.j, ee.q.k, ee.q.w};
+#pragma unroll
+        for (int i = 0; i < 7; ++i) a.pose[(size_t)i * a.B + b] = p[i];
+    }
+}
+
 struct SeedLaunch {
     uint32_t key[8];
     double lb[MAX_DOF];
@@ -405,6 +451,11 @@ struct optik_hip_chain {
     double scale[MAX_DOF];
     int range_rule = 0;  // OPTIK_HIP_RANGE_*: how `scale` was formed
     int device_id = 0;   // the HIP device the chain lives on (the current device at creation)
+    // a chain with prismatic joints: FK only (as in the reference); the joint table for fk_general_kernel
+    bool prismatic = false;
+    int n_joints = 0;
+    int32_t types[MAX_JOINTS] = {};
+    double axis_all[MAX_JOINTS][3] = {};
     // launch workspace (grown on demand; one in-flight ik call per chain handle)
     std::mutex mu;
     std::mutex host_mu;  // serialises optik_hip_ik_host calls (they share the workspace below)
@@ -588,9 +639,10 @@ int ensure_device() {
 #define BIND_DEVICE(CH) HIP_TRY(hipSetDevice((CH)->device_id))
 
 // Dispatch on (n, trailing fixed joint).
-// Kernels are instantiated for 2 <= n <= 7 revolute joints (n + 1 <= 8 rows fit the
-// register-resident NNLS of the engine), each with and without a trailing fixed joint.
-#define OPTIK_N_RANGE_MSG "kernels are built for 2 <= n <= 7 revolute joints"
+// Kernels are instantiated for 1 <= n <= 8 revolute joints, each with and without a trailing
+// fixed joint; the streaming engine for n <= 7 (n + 1 <= 8 rows fit its register-resident
+// NNLS) -- an 8-DoF chain's engine jobs run on the single-kernel path, same results.
+#define OPTIK_N_RANGE_MSG "kernels are built for 1 <= n <= 8 revolute joints"
 #define OPTIK_DISPATCH_ONE(NN, CALL)                                                   \
     if (!done_ && n_ == NN) {                                                          \
         if (tip_) { CALL(NN, true); } else { CALL(NN, false); }                        \
@@ -601,8 +653,10 @@ int ensure_device() {
         const int n_ = (CH)->n;                                                        \
         const bool tip_ = (CH)->tip;                                                   \
         bool done_ = false;                                                            \
+        OPTIK_DISPATCH_ONE(1, CALL)                                                     \
         OPTIK_DISPATCH_ONE(2, CALL) OPTIK_DISPATCH_ONE(3, CALL) OPTIK_DISPATCH_ONE(4, CALL) \
         OPTIK_DISPATCH_ONE(5, CALL) OPTIK_DISPATCH_ONE(6, CALL) OPTIK_DISPATCH_ONE(7, CALL) \
+        OPTIK_DISPATCH_ONE(8, CALL)                                                     \
         if (!done_) return fail(OPTIK_HIP_EUNSUPPORTED, OPTIK_N_RANGE_MSG);            \
     } while (0)
 
@@ -646,10 +700,12 @@ int optik_hip_chain_create(const double *origins, const double *axes, const int3
     if (n < 1 || n > MAX_DOF) return fail(OPTIK_HIP_EUNSUPPORTED, "num_positions must be in 1..8");
     if (n_joints != n && n_joints != n + 1)
         return fail(OPTIK_HIP_EUNSUPPORTED, "chain must be n revolute joints plus an optional trailing fixed joint");
-    for (int j = 0; j < n; ++j)
-        if (types[j] != OPTIK_JOINT_REVOLUTE)
-            return fail(OPTIK_HIP_EUNSUPPORTED,
-                        "only revolute joints are supported (the reference's Jacobian panics on prismatic, kinematics.rs:185)");
+    bool prismatic = false;
+    for (int j = 0; j < n; ++j) {
+        if (types[j] == OPTIK_JOINT_PRISMATIC) prismatic = true;
+        else if (types[j] != OPTIK_JOINT_REVOLUTE)
+            return fail(OPTIK_HIP_EUNSUPPORTED, "the first n joints of the chain must be revolute or prismatic");
+    }
     if (n_joints == n + 1 && types[n] != OPTIK_JOINT_FIXED)
         return fail(OPTIK_HIP_EUNSUPPORTED, "joint after the last revolute joint must be fixed");
     if (int rc = ensure_device()) return rc;
@@ -657,6 +713,12 @@ int optik_hip_chain_create(const double *origins, const double *axes, const int3
     auto *ch = new optik_hip_chain();
     std::memset(&ch->host, 0, sizeof ch->host);
     ch->n = n;
+    ch->prismatic = prismatic;
+    ch->n_joints = n_joints;
+    for (int j = 0; j < n_joints; ++j) {
+        ch->types[j] = types[j];
+        for (int k = 0; k < 3; ++k) ch->axis_all[j][k] = axes[j * 3 + k];
+    }
     ch->tip = (n_joints == n + 1);
     ch->host.n_pos = n;
     ch->host.has_tip = ch->tip;
@@ -742,6 +804,9 @@ int optik_hip_eval_batch(const optik_hip_chain *ch, const optik_solver_config *c
                          void *stream) {
     if (!ch || !cfg || !target7 || !d_q || !d_f || B < 0) return fail(OPTIK_HIP_EINVAL, "bad argument");
     if (B == 0) return 0;
+    if (ch->prismatic)
+        return fail(OPTIK_HIP_EUNSUPPORTED,
+                    "prismatic joints: only forward kinematics is available (the reference's Jacobian panics, kinematics.rs:185)");
     BIND_DEVICE(ch);
     EvalLaunch a;
     a.chain = ch->dev;
@@ -761,6 +826,24 @@ int optik_hip_fk_batch(const optik_hip_chain *ch, const double *ee_offset7, cons
     if (!ch || !d_q || !d_pose || B < 0) return fail(OPTIK_HIP_EINVAL, "bad argument");
     if (B == 0) return 0;
     BIND_DEVICE(ch);
+    if (ch->prismatic) {
+        if (d_jac)
+            return fail(OPTIK_HIP_EUNSUPPORTED,
+                        "joint_jacobian: prismatic joints are not implemented (the reference panics: kinematics.rs:185 todo!())");
+        FkGeneralLaunch g;
+        std::memset(&g, 0, sizeof g);
+        g.n_joints = ch->n_joints;
+        g.n_pos = ch->n;
+        std::memcpy(g.types, ch->types, sizeof g.types);
+        std::memcpy(g.origin, ch->host.origin, sizeof g.origin);
+        std::memcpy(g.axis, ch->axis_all, sizeof g.axis);
+        const double ident[7] = {0, 0, 0, 0, 0, 0, 1};
+        std::memcpy(g.ee_offset, ee_offset7 ? ee_offset7 : ident, sizeof ident);
+        g.q = d_q; g.B = B; g.pose = d_pose;
+        hipLaunchKernelGGL(fk_general_kernel, dim3(grid_for(ch, B, 256, 8)), dim3(256), 0, (hipStream_t)stream, g);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     FkLaunch a;
     a.chain = ch->dev;
     const double one[3] = {1, 1, 1};
@@ -794,10 +877,32 @@ int optik_hip_seed_batch(const optik_hip_chain *ch, uint64_t first, int64_t coun
     return 0;
 }
 
+}  // extern "C"
+
+// optik_hip_ik_batch with the chain's launch mutex already held.
+static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, const double *d_targets,
+                           const double *d_x0, int32_t T, const double *ee_offset7, uint64_t restart_begin,
+                           uint64_t restart_end, uint32_t flags, double deadline_s, const optik_hip_ik_outputs *out,
+                           void *stream_v);
+
+extern "C" {
+
 int optik_hip_ik_batch(optik_hip_chain *ch, const optik_solver_config *cfg, const double *d_targets,
                        const double *d_x0, int32_t T, const double *ee_offset7, uint64_t restart_begin,
                        uint64_t restart_end, uint32_t flags, double deadline_s, const optik_hip_ik_outputs *out,
                        void *stream_v) {
+    if (!ch) return fail(OPTIK_HIP_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> lock(ch->mu);
+    return ik_batch_locked(ch, cfg, d_targets, d_x0, T, ee_offset7, restart_begin, restart_end, flags, deadline_s, out,
+                           stream_v);
+}
+
+}  // extern "C"
+
+static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, const double *d_targets,
+                           const double *d_x0, int32_t T, const double *ee_offset7, uint64_t restart_begin,
+                           uint64_t restart_end, uint32_t flags, double deadline_s, const optik_hip_ik_outputs *out,
+                           void *stream_v) {
     if (!ch || !cfg || !d_targets || !d_x0 || !out || T < 1) return fail(OPTIK_HIP_EINVAL, "bad argument");
     if (restart_end <= restart_begin) return fail(OPTIK_HIP_EINVAL, "empty restart range");
     if (cfg->solution_mode != 1 && cfg->solution_mode != 2)
@@ -808,7 +913,9 @@ int optik_hip_ik_batch(optik_hip_chain *ch, const optik_solver_config *cfg, cons
             if (std::isnan(ch->scale[k]))
                 return fail(OPTIK_HIP_EINVAL, "random restarts need finite joint limits (reference: random_range panics)");
     hipStream_t stream = (hipStream_t)stream_v;
-    std::lock_guard<std::mutex> lock(ch->mu);
+    if (ch->prismatic)
+        return fail(OPTIK_HIP_EUNSUPPORTED,
+                    "prismatic joints: only forward kinematics is available (the reference's Jacobian panics, kinematics.rs:185)");
     BIND_DEVICE(ch);
 
     // selection tiles: 4096 restarts per 256-thread block
@@ -943,6 +1050,8 @@ int optik_hip_ik_batch(optik_hip_chain *ch, const optik_solver_config *cfg, cons
     return 0;
 }
 
+extern "C" {
+
 // ---- streaming engine: submit jobs, then run them through the shared slot pool ----
 
 
@@ -958,6 +1067,9 @@ int optik_hip_engine_submit(optik_hip_chain *ch, const optik_solver_config *cfg,
             if (std::isnan(ch->scale[k]))
                 return fail(OPTIK_HIP_EINVAL, "random restarts need finite joint limits (reference: random_range panics)");
     std::lock_guard<std::mutex> lock(ch->mu);
+    if (ch->prismatic)
+        return fail(OPTIK_HIP_EUNSUPPORTED,
+                    "prismatic joints: only forward kinematics is available (the reference's Jacobian panics, kinematics.rs:185)");
     BIND_DEVICE(ch);
     const double ident[7] = {0, 0, 0, 0, 0, 0, 1};
     const double *ee = ee_offset7 ? ee_offset7 : ident;
@@ -1090,6 +1202,29 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
     const auto t_call = std::chrono::steady_clock::now();
     auto since_call = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call).count(); };
     int rc = 0;
+    if (ch->n > 7) {
+        // the engine's register-resident NNLS holds n + 1 <= 8 rows: an 8-DoF chain's jobs run
+        // one after the other on the single-kernel path (same restarts, same results)
+        for (auto &j : ch->eng_jobs) {
+            if (rc) break;
+            optik_solver_config cfg = ch->eng_cfg;
+            cfg.solution_mode = j.dev.quality ? 1 : 2;
+            double left = 0.0;
+            if (deadline_s > 0.0) { left = deadline_s - since_call(); if (left <= 0.0) left = 1e-9; }
+            rc = ik_batch_locked(ch, &cfg, j.dev.targets, j.dev.x0, j.T, ch->eng_has_ee ? ch->eng_ee : nullptr,
+                                 j.dev.restart_begin, j.dev.restart_begin + j.dev.n_restarts,
+                                 j.own_fs ? OPTIK_HIP_IK_EARLY_EXIT : 0u, left, &j.out, stream);
+            if (!rc && hipStreamSynchronize(stream) != hipSuccess) rc = fail(OPTIK_HIP_ENODEVICE, "engine job failed");
+        }
+        for (auto &j : ch->eng_jobs) {
+            if (j.own_x) (void)hipFree(j.own_x);
+            if (j.own_f) (void)hipFree(j.own_f);
+            if (j.own_key) (void)hipFree(j.own_key);
+            if (j.own_fs) (void)hipFree(j.own_fs);
+        }
+        ch->eng_jobs.clear();
+        return rc;
+    }
     // at most ENG_MAX_JOBS jobs share one run of the pool; more are executed as consecutive runs
     for (size_t g0 = 0; g0 < ch->eng_jobs.size() && rc == 0; g0 += ENG_MAX_JOBS) {
     const size_t g1 = std::min(ch->eng_jobs.size(), g0 + (size_t)ENG_MAX_JOBS);
@@ -1124,6 +1259,7 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
 #define DISPATCH_N(M)                                                                            \
     do {                                                                                         \
         switch (ch->n) {                                                                         \
+        case 1: M(1); break;                                                                     \
         case 2: M(2); break; case 3: M(3); break; case 4: M(4); break;                           \
         case 5: M(5); break; case 6: M(6); break; case 7: M(7); break;                           \
         default: return fail(OPTIK_HIP_EUNSUPPORTED, OPTIK_N_RANGE_MSG);                         \
@@ -1572,7 +1708,7 @@ int optik_hip_engine_reserve(optik_hip_chain *ch, uint64_t slots, void *stream_v
     int nd = 0, ni = 0, rec_len = 0;
     switch (ch->n) {
 #define M_LAYOUT(NN) case NN: nd = EngLayout<NN>::ND; ni = EngLayout<NN>::NI; rec_len = rec_stride<NN>(); break
-    M_LAYOUT(2); M_LAYOUT(3); M_LAYOUT(4); M_LAYOUT(5); M_LAYOUT(6); M_LAYOUT(7);
+    M_LAYOUT(1); M_LAYOUT(2); M_LAYOUT(3); M_LAYOUT(4); M_LAYOUT(5); M_LAYOUT(6); M_LAYOUT(7);
 #undef M_LAYOUT
     default: return fail(OPTIK_HIP_EUNSUPPORTED, OPTIK_N_RANGE_MSG);
     }

@@ -92,6 +92,19 @@ OPTIK_DEV dvec8 vsel(bool c, const dvec8 a, const dvec8 b) {
     return o;
 }
 
+// ... and for the 9 rows of an 8-DoF chain's dual problem (single-kernel path only)
+typedef double dvec16 __attribute__((ext_vector_type(16)));
+
+OPTIK_DEV double vpick(const dvec16 a, int idx) {
+    double v = a[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) v = (idx == i + 1) ? a[i] : v;
+    return v;
+}
+
+template <bool SMALL> struct RowVecOf { typedef dvec8 type; };
+template <> struct RowVecOf<false> { typedef dvec16 type; };
+
 // ---- elementary functions (same operation sequence as the oracle) ---------
 
 OPTIK_DEV double k_sin(double x, double y) {

@@ -110,7 +110,8 @@ template <int N>
 OPTIK_DEV int nnls(const NnlsWs<N> &ws, double &rnorm) {
     using L = NnlsLayout<N>;
     constexpr int m = N + 1, n = 2 * N;
-    static_assert(m <= 8, "row vectors are dvec8");
+    static_assert(m <= 16 && n <= 16, "row vectors are dvec8 / dvec16, the permutation is 16 nibbles");
+    typedef typename RowVecOf<(m <= 8)>::type rowvec;
     const double factor = 0.01;
     int mode = 1, iter = 0;
     const int itmax = 3 * n;
@@ -160,7 +161,7 @@ OPTIK_DEV int nnls(const NnlsWs<N> &ws, double &rnorm) {
             // step five: does column j enter the positive set?  (H12 construction on
             // column j, pivot row npp1, rows npp1+1..m)
             double *const cj = col(j);
-            dvec8 u = 0.0;
+            rowvec u = 0.0;
 #pragma unroll
             for (int r = 0; r < m; ++r) u[r] = cj[r * 64];
             const double asave = vpick(u, npp1);
@@ -212,7 +213,7 @@ OPTIK_DEV int nnls(const NnlsWs<N> &ws, double &rnorm) {
             }
             const double t = factor * __builtin_fabs(ulp);
             const double d1 = unorm + t;
-            dvec8 zz = 0.0;
+            rowvec zz = 0.0;
             // b factor of the H12 application (same for every vector it is applied to)
             double hb = 0.0;
             bool apply_live = false;
@@ -255,7 +256,7 @@ OPTIK_DEV int nnls(const NnlsWs<N> &ws, double &rnorm) {
                     for (int c = 1; c <= n; ++c) {
                         if (!(zmask & (1u << (c - 1)))) continue;
                         double *cp = col(c);
-                        dvec8 cv = 0.0;
+                        rowvec cv = 0.0;
 #pragma unroll
                         for (int r = 0; r < m; ++r) cv[r] = cp[r * 64];
                         double sm = vpick(cv, nsetp) * up;
@@ -288,13 +289,13 @@ OPTIK_DEV int nnls(const NnlsWs<N> &ws, double &rnorm) {
         if (!found) break;
 
         for (;;) {  // step six: solve the triangular system R z = Q'b on set P
-            dvec8 zz = 0.0;
+            rowvec zz = 0.0;
 #pragma unroll
             for (int r = 0; r < m; ++r) zz[r] = ws.b(r + 1);
             for (int ip = nsetp; ip >= 1; --ip) {
                 jj = indx.get(ip);
                 const double *cp = col(jj);
-                dvec8 cv = 0.0;
+                rowvec cv = 0.0;
 #pragma unroll
                 for (int r = 0; r < m; ++r) cv[r] = cp[r * 64];
                 const double zi = vpick(zz, ip) / vpick(cv, ip);

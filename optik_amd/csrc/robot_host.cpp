@@ -18,6 +18,7 @@
 #include <mutex>
 #include <random>
 #include <sstream>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -84,6 +85,12 @@ optik_robot *make_robot(const std::string &urdf, const char *base, const char *e
         throw;
     }
     r->n = r->chain.num_positions();
+    if (r->n > OPTIK_HIP_MAX_DOF) {
+        const int n = r->n;
+        delete r;
+        throw std::runtime_error("chain has " + std::to_string(n) + " joint positions; the gfx950 kernels are built for "
+                                 "at most 8 (a limit of this implementation, not of the reference)");
+    }
     for (const auto &j : r->chain.joints) {
         for (int k = 0; k < 3; ++k) r->origins.push_back(j.origin.t[k]);
         for (int k = 0; k < 4; ++k) r->origins.push_back(j.origin.q[k]);

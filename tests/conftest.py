@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 REF_GOLDEN = os.path.join(GOLDEN, "reference")
 ROBOTS = os.path.join(ROOT, "optik_amd", "robots")
+TEST_ROBOTS = os.path.join(GOLDEN, "robots")  # synthetic chains written for the tests
 
 
 def pytest_configure(config):
@@ -39,6 +40,11 @@ ROBOT_SPECS = {
     "panda3": (os.path.join(ROBOTS, "panda.urdf"), "panda_link0", "panda_link3"),
     "panda4": (os.path.join(ROBOTS, "panda.urdf"), "panda_link0", "panda_link4"),
     "panda5": (os.path.join(ROBOTS, "panda.urdf"), "panda_link0", "panda_link5"),
+    # the ends of the supported range: 1 joint, and 8 joints + trailing fixed joint
+    "panda1": (os.path.join(ROBOTS, "panda.urdf"), "panda_link0", "panda_link1"),
+    "arm8": (os.path.join(TEST_ROBOTS, "arm8.urdf"), "l0", "l9"),
+    # prismatic joints: forward kinematics only (kinematics.rs:185, 243-255)
+    "gantry": (os.path.join(TEST_ROBOTS, "gantry.urdf"), "g0", "g5"),
 }
 
 

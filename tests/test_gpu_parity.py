@@ -159,11 +159,12 @@ def test_every_restart_bit_exact(dev, oracle, chains, hip_chains, robot, tol_f, 
     assert 0.02 < ref["success"].mean() < 0.98  # both outcomes are exercised
 
 
-@pytest.mark.parametrize("robot", ["panda2", "panda3", "panda4", "panda5"])
+@pytest.mark.parametrize("robot", ["panda1", "panda2", "panda3", "panda4", "panda5", "arm8"])
 @pytest.mark.parametrize("path", ["kernel", "engine"])
 def test_other_joint_counts_bit_exact(dev, oracle, chains, hip_chains, robot, path):
-    """Kernels are instantiated for 2 <= n <= 7: sub-chains of the Panda (no trailing fixed
-    joint) through both paths, every restart against the oracle."""
+    """Kernels are instantiated for 1 <= n <= 8: sub-chains of the Panda (no trailing fixed
+    joint) and a synthetic 8-joint arm through both paths, every restart against the oracle
+    (an 8-DoF chain's engine jobs run on the single-kernel path: the engine's NNLS holds 8 rows)."""
     from optik_amd import _native as nat
     d, ch = chains[robot]
     rng = np.random.default_rng(17)
@@ -451,3 +452,30 @@ def test_engine_deadline_abandons_and_keeps_what_was_found(dev, oracle, chains, 
         assert_bit_equal(xs[:, i], np.array(r.x[:7]), f"restart {i}")
     ok = np.flatnonzero(status == nat.RES_STOPVAL)
     assert int(out["win_idx"].cpu()[0]) == (ok.min() if len(ok) else -1)
+
+
+def test_prismatic_chain_has_forward_kinematics_only(dev, oracle, chains, hip_chains):
+    """kinematics.rs:243-255 handles prismatic joints in FK; the Jacobian is todo!() (:185), so
+    ik() on such a chain panics in the reference -- here FK matches the oracle bit for bit and
+    the Jacobian / objective / ik entry points refuse the chain."""
+    from optik_amd import _native as nat
+    d, ch = chains["gantry"]
+    assert list(d["types"]) == [2, 1, 2, 1, 0]
+    hc = hip_chains["gantry"]
+    rng = np.random.default_rng(31)
+    B = 500
+    q = rng.uniform(d["lb"], d["ub"], size=(B, 4))
+    ee_off = np.array([0.01, -0.02, 0.03, 0.0, 0.0, np.sin(0.2), np.cos(0.2)])
+    qd = torch.tensor(q.T.copy(), device="cuda")
+    for off, pose_off in ((None, None), (ee_off, oracle.Pose.make(ee_off[:3], ee_off[3:]))):
+        got = hc.fk_batch(qd, ee_offset7=off).cpu().numpy()
+        want = np.array([oracle.fk(ch, q[i], ee_offset=pose_off)[1] for i in range(B)]).T
+        assert_bit_equal(got, want, "prismatic fk")
+    with pytest.raises(nat.OptikHipError, match="prismatic"):
+        hc.fk_batch(qd, jacobian=True)
+    with pytest.raises(nat.OptikHipError, match="prismatic"):
+        hc.eval_batch(qd, np.array([0, 0, 0, 0, 0, 0, 1.0]))
+    tg = torch.zeros((1, 7), dtype=torch.float64, device="cuda")
+    tg[0, 6] = 1.0
+    with pytest.raises(nat.OptikHipError, match="prismatic"):
+        hc.ik_batch(nat.make_config(), tg, torch.zeros((1, 4), dtype=torch.float64, device="cuda"), 0, 4)
