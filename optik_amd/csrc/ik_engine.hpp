@@ -158,7 +158,18 @@ struct EngArgs {
     // counts the re-evaluation of an accepted trial point that the kernels skip): 64 counters, one
     // per workgroup index mod 64, so that the per-wave additions do not queue on one L2 word
     unsigned long long *exec_evals;
+    // same-trip continuation of the NNLS launch: problems that used up their (tight) pass
+    // budget in the main launch are appended to one of NN_CONT_SHARDS lists (by workgroup
+    // index, so that the appending waves do not queue on one L2 word) and a second, small
+    // launch of the same kernel (cont_pass = 1) resumes them from their carry records.  A
+    // wave runs as many passes as the slowest of its 16 problems: with the cap at the
+    // predicted count almost every problem of a wave is done when the wave is.
+    unsigned int *cont_count;           // [NN_CONT_SHARDS], reset by the eval kernel
+    unsigned int *cont_list;            // [NN_CONT_SHARDS][cont_cap] slots
+    unsigned int cont_cap;
+    int cont_pass;                      // 0 = main launch, 1 = continuation launch
 };
+constexpr int NN_CONT_SHARDS = 8;
 constexpr int ENG_EXEC_SHARDS = 64;
 
 // double planes: tiled by 64 slots, two planes interleaved per lane -- the planes of slots
@@ -782,14 +793,24 @@ OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a, double *wave_lds) {
     constexpr unsigned PPW = 64 / G;          // problems per wave
     const unsigned int *cls_cnt = a.nn_class_count[a.parity];
     unsigned cnt = 0;
-    for (int c = 0; c < NN_CLASSES; ++c) cnt += cls_cnt[c];
+    unsigned shard_cnt[NN_CONT_SHARDS];
+    if (a.cont_pass) {
+#pragma unroll
+        for (int c = 0; c < NN_CONT_SHARDS; ++c) {
+            const unsigned v = a.cont_count[c];
+            shard_cnt[c] = v < a.cont_cap ? v : a.cont_cap;
+            cnt += shard_cnt[c];
+        }
+    } else {
+        for (int c = 0; c < NN_CLASSES; ++c) cnt += cls_cnt[c];
+    }
     double *ybuf = a.nn_y;
     double *meta = a.nn_meta;
     const unsigned lane = threadIdx.x & 63u;
     const unsigned group = lane / G, gl = lane % G;
     const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) / 64u;
     const unsigned n_waves = (gridDim.x * blockDim.x) / 64u;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && !a.cont_pass) {
         if (a.nn_total) atomicAdd(a.nn_total, (unsigned long long)cnt);
         if (a.trip_log) { a.trip_log[2 * a.trip] = *a.n_active; a.trip_log[2 * a.trip + 1] = cnt; }
     }
@@ -804,7 +825,16 @@ OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a, double *wave_lds) {
         // the slot of the (q0 + group)-th problem in class order, largest predicted pass count first
         unsigned q = 0;
         int cls = NN_CLASSES - 1;
-        {
+        if (a.cont_pass) {
+            // the (q0 + group)-th suspended problem over the shard lists
+            unsigned i = q0 + group;
+            bool placed = !live;
+#pragma unroll
+            for (int c = 0; c < NN_CONT_SHARDS; ++c) {
+                if (!placed && i < shard_cnt[c]) { q = a.cont_list[(size_t)c * a.cont_cap + i]; placed = true; }
+                if (!placed) i -= shard_cnt[c];
+            }
+        } else {
             unsigned i = q0 + group;
             bool placed = !live;
             for (int c = NN_CLASSES - 1; c >= 0; --c) {
@@ -817,7 +847,7 @@ OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a, double *wave_lds) {
         // wave runs as many passes as its slowest problem: the ~8 % that need more than
         // predicted + slack continue next trip among the long ones instead of holding 15 others)
         const int want = cls + a.nn_slack < 1 ? 1 : cls + a.nn_slack;
-        const int budget = (cls == NN_CLASSES - 1 || want > a.nn_budget) ? a.nn_budget : want;
+        const int budget = (a.cont_pass || cls == NN_CLASSES - 1 || want > a.nn_budget) ? a.nn_budget : want;
         const bool resume = live && meta[(size_t)q * 2 + 1] < 0.0;
         dvec8 col[CPL];
         CoopCarry<CPL> cs;
@@ -902,7 +932,25 @@ OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a, double *wave_lds) {
                 const unsigned c = gl * CPL + k;
                 if (c < (unsigned)n) ybuf[(size_t)q * n + c] = cs.xv[k];
             }
-            if (gl == 0) { meta[(size_t)q * 2] = (double)(mode + 8 * iters); meta[(size_t)q * 2 + 1] = rnorm; }
+            if (gl == 0) {
+                meta[(size_t)q * 2] = (double)(mode + 8 * iters);
+                meta[(size_t)q * 2 + 1] = rnorm;
+                // finished after all: take it off the next trip's list (park put it there)
+                if (a.cont_pass) a.nn_cls[a.parity ^ 1][q - a.slot_base] = NN_NONE;
+            }
+        }
+        if (!a.cont_pass && a.cont_count) {
+            // suspended in the main launch: hand the problem to this trip's continuation launch
+            const bool sus = live && mode == NNLS_SUSPENDED && gl == 0;
+            const unsigned long long sm = __ballot(sus);
+            if (sm) {
+                const unsigned shard = blockIdx.x % NN_CONT_SHARDS;
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(a.cont_count + shard, (unsigned)__popcll(sm));
+                base = (unsigned)__shfl((int)base, 0, 64);
+                const unsigned at = base + (unsigned)__popcll(sm & ((1ull << lane) - 1ull));
+                if (sus && at < a.cont_cap) a.cont_list[(size_t)shard * a.cont_cap + at] = q;
+            }
         }
 #ifdef OPTIK_NNLS_TRACE
         {

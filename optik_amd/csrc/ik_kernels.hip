@@ -204,6 +204,7 @@ __global__ __launch_bounds__(OPTIK_ENG_SLOT_BLOCK, OPTIK_ENG_EVAL_WAVES) void en
         if (threadIdx.x < (unsigned)NN_CLASSES) a.nn_class_count[a.parity ^ 1][threadIdx.x] = 0u;
         if (threadIdx.x == (unsigned)NN_CLASSES) *a.n_active = 0u;
         if (threadIdx.x == (unsigned)NN_CLASSES + 1u) *a.refill_count = 0u;
+        if (a.cont_count && threadIdx.x >= 32u && threadIdx.x < 32u + (unsigned)NN_CONT_SHARDS) a.cont_count[threadIdx.x - 32u] = 0u;
     }
     const bool evaluated = local < a.n_slots && eng_eval_body<N, TIP>(a, sch, sjobs, slot);
     const unsigned long long em = __ballot(evaluated);
@@ -490,6 +491,7 @@ struct optik_hip_chain {
     double *eng_carry = nullptr;           // [C][NN_CARRY]
     unsigned int *eng_list = nullptr;      // 2 x [C] class entries by slot, per trip parity
     unsigned int *eng_refill = nullptr;    // [C] slots wanting a work item, per sub-pool range
+    unsigned int *eng_cont = nullptr;      // continuation lists: [C] entries (a sub-pool's shards share its range), then [ENG_MAX_POOLS][NN_CONT_SHARDS] counters
     double *hw_dev = nullptr, *hw_pin = nullptr;  // optik_hip_ik_host: device block and pinned staging
     size_t hw_cap = 0;                            // doubles
     unsigned long long *nnls_trace = nullptr;  // OPTIK_NNLS_TRACE builds
@@ -767,6 +769,7 @@ void optik_hip_chain_destroy(optik_hip_chain *ch) {
     if (ch->eng_compact) hipFree(ch->eng_compact);
     if (ch->eng_list) hipFree(ch->eng_list);
     if (ch->eng_refill) hipFree(ch->eng_refill);
+    if (ch->eng_cont) hipFree(ch->eng_cont);
     if (ch->hw_dev) hipFree(ch->hw_dev);
     if (ch->hw_pin) hipHostFree(ch->hw_pin);
     if (ch->eng_prob) hipFree(ch->eng_prob);
@@ -1147,6 +1150,8 @@ static int engine_reserve(optik_hip_chain *ch, size_t AC, int nd, int ni, int re
         if (ch->eng_compact) HIP_TRY(hipFree(ch->eng_compact));
         if (ch->eng_list) HIP_TRY(hipFree(ch->eng_list));
         if (ch->eng_refill) HIP_TRY(hipFree(ch->eng_refill));
+        if (ch->eng_cont) HIP_TRY(hipFree(ch->eng_cont));
+        ch->eng_cont = nullptr;
         ch->eng_compact = nullptr; ch->eng_list = nullptr; ch->eng_refill = nullptr;
         ch->eng_order = nullptr; ch->eng_carry = nullptr;
         ch->eng_d = nullptr; ch->eng_i32 = nullptr; ch->eng_item = nullptr;
@@ -1160,6 +1165,8 @@ static int engine_reserve(optik_hip_chain *ch, size_t AC, int nd, int ni, int re
         HIP_TRY(hipMalloc(&ch->eng_meta, sizeof(double) * AC * 2));
         HIP_TRY(hipMalloc(&ch->eng_list, sizeof(unsigned int) * 2 * AC));
         HIP_TRY(hipMalloc(&ch->eng_refill, sizeof(unsigned int) * AC));
+        HIP_TRY(hipMalloc(&ch->eng_cont, sizeof(unsigned int) * (AC + ENG_MAX_POOLS * NN_CONT_SHARDS)));
+        HIP_TRY(hipMemsetAsync(ch->eng_cont, 0, sizeof(unsigned int) * (AC + ENG_MAX_POOLS * NN_CONT_SHARDS), stream));
         HIP_TRY(hipMalloc(&ch->eng_order, sizeof(unsigned int) * 2 * NN_CLASSES * AC));
         HIP_TRY(hipMalloc(&ch->eng_carry, sizeof(double) * NN_CARRY * AC));
         HIP_TRY(hipMalloc(&ch->eng_compact, sizeof(unsigned int) * (2 * ENG_MAX_POOLS + 2 * AC)));
@@ -1313,8 +1320,18 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
         if (const char *e = getenv("OPTIK_ENG_NNLS_BUDGET")) a.nn_budget = atoi(e) > 0 ? atoi(e) : 1;
         a.nn_pred_viol = 1;
         if (const char *e = getenv("OPTIK_ENG_NNLS_PRED_VIOL")) a.nn_pred_viol = atoi(e);
-        a.nn_slack = 1;  // (measured: no per-problem cap 23.9, slack 1 -> 24.6, slack 0 -> 23.2 M restarts/s)
+        // per-problem pass cap = predicted count + slack.  With the same-trip continuation launch
+        // the cap sits at the prediction itself (slack 0): the problems that need more continue a
+        // few microseconds later instead of holding their wave's other 15 (without it: no cap
+        // 23.9, slack 1 -> 24.6, slack 0 -> 23.2 M restarts/s -- a suspended solve cost its slot a trip)
+        bool nn_cont = false;  // (measured r2: 23.5 M restarts/s with the continuation launch against 26.4 M without -- the extra launch on each trip's critical path costs more than the tighter cap saves; kept as a knob)
+        if (const char *e = getenv("OPTIK_ENG_NNLS_CONT")) nn_cont = atoi(e) != 0;
+        a.nn_slack = nn_cont ? 0 : 1;
         if (const char *e = getenv("OPTIK_ENG_NNLS_SLACK")) a.nn_slack = atoi(e) > 0 ? atoi(e) : 0;
+        a.cont_pass = 0;
+        a.cont_count = nullptr; a.cont_list = nullptr; a.cont_cap = 0;
+        unsigned cont_waves_per_cu = 4;  // grid of the continuation launch (it grid-strides over the lists)
+        if (const char *e = getenv("OPTIK_ENG_NNLS_CONT_WAVES")) cont_waves_per_cu = (unsigned)atoi(e) > 0 ? (unsigned)atoi(e) : 1u;
         a.nn_total = ch->eng_nn_total;
         a.exec_evals = ch->eng_nn_total + 1;
         a.tail_deadline_ticks = 0;
@@ -1347,6 +1364,7 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
         if (nn_waves_per_cu < 1) nn_waves_per_cu = 1;
         const unsigned nn_blocks = (unsigned)cus * nn_waves_per_cu * 64u / OPTIK_ENG_NNLS_BLOCK;
         HIP_TRY(hipMemsetAsync(ch->eng_counters, 0, ENG_MAX_POOLS * PCB * sizeof(unsigned int), stream));
+        HIP_TRY(hipMemsetAsync(ch->eng_cont + ch->eng_C, 0, ENG_MAX_POOLS * NN_CONT_SHARDS * sizeof(unsigned int), stream));
         hipLaunchKernelGGL(eng_init_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, ch->eng_i32, ch->eng_list, (unsigned long long)ch->eng_C);
         HIP_TRY(hipGetLastError());
 
@@ -1390,6 +1408,11 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
                 P.a.refill_count = cnt + 2 * NN_CLASSES;
                 P.a.n_active = cnt + 2 * NN_CLASSES + 1;
                 P.a.refill_list = ch->eng_refill + lo;
+                if (nn_cont) {
+                    P.a.cont_count = ch->eng_cont + ch->eng_C + (size_t)p2 * NN_CONT_SHARDS;
+                    P.a.cont_list = ch->eng_cont + lo;
+                    P.a.cont_cap = (unsigned)(size / NN_CONT_SHARDS);
+                }
                 P.stream = p2 == 0 ? stream : ch->eng_streams[p2];
                 P.blocks = (unsigned)((size + OPTIK_ENG_SLOT_BLOCK - 1) / OPTIK_ENG_SLOT_BLOCK);
                 P.trip = 0; P.pending = 0; P.ring = 0; P.done = false;
@@ -1405,6 +1428,10 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
         }
 
         const int CHECK = 4;  // trips between termination checks
+        int queue_depth = 2;  // chunks queued ahead of the one whose in-use count the host waits for
+        if (const char *e = getenv("OPTIK_ENG_DEPTH")) queue_depth = atoi(e);
+        if (queue_depth < 1) queue_depth = 1;
+        if (queue_depth > 6) queue_depth = 6;
         const bool tip = ch->tip;
         double dbg_wait_bulk = 0.0, dbg_wait_drain = 0.0;  // host time blocked on the GPU (OPTIK_ENG_DEBUG)
         double dbg_drain_t0 = -1.0;  // when the first sub-pool fell under half of its live prefix
@@ -1472,6 +1499,16 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
 #define M_NNLS(NN) ENG_LAUNCH((eng_nnls_coop_kernel<NN>), dim3(nn_blocks), dim3(OPTIK_ENG_NNLS_BLOCK))
                 DISPATCH_N(M_NNLS);
 #undef M_NNLS
+                if (nn_cont) {
+                    // the problems the main launch suspended at their predicted pass count
+                    tev0 = tev1 = nullptr;
+                    a.cont_pass = 1;
+                    const unsigned cont_blocks = (unsigned)cus * cont_waves_per_cu * 64u / OPTIK_ENG_NNLS_BLOCK;
+#define M_NNLS_C(NN) ENG_LAUNCH((eng_nnls_coop_kernel<NN>), dim3(cont_blocks), dim3(OPTIK_ENG_NNLS_BLOCK))
+                    DISPATCH_N(M_NNLS_C);
+#undef M_NNLS_C
+                    a.cont_pass = 0;
+                }
                 TEV(3);
 #define M_FIN(NN) ENG_LAUNCH((eng_finish_kernel<NN>), dim3(blocks * (OPTIK_ENG_SLOT_BLOCK / OPTIK_ENG_UPD_BLOCK)), dim3(OPTIK_ENG_UPD_BLOCK))
                 DISPATCH_N(M_FIN);
@@ -1486,8 +1523,14 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
             // the chunk's last finish kernel wrote its in-use count to pinned memory; the host looks
             // at the previous chunk's value
             HIP_TRY(hipEventRecord(P.ev[P.ring], stream));
-            if (P.pending) {
-                const int prev = (P.ring + 7) % 8;
+            // The host keeps `depth` chunks queued behind the one it waits for: with a single
+            // chunk in flight (wait for chunk c - 1 right after queuing chunk c) every stream ran
+            // dry for 0.3 - 0.6 ms each fourth trip while the host sat in the other sub-pools'
+            // waits (rocprofv3 kernel trace, profiles/r2a_*: a quarter of each stream's time).
+            // Once the sub-pool drains the lag is cut back to one chunk (trips are short then).
+            const int depth = P.drained ? 1 : queue_depth;
+            if (P.pending >= depth) {
+                const int prev = (P.ring + 8 - depth) % 8;
                 const auto w0 = std::chrono::steady_clock::now();
                 HIP_TRY(hipEventSynchronize(P.ev[prev]));
                 const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
@@ -1521,7 +1564,8 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
                     ch->eng_compactions += 1;
                 }
             }
-            P.pending = 1;
+            if (P.pending < depth) P.pending += 1;
+            else if (P.pending > depth) P.pending = depth;
             P.ring = (P.ring + 1) % 8;
             return 0;
         };
