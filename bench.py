@@ -369,7 +369,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": workload,
+            "config": {"workload": workload, "command_key": key,
                        "path": args.path, "restarts_per_gpu": cols, "tol_f": 1e-6, "solution_mode": mode,
                        "parallelism": (f"targets x{world}" if T else f"restart-range x{world}"),
                        "success_rate_last_step": (n_success / cols) if n_success is not None else None,

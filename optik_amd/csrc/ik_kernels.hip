@@ -302,15 +302,15 @@ __global__ __launch_bounds__(256) void eval_batch_kernel(const EvalLaunch a) {
     const Pose target = load_pose(a.target);
     for (long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x; b < a.B;
          b += (long long)gridDim.x * blockDim.x) {
-        double q[N], g[N];
+        double q[N];
 #pragma unroll
         for (int i = 0; i < N; ++i) q[i] = a.q[(size_t)i * a.B + b];
-        const double f = eval_fg<N, TIP>(sch, a.ep, target, q, g);
+        // the gradient streams to its column as each component is known (as in eng_eval_kernel:
+        // neither it nor the joint positions stay in registers across the evaluation)
+        const double f = eval_fg_stream<N, TIP>(sch, a.ep, target, q, [&](int k, double v) {
+            if (a.g) a.g[(size_t)k * a.B + b] = v;
+        });
         a.f[b] = f;
-        if (a.g) {
-#pragma unroll
-            for (int i = 0; i < N; ++i) a.g[(size_t)i * a.B + b] = g[i];
-        }
     }
 }
 

@@ -594,10 +594,16 @@ const double *optik_robot_ik(const optik_robot *r, const CSolverConfig *config, 
 // The reference hands this LP to Clarabel (an interior-point solver; un-vendored).  It has at
 // most 8 unknowns, so it is solved exactly here: the equality constraints are eliminated
 // (null space of [J_W | -V] by Gauss-Jordan with full pivoting) and the vertices of the
-// remaining polytope (dimension <= 3) are enumerated.  The optimal alpha is unique; when the
-// optimal v is not (a redundant arm with alpha = 1), the minimum-norm optimal v is returned,
-// where Clarabel returns the analytic centre of the optimal face -- both pass the reference's
-// test (tests/test_ik.rs:185-209).  FK and the Jacobian come from the HIP kernels.
+// remaining polytope (any dimension: d = n + 1 - rank) are enumerated.  The optimal alpha is
+// unique.  Where the reference's own code can run the optimal v is unique too: lib.rs:196-197
+// sizes the equality block as `b.extend(vec![0.0; n]); K.push(ZeroConeT(n))` for a 6-row
+// matrix, so DefaultSolver::new only accepts n = 6 (for any other n the dimensions disagree
+// and the `expect("solver initialization failed")` panics), and a non-singular 6 x 6 Jacobian
+// leaves a single ray v = alpha J^-1 V (tests: closed form on UR3e).  For n != 6 -- an
+// extension -- and at singularities the optimal face may have positive dimension: for d = 2
+// the minimum-norm point of the optimal edge is returned, for d > 2 an optimal vertex of
+// minimum norm among the vertices (an interior-point solver would return a point inside the
+// face).  FK and the Jacobian come from the HIP kernels.
 int optik_robot_diff_ik_ex(const optik_robot *r, const double *x0, const double *V_WE, const double *v_max,
                            const double *ee16, double *alpha_out, double *v_out) {
     if (!r || !x0 || !V_WE || !v_max) return set_err(-1, "null argument");
@@ -649,11 +655,11 @@ int optik_robot_diff_ik_ex(const optik_robot *r, const double *x0, const double 
     const int d = nz - rank;  // dimension of {z = (v, alpha) : [J_W | -V] z = 0}
     std::vector<double> best_z((size_t)nz, 0.0);  // z = 0 (alpha = 0, v = 0) is always feasible
     double best_alpha = 0.0, best_norm = 0.0;
-    if (d >= 1 && d <= 3) {
+    if (d >= 1) {
         // basis B (nz x d): free variable k = 1, pivot variables from the reduced rows
-        int freec[3], nf = 0;
+        int freec[9], nf = 0;
         for (int c = 0; c < nz; ++c) if (!is_pivot[c]) freec[nf++] = c;
-        double B[9][3];
+        double B[9][9];
         for (int k = 0; k < d; ++k) {
             for (int c = 0; c < nz; ++c) B[c][k] = 0.0;
             B[freec[k]][k] = 1.0;
@@ -684,7 +690,7 @@ int optik_robot_diff_ik_ex(const optik_robot *r, const double *x0, const double 
             }
         };
         auto vertex = [&](const int *idx) {  // the point where the d constraints idx[] are tight
-            double A[3][4];
+            double A[9][10];
             for (int q = 0; q < d; ++q) {
                 double sgn; const double val = bound(idx[q], sgn);
                 for (int k = 0; k < d; ++k) A[q][k] = sgn * B[idx[q] / 2][k];
@@ -701,17 +707,21 @@ int optik_robot_diff_ik_ex(const optik_robot *r, const double *x0, const double 
                         for (int k = q; k <= d; ++k) A[a][k] -= f * A[q][k];
                     }
             }
-            double t[3];
+            double t[9];
             for (int q = 0; q < d; ++q) t[q] = A[q][d] / A[q][q];
             consider(t);
         };
-        int idx[3];
-        for (idx[0] = 0; idx[0] < nh; ++idx[0]) {
-            if (d == 1) { vertex(idx); continue; }
-            for (idx[1] = idx[0] + 1; idx[1] < nh; ++idx[1]) {
-                if (d == 2) { vertex(idx); continue; }
-                for (idx[2] = idx[1] + 1; idx[2] < nh; ++idx[2]) vertex(idx);
-            }
+        // every choice of d of the nh half-spaces (d <= 9, nh <= 18: at most 48 620 small solves,
+        // and d > 2 only at a kinematic singularity)
+        int idx[9];
+        for (int q = 0; q < d; ++q) idx[q] = q;
+        for (bool more = d <= nh; more;) {
+            vertex(idx);
+            int q = d - 1;
+            while (q >= 0 && idx[q] == nh - d + q) --q;
+            if (q < 0) { more = false; break; }
+            ++idx[q];
+            for (int k = q + 1; k < d; ++k) idx[k] = idx[k - 1] + 1;
         }
         // a redundant arm at the optimum: slide along the optimal face to the minimum-norm v
         if (d == 2) {

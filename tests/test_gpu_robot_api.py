@@ -356,3 +356,24 @@ def test_pose_validation_matches_parse_pose(ur3e):
             ur3e.ik(cfg, bad.tolist(), x)
     with pytest.raises(ValueError, match="invalid target transform specified"):
         ur3e.fk(x, ee_offset=(good * 2.0).tolist())
+
+
+def test_diff_ik_six_dof_solution_is_the_unique_ray(ur3e):
+    """Where the reference's diff_ik can run at all (n = 6: lib.rs:196-197 sizes the equality
+    cone with n for a 6-row block) a non-singular Jacobian leaves one ray v = alpha J^-1 V, so the
+    LP has a unique solution -- what any solver, Clarabel included, must return:
+    alpha = min(1, min_i v_max_i / |w_i|), v = alpha w, w = J_W^-1 V."""
+    rng = np.random.default_rng(77)
+    lb, ub = (np.array(v) for v in ur3e.joint_limits())
+    for trial in range(30):
+        x0 = rng.uniform(lb, ub)
+        V = rng.normal(size=6) * (0.05 if trial % 3 == 0 else 1.0)
+        v_max = rng.uniform(0.2, 2.0, size=6)
+        JW = _world_jacobian(ur3e, x0.tolist())
+        if np.linalg.cond(JW) > 1e6:
+            continue
+        w = np.linalg.solve(JW, V)
+        alpha_ref = min(1.0, float(np.min(v_max / np.abs(w))))
+        alpha, v = ur3e.diff_ik(x0.tolist(), V.tolist(), v_max.tolist())
+        assert abs(alpha - alpha_ref) < 1e-9
+        np.testing.assert_allclose(v, alpha_ref * w, atol=1e-8, rtol=0)
