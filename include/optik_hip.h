@@ -190,6 +190,10 @@ int optik_hip_engine_stats(const optik_hip_chain *chain, double *kernel_ms4, int
  * included).  d_evals reports NLopt's count per restart, which also includes the re-evaluation
  * of an accepted line-search point that was not the first trial; the kernels skip that one. */
 uint64_t optik_hip_engine_executed_evals(const optik_hip_chain *chain);
+/* 1 when the last run used fused trips (OPTIK_ENG_FUSED=1: bucket -> NNLS -> eng_slot_kernel): the
+ * four durations of optik_hip_engine_stats are then {slot kernel, bucket, NNLS, 0}; 0 for the
+ * default five-kernel trips ({eval, update, NNLS, finish}). */
+int optik_hip_engine_last_fused(const optik_hip_chain *chain);
 
 /* Host-buffer convenience over optik_hip_ik_batch (what Robot::ik calls): copies
  * targets/x0 in, runs, synchronises, copies the per-target winners out.

@@ -90,6 +90,7 @@ def lib():
     L.optik_hip_engine_run_ex.argtypes = [vp, vp, C.c_double]
     L.optik_hip_engine_executed_evals.argtypes = [vp]
     L.optik_hip_engine_executed_evals.restype = C.c_uint64
+    L.optik_hip_engine_last_fused.argtypes = [vp]
     L.optik_hip_engine_reserve.argtypes = [vp, C.c_uint64, vp]
     L.optik_hip_engine_last_trips.argtypes = [vp]
     L.optik_hip_engine_last_pools.argtypes = [vp, C.POINTER(C.c_int32)]

@@ -258,6 +258,52 @@ __global__ __launch_bounds__(OPTIK_ENG_UPD_BLOCK, OPTIK_ENG_UPD_WAVES) void eng_
     eng_finish_body<N>(a, sch, local < a.n_slots ? slot : (size_t)a.slot_base, local, local < a.n_slots);
 }
 
+// Fused trips: everything a slot's owner lane does in a trip, in one launch -- the finishing pass of
+// the direction the NNLS kernel just answered (and the refill of the listed slots), the
+// evaluation of the trial point, and on an accepted step the BFGS update with the next
+// direction search.  Between the three phases nothing is kept in registers (a full memory
+// fence and a scheduling barrier: the register allocator sees three separate live ranges, 240
+// VGPRs, 2 waves per SIMD like the three kernels it replaces); what a phase wrote is read back
+// by the same wave from L2 instead of crossing a kernel boundary through HBM, and a trip is
+// three dependent launches (bucket, NNLS, slot) instead of five.
+#define OPTIK_PHASE_BOUNDARY() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+template <int N, bool TIP>
+__global__ __launch_bounds__(OPTIK_ENG_UPD_BLOCK, OPTIK_ENG_UPD_WAVES) void eng_slot_kernel(const EngArgs a) {
+    __shared__ ChainDev sch;
+    extern __shared__ __attribute__((aligned(16))) unsigned char slot_dyn_lds[];  // n_jobs job records
+    EngJob *sjobs = reinterpret_cast<EngJob *>(slot_dyn_lds);
+    __shared__ double rec_win[(OPTIK_ENG_UPD_BLOCK / 64) * RecIo<N>::WINDOW];
+    {
+        static_assert(sizeof(EngJob) % sizeof(double) == 0, "EngJob is a whole number of doubles");
+        const double *src = reinterpret_cast<const double *>(a.jobs);
+        double *dst = reinterpret_cast<double *>(sjobs);
+        const int nd = a.n_jobs * (int)(sizeof(EngJob) / sizeof(double));
+        for (int i = threadIdx.x; i < nd; i += blockDim.x) dst[i] = src[i];
+    }
+    stage_chain(sch, a.chain);
+    const size_t local = (size_t)blockIdx.x * OPTIK_ENG_UPD_BLOCK + threadIdx.x;
+    const size_t slot = (size_t)a.slot_base + local;
+    const bool in = local < a.n_slots;
+    if (blockIdx.x == 0) {
+        // the in-use count of this trip's bucket pass goes to the host; then the counters the next
+        // trip's bucket pass accumulates into are cleared (nothing in this launch reads them)
+        if (threadIdx.x == 0) {
+            if (a.host_in_use) __hip_atomic_store(a.host_in_use, *a.n_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            *a.n_active = 0u;
+            *a.refill_count_next = 0u;
+        }
+        if (threadIdx.x >= 8u && threadIdx.x < 8u + (unsigned)NN_CLASSES) a.nn_class_count[a.parity ^ 1][threadIdx.x - 8u] = 0u;
+    }
+    eng_finish_body<N>(a, sch, in ? slot : (size_t)a.slot_base, local, in);
+    OPTIK_PHASE_BOUNDARY();
+    const bool evaluated = in && eng_eval_body<N, TIP>(a, sch, sjobs, slot);
+    const unsigned long long em = __ballot(evaluated);
+    if (a.exec_evals && em && (threadIdx.x & 63u) == 0)
+        atomicAdd(a.exec_evals + (blockIdx.x % ENG_EXEC_SHARDS), (unsigned long long)__popcll(em));
+    OPTIK_PHASE_BOUNDARY();
+    eng_update_body<N>(a, sch, in ? slot : (size_t)a.slot_base, local, in, rec_win + (threadIdx.x / 64u) * RecIo<N>::WINDOW);
+}
+
 // the last restarts of a run, one per lane, to the end without kernel boundaries (ik_tail.hpp)
 template <int N, bool TIP>
 __global__ __launch_bounds__(WAVE) void eng_tail_kernel(const EngArgs a, const unsigned int *list,
@@ -501,6 +547,7 @@ struct optik_hip_chain {
     hipEvent_t eng_pool_ev[ENG_MAX_POOLS][8] = {};
     hipEvent_t eng_fork_ev = nullptr, eng_join_ev[ENG_MAX_POOLS] = {};
     int eng_pools = 1;
+    int eng_fused = 0;                         // the last run used fused trips (eng_kernel_ms = {slot, bucket, nnls, -})
     int eng_launches = 0;                      // NNLS launches of the last run, all sub-pools
     int eng_tail_restarts = 0;                 // restarts (upper bound) the tail kernel took over in the last run
     int eng_compactions = 0;
@@ -1330,6 +1377,18 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
         if (const char *e = getenv("OPTIK_ENG_NNLS_SLACK")) a.nn_slack = atoi(e) > 0 ? atoi(e) : 0;
         a.cont_pass = 0;
         a.cont_count = nullptr; a.cont_list = nullptr; a.cont_cap = 0;
+        // five-kernel trips (default), or fused trips (OPTIK_ENG_FUSED=1: bucket -> NNLS -> slot kernel).
+        // Measured (r2, Panda, 20 / 48 steps): fused 21.5 / 24.7 M restarts/s against 22.2 / 25.7 M --
+        // the slot kernel takes 150 us where eval + update + finish take 190, but its waves live three
+        // times as long, so the two small kernels of a trip wait longer for CU slots behind the other
+        // sub-pools' slot kernels (bucket 17 -> 55 us, NNLS 97 -> 110 us), and a refilled slot waits a
+        // trip for its first evaluation; HBM bytes per restart fall by 4 % only (111 -> 106 KB: the
+        // stores, 45 % of the traffic, go to memory either way and most loads are of lines the
+        // previous trip wrote).  Kept as a knob: identical results (tests/test_gpu_parity.py).
+        bool fused = false;
+        if (const char *e = getenv("OPTIK_ENG_FUSED")) fused = atoi(e) != 0;
+        a.fused = fused ? 1 : 0;
+        ch->eng_fused = a.fused;
         unsigned cont_waves_per_cu = 4;  // grid of the continuation launch (it grid-strides over the lists)
         if (const char *e = getenv("OPTIK_ENG_NNLS_CONT_WAVES")) cont_waves_per_cu = (unsigned)atoi(e) > 0 ? (unsigned)atoi(e) : 1u;
         a.nn_total = ch->eng_nn_total;
@@ -1406,6 +1465,7 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
                     P.a.nn_cls[par] = ch->eng_list + (size_t)par * ch->eng_C + lo;
                 }
                 P.a.refill_count = cnt + 2 * NN_CLASSES;
+                P.a.refill_count_next = cnt + 2 * NN_CLASSES + 2;
                 P.a.n_active = cnt + 2 * NN_CLASSES + 1;
                 P.a.refill_list = ch->eng_refill + lo;
                 if (nn_cont) {
@@ -1472,6 +1532,29 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
 #define ENG_LAUNCH_LDS(kernel, grid, block, lds) do { if (tev0) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, tev0, tev1, 0, a); \
                                                        else hipLaunchKernelGGL(kernel, grid, block, lds, stream, a); } while (0)
 #define ENG_LAUNCH(kernel, grid, block) ENG_LAUNCH_LDS(kernel, grid, block, 0)
+                if (fused) {
+                    // trip t: bucket pass over what the previous slot kernel left, NNLS, slot kernel
+                    unsigned int *cnt = ch->eng_counters + (size_t)(&P - pools) * PCB;
+                    a.refill_count = cnt + 2 * NN_CLASSES + ((trip & 1) ? 2 : 0);
+                    a.refill_count_next = cnt + 2 * NN_CLASSES + ((trip & 1) ? 0 : 2);
+                    TEV(1);
+                    if (tev0) hipExtLaunchKernelGGL(eng_bucket_kernel, dim3((unsigned)cus), dim3(256), 0, stream, tev0, tev1, 0, a);
+                    else hipLaunchKernelGGL(eng_bucket_kernel, dim3((unsigned)cus), dim3(256), 0, stream, a);
+                    TEV(2);
+#define M_NNLS(NN) ENG_LAUNCH((eng_nnls_coop_kernel<NN>), dim3(nn_blocks), dim3(OPTIK_ENG_NNLS_BLOCK))
+                    DISPATCH_N(M_NNLS);
+#undef M_NNLS
+                    TEV(0);
+#define M_SLOT_T(NN) ENG_LAUNCH_LDS((eng_slot_kernel<NN, true>), dim3(blocks * (OPTIK_ENG_SLOT_BLOCK / OPTIK_ENG_UPD_BLOCK)), dim3(OPTIK_ENG_UPD_BLOCK), eval_lds)
+#define M_SLOT_F(NN) ENG_LAUNCH_LDS((eng_slot_kernel<NN, false>), dim3(blocks * (OPTIK_ENG_SLOT_BLOCK / OPTIK_ENG_UPD_BLOCK)), dim3(OPTIK_ENG_UPD_BLOCK), eval_lds)
+                    if (tip) DISPATCH_N(M_SLOT_T);
+                    else DISPATCH_N(M_SLOT_F);
+#undef M_SLOT_T
+#undef M_SLOT_F
+                    if (timed) ch->eng_tcount += 1;
+                    ch->eng_launches += 1;
+                    continue;
+                }
                 TEV(0);
                 if (trip > 0) {
 #define M_EVAL_T(NN) ENG_LAUNCH_LDS((eng_eval_kernel<NN, true>), dim3(blocks), dim3(OPTIK_ENG_SLOT_BLOCK), eval_lds)
@@ -1554,7 +1637,8 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
                     c.nn_prob = ch->eng_prob; c.nn_meta = ch->eng_meta; c.nn_carry = ch->eng_carry;
                     c.nn_cls = a.nn_cls[trip & 1];  // the entries the next trip consumes
                     c.rec_len = rec_len;
-                    c.pad = 0;
+                    c.nn_y = nullptr;
+                    c.ny = 2 * ch->n;
                     HIP_TRY(hipMemsetAsync(P.compact_counts, 0, 2 * sizeof(unsigned int), stream));
                     hipLaunchKernelGGL(eng_compact_scan_kernel, dim3((unsigned)((a.n_slots + 255) / 256)), dim3(256), 0, stream, c);
                     hipLaunchKernelGGL(eng_compact_move_kernel, dim3((unsigned)((a.n_slots - n_new + 255) / 256)), dim3(256), 0, stream, c);
@@ -1684,7 +1768,8 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
         for (int k = 0; k < 4; ++k) {
             double sum = 0.0;
             int cnt = 0;
-            for (int i = 0; i < ch->eng_tcount; ++i) {
+            // (fused trips time three kernels: [0] slot, [1] bucket, [2] NNLS)
+            for (int i = 0; i < ch->eng_tcount && !(fused && k == 3); ++i) {
                 const int trip_i = i + 1;  // sample i was taken on trip i + 1
                 if (k != 2 && trip_i % 8 != 2) continue;
                 float ms = 0.0f;
@@ -1705,7 +1790,7 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
                     const int i = t - 1;
                     if (i >= 0 && i < ch->eng_tcount)
                         for (int k = 0; k < 4; ++k)
-                            if (k == 2 || t % 8 == 2) hipEventElapsedTime(&ms[k], ch->eng_tev[k][i][0], ch->eng_tev[k][i][1]);
+                            if ((k == 2 || t % 8 == 2) && !(fused && k == 3)) hipEventElapsedTime(&ms[k], ch->eng_tev[k][i][0], ch->eng_tev[k][i][1]);
                     fprintf(fp, "%d,%u,%u,%.4f,%.4f,%.4f,%.4f\n", t, h[2 * t], h[2 * t + 1], ms[0], ms[1], ms[2], ms[3]);
                 }
                 fclose(fp);
@@ -1781,6 +1866,7 @@ int optik_hip_engine_stats(const optik_hip_chain *ch, double *kernel_ms4, int32_
 }
 
 uint64_t optik_hip_engine_executed_evals(const optik_hip_chain *ch) { return ch ? ch->eng_exec_evals : 0; }
+int optik_hip_engine_last_fused(const optik_hip_chain *ch) { return ch ? ch->eng_fused : 0; }
 
 int optik_hip_ik_host(optik_hip_chain *ch, const optik_solver_config *cfg, const double *targets,
                       const double *x0, int32_t T, const double *ee_offset7, uint64_t restart_begin,

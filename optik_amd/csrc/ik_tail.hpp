@@ -73,7 +73,7 @@ OPTIK_DEV void tail_wave(const EngArgs &a, const ChainDev &ch, const EngJob *job
             }
             if (st == ST_DEAD) {
                 ret = ENG_I(E::STATUS);
-            } else if (st == ST_EVAL_FIRST) {
+            } else if (st == ST_EVAL_FIRST || st == ST_FRESH0 || st == ST_FRESH1) {
                 first = true;
             } else {
 #pragma unroll

@@ -177,7 +177,11 @@ class HipChain:
         launches = C.c_int32(0)
         pools = int(nat.lib().optik_hip_engine_last_pools(self._h, C.byref(launches)))
         executed = int(nat.lib().optik_hip_engine_executed_evals(self._h))
-        return dict(eval_ms=ms[0], update_ms=ms[1], nnls_ms=ms[2], finish_ms=ms[3],
+        if int(nat.lib().optik_hip_engine_last_fused(self._h)):
+            return dict(slot_ms=ms[0], bucket_ms=ms[1], nnls_ms=ms[2], fused=True,
+                        sampled_trips=cnt.value, nnls_problems=prob.value, pools=pools,
+                        launches=launches.value, evals_executed=executed, slot_trips=executed)
+        return dict(eval_ms=ms[0], update_ms=ms[1], nnls_ms=ms[2], finish_ms=ms[3], fused=False,
                     sampled_trips=cnt.value, nnls_problems=prob.value, pools=pools,
                     launches=launches.value, evals_executed=executed, slot_trips=executed)
 

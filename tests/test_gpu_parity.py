@@ -273,6 +273,11 @@ def test_engine_pools_jobs_and_matches_the_single_kernel_path(dev, oracle, chain
     {"OPTIK_ENG_NO_TAIL": "1"},                                                    # the engine finishes every restart itself
     {"OPTIK_ENG_TAIL_MAX": "100000", "OPTIK_ENGINE_SLOTS": "4096"},                # tail kernel takes over as soon as the queue is empty
     {"OPTIK_ENG_TAIL_MAX": "7", "OPTIK_ENG_POOLS": "2"},                           # ... or only for the last handful
+    {"OPTIK_ENG_FUSED": "1"},                                                      # fused trips: bucket -> NNLS -> slot kernel
+    {"OPTIK_ENG_FUSED": "1", "OPTIK_ENGINE_SLOTS": "3072", "OPTIK_ENG_POOLS": "3", "OPTIK_ENG_NNLS_BUDGET": "2"},
+    {"OPTIK_ENG_FUSED": "1", "OPTIK_ENG_NO_TAIL": "1", "OPTIK_ENGINE_SLOTS": "2048"},
+    {"OPTIK_ENG_NNLS_CONT": "1", "OPTIK_ENGINE_SLOTS": "4096"},                    # same-trip NNLS continuation launch
+    {"OPTIK_ENG_DEPTH": "1"}, {"OPTIK_ENG_DEPTH": "4", "OPTIK_ENGINE_SLOTS": "4096"},  # chunks the host keeps queued ahead
 ])
 def test_engine_scheduling_does_not_change_results(dev, oracle, chains, hip_chains, knobs):
     """Sub-pools, the per-launch NNLS pass budget (suspend / resume), pool size (refills) and
