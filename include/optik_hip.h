@@ -117,6 +117,13 @@ int optik_hip_seed_batch(const optik_hip_chain *chain, uint64_t first, int64_t c
 
 /* flags of optik_hip_ik_batch */
 #define OPTIK_HIP_IK_EARLY_EXIT 1u /* Speed: abandon restarts above a known success (lib.rs:382-384) */
+/* With EARLY_EXIT: abandon every other restart of a target as soon as ANY restart of it has
+ * succeeded -- the reference's behaviour with more than one rayon thread (find_any, lib.rs:409-412;
+ * README.md:17, 96: "non-deterministic").  The winner is then the lowest index among the restarts
+ * that happened to finish successfully: a valid solution -- its x / f are what that restart
+ * returns on its own, bit for bit -- but which one depends on timing.  Without it (the default)
+ * only restarts ABOVE a success are abandoned and the answer is the reference's 1-thread one. */
+#define OPTIK_HIP_IK_FIND_ANY 2u
 
 /* Outputs of optik_hip_ik_batch; any pointer may be NULL to skip that output.
  * R = restart_end - restart_begin. */

@@ -83,6 +83,8 @@ struct EngJob {
     // higher indices are then abandoned before they are ever evaluated)
     int restart_major;
     unsigned long long n_targets;      // T
+    int find_any;                      // Speed early exit on ANY success of the target (lib.rs:409-412 with several threads)
+    int pad_fa;
 };
 
 // jobs pooled in one run (the table is staged in the eval kernel's LDS, 120 bytes a job); more
@@ -496,7 +498,7 @@ OPTIK_DEV bool eng_eval_body(const EngArgs &a, const ChainDev &ch, const EngJob 
         if (J.first_success) {
             const unsigned long long fs = __hip_atomic_load(J.first_success + tslot, __ATOMIC_RELAXED,
                                                             __HIP_MEMORY_SCOPE_AGENT);
-            if (fs < index) ret = RES_FORCED_STOP;
+            if (J.find_any ? (fs != ~0ull) : (fs < index)) ret = RES_FORCED_STOP;
         }
         if (a.abort) ret = RES_FORCED_STOP;  // lib.rs:308: timed out
     }
@@ -649,7 +651,7 @@ OPTIK_DEV bool refill_slot(const EngArgs &a, const ChainDev &ch, size_t slot, un
         if (!skip && J.first_success) {
             const unsigned long long fs = __hip_atomic_load(J.first_success + tslot, __ATOMIC_RELAXED,
                                                             __HIP_MEMORY_SCOPE_AGENT);
-            skip = fs < index;  // abandoned before it started (key is +inf from the job's set-up)
+            skip = J.find_any ? (fs != ~0ull) : (fs < index);  // abandoned before it started (key is +inf from the job's set-up)
         }
         if (skip) {
             if (J.out_status) J.out_status[item] = RES_FORCED_STOP;

@@ -1031,6 +1031,7 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     a.wq.targets = d_targets;
     a.wq.x0 = d_x0;
     a.wq.first_success = early ? ch->first_success : nullptr;
+    a.wq.find_any = (early && (flags & OPTIK_HIP_IK_FIND_ANY)) ? 1 : 0;
     a.wq.deadline = 0;
     a.wq.quality = (cfg->solution_mode == 1);
     a.wq.out_x = px;
@@ -1177,6 +1178,7 @@ int optik_hip_engine_submit(optik_hip_chain *ch, const optik_solver_config *cfg,
     j.dev.first_success = j.own_fs;
     j.dev.quality = (cfg->solution_mode == 1);
     j.dev.restart_major = (early && T > 1) ? 1 : 0;
+    j.dev.find_any = (early && (flags & OPTIK_HIP_IK_FIND_ANY)) ? 1 : 0;
     j.dev.n_targets = (unsigned long long)T;
     ch->eng_jobs.push_back(j);
     return 0;
@@ -1267,7 +1269,8 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
             if (deadline_s > 0.0) { left = deadline_s - since_call(); if (left <= 0.0) left = 1e-9; }
             rc = ik_batch_locked(ch, &cfg, j.dev.targets, j.dev.x0, j.T, ch->eng_has_ee ? ch->eng_ee : nullptr,
                                  j.dev.restart_begin, j.dev.restart_begin + j.dev.n_restarts,
-                                 j.own_fs ? OPTIK_HIP_IK_EARLY_EXIT : 0u, left, &j.out, stream);
+                                 (j.own_fs ? OPTIK_HIP_IK_EARLY_EXIT : 0u) | (j.dev.find_any ? OPTIK_HIP_IK_FIND_ANY : 0u), left,
+                                 &j.out, stream);
             if (!rc && hipStreamSynchronize(stream) != hipSuccess) rc = fail(OPTIK_HIP_ENODEVICE, "engine job failed");
         }
         for (auto &j : ch->eng_jobs) {

@@ -156,6 +156,11 @@ struct WorkQueue {
     // 382-384) in its deterministic reading: a restart is abandoned only if a
     // LOWER index of the same target already succeeded.
     unsigned long long *first_success;   // [T] or nullptr
+    // 1: the reference's multi-thread reading of should_exit (find_any, lib.rs:409-412): ANY
+    // success of the target makes every other restart of it give up at its next evaluation --
+    // the answer is then whichever restart got there first (a valid solution, not a fixed one)
+    int find_any;
+    int pad_fa;
     unsigned long long deadline;         // wall_clock64() ticks, 0 = none
     int quality;                         // selection key: 1 = ||x - x0||_2, 0 = index
     int lanes;                           // lanes of a wave that take work items (1 .. 64): a launch too small to
@@ -254,7 +259,7 @@ OPTIK_DEV void solve_wave(const ChainDev &ch, const EvalParams &ep, const SolveP
             if (wq.first_success) {
                 const unsigned long long fs = __hip_atomic_load(wq.first_success + tslot, __ATOMIC_RELAXED,
                                                                 __HIP_MEMORY_SCOPE_AGENT);
-                stop = fs < index;
+                stop = wq.find_any ? (fs != ~0ull) : (fs < index);
             }
             if (wq.deadline && (unsigned long long)wall_clock64() > wq.deadline) stop = true;
             if (stop) ret = RES_FORCED_STOP;

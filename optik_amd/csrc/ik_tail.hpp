@@ -104,7 +104,7 @@ OPTIK_DEV void tail_wave(const EngArgs &a, const ChainDev &ch, const EngJob *job
             // lib.rs:308: abandon when a lower-index restart of the same target succeeded
             const unsigned long long fs = __hip_atomic_load(J.first_success + tslot, __ATOMIC_RELAXED,
                                                             __HIP_MEMORY_SCOPE_AGENT);
-            if (fs < index) ret = RES_FORCED_STOP;
+            if (J.find_any ? (fs != ~0ull) : (fs < index)) ret = RES_FORCED_STOP;
         }
         double gn[N];
         double fn = 0.0;

@@ -49,7 +49,12 @@ struct optik_robot {
     std::vector<double> lb, ub;
     std::vector<double> origins, axes;  // n_joints x 7, n_joints x 3
     std::vector<int32_t> types;
-    unsigned parallelism = 0;  // accepted for API compatibility (lib.rs:66-72); unused
+    // set_parallelism (lib.rs:66-72).  The rayon pool size has no counterpart, but its one
+    // observable consequence has: with one thread SolutionMode::Speed returns the lowest
+    // successful restart (deterministic; tests/test_ik.rs:45-89 sets 1 for that), with more it
+    // returns whichever success comes first (find_any, lib.rs:409-412).  0 = never set and 1 give
+    // the deterministic answer; n > 1 lets a Speed call stop at the first success anywhere.
+    unsigned parallelism = 0;
     mutable std::mutex mu;     // guards the lazily created device contexts and the FK scratch
     // GPUs this robot spreads restart ranges / targets over (optik_robot_set_devices,
     // OPTIK_DEVICES); empty = the HIP device current at first use.  The same id may be listed
@@ -292,7 +297,7 @@ int optik_robot_set_devices(optik_robot *r, const int32_t *device_ids, int32_t c
 int32_t optik_robot_num_devices(const optik_robot *r) { return r ? (int32_t)device_count(r) : 0; }
 
 void optik_robot_set_parallelism(optik_robot *r, unsigned int n) {
-    // The rayon pool size has no counterpart: the GPU grid is sized from the device.
+    // The GPU grid is sized from the device; n only selects Speed's early-exit rule (see optik_robot).
     if (r) r->parallelism = n;
 }
 
@@ -371,6 +376,7 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
     const uint64_t cus = (uint64_t)(c0->num_cus > 0 ? c0->num_cus : 256);
     const uint64_t first_batch = cus * 2, later_batch = cus * 2 * 64 * 2;
     const size_t G = device_count(r);
+    const uint32_t speed_flags = OPTIK_HIP_IK_EARLY_EXIT | (r->parallelism > 1 ? OPTIK_HIP_IK_FIND_ANY : 0u);
     struct Part {
         DeviceCtx *ctx = nullptr;
         uint64_t begin = 0, end = 0, widx = UINT64_MAX;
@@ -405,7 +411,7 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
         }
         auto run_part = [&](Part &p) {
             p.rc = optik_hip_ik_host(p.ctx->chain, config, tgt7, x0, 1, ee16 ? ee7 : nullptr, p.begin, p.end,
-                                     quality ? 0u : OPTIK_HIP_IK_EARLY_EXIT, deadline, p.wx.data(), &p.wf, &p.widx,
+                                     quality ? 0u : speed_flags, deadline, p.wx.data(), &p.wf, &p.widx,
                                      &p.wkey);
             if (p.rc) p.err = optik_hip_last_error();
         };
@@ -499,7 +505,8 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
         std::memset(&o, 0, sizeof o);
         o.d_win_x = d_wx; o.d_win_f = d_wf; o.d_win_idx = d_wi; o.d_win_key = d_wk;
         int rc = optik_hip_engine_submit(c->chain, config, d_t, d_x0, (int32_t)L, ee7, begin, end,
-                                         quality ? 0u : OPTIK_HIP_IK_EARLY_EXIT, &o);
+                                         quality ? 0u : (OPTIK_HIP_IK_EARLY_EXIT | (r->parallelism > 1 ? OPTIK_HIP_IK_FIND_ANY : 0u)),
+                                         &o);
         if (!rc) rc = optik_hip_engine_run_ex(c->chain, nullptr, deadline);
         if (rc) { err = optik_hip_last_error(); return -1; }
         if (hipMemcpyAsync(h_out, d_wx, sizeof(double) * (size_t)(n + 3) * L, hipMemcpyDeviceToHost, nullptr) != hipSuccess

@@ -377,3 +377,33 @@ def test_diff_ik_six_dof_solution_is_the_unique_ray(ur3e):
         alpha, v = ur3e.diff_ik(x0.tolist(), V.tolist(), v_max.tolist())
         assert abs(alpha - alpha_ref) < 1e-9
         np.testing.assert_allclose(v, alpha_ref * w, atol=1e-8, rtol=0)
+
+
+def test_set_parallelism_selects_find_any(oracle, chains):
+    """set_parallelism(n > 1): SolutionMode::Speed stops at the first success of ANY restart
+    (rayon's find_any with several threads, lib.rs:409-412) -- the returned restart is then not
+    fixed, but it is a restart that succeeds, and its x / f are exactly what that restart
+    computes on its own (checked against the oracle by index)."""
+    from optik_amd import Robot, SolverConfig
+    r = Robot.from_urdf_file(os.path.join(ROBOTS, "panda.urdf"), "panda_link0", "panda_link8")
+    r.set_parallelism(8)
+    _, ch = chains["panda"]
+    rng = np.random.default_rng(52)
+    lb, ub = (np.array(v) for v in r.joint_limits())
+    cfg = SolverConfig(max_time=0.0, max_restarts=4000)
+    for _ in range(6):
+        tgt = np.array(r.fk(rng.uniform(lb, ub)))
+        x0 = rng.uniform(lb, ub)
+        x, f, idx = r.ik(cfg, tgt, x0.tolist(), return_index=True)
+        ref = oracle.solve_restart(ch, oracle.make_config("speed"), _mat_to_pose7(tgt), x0, int(idx))
+        # (the target reaches the kernels through the host layer's 4x4 -> pose conversion, the
+        # oracle through the test's: agreement to roundoff, as in test_determinism_and_oracle_agreement)
+        assert ref.success and abs(ref.f - f) < 1e-9
+        np.testing.assert_allclose(x, np.array(ref.x[:7]), atol=1e-6, rtol=0)
+    # ik_batch with the same rule
+    targets = [np.array(r.fk(rng.uniform(lb, ub))) for _ in range(16)]
+    x0s = rng.uniform(lb, ub, size=(16, 7))
+    out = r.ik_batch(SolverConfig(max_time=0.0, max_restarts=256), targets, x0s)
+    for t, o in enumerate(out):
+        assert o is not None and o[1] < 1e-6
+        np.testing.assert_allclose(np.array(r.fk(o[0]))[:3, 3], targets[t][:3, 3], atol=2e-3)

@@ -15,6 +15,8 @@ robot = Robot.from_urdf_file(os.path.join(ROOT, "optik_amd", "robots", "panda.ur
 lb, ub = (np.array(v) for v in robot.joint_limits())
 rng = np.random.default_rng(42)
 cfg = SolverConfig()
+if len(sys.argv) > 2:
+    robot.set_parallelism(int(sys.argv[2]))  # > 1: Speed stops at the first success of any restart (find_any)
 robot.ik(cfg, np.array(robot.fk(rng.uniform(lb, ub))), rng.uniform(lb, ub).tolist())  # warm-up
 tot, ok = 0.0, 0
 for _ in range(N):
@@ -26,4 +28,5 @@ for _ in range(N):
     if sol is not None:
         tot += dt
         ok += 1
-print(f"Average time: {1e6 * tot / max(ok, 1):.0f}us   Success rate: {100.0 * ok / N:.1f}%   ({N} calls, Panda, default config)")
+print(f"Average time: {1e6 * tot / max(ok, 1):.0f}us   Success rate: {100.0 * ok / N:.1f}%   ({N} calls, Panda, default config, "
+      f"parallelism {sys.argv[2] if len(sys.argv) > 2 else 'unset'})")
