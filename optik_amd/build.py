@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "liboptik_amd.so")
 SOURCES = ["ik_kernels.hip", "robot_host.cpp"]
 HEADERS = ["ik_math.hpp", "ik_eval.hpp", "ik_slsqp.hpp", "ik_solve.hpp", "ik_nnls_coop.hpp", "ik_engine.hpp",
-           "ik_tail.hpp",
+           "ik_tail.hpp", "ik_coop.hpp",
            "urdf_chain.hpp",
            os.path.join("..", "..", "include", "optik_hip.h"),
            os.path.join("..", "..", "include", "optik.h")]

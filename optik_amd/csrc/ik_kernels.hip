@@ -24,6 +24,7 @@
 #include "../../include/optik_hip.h"
 #include "ik_engine.hpp"
 #include "ik_tail.hpp"
+#include "ik_coop.hpp"
 
 using namespace optik;
 
@@ -80,6 +81,20 @@ __global__ __launch_bounds__(WAVE) void ik_solve_kernel(const SolveLaunch a) {
     WorkQueue wq = a.wq;
     wq.deadline = a.deadline_ticks ? wall_clock64() + a.deadline_ticks : 0ull;
     solve_wave<N, TIP>(sch, a.ep, a.sp, a.key, a.scale, wq, ws);
+}
+
+// The same restarts with one restart per group of four lanes and the cooperative NNLS
+// (ik_coop.hpp): the latency-oriented form, used whenever the chain has n <= 7 joints.
+template <int N, bool TIP>
+__global__ __launch_bounds__(WAVE) void ik_coop_kernel(const SolveLaunch a) {
+    __shared__ ChainDev sch;
+    __shared__ __attribute__((aligned(16))) double nnls_lds[coop_wave_lds<4>()];
+    __shared__ __attribute__((aligned(16))) double rec_lds[COOP_GROUPS_PER_WAVE * coop_rec_lds<N>()];
+    stage_chain(sch, a.chain);
+    if (threadIdx.x < 8) nnls_lds[coop_wave_lds<4>() - 8 + threadIdx.x] = 0.0;  // the column of zeros
+    WorkQueue wq = a.wq;
+    wq.deadline = a.deadline_ticks ? wall_clock64() + a.deadline_ticks : 0ull;
+    coop_wave<N, TIP>(sch, a.ep, a.sp, a.key, a.scale, wq, nnls_lds, rec_lds);
 }
 
 struct SelectLaunch {
@@ -1052,14 +1067,20 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         if (a.deadline_ticks == 0) a.deadline_ticks = 1;
     }
 
-    // Persistent waves: as many 64-lane workgroups as the LDS lets a CU hold (2), times
-    // the CU count; each pulls work items until the queue is dry.
+    // Which solver: the cooperative one (ik_coop.hpp, a restart per group of four lanes, NNLS in
+    // registers; n <= 7) unless OPTIK_SOLVE_KERNEL=lane asks for round 1's one-restart-per-lane
+    // kernel with its per-lane LDS NNLS (the only one for n = 8).
+    bool coop = ch->n <= 7;
+    if (const char *e = std::getenv("OPTIK_SOLVE_KERNEL")) coop = coop && std::strcmp(e, "lane") != 0;
+    // Persistent waves, each pulling work items until the queue is dry: as many as a CU holds
+    // (lane kernel: 2 workgroups, LDS-bound; cooperative kernel: 4, one per SIMD), times the CU count.
     const int cus = ch->num_cus > 0 ? ch->num_cus : 256;
-    const long long cap = (long long)cus * ch->waves_per_cu;
-    // fewer work items than lanes on the chip: one restart per wave (or as few as fit)
+    const long long cap = (long long)cus * (coop ? 4 : ch->waves_per_cu);
+    const long long per_wave_max = coop ? COOP_GROUPS_PER_WAVE : WAVE;
+    // fewer work items than the chip holds: one restart per wave (or as few as fit)
     long long lanes = ((long long)cols + cap - 1) / cap;
     if (lanes < 1) lanes = 1;
-    if (lanes > WAVE) lanes = WAVE;
+    if (lanes > per_wave_max) lanes = per_wave_max;
     a.wq.lanes = (int)lanes;
     long long grid_ll = ((long long)cols + lanes - 1) / lanes;
     if (grid_ll > cap) grid_ll = cap;
@@ -1071,11 +1092,25 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         HIP_TRY(hipEventRecord(ch->ev0[ev_slot], stream));
     }
     int lds = 0;
+    if (coop) {
+#define CALL_COOP(NN, TT)                                                                            \
+    lds = (int)(sizeof(ChainDev) + sizeof(double) * (coop_wave_lds<4>() + COOP_GROUPS_PER_WAVE * coop_rec_lds<NN>())); \
+    hipLaunchKernelGGL((ik_coop_kernel<NN, TT>), dim3(grid), dim3(WAVE), 0, stream, a)
+#define CALL_COOP_N(NN) do { if (ch->tip) { CALL_COOP(NN, true); } else { CALL_COOP(NN, false); } } while (0)
+        switch (ch->n) {
+        case 1: CALL_COOP_N(1); break; case 2: CALL_COOP_N(2); break; case 3: CALL_COOP_N(3); break;
+        case 4: CALL_COOP_N(4); break; case 5: CALL_COOP_N(5); break; case 6: CALL_COOP_N(6); break;
+        default: CALL_COOP_N(7); break;
+        }
+#undef CALL_COOP_N
+#undef CALL_COOP
+    } else {
 #define CALL(NN, TT)                                                                                 \
     lds = (int)(sizeof(ChainDev) + sizeof(double) * NnlsLayout<NN>::SLOTS * WAVE);                   \
     hipLaunchKernelGGL((ik_solve_kernel<NN, TT>), dim3(grid), dim3(WAVE), 0, stream, a)
     OPTIK_DISPATCH(ch, CALL);
 #undef CALL
+    }
     HIP_TRY(hipGetLastError());
     if (ch->timing) { HIP_TRY(hipEventRecord(ch->ev1[ev_slot], stream)); ch->ev_count += 1; }
     ch->last.grid = grid; ch->last.block = WAVE; ch->last.lds_bytes = lds; ch->last.tiles = n_tiles;
