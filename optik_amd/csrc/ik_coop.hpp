@@ -28,21 +28,231 @@ constexpr int COOP_GROUPS_PER_WAVE = 64 / COOP_GROUP;
 template <int N>
 constexpr int coop_rec_lds() { return rec_stride<N>() + 2 * N + 2; }
 
+// NLopt bookkeeping and Kraft's line search after an evaluation (labels 100 / 220 / 260): what
+// solve_wave does between its evaluation and its direction search, for the lane `do_eval` holds.
+template <int N>
+OPTIK_DEV void coop_after_eval(const SolveParams &sp, bool do_eval, double fn, const double (&gn)[N], double (&x)[N],
+                               double (&g)[N], double (&s)[N], double (&l)[N * (N + 1) / 2], double (&xbest)[N],
+                               double (&xprev)[N], double &f, double &t0, double &h3, double &alpha, double &minf,
+                               double &fprev, int &line, int &nevals, bool &first, int32_t &ret, bool &need_dir,
+                               bool &reset) {
+    const double alfmin = 0.1;
+    if (do_eval) {
+        f = fn;
+        ++nevals;
+        // NLopt: update best point so far; stopval is tested after every evaluation
+        if (f < minf) {
+            minf = f;
+#pragma unroll
+            for (int i = 0; i < N; ++i) xbest[i] = x[i];
+        }
+        if (minf < sp.stopval) {
+            ret = RES_STOPVAL_REACHED;
+        } else if (nevals >= MAX_EVALS_CAP) {
+            ret = RES_ITER_CAP;
+        } else if (first) {
+            // SLSQPB label 100/110: initialise, reset the BFGS matrix
+            first = false;
+#pragma unroll
+            for (int i = 0; i < N; ++i) g[i] = gn[i];
+            need_dir = true;
+            reset = true;
+        } else {
+            // label 220: L1 merit (m = 0: the objective itself)
+            const double h1 = f - t0;
+            bool accept = false;
+            if (__builtin_isfinite(h1)) {
+                if (h1 <= h3 / 10.0 || line > 10) accept = true;
+                else {
+                    const double a = h3 / ((h3 - h1) * 2.0);
+                    alpha = (a > alfmin) ? a : alfmin;
+                }
+            } else {
+                const double a = alpha * 0.5;
+                alpha = (a > alfmin) ? a : alfmin;
+            }
+            if (accept) {
+                // line search complete (mode -1): NLopt re-evaluates f and the gradient there
+                // unless the accepted trial was the first one
+                if (line > 1) ++nevals;
+                if (!__builtin_isinf(fprev)) {
+                    if (__builtin_fabs(f - fprev) < sp.ftol_abs) ret = RES_FTOL_REACHED;
+                    // (xprev_live: when neither x test can fire after the ftol test the engine does not
+                    // keep the previous iterate, and a slot handed over from it carries a stale one)
+                    else if (xprev_live(sp) && stop_x<N>(sp, x, xprev)) ret = RES_XTOL_REACHED;
+                }
+                fprev = f;
+#pragma unroll
+                for (int i = 0; i < N; ++i) xprev[i] = x[i];
+                if (ret == 0 && nevals >= MAX_EVALS_CAP) ret = RES_ITER_CAP;
+                if (ret == 0) {
+                    // label 260: BFGS update with u = g_new - g_old
+                    double u[N];
+#pragma unroll
+                    for (int i = 0; i < N; ++i) { u[i] = gn[i] - g[i]; g[i] = gn[i]; }
+                    OPTIK_SCHED_FENCE();
+                    bfgs_update<N>(l, s, u);
+                    OPTIK_SCHED_FENCE();
+                    need_dir = true;
+                }
+            }
+        }
+    }
+}
+
+// Labels 110/130: (reset,) search direction, descent test.  Wave-uniform loop: the leaders
+// prepare their LSQ problems, the whole wave solves the bounded ones (one per group of four
+// lanes, ik_nnls_coop.hpp), the leaders finish; a leader whose direction is not a descent
+// direction resets and goes round again (at most five times, Kraft's ireset).
+template <int N>
+OPTIK_DEV void coop_direction(const ChainDev &ch, const SolveParams &sp, double *nnls_lds, double *grec, bool &need_dir,
+                              bool &reset, int &ireset, double (&l)[N * (N + 1) / 2], const double (&g)[N],
+                              const double (&x)[N], double (&x0)[N], double (&s)[N], double f, double &f0, double &t0,
+                              double &h3, double &alpha, int &line, int32_t &ret) {
+    constexpr int NL = N * (N + 1) / 2;
+    constexpr int n = 2 * N;
+    constexpr int CPL = 4;
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned group = lane / COOP_GROUP, gl = lane % COOP_GROUP;
+    double *const gy = grec + rec_stride<N>();
+    double *const gmeta = gy + 2 * N;
+    const RecIo<N> rec{grec, nullptr};
+        while (wave_any(need_dir)) {
+        bool pass = need_dir;
+        if (pass && reset) {
+            ++ireset;
+            if (ireset > 5) {
+                // label 255 with acc = 0 -> mode 8; NLopt's relaxed test vs (f0, x0)
+                ret = RES_ROUNDOFF_LIMITED;
+                if (__builtin_fabs(f - f0) < sp.ftol_abs && !__builtin_isinf(f0)) ret = RES_FTOL_REACHED;
+                else if (stop_x<N>(sp, x, x0)) ret = RES_XTOL_REACHED;
+                need_dir = false;
+                pass = false;
+            } else {
+#pragma unroll
+                for (int i = 0; i < NL; ++i) l[i] = 0.0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) l[lidx<N>(i, i)] = 1.0;
+            }
+        }
+        double E[N][N], fv[N], lo[N], hi[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            lo[i] = ch.lb[i] - x[i];
+            hi[i] = ch.ub[i] - x[i];
+            fv[i] = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) E[i][j] = 0.0;
+        }
+        int lmode = 1;
+        bool need_nnls = false;
+        OPTIK_SCHED_FENCE();
+        if (pass) {
+            lmode = lsq_factor<N>(l, g, E, fv);
+            if (lmode == 1) {
+                need_nnls = lsq_bound_rows<N>(E, fv, lo, hi, [&](int i, const double (&row)[N], double h_lo, double h_hi) {
+#pragma unroll
+                    for (int r = i; r < N; ++r) rec.put(rec_g<N>(i, r), row[r]);
+                    rec.put(rec_hlo<N>(i), h_lo);
+                    rec.put(rec_hhi<N>(i), h_hi);
+                });
+            }
+        }
+        OPTIK_SCHED_FENCE();
+        // ---- the bounded dual problems of this round, one per group, all 64 lanes ------
+        if (wave_any(need_nnls)) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const bool live = __shfl((int)need_nnls, (int)(lane & ~(unsigned)(COOP_GROUP - 1)), 64) != 0;
+            dvec8 col[CPL];
+            CoopCarry<CPL> cs;
+            cs.b = 0.0;
+            cs.up = 0.0;
+            cs.nsetp = 0;
+            cs.iter = 0;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                col[k] = 0.0;
+                cs.xv[k] = 0.0;
+                cs.pos[k] = 0;
+                const unsigned c = gl * CPL + k;
+                if (live && c < (unsigned)n) {
+                    // column c < N: row c of E^-1 on rows c .. N-1, h_lo[c] below; column N + c: its
+                    // negation, h_hi[c] below (as eng_nnls_coop_body reads a record)
+                    const bool neg = c >= (unsigned)N;
+                    const int cc = (int)(neg ? c - N : c);
+                    const int off = cc * (N + 2) - (cc * (cc - 1)) / 2 - cc;  // rec_row(cc) - cc
+#pragma unroll
+                    for (int r = 0; r < N; ++r) {
+                        const double v = (r >= cc) ? grec[off + r] : 0.0;
+                        col[k][r] = neg ? ((r >= cc) ? -v : 0.0) : v;
+                    }
+                    col[k][N] = grec[off + N + (neg ? 1 : 0)];
+                }
+            }
+            int mode, iters;
+            double rnorm;
+            auto park = [&](const dvec8 (&)[CPL], const CoopCarry<CPL> &) {};  // (never suspended: no budget)
+            nnls_coop<N, CPL>(live, false, 0x3fffffff, (int)(gl * CPL), col, cs, mode, rnorm, iters,
+                              nnls_lds + group * COOP_WIN, nnls_lds + COOP_GROUPS_PER_WAVE * COOP_WIN, park);
+            if (live) {
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) {
+                    const unsigned c = gl * CPL + k;
+                    if (c < (unsigned)n) gy[c] = cs.xv[k];
+                }
+                if (gl == 0) { gmeta[0] = (double)(mode + 8 * iters); gmeta[1] = rnorm; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        OPTIK_SCHED_FENCE();
+        if (pass) {
+            if (lmode == 1) {
+                if (need_nnls) {
+                    lmode = ldp_from_record<N>(rec, gy, gmeta, s);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < N; ++j) s[j] = 0.0;
+                }
+            }
+            if (lmode != 1) {
+                // NLopt: modes 5,6,7 -> ROUNDOFF_LIMITED; 3,4,9 -> FAILURE
+                ret = (lmode == 5 || lmode == 6 || lmode == 7) ? RES_ROUNDOFF_LIMITED : RES_FAILURE;
+                need_dir = false;
+            } else {
+                lsq_finish<N>(E, fv, lo, hi, s);
+                OPTIK_SCHED_FENCE();
+                // (g is also Kraft's v: the gradient at the start of the line search)
+                double gs = 0.0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) x0[i] = x[i];
+                f0 = f;
+#pragma unroll
+                for (int i = 0; i < N; ++i) gs += g[i] * s[i];
+                t0 = f;
+                h3 = gs;  // h3 = gs - h1 * h4 with h1 = 0 (no constraints)
+                if (h3 >= 0.0) {
+                    reset = true;  // not a descent direction: reset B and repeat
+                } else {
+                    line = 0;
+                    alpha = 1.0;
+                    need_dir = false;
+                }
+            }
+        }
+    }
+}
+
 template <int N, bool TIP>
 OPTIK_DEV void coop_wave(const ChainDev &ch, const EvalParams &ep, const SolveParams &sp,
                          const uint32_t (&key)[8], const double (&scale)[MAX_DOF], const WorkQueue &wq,
                          double *nnls_lds /* coop_wave_lds<4>() doubles */, double *rec_lds /* 16 x coop_rec_lds<N>() */) {
     constexpr int NL = N * (N + 1) / 2;
-    constexpr int m = N + 1, n = 2 * N;
-    constexpr int CPL = 4;
-    const double alfmin = 0.1;
     const unsigned lane = threadIdx.x & 63u;
     const unsigned group = lane / COOP_GROUP, gl = lane % COOP_GROUP;
     const bool leader = gl == 0 && (int)group < wq.lanes;  // wq.lanes = restarts (groups) a wave holds at a time
     double *const grec = rec_lds + group * coop_rec_lds<N>();
-    double *const gy = grec + rec_stride<N>();
-    double *const gmeta = gy + 2 * N;
-    const RecIo<N> rec{grec, nullptr};
 
     // SLSQP state of the leader's current restart (names as in solve_wave)
     double x[N], x0[N], g[N], s[N], l[NL];
@@ -112,194 +322,9 @@ OPTIK_DEV void coop_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
         if (do_eval) fn = eval_fg<N, TIP>(ch, ep, target, x, gn);
         OPTIK_SCHED_FENCE();
         bool need_dir = false, reset = false;
-        if (do_eval) {
-            f = fn;
-            ++nevals;
-            // NLopt: update best point so far; stopval is tested after every evaluation
-            if (f < minf) {
-                minf = f;
-#pragma unroll
-                for (int i = 0; i < N; ++i) xbest[i] = x[i];
-            }
-            if (minf < sp.stopval) {
-                ret = RES_STOPVAL_REACHED;
-            } else if (nevals >= MAX_EVALS_CAP) {
-                ret = RES_ITER_CAP;
-            } else if (first) {
-                // SLSQPB label 100/110: initialise, reset the BFGS matrix
-                first = false;
-#pragma unroll
-                for (int i = 0; i < N; ++i) g[i] = gn[i];
-                need_dir = true;
-                reset = true;
-            } else {
-                // label 220: L1 merit (m = 0: the objective itself)
-                const double h1 = f - t0;
-                bool accept = false;
-                if (__builtin_isfinite(h1)) {
-                    if (h1 <= h3 / 10.0 || line > 10) accept = true;
-                    else {
-                        const double a = h3 / ((h3 - h1) * 2.0);
-                        alpha = (a > alfmin) ? a : alfmin;
-                    }
-                } else {
-                    const double a = alpha * 0.5;
-                    alpha = (a > alfmin) ? a : alfmin;
-                }
-                if (accept) {
-                    // line search complete (mode -1): NLopt re-evaluates f and the gradient there
-                    // unless the accepted trial was the first one
-                    if (line > 1) ++nevals;
-                    if (!__builtin_isinf(fprev)) {
-                        if (__builtin_fabs(f - fprev) < sp.ftol_abs) ret = RES_FTOL_REACHED;
-                        else if (stop_x<N>(sp, x, xprev)) ret = RES_XTOL_REACHED;
-                    }
-                    fprev = f;
-#pragma unroll
-                    for (int i = 0; i < N; ++i) xprev[i] = x[i];
-                    if (ret == 0 && nevals >= MAX_EVALS_CAP) ret = RES_ITER_CAP;
-                    if (ret == 0) {
-                        // label 260: BFGS update with u = g_new - g_old
-                        double u[N];
-#pragma unroll
-                        for (int i = 0; i < N; ++i) { u[i] = gn[i] - g[i]; g[i] = gn[i]; }
-                        OPTIK_SCHED_FENCE();
-                        bfgs_update<N>(l, s, u);
-                        OPTIK_SCHED_FENCE();
-                        need_dir = true;
-                    }
-                }
-            }
-        }
-        // ---- labels 110/130: (reset,) search direction, descent test.  Wave-uniform loop: the
-        // leaders prepare their LSQ problems, the whole wave solves the bounded ones, the
-        // leaders finish; a leader whose direction is not a descent direction resets and goes
-        // round again (at most five times, Kraft's ireset) ---------------------------------
-        while (wave_any(need_dir)) {
-            bool pass = need_dir;
-            if (pass && reset) {
-                ++ireset;
-                if (ireset > 5) {
-                    // label 255 with acc = 0 -> mode 8; NLopt's relaxed test vs (f0, x0)
-                    ret = RES_ROUNDOFF_LIMITED;
-                    if (__builtin_fabs(f - f0) < sp.ftol_abs && !__builtin_isinf(f0)) ret = RES_FTOL_REACHED;
-                    else if (stop_x<N>(sp, x, x0)) ret = RES_XTOL_REACHED;
-                    need_dir = false;
-                    pass = false;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < NL; ++i) l[i] = 0.0;
-#pragma unroll
-                    for (int i = 0; i < N; ++i) l[lidx<N>(i, i)] = 1.0;
-                }
-            }
-            double E[N][N], fv[N], lo[N], hi[N];
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                lo[i] = ch.lb[i] - x[i];
-                hi[i] = ch.ub[i] - x[i];
-                fv[i] = 0.0;
-#pragma unroll
-                for (int j = 0; j < N; ++j) E[i][j] = 0.0;
-            }
-            int lmode = 1;
-            bool need_nnls = false;
-            OPTIK_SCHED_FENCE();
-            if (pass) {
-                lmode = lsq_factor<N>(l, g, E, fv);
-                if (lmode == 1) {
-                    need_nnls = lsq_bound_rows<N>(E, fv, lo, hi, [&](int i, const double (&row)[N], double h_lo, double h_hi) {
-#pragma unroll
-                        for (int r = i; r < N; ++r) rec.put(rec_g<N>(i, r), row[r]);
-                        rec.put(rec_hlo<N>(i), h_lo);
-                        rec.put(rec_hhi<N>(i), h_hi);
-                    });
-                }
-            }
-            OPTIK_SCHED_FENCE();
-            // ---- the bounded dual problems of this round, one per group, all 64 lanes ------
-            if (wave_any(need_nnls)) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const bool live = __shfl((int)need_nnls, (int)(lane & ~(unsigned)(COOP_GROUP - 1)), 64) != 0;
-                dvec8 col[CPL];
-                CoopCarry<CPL> cs;
-                cs.b = 0.0;
-                cs.up = 0.0;
-                cs.nsetp = 0;
-                cs.iter = 0;
-#pragma unroll
-                for (int k = 0; k < CPL; ++k) {
-                    col[k] = 0.0;
-                    cs.xv[k] = 0.0;
-                    cs.pos[k] = 0;
-                    const unsigned c = gl * CPL + k;
-                    if (live && c < (unsigned)n) {
-                        // column c < N: row c of E^-1 on rows c .. N-1, h_lo[c] below; column N + c: its
-                        // negation, h_hi[c] below (as eng_nnls_coop_body reads a record)
-                        const bool neg = c >= (unsigned)N;
-                        const int cc = (int)(neg ? c - N : c);
-                        const int off = cc * (N + 2) - (cc * (cc - 1)) / 2 - cc;  // rec_row(cc) - cc
-#pragma unroll
-                        for (int r = 0; r < N; ++r) {
-                            const double v = (r >= cc) ? grec[off + r] : 0.0;
-                            col[k][r] = neg ? ((r >= cc) ? -v : 0.0) : v;
-                        }
-                        col[k][N] = grec[off + N + (neg ? 1 : 0)];
-                    }
-                }
-                int mode, iters;
-                double rnorm;
-                auto park = [&](const dvec8 (&)[CPL], const CoopCarry<CPL> &) {};  // (never suspended: no budget)
-                nnls_coop<N, CPL>(live, false, 0x3fffffff, (int)(gl * CPL), col, cs, mode, rnorm, iters,
-                                  nnls_lds + group * COOP_WIN, nnls_lds + COOP_GROUPS_PER_WAVE * COOP_WIN, park);
-                if (live) {
-#pragma unroll
-                    for (int k = 0; k < CPL; ++k) {
-                        const unsigned c = gl * CPL + k;
-                        if (c < (unsigned)n) gy[c] = cs.xv[k];
-                    }
-                    if (gl == 0) { gmeta[0] = (double)(mode + 8 * iters); gmeta[1] = rnorm; }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-            OPTIK_SCHED_FENCE();
-            if (pass) {
-                if (lmode == 1) {
-                    if (need_nnls) {
-                        lmode = ldp_from_record<N>(rec, gy, gmeta, s);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < N; ++j) s[j] = 0.0;
-                    }
-                }
-                if (lmode != 1) {
-                    // NLopt: modes 5,6,7 -> ROUNDOFF_LIMITED; 3,4,9 -> FAILURE
-                    ret = (lmode == 5 || lmode == 6 || lmode == 7) ? RES_ROUNDOFF_LIMITED : RES_FAILURE;
-                    need_dir = false;
-                } else {
-                    lsq_finish<N>(E, fv, lo, hi, s);
-                    OPTIK_SCHED_FENCE();
-                    // (g is also Kraft's v: the gradient at the start of the line search)
-                    double gs = 0.0;
-#pragma unroll
-                    for (int i = 0; i < N; ++i) x0[i] = x[i];
-                    f0 = f;
-#pragma unroll
-                    for (int i = 0; i < N; ++i) gs += g[i] * s[i];
-                    t0 = f;
-                    h3 = gs;  // h3 = gs - h1 * h4 with h1 = 0 (no constraints)
-                    if (h3 >= 0.0) {
-                        reset = true;  // not a descent direction: reset B and repeat
-                    } else {
-                        line = 0;
-                        alpha = 1.0;
-                        need_dir = false;
-                    }
-                }
-            }
-        }
+        coop_after_eval<N>(sp, do_eval, fn, gn, x, g, s, l, xbest, xprev, f, t0, h3, alpha, minf, fprev, line, nevals,
+                           first, ret, need_dir, reset);
+        coop_direction<N>(ch, sp, nnls_lds, grec, need_dir, reset, ireset, l, g, x, x0, s, f, f0, t0, h3, alpha, line, ret);
         if (do_eval && ret == 0) {
             // label 190: next trial point x = x0 + alpha * s, clipped (NLopt)
             ++line;

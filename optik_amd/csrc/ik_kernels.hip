@@ -329,6 +329,16 @@ __global__ __launch_bounds__(WAVE) void eng_tail_kernel(const EngArgs a, const u
     const NnlsWs<N> ws{nnls_lds + threadIdx.x};
     tail_wave<N, TIP>(a, sch, a.jobs, list, *count, lanes, ws);
 }
+template <int N, bool TIP>
+__global__ __launch_bounds__(WAVE) void eng_tail_coop_kernel(const EngArgs a, const unsigned int *list,
+                                                             const unsigned int *count, int groups) {
+    __shared__ ChainDev sch;
+    __shared__ __attribute__((aligned(16))) double nnls_lds[coop_wave_lds<4>()];
+    __shared__ __attribute__((aligned(16))) double rec_lds[COOP_GROUPS_PER_WAVE * coop_rec_lds<N>()];
+    stage_chain(sch, a.chain);
+    if (threadIdx.x < 8) nnls_lds[coop_wave_lds<4>() - 8 + threadIdx.x] = 0.0;  // the column of zeros
+    tail_wave_coop<N, TIP>(a, sch, a.jobs, list, *count, groups, nnls_lds, rec_lds);
+}
 __global__ __launch_bounds__(256) void eng_tail_list_kernel(const int32_t *state, unsigned long long n_slots,
                                                             unsigned int *count, unsigned int *list) {
     tail_list_body(state, n_slots, count, list);
@@ -1693,8 +1703,12 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
         };
         ch->eng_launches = 0;
         // hand-over to the tail kernel once this few restarts are left in all sub-pools together
+        // (the cooperative tail holds 16 restarts per wave, 16 384 resident at once, at half the time
+        // per iteration of the per-lane one: measured best between 12 k and 24 k, 23.7 against 22.4 M
+        // restarts/s at 4 096 for a 20-step run)
         unsigned long long tail_max = total / 16;
-        if (tail_max > 4096) tail_max = 4096;
+        const unsigned long long tail_cap = (getenv("OPTIK_SOLVE_KERNEL") && std::strcmp(getenv("OPTIK_SOLVE_KERNEL"), "lane") == 0) ? 4096ull : 16384ull;
+        if (tail_max > tail_cap) tail_max = tail_cap;
         if (tail_max < 64) tail_max = 64;
         if (getenv("OPTIK_ENG_NO_TAIL")) tail_max = 0;
         if (const char *e = getenv("OPTIK_ENG_TAIL_MAX")) tail_max = (unsigned long long)atoll(e);
@@ -1729,10 +1743,12 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
             HIP_TRY(hipMemsetAsync(t_count, 0, sizeof(unsigned int), stream));
             hipLaunchKernelGGL(eng_tail_list_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream,
                                ch->eng_i32, (unsigned long long)C, t_count, t_list);
-            const unsigned long long cap_waves = (unsigned long long)cus * (unsigned long long)ch->waves_per_cu;
+            bool tail_coop = true;  // (n <= 7 always here) the cooperative tail, unless the per-lane one is asked for
+            if (const char *e = getenv("OPTIK_SOLVE_KERNEL")) tail_coop = std::strcmp(e, "lane") != 0;
+            const unsigned long long cap_waves = (unsigned long long)cus * (unsigned long long)(tail_coop ? 4 : ch->waves_per_cu);
             unsigned long long lanes = (left + cap_waves - 1) / cap_waves;
             if (lanes < 1) lanes = 1;
-            if (lanes > WAVE) lanes = WAVE;
+            if (lanes > (tail_coop ? (unsigned long long)COOP_GROUPS_PER_WAVE : (unsigned long long)WAVE)) lanes = tail_coop ? COOP_GROUPS_PER_WAVE : WAVE;
             const unsigned t_grid = (unsigned)((left + lanes - 1) / lanes);
             const int lanes_i = (int)lanes;
             EngArgs ta = pools[0].a;
@@ -1746,8 +1762,13 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
             }
 #define M_TAIL_T(NN) hipLaunchKernelGGL((eng_tail_kernel<NN, true>), dim3(t_grid), dim3(WAVE), 0, stream, ta, t_list, t_count, lanes_i)
 #define M_TAIL_F(NN) hipLaunchKernelGGL((eng_tail_kernel<NN, false>), dim3(t_grid), dim3(WAVE), 0, stream, ta, t_list, t_count, lanes_i)
-            if (tip) DISPATCH_N(M_TAIL_T);
+#define M_TAILC_T(NN) hipLaunchKernelGGL((eng_tail_coop_kernel<NN, true>), dim3(t_grid), dim3(WAVE), 0, stream, ta, t_list, t_count, lanes_i)
+#define M_TAILC_F(NN) hipLaunchKernelGGL((eng_tail_coop_kernel<NN, false>), dim3(t_grid), dim3(WAVE), 0, stream, ta, t_list, t_count, lanes_i)
+            if (tail_coop) { if (tip) DISPATCH_N(M_TAILC_T); else DISPATCH_N(M_TAILC_F); }
+            else if (tip) DISPATCH_N(M_TAIL_T);
             else DISPATCH_N(M_TAIL_F);
+#undef M_TAILC_T
+#undef M_TAILC_F
 #undef M_TAIL_T
 #undef M_TAIL_F
             HIP_TRY(hipGetLastError());

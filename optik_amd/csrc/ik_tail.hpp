@@ -16,7 +16,7 @@
 // Results are published through the slot's job exactly as eng_eval_body does.
 #pragma once
 
-#include "ik_engine.hpp"
+#include "ik_coop.hpp"
 
 namespace optik {
 
@@ -232,6 +232,159 @@ OPTIK_DEV void tail_wave(const EngArgs &a, const ChainDev &ch, const EngJob *job
                     else if (xi > ch.ub[i]) xi = ch.ub[i];
                     x[i] = xi;
                 }
+            }
+        }
+        // ---- the restart ended: classify (lib.rs:376-379), publish, free the slot ----
+        if (active && ret != 0) {
+            const bool success = (sp.ok_stopval && ret == RES_STOPVAL_REACHED)
+                                 || (sp.ok_ftol && ret == RES_FTOL_REACHED)
+                                 || (sp.ok_xtol && ret == RES_XTOL_REACHED);
+            if (J.out_x) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) J.out_x[(size_t)i * J.n_items + item] = xbest[i];
+            }
+            if (J.out_f) J.out_f[item] = minf;
+            if (J.out_status) J.out_status[item] = ret;
+            if (J.out_evals) J.out_evals[item] = nevals;
+            double k = __builtin_huge_val();
+            if (success) {
+                if (J.quality) {
+                    const double *x0p = J.x0 + (size_t)tslot * N;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) { const double d = xbest[i] - x0p[i]; acc += d * d; }
+                    k = __builtin_sqrt(acc);
+                } else {
+                    k = (double)index;
+                    if (J.first_success) atomicMin(J.first_success + tslot, index);
+                }
+            }
+            if (J.out_key) J.out_key[item] = k;
+            ENG_I(E::STATE) = ST_EMPTY;
+            active = false;
+        }
+    }
+    if (a.exec_evals) {
+        unsigned tot = n_exec;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) tot += (unsigned)__shfl_xor((int)tot, off, 64);
+        if (lane == 0 && tot) atomicAdd(a.exec_evals + (blockIdx.x % ENG_EXEC_SHARDS), (unsigned long long)tot);
+    }
+}
+
+// The same hand-over with one restart per group of four lanes and the cooperative NNLS
+// (ik_coop.hpp): no per-lane LDS matrix, half the time per iteration.  `groups` restarts per wave.
+template <int N, bool TIP>
+OPTIK_DEV void tail_wave_coop(const EngArgs &a, const ChainDev &ch, const EngJob *jobs, const unsigned int *list,
+                              unsigned count, int groups, double *nnls_lds, double *rec_lds) {
+    using E = EngLayout<N>;
+    constexpr int NL = N * (N + 1) / 2;
+    const SolveParams &sp = a.sp;
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) / 64u;
+    const unsigned group = lane / COOP_GROUP, gl = lane % COOP_GROUP;
+    const unsigned entry = wave * (unsigned)groups + group;
+    bool active = gl == 0 && (int)group < groups && entry < count;
+    const size_t slot = active ? (size_t)list[entry] : 0;
+    double *const grec = rec_lds + group * coop_rec_lds<N>();
+
+    // SLSQP state of the lane's restart (names as in solve_wave)
+    double x[N], x0[N], g[N], s[N], l[NL], xbest[N], xprev[N];
+    double f = 0.0, f0 = 0.0, t0 = 0.0, h3 = 0.0, alpha = 1.0;
+    double minf = __builtin_huge_val(), fprev = __builtin_huge_val();
+    int ireset = 0, line = 0, nevals = 0;
+    bool first = false, pending_dir = false;
+    int32_t ret = 0;
+    Pose target;
+    target.t = V3{0, 0, 0};
+    target.q = Q4{0, 0, 0, 1};
+    unsigned long long item = 0, index = 0, tslot = 0;
+    int job = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { x[i] = 0.0; x0[i] = 0.0; g[i] = 0.0; s[i] = 0.0; xbest[i] = 0.0; xprev[i] = 0.0; }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) l[i] = 0.0;
+    if (active) {
+        const int st = ENG_I(E::STATE);
+        if (st == ST_EMPTY || st == ST_REFILL) {
+            active = false;
+        } else {
+            job = ENG_I(E::JOB);
+            const EngJob &J = jobs[job];
+            item = a.item[slot];
+            tslot = item / J.n_restarts;
+            index = J.restart_begin + (item - tslot * J.n_restarts);
+            target = load_pose(J.targets + (size_t)tslot * 7);
+            nevals = ENG_I(E::NEVALS);
+            ireset = ENG_I(E::IRESET);
+            line = ENG_I(E::LINE);
+            minf = ENG_D(E::MF, 0);
+            fprev = ENG_D(E::FP, 0);
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                x[i] = ENG_D(E::X, i);
+                xbest[i] = ENG_D(E::XB, i);
+                xprev[i] = ENG_D(E::XP, i);
+            }
+            if (st == ST_DEAD) {
+                ret = ENG_I(E::STATUS);
+            } else if (st == ST_EVAL_FIRST || st == ST_FRESH0 || st == ST_FRESH1) {
+                first = true;
+            } else {
+#pragma unroll
+                for (int i = 0; i < NL; ++i) l[i] = ENG_D(E::L, i);
+#pragma unroll
+                for (int i = 0; i < N; ++i) g[i] = ENG_D(E::G, i);
+                if (st == ST_NNLS) {
+                    pending_dir = true;  // resume at the LSQ call (labels 110/130)
+                    f = ENG_D(E::FC, 0);
+                } else {  // ST_EVAL_TRIAL
+#pragma unroll
+                    for (int i = 0; i < N; ++i) { x0[i] = ENG_D(E::X0, i); s[i] = ENG_D(E::S, i); }
+                    t0 = ENG_D(E::F0, 0);
+                    h3 = ENG_D(E::H3, 0);
+                    alpha = ENG_D(E::AL, 0);
+                }
+            }
+        }
+    }
+    const EngJob &J = jobs[job];
+    // max_time (lib.rs:308): restarts still running at the deadline are abandoned
+    const unsigned long long deadline = a.tail_deadline_ticks ? (unsigned long long)wall_clock64() + a.tail_deadline_ticks : 0ull;
+
+    unsigned n_exec = 0;  // evaluations this lane executed
+    while (wave_any(active)) {
+        if (active && ret == 0 && deadline && (unsigned long long)wall_clock64() > deadline) ret = RES_FORCED_STOP;
+        if (active && ret == 0 && J.first_success) {
+            // lib.rs:308: abandon when another restart of the same target succeeded
+            const unsigned long long fs = __hip_atomic_load(J.first_success + tslot, __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT);
+            if (J.find_any ? (fs != ~0ull) : (fs < index)) ret = RES_FORCED_STOP;
+        }
+        double gn[N];
+        double fn = 0.0;
+        const bool stepping = active && ret == 0;
+        const bool do_eval = stepping && !pending_dir;
+        OPTIK_SCHED_FENCE();
+        if (do_eval) { fn = eval_fg<N, TIP>(ch, a.ep, target, x, gn); ++n_exec; }
+        OPTIK_SCHED_FENCE();
+        bool need_dir = stepping && pending_dir, reset = false;  // a deferred direction resumes at its LSQ call
+        pending_dir = false;
+        coop_after_eval<N>(sp, do_eval, fn, gn, x, g, s, l, xbest, xprev, f, t0, h3, alpha, minf, fprev, line, nevals,
+                           first, ret, need_dir, reset);
+        coop_direction<N>(ch, sp, nnls_lds, grec, need_dir, reset, ireset, l, g, x, x0, s, f, f0, t0, h3, alpha, line, ret);
+        if (stepping && ret == 0) {
+            // label 190: next trial point x = x0 + alpha * s, clipped (NLopt)
+            ++line;
+            h3 = alpha * h3;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                s[i] *= alpha;
+                double xi = x0[i];
+                xi += s[i];
+                if (xi < ch.lb[i]) xi = ch.lb[i];
+                else if (xi > ch.ub[i]) xi = ch.ub[i];
+                x[i] = xi;
             }
         }
         // ---- the restart ended: classify (lib.rs:376-379), publish, free the slot ----
