@@ -51,9 +51,11 @@ struct optik_robot {
     std::vector<int32_t> types;
     // set_parallelism (lib.rs:66-72).  The rayon pool size has no counterpart, but its one
     // observable consequence has: with one thread SolutionMode::Speed returns the lowest
-    // successful restart (deterministic; tests/test_ik.rs:45-89 sets 1 for that), with more it
-    // returns whichever success comes first (find_any, lib.rs:409-412).  0 = never set and 1 give
-    // the deterministic answer; n > 1 lets a Speed call stop at the first success anywhere.
+    // successful restart (deterministic; tests/test_ik.rs:45-89 sets 1 for exactly that), with more
+    // it returns whichever success comes first (find_any, lib.rs:409-412; README.md:17, 96).
+    // 0 = never set = the reference's default pool (ThreadPoolBuilder::default(): every core,
+    // lib.rs:42-47) and n > 1 let a Speed call stop at the first success anywhere; 1 gives the
+    // deterministic 1-thread answer.
     unsigned parallelism = 0;
     mutable std::mutex mu;     // guards the lazily created device contexts and the FK scratch
     // GPUs this robot spreads restart ranges / targets over (optik_robot_set_devices,
@@ -376,7 +378,7 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
     const uint64_t cus = (uint64_t)(c0->num_cus > 0 ? c0->num_cus : 256);
     const uint64_t first_batch = cus * 2, later_batch = cus * 2 * 64 * 2;
     const size_t G = device_count(r);
-    const uint32_t speed_flags = OPTIK_HIP_IK_EARLY_EXIT | (r->parallelism > 1 ? OPTIK_HIP_IK_FIND_ANY : 0u);
+    const uint32_t speed_flags = OPTIK_HIP_IK_EARLY_EXIT | (r->parallelism != 1 ? OPTIK_HIP_IK_FIND_ANY : 0u);
     struct Part {
         DeviceCtx *ctx = nullptr;
         uint64_t begin = 0, end = 0, widx = UINT64_MAX;
@@ -505,7 +507,7 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
         std::memset(&o, 0, sizeof o);
         o.d_win_x = d_wx; o.d_win_f = d_wf; o.d_win_idx = d_wi; o.d_win_key = d_wk;
         int rc = optik_hip_engine_submit(c->chain, config, d_t, d_x0, (int32_t)L, ee7, begin, end,
-                                         quality ? 0u : (OPTIK_HIP_IK_EARLY_EXIT | (r->parallelism > 1 ? OPTIK_HIP_IK_FIND_ANY : 0u)),
+                                         quality ? 0u : (OPTIK_HIP_IK_EARLY_EXIT | (r->parallelism != 1 ? OPTIK_HIP_IK_FIND_ANY : 0u)),
                                          &o);
         if (!rc) rc = optik_hip_engine_run_ex(c->chain, nullptr, deadline);
         if (rc) { err = optik_hip_last_error(); return -1; }

@@ -136,10 +136,11 @@ class Robot:
 
     def set_parallelism(self, n: int) -> None:
         """lib.rs:66-72.  The GPU needs no thread count; what n keeps from the reference is Speed
-        mode's early-exit rule: n <= 1 (and never calling this) returns the lowest successful
-        restart -- the reference's deterministic 1-thread answer -- while n > 1 stops at the first
-        success of any restart, like rayon's find_any with several threads (README.md:17, 96):
-        lower latency, a valid but timing-dependent choice among the solutions."""
+        mode's early-exit rule.  n = 1 returns the lowest successful restart -- the reference's
+        deterministic 1-thread answer (its own determinism test sets 1, tests/test_ik.rs:45-89).
+        Never calling this (the reference's default pool has every core) or n > 1 stops at the
+        first success of any restart, like rayon's find_any with several threads (README.md:17,
+        96): lower latency, a valid but timing-dependent choice among the solutions."""
         self._L.optik_robot_set_parallelism(self._h, int(n))
 
     def set_devices(self, device_ids) -> None:
