@@ -5,9 +5,10 @@
 // (measured: 36 % VALU lane utilisation, 2 waves per CU because of the NNLS LDS).
 // For throughput the same arithmetic is re-cut along the phases instead:
 //
-//   * a pool of C restart *slots* lives in HBM as struct-of-arrays planes
-//     (plane k of slot s at [k*C + s]): thread s of every per-slot kernel owns slot s, so
-//     all state traffic is coalesced;
+//   * a pool of C restart *slots* lives in HBM as struct-of-arrays planes, tiled by 64 slots
+//     with neighbouring planes interleaved in pairs (ENG_D_AT below: plane k of slot s at
+//     [(s/64) * ceil(ND/2) * 128 + (k/2) * 128 + (s%64) * 2 + k%2]): thread s of every per-slot
+//     kernel owns slot s, so all state traffic is coalesced, mostly 16 bytes per lane;
 //   * one *trip* = five kernels over a sub-pool, each doing one phase for the slots that
 //     are in it:
 //       eng_eval_kernel     objective + gradient at x, NLopt bookkeeping / stop tests,
@@ -21,8 +22,9 @@
 //                           (ik_nnls_coop.hpp)
 //       eng_finish_kernel   refill of finished slots from the work queue; LDP tail,
 //                           descent test and next trial point from the NNLS answers
-//     (the last few thousand restarts of a run are finished by eng_tail_kernel,
-//     ik_tail.hpp, without kernel boundaries);
+//     (the last restarts of a run -- up to 16 384 -- are finished by eng_tail_coop_kernel,
+//     ik_tail.hpp / ik_coop.hpp, without kernel boundaries; OPTIK_ENG_FUSED=1 runs finish, eval
+//     and update as one launch, eng_slot_kernel);
 //   * jobs (one optik_hip_ik_batch call each) submitted before a run share the pool:
 //     a slot that finishes a restart of one job may continue with another job's.
 //
