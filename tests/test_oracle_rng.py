@@ -73,3 +73,13 @@ def test_restart_seeds_ur3e(oracle, chains):
         assert np.all(s >= d["lb"]) and np.all(s <= d["ub"])
         seen.add(tuple(s))
     assert len(seen) == 199
+
+
+def test_rand_chacha_construction_kat(oracle):
+    """rand_chacha's own unit test `test_chacha_construction` (src/chacha.rs, recalled from the crate:
+    seed bytes [0 x8, 1, 0 x7, 2, 0 x7, 3, 0 x7], ChaCha20Rng::from_seed(seed).next_u32() ==
+    137206642): pins the seed-bytes -> key-words order (little endian) and the zero counter /
+    stream layout of the block function the restart seeds use (there with 8 rounds)."""
+    seed = bytes([0] * 8 + [1] + [0] * 7 + [2] + [0] * 7 + [3] + [0] * 7)
+    block = _block(oracle, seed, 0, 0, 20)
+    assert int.from_bytes(block[:4], "little") == 137206642
