@@ -22,7 +22,12 @@ KNOBS = {"OPTIK_ENGINE_SLOTS": [None, "1024", "1000", "2560", "4096", "20000"],
          "OPTIK_ENG_NNLS_BUDGET": [None, "1", "2", "3", "6", "12"],
          "OPTIK_ENG_NNLS_SLACK": [None, "0", "1", "2", "100"],
          "OPTIK_ENG_TAIL_MAX": [None, "0", "7", "300", "100000"],
-         "OPTIK_ENG_NO_COMPACT": [None, None, "1"]}
+         "OPTIK_ENG_NO_COMPACT": [None, None, "1"],
+         # round 2: fused trips, same-trip NNLS continuation, host queue depth, per-lane tail / solve kernels
+         "OPTIK_ENG_FUSED": [None, None, "1"],
+         "OPTIK_ENG_NNLS_CONT": [None, None, "1"],
+         "OPTIK_ENG_DEPTH": [None, "1", "3"],
+         "OPTIK_SOLVE_KERNEL": [None, None, "lane"]}
 
 
 def main():
