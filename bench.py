@@ -144,8 +144,6 @@ def main():
         args.path = "engine"
     if args.restarts is None:
         args.restarts = 256 if args.targets else 65536
-    if args.targets and args.path != "engine":
-        raise SystemExit("--targets runs on the engine path")
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -217,6 +215,8 @@ def main():
                    "win_key": torch.zeros(1, dtype=torch.float64, device=dev)}, mode, distributed and not T)
     torch.cuda.synchronize()
     flags = nat.IK_EARLY_EXIT if T else 0
+    if T and args.path == "kernel":
+        flags |= nat.IK_RESTART_MAJOR  # every target's low restart indices first
 
     def run_steps(first, count):
         """`count` steps starting at step `first`; returns the per-step winners ([count, T_loc])."""
@@ -235,8 +235,9 @@ def main():
         winners = []
         for k in range(count):
             i = (first + k) * per_step + t_lo
-            hc.ik_batch(cfg, targets[i:i + T_loc], x0[i:i + T_loc], begin, end, bufs=bufs[0])
-            winners.append(select_winner(bufs[0], mode, distributed))
+            hc.ik_batch(cfg, targets[i:i + T_loc], x0[i:i + T_loc], begin, end, flags=flags, bufs=bufs[0],
+                        per_restart=not T)
+            winners.append(select_winner(bufs[0], mode, distributed and not T).clone())
         return torch.stack(winners)
 
     if W:
@@ -345,7 +346,7 @@ def main():
             info = hc.last_launch()
             achieved = out_bytes * cols / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "ik_solve_kernel",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "ik_coop_kernel",
                     "kernel_ms": kernel_ms, "launches_timed": launches,
                     "algorithmic_bytes_per_unit": out_bytes, "units_per_launch": cols, "secondary": None}
         if T:

@@ -124,6 +124,12 @@ int optik_hip_seed_batch(const optik_hip_chain *chain, uint64_t first, int64_t c
  * returns on its own, bit for bit -- but which one depends on timing.  Without it (the default)
  * only restarts ABOVE a success are abandoned and the answer is the reference's 1-thread one. */
 #define OPTIK_HIP_IK_FIND_ANY 2u
+/* optik_hip_ik_batch / _ik_host with T > 1 targets: hand the (target, restart) work items out
+ * restart-major (every target's restart 0, then every target's restart 1, ...) instead of
+ * target-major; with EARLY_EXIT about eight restarts per target are kept in flight and most
+ * higher indices are never started.  Scheduling only: per-restart results and winners are the
+ * same (an abandoned restart's status is FORCED_STOP either way).  n <= 7. */
+#define OPTIK_HIP_IK_RESTART_MAJOR 4u
 
 /* Outputs of optik_hip_ik_batch; any pointer may be NULL to skip that output.
  * R = restart_end - restart_begin. */

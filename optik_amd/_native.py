@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "liboptik_amd.so")
 MAX_DOF = 8
 IK_EARLY_EXIT = 1
 IK_FIND_ANY = 2
+IK_RESTART_MAJOR = 4
 UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 
 RES_FAILURE, RES_ROUNDOFF, RES_FORCED_STOP, RES_ITER_CAP = -1, -4, -5, -100

@@ -1057,6 +1057,8 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     a.wq.x0 = d_x0;
     a.wq.first_success = early ? ch->first_success : nullptr;
     a.wq.find_any = (early && (flags & OPTIK_HIP_IK_FIND_ANY)) ? 1 : 0;
+    a.wq.restart_major = (flags & OPTIK_HIP_IK_RESTART_MAJOR) ? 1 : 0;
+    a.wq.n_targets = (unsigned long long)T;
     a.wq.deadline = 0;
     a.wq.quality = (cfg->solution_mode == 1);
     a.wq.out_x = px;
@@ -1087,12 +1089,16 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     const int cus = ch->num_cus > 0 ? ch->num_cus : 256;
     const long long cap = (long long)cus * (coop ? 4 : ch->waves_per_cu);
     const long long per_wave_max = coop ? COOP_GROUPS_PER_WAVE : WAVE;
-    // fewer work items than the chip holds: one restart per wave (or as few as fit)
-    long long lanes = ((long long)cols + cap - 1) / cap;
+    // fewer work items than the chip holds: one restart per wave (or as few as fit).  A
+    // restart-major Speed batch keeps about eight restarts per target in flight: the waves pull
+    // the higher indices of the targets still unsolved as they go
+    long long resident = (long long)cols;
+    if (coop && early && (flags & OPTIK_HIP_IK_RESTART_MAJOR) && resident > (long long)T * 8) resident = (long long)T * 8;
+    long long lanes = (resident + cap - 1) / cap;
     if (lanes < 1) lanes = 1;
     if (lanes > per_wave_max) lanes = per_wave_max;
     a.wq.lanes = (int)lanes;
-    long long grid_ll = ((long long)cols + lanes - 1) / lanes;
+    long long grid_ll = (resident + lanes - 1) / lanes;
     if (grid_ll > cap) grid_ll = cap;
     const int grid = (int)grid_ll;
 

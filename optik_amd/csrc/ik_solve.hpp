@@ -160,7 +160,11 @@ struct WorkQueue {
     // success of the target makes every other restart of it give up at its next evaluation --
     // the answer is then whichever restart got there first (a valid solution, not a fixed one)
     int find_any;
-    int pad_fa;
+    // 1: work items are restart-major (item = r * T + t: every target's low restart indices
+    // first) instead of target-major -- with early exit most higher indices are then never
+    // started (cooperative kernel only; the output column stays t * R + r)
+    int restart_major;
+    unsigned long long n_targets;        // T
     unsigned long long deadline;         // wall_clock64() ticks, 0 = none
     int quality;                         // selection key: 1 = ||x - x0||_2, 0 = index
     int lanes;                           // lanes of a wave that take work items (1 .. 64): a launch too small to

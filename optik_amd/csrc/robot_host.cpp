@@ -506,11 +506,31 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
         optik_hip_ik_outputs o;
         std::memset(&o, 0, sizeof o);
         o.d_win_x = d_wx; o.d_win_f = d_wf; o.d_win_idx = d_wi; o.d_win_key = d_wk;
+        // Which path.  A Speed batch is latency-bound at any size -- early exit abandons most of its
+        // restarts, what is left is each target's few first restarts run to the end: the cooperative
+        // single-kernel solver with restart-major hand-out (no trips of five dependent launches)
+        // beats the engine from 1 target (0.8 against 2.1 ms) to 131 072 (measured, Panda:
+        // 64 targets 1.2 against 2.9 ms, 4 096: 841 k against 324 k calls/s, 16 384: 1.13 M against
+        // 0.81 M).  A Quality batch runs every restart to the end: throughput-bound, the engine's
+        // domain, unless the whole round is a few launches' worth of restarts.
+        static const size_t small_batch = [] {
+            const char *e = std::getenv("OPTIK_IK_BATCH_KERNEL_MAX");  // targets; 0 = always the engine
+            return e ? (size_t)std::atoll(e) : (size_t)-1;
+        }();
+        const bool kernel_path = r->n <= 7 && L <= small_batch && (!quality || (uint64_t)L * (end - begin) <= 32768ull);
+        if (kernel_path) {
+            const int rck = optik_hip_ik_batch(c->chain, config, d_t, d_x0, (int32_t)L, ee7, begin, end,
+                                               (quality ? 0u : (OPTIK_HIP_IK_EARLY_EXIT | (r->parallelism != 1 ? OPTIK_HIP_IK_FIND_ANY : 0u)))
+                                                   | OPTIK_HIP_IK_RESTART_MAJOR,
+                                               deadline, &o, nullptr);
+            if (rck) { err = optik_hip_last_error(); return -1; }
+        } else {
         int rc = optik_hip_engine_submit(c->chain, config, d_t, d_x0, (int32_t)L, ee7, begin, end,
                                          quality ? 0u : (OPTIK_HIP_IK_EARLY_EXIT | (r->parallelism != 1 ? OPTIK_HIP_IK_FIND_ANY : 0u)),
                                          &o);
         if (!rc) rc = optik_hip_engine_run_ex(c->chain, nullptr, deadline);
         if (rc) { err = optik_hip_last_error(); return -1; }
+        }
         if (hipMemcpyAsync(h_out, d_wx, sizeof(double) * (size_t)(n + 3) * L, hipMemcpyDeviceToHost, nullptr) != hipSuccess
             || hipStreamSynchronize(nullptr) != hipSuccess) {
             err = "download failed";

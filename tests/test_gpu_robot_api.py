@@ -202,9 +202,21 @@ def test_c_abi_ik_returns_malloced_buffer(ur3e):
     assert not bool(L.optik_robot_ik(ur3e._h, C.byref(cfg), far, x0))   # NULL = no solution
 
 
-def test_ik_batch_equals_individual_calls(panda, oracle, chains):
-    """Robot.ik_batch (engine, restart-major queue, early exit) returns for every target exactly
-    what ik() returns for it alone -- and what the oracle's restart loop returns."""
+@pytest.mark.parametrize("kernel_max", [None, "0"])
+def test_ik_batch_equals_individual_calls(panda, oracle, chains, kernel_max, monkeypatch):
+    """Robot.ik_batch (restart-major queue, early exit; on the cooperative kernel, or on the
+    streaming engine with OPTIK_IK_BATCH_KERNEL_MAX=0 -- read once per process, so the engine leg
+    runs in a fresh interpreter) returns for every target exactly what ik() returns for it
+    alone -- and what the oracle's restart loop returns."""
+    if kernel_max is not None:
+        import subprocess
+        import sys
+        env = dict(os.environ, OPTIK_IK_BATCH_KERNEL_MAX=kernel_max)
+        res = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__, "-k",
+                              "test_ik_batch_equals_individual_calls and None"], env=env, capture_output=True,
+                             text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-1000:]
+        return
     from optik_amd import SolverConfig
     _, ch = chains["panda"]
     rng = np.random.default_rng(8)
