@@ -108,7 +108,7 @@ template <int N>
 OPTIK_DEV void coop_direction(const ChainDev &ch, const SolveParams &sp, double *nnls_lds, double *grec, bool &need_dir,
                               bool &reset, int &ireset, double (&l)[N * (N + 1) / 2], const double (&g)[N],
                               const double (&x)[N], double (&x0)[N], double (&s)[N], double f, double &f0, double &t0,
-                              double &h3, double &alpha, int &line, int32_t &ret) {
+                              double &h3, double &alpha, int &line, int32_t &ret, unsigned long long *nnls_cycles = nullptr) {
     constexpr int NL = N * (N + 1) / 2;
     constexpr int n = 2 * N;
     constexpr int CPL = 4;
@@ -161,6 +161,7 @@ OPTIK_DEV void coop_direction(const ChainDev &ch, const SolveParams &sp, double 
         OPTIK_SCHED_FENCE();
         // ---- the bounded dual problems of this round, one per group, all 64 lanes ------
         if (wave_any(need_nnls)) {
+            const unsigned long long t_nn = nnls_cycles ? __builtin_readcyclecounter() : 0ull;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const bool live = __shfl((int)need_nnls, (int)(lane & ~(unsigned)(COOP_GROUP - 1)), 64) != 0;
@@ -205,6 +206,7 @@ OPTIK_DEV void coop_direction(const ChainDev &ch, const SolveParams &sp, double 
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            if (nnls_cycles) *nnls_cycles += __builtin_readcyclecounter() - t_nn;
         }
         OPTIK_SCHED_FENCE();
         if (pass) {
@@ -271,8 +273,10 @@ OPTIK_DEV void coop_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
     for (int i = 0; i < NL; ++i) l[i] = 0.0;
     target.t = V3{0, 0, 0};
     target.q = Q4{0, 0, 0, 1};
+    OPTIK_PROF_DECL;  // (-DOPTIK_PROFILE: tools/phase_profile.py; slots: 0 refill, 1 eval, 4 bookkeeping + BFGS, 5 direction, 6 NNLS of it, 3 publish, 7 trips)
 
     for (;;) {
+        OPTIK_PROF_BEGIN();
         // ---- refill: leaders without a restart pull the next work item -----------------
         const unsigned n_want = (unsigned)__popcll(__ballot(want));
         if (n_want >= (unsigned)(wq.lanes < REFILL_BATCH ? wq.lanes : REFILL_BATCH) || (n_want > 0 && !wave_any(active))) {
@@ -303,7 +307,9 @@ OPTIK_DEV void coop_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
                 }
             }
         }
+        OPTIK_PROF_END(0);
         if (!wave_any(active)) break;
+        OPTIK_PROF_COUNT(7, 1);
 
         int32_t ret = 0;
         if (active) {
@@ -321,12 +327,26 @@ OPTIK_DEV void coop_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
         double fn = 0.0;
         const bool do_eval = active && ret == 0;
         OPTIK_SCHED_FENCE();
+        OPTIK_PROF_BEGIN();
         if (do_eval) fn = eval_fg<N, TIP>(ch, ep, target, x, gn);
+        OPTIK_PROF_END(1);
         OPTIK_SCHED_FENCE();
         bool need_dir = false, reset = false;
+        OPTIK_PROF_BEGIN();
         coop_after_eval<N>(sp, do_eval, fn, gn, x, g, s, l, xbest, xprev, f, t0, h3, alpha, minf, fprev, line, nevals,
                            first, ret, need_dir, reset);
+        OPTIK_PROF_END(4);
+        OPTIK_PROF_BEGIN();
+#ifdef OPTIK_PROFILE
+        unsigned long long nnls_cycles = 0;
+        coop_direction<N>(ch, sp, nnls_lds, grec, need_dir, reset, ireset, l, g, x, x0, s, f, f0, t0, h3, alpha, line, ret,
+                          &nnls_cycles);
+        OPTIK_PROF_COUNT(6, nnls_cycles);
+#else
         coop_direction<N>(ch, sp, nnls_lds, grec, need_dir, reset, ireset, l, g, x, x0, s, f, f0, t0, h3, alpha, line, ret);
+#endif
+        OPTIK_PROF_END(5);
+        OPTIK_PROF_BEGIN();
         if (do_eval && ret == 0) {
             // label 190: next trial point x = x0 + alpha * s, clipped (NLopt)
             ++line;
@@ -371,7 +391,9 @@ OPTIK_DEV void coop_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
             active = false;
             want = true;
         }
+        OPTIK_PROF_END(3);
     }
+    OPTIK_PROF_FLUSH(wq.prof);
 }
 
 }  // namespace optik

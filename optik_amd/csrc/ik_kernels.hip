@@ -1931,6 +1931,15 @@ int optik_hip_engine_stats(const optik_hip_chain *ch, double *kernel_ms4, int32_
 }
 
 uint64_t optik_hip_engine_executed_evals(const optik_hip_chain *ch) { return ch ? ch->eng_exec_evals : 0; }
+#ifdef OPTIK_PROFILE_NNLS
+/* diagnostic builds only: reads and clears the per-step cycle counters of nnls_coop */
+int optik_hip_nnls_step_profile(unsigned long long *out8) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(optik::g_nnls_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[8] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(optik::g_nnls_prof), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#endif
 int optik_hip_engine_last_fused(const optik_hip_chain *ch) { return ch ? ch->eng_fused : 0; }
 
 int optik_hip_ik_host(optik_hip_chain *ch, const optik_solver_config *cfg, const double *targets,

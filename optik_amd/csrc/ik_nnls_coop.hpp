@@ -76,6 +76,16 @@ struct CoopCarry {
 
 constexpr int NNLS_SUSPENDED = 7;  // mode: pass budget of this launch used up, state in `cs`
 
+// -DOPTIK_PROFILE_NNLS: wave cycles per step of the loop below, accumulated into g_nnls_prof[8]
+// (tools/nnls_step_profile.py): 0 steps two-three, 1 step five construction, 2 step five applied to
+// the columns, 3 step six, 4 steps seven-ten, 5 step eleven, 6 loop trips, 7 calls
+#ifdef OPTIK_PROFILE_NNLS
+__device__ unsigned long long g_nnls_prof[8];
+#define NNLS_PROBE(slot) do { const unsigned long long now_ = __builtin_readcyclecounter(); np_[slot] += now_ - nt_; nt_ = now_; } while (0)
+#else
+#define NNLS_PROBE(slot)
+#endif
+
 // Solves the problem whose columns cid0+1 .. cid0+CPL (1-based ids; ids > 2N are padding)
 // this lane holds in col[].  `live` = the group has a problem; `resume` = cs holds the
 // state of a suspended problem (else it is initialised here).  At most `budget` solve
@@ -138,6 +148,10 @@ OPTIK_DEV void nnls_coop(bool live, bool resume, int budget, int cid0, dvec8 (&c
     // phases: 0 = step two (recompute duals, then choose), 1 = step three (choose again),
     // 2 = step six (solve), 3 = step eleven (remove), 4 = done, 5 = suspended at step two
     int phase = live ? 0 : 4;
+#ifdef OPTIK_PROFILE_NNLS
+    unsigned long long np_[8] = {0, 0, 0, 0, 0, 0, 0, 1};
+    unsigned long long nt_ = __builtin_readcyclecounter();
+#endif
 
     // The loop body is straight-line code: every conditional update is a select, and rows /
     // columns an update must not touch get an exact no-op instead of a branch -- products
@@ -145,6 +159,10 @@ OPTIK_DEV void nnls_coop(bool live, bool resume, int budget, int cid0, dvec8 (&c
     // included) where an addend has to be neutralised.  Divergent branches here cost more
     // in exec-mask handling and register copies than the arithmetic they skip.
     while (wave_any(phase < 4)) {
+#ifdef OPTIK_PROFILE_NNLS
+        np_[6] += 1;
+        nt_ = __builtin_readcyclecounter();
+#endif
         // ---------------- steps two .. five --------------------------------------------
         if (wave_any(phase == 0 || phase == 1)) {
             const bool inA = (phase == 0 || phase == 1);
@@ -198,6 +216,7 @@ OPTIK_DEV void nnls_coop(bool live, bool resume, int budget, int cid0, dvec8 (&c
                 park(col, cs);
             }
             const bool cand = run && !none && phase != 5;
+            NNLS_PROBE(0);
             // (the last trip of most waves: every problem left has just finished)
             if (wave_any(cand)) {
             // step five: Householder construction on the chosen column j (position bp)
@@ -309,6 +328,7 @@ OPTIK_DEV void nnls_coop(bool live, bool resume, int budget, int cid0, dvec8 (&c
             }
             nsetp = found ? npp1 : nsetp;
             npp1 = nsetp + 1;
+            NNLS_PROBE(1);
             // the column that entered P: untouched above the pivot row, ulp on it (the rows below
             // are never read from the window)
             if (found && Gr::lane() == 0) {
@@ -349,6 +369,7 @@ OPTIK_DEV void nnls_coop(bool live, bool resume, int budget, int cid0, dvec8 (&c
             }
             // found: solve (step six); else choose again without recomputing the duals
             phase = cand ? (found ? 2 : 1) : phase;
+            NNLS_PROBE(2);
             }
         }
         // ---------------- steps six .. ten ---------------------------------------------
@@ -395,6 +416,7 @@ OPTIK_DEV void nnls_coop(bool live, bool resume, int budget, int cid0, dvec8 (&c
                 ++iter;
                 if (iter > itmax) { mode = 3; phase = 4; }
             }
+            NNLS_PROBE(3);
             const bool go = phase == 2;
             // steps seven..ten: step length; scan the positions in order, as the serial code does
             double alpha = 1.0;
@@ -428,6 +450,7 @@ OPTIK_DEV void nnls_coop(bool live, bool resume, int budget, int cid0, dvec8 (&c
             }
             rem_jj = (go && jj != 0) ? jj : rem_jj;
             phase = go ? (jj == 0 ? 0 : 3) : phase;  // back to step two, or remove position jj
+            NNLS_PROBE(4);
         }
         // ---------------- step eleven ----------------------------------------------------
         if (wave_any(phase == 3)) {
@@ -511,8 +534,13 @@ OPTIK_DEV void nnls_coop(bool live, bool resume, int budget, int cid0, dvec8 (&c
                     phase = 2;
                 }
             }
+            NNLS_PROBE(5);
         }
     }
+#ifdef OPTIK_PROFILE_NNLS
+    if ((threadIdx.x & 63u) == 0 && live)
+        for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_nnls_prof[i_], np_[i_]);
+#endif
     // rnorm = ||b(npp1..m)||
     {
         const int k0 = (npp1 < m) ? npp1 : m;
