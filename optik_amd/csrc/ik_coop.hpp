@@ -25,8 +25,48 @@ constexpr int COOP_GROUPS_PER_WAVE = 64 / COOP_GROUP;
 
 // doubles of the group's LDS window: the problem record, the multipliers, {mode + 8 passes, rnorm}
 // (parking the leader's LSQ factor here across the solve does not help: 396 against 372 B of scratch)
+// ... then the evaluation's hand-over area: x and the target pose from the leader, the joint frames
+// of the forward pass (N x 7), the gradient components coming back (eval_fg_group)
 template <int N>
-constexpr int coop_rec_lds() { return rec_stride<N>() + 2 * N + 2; }
+constexpr int coop_rec_lds() { return rec_stride<N>() + 2 * N + 2 + (N + 7 + 7 * N + N + 1) / 2 * 2; }
+
+// Objective and gradient at the leader's x, computed by the four lanes of its group together:
+// everyone walks the chain, each lane takes the Jacobian columns k = gl, gl + 4 (ik_eval.hpp:
+// eval_fg_group).  All 64 lanes call; `do_eval` is the leader's flag.  fn / gn are valid in the leader.
+template <int N, bool TIP>
+OPTIK_DEV void coop_eval(const ChainDev &ch, const EvalParams &ep, bool do_eval, const Pose &target, const double (&x)[N],
+                         double *grec, double &fn, double (&gn)[N]) {
+    if (!wave_any(do_eval)) return;
+    const unsigned lane = threadIdx.x & 63u;
+    const int gl = (int)(lane % COOP_GROUP);
+    double *const gx = grec + rec_stride<N>() + 2 * N + 2;
+    double *const gt = gx + N;
+    double *const gframes = gt + 7;
+    double *const ggrad = gframes + 7 * N;
+    if (do_eval) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) gx[i] = x[i];
+        gt[0] = target.t.x; gt[1] = target.t.y; gt[2] = target.t.z;
+        gt[3] = target.q.i; gt[4] = target.q.j; gt[5] = target.q.k; gt[6] = target.q.w;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const bool grp = __shfl((int)do_eval, (int)(lane & ~(unsigned)(COOP_GROUP - 1)), 64) != 0;
+    if (grp) {
+        double xg[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) xg[i] = gx[i];
+        const Pose tg = load_pose(gt);
+        const double fg = eval_fg_group<N, TIP, COOP_GROUP>(ch, ep, tg, xg, gl, gframes, ggrad);
+        fn = do_eval ? fg : fn;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (do_eval) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) gn[i] = ggrad[i];
+    }
+}
 
 // NLopt bookkeeping and Kraft's line search after an evaluation (labels 100 / 220 / 260): what
 // solve_wave does between its evaluation and its direction search, for the lane `do_eval` holds.
@@ -328,7 +368,7 @@ OPTIK_DEV void coop_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
         const bool do_eval = active && ret == 0;
         OPTIK_SCHED_FENCE();
         OPTIK_PROF_BEGIN();
-        if (do_eval) fn = eval_fg<N, TIP>(ch, ep, target, x, gn);
+        coop_eval<N, TIP>(ch, ep, do_eval, target, x, grec, fn, gn);
         OPTIK_PROF_END(1);
         OPTIK_SCHED_FENCE();
         bool need_dir = false, reset = false;

@@ -366,7 +366,8 @@ OPTIK_DEV void tail_wave_coop(const EngArgs &a, const ChainDev &ch, const EngJob
         const bool stepping = active && ret == 0;
         const bool do_eval = stepping && !pending_dir;
         OPTIK_SCHED_FENCE();
-        if (do_eval) { fn = eval_fg<N, TIP>(ch, a.ep, target, x, gn); ++n_exec; }
+        coop_eval<N, TIP>(ch, a.ep, do_eval, target, x, grec, fn, gn);
+        if (do_eval) ++n_exec;
         OPTIK_SCHED_FENCE();
         bool need_dir = stepping && pending_dir, reset = false;  // a deferred direction resumes at its LSQ call
         pending_dir = false;
