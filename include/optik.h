@@ -65,6 +65,17 @@ int optik_robot_ik_ex(const optik_robot *robot, const CSolverConfig *config, con
 int optik_robot_ik_batch_ex(const optik_robot *robot, const CSolverConfig *config, int32_t T,
                             const double *targets16, const double *x0, const double *ee_offset16,
                             double *x_out, double *f_out, int32_t *found_out);
+/* The same with the targets as the Python binding receives them: OPTIK_BATCH_ROW_MAJOR = each
+ * 4x4 is row-major (optik-py/src/lib.rs:8-15 reads nested rows), OPTIK_BATCH_VALIDATE_POSES =
+ * apply parse_pose's isometry test to every target (bottom row exactly 0 0 0 1, R'R = I within
+ * 100 * DBL_EPSILON per entry, det R > 0) and return -3 with "invalid target transform
+ * specified" before any GPU work if one fails.  flags = 0 is optik_robot_ik_batch_ex. */
+#define OPTIK_BATCH_ROW_MAJOR 1u
+#define OPTIK_BATCH_VALIDATE_POSES 2u
+int optik_robot_ik_batch_poses(const optik_robot *robot, const CSolverConfig *config, int32_t T,
+                               const double *targets16, uint32_t flags, const double *x0,
+                               const double *ee_offset16, double *x_out, double *f_out,
+                               int32_t *found_out);
 /* GPUs of this node the robot spreads its work over (restarts shard trivially: lib.rs:297-300
  * hands the same index range to rayon workers).  optik_robot_ik / _ik_ex: after the
  * latency-sized first launch every round's restart range is cut into one contiguous part per

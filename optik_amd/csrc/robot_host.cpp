@@ -450,7 +450,7 @@ namespace {
 // target on the streaming engine; targets already solved (Speed) drop out of later rounds;
 // max_time is enforced inside a run (optik_hip_engine_run_ex) and between rounds.
 int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *config, int32_t T,
-                       const double *targets16, const double *x0, const double *ee7,
+                       const double *targets16, bool row_major, const double *x0, const double *ee7,
                        std::chrono::steady_clock::time_point start, double *x_out, double *f_out,
                        int32_t *found_out, std::string &err) {
     const int n = r->n;
@@ -465,7 +465,16 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
 
     std::vector<double> tgt7((size_t)T * 7), best_key((size_t)T, 0.0);
     std::vector<uint64_t> best_idx((size_t)T, UINT64_MAX);
-    for (int t = 0; t < T; ++t) pose7_from_mat16(targets16 + (size_t)t * 16, &tgt7[(size_t)t * 7]);
+    for (int t = 0; t < T; ++t) {
+        const double *m = targets16 + (size_t)t * 16;
+        double cm[16];
+        if (row_major) {
+            for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < 4; ++b) cm[b * 4 + a] = m[a * 4 + b];
+            m = cm;
+        }
+        pose7_from_mat16(m, &tgt7[(size_t)t * 7]);
+    }
     std::vector<int> live((size_t)T);
     for (int t = 0; t < T; ++t) live[t] = t;
     for (int t = 0; t < T; ++t) if (found_out) found_out[t] = 0;
@@ -518,18 +527,16 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
             return e ? (size_t)std::atoll(e) : (size_t)-1;
         }();
         const bool kernel_path = r->n <= 7 && L <= small_batch && (!quality || (uint64_t)L * (end - begin) <= 32768ull);
+        const uint32_t mode_flags =
+            quality ? 0u : (OPTIK_HIP_IK_EARLY_EXIT | (r->parallelism != 1 ? OPTIK_HIP_IK_FIND_ANY : 0u));
         if (kernel_path) {
             const int rck = optik_hip_ik_batch(c->chain, config, d_t, d_x0, (int32_t)L, ee7, begin, end,
-                                               (quality ? 0u : (OPTIK_HIP_IK_EARLY_EXIT | (r->parallelism != 1 ? OPTIK_HIP_IK_FIND_ANY : 0u)))
-                                                   | OPTIK_HIP_IK_RESTART_MAJOR,
-                                               deadline, &o, nullptr);
+                                               mode_flags | OPTIK_HIP_IK_RESTART_MAJOR, deadline, &o, nullptr);
             if (rck) { err = optik_hip_last_error(); return -1; }
         } else {
-        int rc = optik_hip_engine_submit(c->chain, config, d_t, d_x0, (int32_t)L, ee7, begin, end,
-                                         quality ? 0u : (OPTIK_HIP_IK_EARLY_EXIT | (r->parallelism != 1 ? OPTIK_HIP_IK_FIND_ANY : 0u)),
-                                         &o);
-        if (!rc) rc = optik_hip_engine_run_ex(c->chain, nullptr, deadline);
-        if (rc) { err = optik_hip_last_error(); return -1; }
+            int rc = optik_hip_engine_submit(c->chain, config, d_t, d_x0, (int32_t)L, ee7, begin, end, mode_flags, &o);
+            if (!rc) rc = optik_hip_engine_run_ex(c->chain, nullptr, deadline);
+            if (rc) { err = optik_hip_last_error(); return -1; }
         }
         if (hipMemcpyAsync(h_out, d_wx, sizeof(double) * (size_t)(n + 3) * L, hipMemcpyDeviceToHost, nullptr) != hipSuccess
             || hipStreamSynchronize(nullptr) != hipSuccess) {
@@ -570,8 +577,38 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
 int optik_robot_ik_batch_ex(const optik_robot *r, const CSolverConfig *config, int32_t T,
                             const double *targets16, const double *x0, const double *ee16, double *x_out,
                             double *f_out, int32_t *found_out) {
+    return optik_robot_ik_batch_poses(r, config, T, targets16, 0u, x0, ee16, x_out, f_out, found_out);
+}
+
+int optik_robot_ik_batch_poses(const optik_robot *r, const CSolverConfig *config, int32_t T,
+                               const double *targets16, uint32_t flags, const double *x0, const double *ee16,
+                               double *x_out, double *f_out, int32_t *found_out) {
     if (!r || !config || !targets16 || !x0 || T < 1) return set_err(-1, "bad argument");
     const int n = r->n;
+    const bool row_major = (flags & OPTIK_BATCH_ROW_MAJOR) != 0;
+    if (flags & OPTIK_BATCH_VALIDATE_POSES) {
+        // nalgebra try_convert::<Matrix4, Isometry3> (optik-py/src/lib.rs:8-15): bottom row exactly
+        // (0, 0, 0, 1), R'R = I within 100 eps per entry, det R > 0.  Neither test depends on
+        // whether the 3x3 block is read by rows or by columns up to the bottom-row position.
+        const double eps = 100.0 * 2.220446049250313e-16;
+        for (int t = 0; t < T; ++t) {
+            const double *m = targets16 + (size_t)t * 16;
+            auto M = [&](int a, int b) { return row_major ? m[a * 4 + b] : m[b * 4 + a]; };
+            bool ok = M(3, 0) == 0.0 && M(3, 1) == 0.0 && M(3, 2) == 0.0 && M(3, 3) == 1.0;
+            for (int a = 0; a < 3 && ok; ++a)
+                for (int b = 0; b < 3 && ok; ++b) {
+                    const double d = M(0, a) * M(0, b) + M(1, a) * M(1, b) + M(2, a) * M(2, b) - (a == b ? 1.0 : 0.0);
+                    ok = std::fabs(d) <= eps;  // false for NaN
+                }
+            if (ok) {
+                const double det = M(0, 0) * (M(1, 1) * M(2, 2) - M(1, 2) * M(2, 1))
+                                   - M(0, 1) * (M(1, 0) * M(2, 2) - M(1, 2) * M(2, 0))
+                                   + M(0, 2) * (M(1, 0) * M(2, 1) - M(1, 1) * M(2, 0));
+                ok = det > 0.0;
+            }
+            if (!ok) return set_err(-3, "invalid target transform specified");
+        }
+    }
     for (int t = 0; t < T; ++t)
         for (int i = 0; i < n; ++i)
             if (x0[(size_t)t * n + i] < r->lb[i] || x0[(size_t)t * n + i] > r->ub[i])
@@ -590,7 +627,7 @@ int optik_robot_ik_batch_ex(const optik_robot *r, const CSolverConfig *config, i
         parts.push_back(p);
     }
     auto run_part = [&](Part &p) {
-        p.rc = ik_batch_on_device(r, p.ctx, config, p.t1 - p.t0, targets16 + (size_t)p.t0 * 16,
+        p.rc = ik_batch_on_device(r, p.ctx, config, p.t1 - p.t0, targets16 + (size_t)p.t0 * 16, row_major,
                                   x0 + (size_t)p.t0 * n, ee16 ? ee7 : nullptr, start,
                                   x_out ? x_out + (size_t)p.t0 * n : nullptr, f_out ? f_out + p.t0 : nullptr,
                                   found_out ? found_out + p.t0 : nullptr, p.err);

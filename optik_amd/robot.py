@@ -31,6 +31,8 @@ def _bind(L):
                                     C.POINTER(C.c_uint64)]
     L.optik_robot_ik_batch_ex.argtypes = [vp, C.POINTER(nat.SolverConfigC), C.c_int32, dp, dp, dp, dp, dp,
                                           C.POINTER(C.c_int32)]
+    L.optik_robot_ik_batch_poses.argtypes = [vp, C.POINTER(nat.SolverConfigC), C.c_int32, dp, C.c_uint32, dp, dp,
+                                             dp, dp, C.POINTER(C.c_int32)]
     L.optik_robot_fk_ex.argtypes = [vp, dp, dp, dp]
     L.optik_robot_diff_ik_ex.argtypes = [vp, dp, dp, dp, dp, C.POINTER(C.c_double), dp]
     L.optik_robot_joint_jacobian_ex.argtypes = [vp, dp, dp, dp]
@@ -43,6 +45,9 @@ def _bind(L):
     L.optik_robot_joint_limits.restype = dp
     L._robot_bound = True
     return L
+
+
+BATCH_ROW_MAJOR, BATCH_VALIDATE_POSES = 1, 2  # include/optik.h: OPTIK_BATCH_*
 
 
 def _err(L):
@@ -206,27 +211,45 @@ class Robot:
             return None
         return (x.tolist(), f.value, idx.value) if return_index else (x.tolist(), f.value)
 
-    def ik_batch(self, config: SolverConfig, targets, x0s, ee_offset=None):
-        """Many ik() calls at once (extension): `targets` [T] 4x4 row-major poses, `x0s` [T][n]
-        seeds -> list of (x, c) or None per target, each with the semantics of ik()."""
+    def ik_batch_arrays(self, config: SolverConfig, targets, x0s, ee_offset=None):
+        """Many ik() calls at once (extension), array form: `targets` [T, 4, 4] row-major poses,
+        `x0s` [T, n] seeds -> (x [T, n], c [T], found [T] bool); rows with found False are zero.
+        Each target gets the semantics of ik() with the same config (poses validated the same way)."""
         tg = np.asarray(targets, dtype=np.float64)
         if tg.ndim != 3 or tg.shape[1:] != (4, 4):
             raise ValueError("targets must be [T, 4, 4]")
         T = tg.shape[0]
         n = self.num_positions()
         x0s = np.ascontiguousarray(x0s, dtype=np.float64).reshape(T, n)
-        tg16 = np.ascontiguousarray(tg.transpose(0, 2, 1)).reshape(T, 16)  # column-major per pose
+        tg16 = np.ascontiguousarray(tg).reshape(T, 16)  # row-major as given; the host layer transposes
         ee = _pose16(ee_offset) if ee_offset is not None else None
         cfg = config.to_c()
         x = np.zeros((T, n))
         f = np.zeros(T)
         found = np.zeros(T, dtype=np.int32)
-        rc = self._L.optik_robot_ik_batch_ex(self._h, C.byref(cfg), T, _dp(tg16), _dp(x0s),
-                                             _dp(ee) if ee is not None else None, _dp(x), _dp(f),
-                                             found.ctypes.data_as(C.POINTER(C.c_int32)))
+        # BATCH_VALIDATE_POSES: parse_pose's isometry test (see _pose16) on every target, in C++
+        rc = self._L.optik_robot_ik_batch_poses(self._h, C.byref(cfg), T, _dp(tg16),
+                                                BATCH_ROW_MAJOR | BATCH_VALIDATE_POSES, _dp(x0s),
+                                                _dp(ee) if ee is not None else None, _dp(x), _dp(f),
+                                                found.ctypes.data_as(C.POINTER(C.c_int32)))
+        if rc == -3:
+            raise ValueError(_err(self._L))
         if rc < 0:
             raise RuntimeError(_err(self._L))
-        return [(x[t].tolist(), float(f[t])) if found[t] else None for t in range(T)]
+        return x, f, found.astype(bool)
+
+    def ik_batch(self, config: SolverConfig, targets, x0s, ee_offset=None):
+        """ik_batch_arrays as a list: (x, c) or None per target, like T calls of ik()."""
+        x, f, found = self.ik_batch_arrays(config, targets, x0s, ee_offset)
+        import gc
+        collecting = gc.isenabled()
+        gc.disable()  # ~10 objects per target are born here; none of them is garbage
+        try:
+            xs, fs = x.tolist(), f.tolist()
+            return [(xs[t], fs[t]) if ok else None for t, ok in enumerate(found.tolist())]
+        finally:
+            if collecting:
+                gc.enable()
 
     def diff_ik(self, x0, V_WE, v_max, ee_offset=None):
         """Returns (alpha, v) or None (optik.pyi:43-49; lib.rs:123-239): the joint velocities

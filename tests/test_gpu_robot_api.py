@@ -245,6 +245,14 @@ def test_ik_batch_equals_individual_calls(panda, oracle, chains, kernel_max, mon
     far[:3, 3] = 50.0
     res = panda.ik_batch(SolverConfig(max_time=0.0, max_restarts=16), [targets[0], far], x0s[:2])
     assert res[1] is None and res[0] is not None
+    # the array form carries the same numbers
+    xa, fa, ok = panda.ik_batch_arrays(SolverConfig(max_time=0.0, max_restarts=16), [targets[0], far], x0s[:2])
+    assert ok.tolist() == [True, False] and xa[0].tolist() == res[0][0] and fa[0] == res[0][1]
+    # parse_pose's isometry test applies to every target of a batch (optik-py/src/lib.rs:8-15)
+    bad = np.array(targets[1])
+    bad[:3, :3] *= 1.001
+    with pytest.raises(ValueError, match="invalid target transform"):
+        panda.ik_batch(SolverConfig(max_time=0.0, max_restarts=16), [targets[0], bad], x0s[:2])
 
 
 def _world_jacobian(robot, x):

@@ -41,6 +41,13 @@ def main():
     solved = sum(r is not None for r in res)
     print(f"GPU  Robot.ik_batch: {T} targets x <= {R} restarts: {dt*1e3:.1f} ms -> {T/dt:,.0f} ik() calls/s, "
           f"{100.0*solved/T:.1f} % solved")
+    dt = 1e30
+    for _ in range(3):
+        t0 = time.perf_counter()
+        _, _, ok = robot.ik_batch_arrays(cfg, targets, x0s)
+        dt = min(dt, time.perf_counter() - t0)
+    print(f"GPU  Robot.ik_batch_arrays (numpy in, numpy out): {dt*1e3:.1f} ms -> {T/dt:,.0f} ik() calls/s, "
+          f"{100.0*ok.mean():.1f} % solved")
 
 
 if __name__ == "__main__":
