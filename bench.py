@@ -22,7 +22,9 @@ Multi-GPU (one process per GPU under torch.distributed.run, RCCL over xGMI):
                     of ||x - x0||, then of the index among the ranks holding the minimum)
   --targets T       BASELINE.json config 5: a step is T independent targets x --restarts
                     restart indices each (Speed with early exit, as Robot::ik), the targets cut
-                    into one contiguous part per rank, no collective; value = ik() calls/s
+                    into one contiguous part per rank, no collective; value = ik() calls/s.
+                    Runs on the cooperative kernel with restart-major hand-out by default (what
+                    Robot.ik_batch picks for a Speed batch); --path engine for the engine
 
 The JSON line carries:
   roofline      algorithmic HBM bytes of the dominant kernel / its mean duration (HIP events
@@ -136,12 +138,15 @@ def main():
     ap.add_argument("--path", default="auto", choices=["auto", "engine", "kernel"],
                     help="engine: streaming phase kernels with continuous batching (steps submitted "
                          "together share the slot pool); kernel: one persistent solve kernel per step; "
-                         "auto (default) = engine; results are identical")
+                         "auto (default) = engine, except Speed batches of --targets (kernel, as "
+                         "Robot.ik_batch does); results are identical")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
     if args.path == "auto":
-        args.path = "engine"
+        # what the product picks (robot_host.cpp:ik_batch_on_device): a Speed batch of targets runs on
+        # the cooperative kernel with restart-major hand-out, everything else on the streaming engine
+        args.path = "kernel" if (args.targets and args.mode == "speed") else "engine"
     if args.restarts is None:
         args.restarts = 256 if args.targets else 65536
 
