@@ -8,6 +8,8 @@
 // of ik_kernels.hip -- there is no CPU implementation of them in this library.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -82,6 +84,24 @@ int set_err(int code, const std::string &msg) {
 }
 
 std::vector<int> devices_from_env();
+
+// fn(begin, end) over [0, count) on a few host threads when the range is long (the per-target
+// host work of a batch -- validation, pose conversion, staging, gathering -- is ~50 ns a target:
+// 13 of 60 ms at 262 144 targets on one thread)
+template <class Fn>
+void parallel_ranges(size_t count, Fn fn) {
+    static const unsigned max_threads = [] {
+        const char *e = std::getenv("OPTIK_HOST_THREADS");
+        unsigned h = e ? (unsigned)std::atoi(e) : std::thread::hardware_concurrency() / 2;
+        return h < 1 ? 1u : (h > 8 ? 8u : h);
+    }();
+    const size_t parts = count < 32768 ? 1 : std::min<size_t>(max_threads, count / 16384);
+    if (parts <= 1) { fn((size_t)0, count); return; }
+    std::vector<std::thread> th;
+    for (size_t p = 1; p < parts; ++p) th.emplace_back(fn, count * p / parts, count * (p + 1) / parts);
+    fn((size_t)0, count / parts);
+    for (auto &t : th) t.join();
+}
 
 optik_robot *make_robot(const std::string &urdf, const char *base, const char *ee) {
     auto *r = new optik_robot();
@@ -459,22 +479,37 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
     };
     const uint64_t max_restarts = config->max_restarts > 0 ? config->max_restarts : UINT64_MAX;
     const bool quality = config->solution_mode == 1;
-    const uint64_t round = 256;  // restart indices per target per engine run
+    // restart indices per target per round: 256, fewer for a Speed batch of very many targets on
+    // the engine -- nearly all of a round's higher indices are abandoned unissued (a third to a half
+    // of the restarts succeed), and skipping an item still costs the refilling lane a queue fetch:
+    // with 262 144 targets x 256 indices the finish kernel spent 0.55 instead of 0.07 ms per trip
+    // on 66 M such fetches.  Rounds of ~4 M items keep that below a few percent; the handful of
+    // targets a short round leaves unsolved go through the next round (on the cooperative kernel).
+    static const uint64_t round_items = [] {
+        const char *e = std::getenv("OPTIK_IK_BATCH_ROUND_ITEMS");
+        return e ? (uint64_t)std::atoll(e) : (uint64_t)4 << 20;
+    }();
+    static const size_t engine_min = [] {
+        const char *e = std::getenv("OPTIK_IK_BATCH_ENGINE_MIN");  // Speed batches from this many targets: engine
+        return e ? (size_t)std::atoll(e) : (size_t)65536;
+    }();
     std::lock_guard<std::mutex> lock(c->batch_mu);
     if (hipSetDevice(c->device) != hipSuccess) { err = "hipSetDevice failed"; return -1; }
 
     std::vector<double> tgt7((size_t)T * 7), best_key((size_t)T, 0.0);
     std::vector<uint64_t> best_idx((size_t)T, UINT64_MAX);
-    for (int t = 0; t < T; ++t) {
-        const double *m = targets16 + (size_t)t * 16;
-        double cm[16];
-        if (row_major) {
-            for (int a = 0; a < 4; ++a)
-                for (int b = 0; b < 4; ++b) cm[b * 4 + a] = m[a * 4 + b];
-            m = cm;
+    parallel_ranges((size_t)T, [&](size_t t0, size_t t1) {
+        for (size_t t = t0; t < t1; ++t) {
+            const double *m = targets16 + t * 16;
+            double cm[16];
+            if (row_major) {
+                for (int a = 0; a < 4; ++a)
+                    for (int b = 0; b < 4; ++b) cm[b * 4 + a] = m[a * 4 + b];
+                m = cm;
+            }
+            pose7_from_mat16(m, &tgt7[t * 7]);
         }
-        pose7_from_mat16(m, &tgt7[(size_t)t * 7]);
-    }
+    });
     std::vector<int> live((size_t)T);
     for (int t = 0; t < T; ++t) live[t] = t;
     for (int t = 0; t < T; ++t) if (found_out) found_out[t] = 0;
@@ -498,16 +533,22 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
             deadline = config->max_time - elapsed();
             if (deadline <= 0.0) break;  // lib.rs:393
         }
-        const uint64_t end = (max_restarts - begin > round) ? begin + round : max_restarts;
         const size_t L = live.size();
+        const bool big_speed = !quality && L >= engine_min;
+        uint64_t round = 256;
+        if (big_speed)
+            while (round > 8 && round * (uint64_t)L > round_items) round >>= 1;
+        const uint64_t end = (max_restarts - begin > round) ? begin + round : max_restarts;
         double *h_t = c->h_batch, *h_x0 = h_t + 7 * L, *h_out = h_x0 + (size_t)n * L;
         double *d_t = c->d_batch, *d_x0 = d_t + 7 * L, *d_wx = d_x0 + (size_t)n * L, *d_wf = d_wx + (size_t)n * L,
                *d_wk = d_wf + L;
         uint64_t *d_wi = reinterpret_cast<uint64_t *>(d_wk + L);
-        for (size_t k = 0; k < L; ++k) {
-            std::memcpy(&h_t[k * 7], &tgt7[(size_t)live[k] * 7], sizeof(double) * 7);
-            std::memcpy(&h_x0[k * n], &x0[(size_t)live[k] * n], sizeof(double) * (size_t)n);
-        }
+        parallel_ranges(L, [&](size_t k0, size_t k1) {
+            for (size_t k = k0; k < k1; ++k) {
+                std::memcpy(&h_t[k * 7], &tgt7[(size_t)live[k] * 7], sizeof(double) * 7);
+                std::memcpy(&h_x0[k * n], &x0[(size_t)live[k] * n], sizeof(double) * (size_t)n);
+            }
+        });
         if (hipMemcpyAsync(d_t, h_t, sizeof(double) * (size_t)(7 + n) * L, hipMemcpyHostToDevice, nullptr) != hipSuccess) {
             err = "upload failed";
             return -1;
@@ -526,7 +567,8 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
             const char *e = std::getenv("OPTIK_IK_BATCH_KERNEL_MAX");  // targets; 0 = always the engine
             return e ? (size_t)std::atoll(e) : (size_t)-1;
         }();
-        const bool kernel_path = r->n <= 7 && L <= small_batch && (!quality || (uint64_t)L * (end - begin) <= 32768ull);
+        const bool kernel_path = r->n <= 7 && !big_speed && L <= small_batch
+                                 && (!quality || (uint64_t)L * (end - begin) <= 32768ull);
         const uint32_t mode_flags =
             quality ? 0u : (OPTIK_HIP_IK_EARLY_EXIT | (r->parallelism != 1 ? OPTIK_HIP_IK_FIND_ANY : 0u));
         if (kernel_path) {
@@ -545,10 +587,13 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
         }
         const double *wx = h_out, *wf = wx + (size_t)n * L, *wk = wf + L;
         const uint64_t *wi = reinterpret_cast<const uint64_t *>(wk + L);
-        std::vector<int> still;
-        for (size_t k = 0; k < L; ++k) {
-            const int t = live[k];
-            if (wi[k] != UINT64_MAX) {
+        // every target appears once in `live`, so ranges of k touch disjoint targets
+        std::vector<uint8_t> keep(L);
+        parallel_ranges(L, [&](size_t k0, size_t k1) {
+            for (size_t k = k0; k < k1; ++k) {
+                const int t = live[k];
+                keep[k] = 1;
+                if (wi[k] == UINT64_MAX) continue;
                 const bool better = best_idx[t] == UINT64_MAX || wk[k] < best_key[t]
                                     || (wk[k] == best_key[t] && wi[k] < best_idx[t]);
                 if (better) {
@@ -557,10 +602,12 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
                     if (f_out) f_out[t] = wf[k];
                     if (found_out) found_out[t] = 1;
                 }
-                if (!quality) continue;  // Speed: the first solution ends this target
+                if (!quality) keep[k] = 0;  // Speed: the first solution ends this target
             }
-            still.push_back(t);
-        }
+        });
+        std::vector<int> still;
+        for (size_t k = 0; k < L; ++k)
+            if (keep[k]) still.push_back(live[k]);
         live.swap(still);
         begin = end;
     }
@@ -591,8 +638,10 @@ int optik_robot_ik_batch_poses(const optik_robot *r, const CSolverConfig *config
         // (0, 0, 0, 1), R'R = I within 100 eps per entry, det R > 0.  Neither test depends on
         // whether the 3x3 block is read by rows or by columns up to the bottom-row position.
         const double eps = 100.0 * 2.220446049250313e-16;
-        for (int t = 0; t < T; ++t) {
-            const double *m = targets16 + (size_t)t * 16;
+        std::atomic<bool> all_ok{true};
+        parallel_ranges((size_t)T, [&](size_t t0, size_t t1) {
+        for (size_t t = t0; t < t1; ++t) {
+            const double *m = targets16 + t * 16;
             auto M = [&](int a, int b) { return row_major ? m[a * 4 + b] : m[b * 4 + a]; };
             bool ok = M(3, 0) == 0.0 && M(3, 1) == 0.0 && M(3, 2) == 0.0 && M(3, 3) == 1.0;
             for (int a = 0; a < 3 && ok; ++a)
@@ -606,8 +655,10 @@ int optik_robot_ik_batch_poses(const optik_robot *r, const CSolverConfig *config
                                    + M(0, 2) * (M(1, 0) * M(2, 1) - M(1, 1) * M(2, 0));
                 ok = det > 0.0;
             }
-            if (!ok) return set_err(-3, "invalid target transform specified");
+            if (!ok) { all_ok = false; return; }
         }
+        });
+        if (!all_ok) return set_err(-3, "invalid target transform specified");
     }
     for (int t = 0; t < T; ++t)
         for (int i = 0; i < n; ++i)

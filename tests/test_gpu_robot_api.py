@@ -255,6 +255,32 @@ def test_ik_batch_equals_individual_calls(panda, oracle, chains, kernel_max, mon
         panda.ik_batch(SolverConfig(max_time=0.0, max_restarts=16), [targets[0], bad], x0s[:2])
 
 
+def test_big_speed_batch_on_the_engine_equals_individual_calls(panda):
+    """From 65 536 targets a Speed batch runs on the streaming engine in short rounds (64 restart
+    indices per round at this size, the unsolved rest goes through later rounds): the answers are
+    still those of ik() alone -- the lowest successful restart index with set_parallelism(1)."""
+    from optik_amd import SolverConfig
+    rng = np.random.default_rng(15)
+    lb, ub = (np.array(v) for v in panda.joint_limits())
+    D, copies = 256, 256
+    distinct = np.array([panda.fk(rng.uniform(lb, ub)) for _ in range(D)])
+    seeds = rng.uniform(lb, ub, size=(D, 7))
+    far = np.eye(4)
+    far[:3, 3] = 50.0
+    distinct[17] = far  # one target nobody can reach: runs every round, stays unsolved
+    targets = np.tile(distinct, (copies, 1, 1))
+    x0s = np.tile(seeds, (copies, 1))
+    cfg = SolverConfig(solution_mode="speed", max_time=0.0, max_restarts=300)
+    x, f, ok = panda.ik_batch_arrays(cfg, targets, x0s)
+    assert x.shape == (D * copies, 7)
+    xr, fr, okr = x.reshape(copies, D, 7), f.reshape(copies, D), ok.reshape(copies, D)
+    assert np.all(okr == okr[0]) and np.all(xr == xr[0]) and np.all(fr == fr[0])
+    assert not okr[0, 17] and okr[0].sum() == D - 1
+    for t in (0, 5, 16, 18, 100, 255):
+        single = panda.ik(cfg, distinct[t], seeds[t].tolist())
+        assert single is not None and single[0] == xr[0, t].tolist() and single[1] == fr[0, t]
+
+
 def _world_jacobian(robot, x):
     fk = np.array(robot.fk(x))
     J = np.array(robot.joint_jacobian(x))
