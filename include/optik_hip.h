@@ -130,6 +130,10 @@ int optik_hip_seed_batch(const optik_hip_chain *chain, uint64_t first, int64_t c
  * higher indices are never started.  Scheduling only: per-restart results and winners are the
  * same (an abandoned restart's status is FORCED_STOP either way).  n <= 7. */
 #define OPTIK_HIP_IK_RESTART_MAJOR 4u
+/* optik_hip_ik_host only: run the call as one job of the streaming engine
+ * (optik_hip_engine_solve) instead of the single solve kernel -- same results; faster from
+ * ~100 000 restarts (1 M restarts: 46 against 118 ms), slower below (16 384: 9.8 against 3.9 ms). */
+#define OPTIK_HIP_IK_ENGINE 8u
 
 /* Outputs of optik_hip_ik_batch; any pointer may be NULL to skip that output.
  * R = restart_end - restart_begin. */
@@ -181,6 +185,14 @@ int optik_hip_engine_run(optik_hip_chain *chain, void *stream);
  * started (FORCED_STOP, 0 evaluations); solutions published before the deadline stay and are
  * selected as usual.  The host checks the clock between chunks of four trips. */
 int optik_hip_engine_run_ex(optik_hip_chain *chain, void *stream, double deadline_s);
+/* One job, submitted and run in one call that other optik_hip_engine_solve callers of the
+ * chain cannot interleave with (submit + run_ex under one lock): what a re-entrant host API
+ * (Robot::ik is, lib.rs:241) calls.  Do not mix with jobs left pending by optik_hip_engine_submit. */
+int optik_hip_engine_solve(optik_hip_chain *chain, const optik_solver_config *cfg,
+                           const double *d_targets, const double *d_x0, int32_t T,
+                           const double *ee_offset7, uint64_t restart_begin, uint64_t restart_end,
+                           uint32_t flags, double deadline_s, const optik_hip_ik_outputs *out,
+                           void *stream);
 /* Allocates the engine's slot pool and work buffers for up to `slots` slots (0 = the default
  * capacity, 393 216) ahead of the first run -- set-up a caller does once; runs allocate on
  * demand otherwise. */

@@ -530,6 +530,7 @@ struct optik_hip_chain {
     double axis_all[MAX_JOINTS][3] = {};
     // launch workspace (grown on demand; one in-flight ik call per chain handle)
     std::mutex mu;
+    std::mutex eng_session_mu;  // optik_hip_engine_solve: submit + run of one job, not interleaved with another's
     std::mutex host_mu;  // serialises optik_hip_ik_host calls (they share the workspace below)
     TileRec *tile_recs = nullptr;
     size_t tile_cap = 0;
@@ -1972,8 +1973,11 @@ int optik_hip_ik_host(optik_hip_chain *ch, const optik_solver_config *cfg, const
     optik_hip_ik_outputs o;
     std::memset(&o, 0, sizeof o);
     o.d_win_x = d_wx; o.d_win_f = d_wf; o.d_win_idx = d_wi; o.d_win_key = d_wk;
-    const int rc = optik_hip_ik_batch(ch, cfg, d_t, d_x0, T, ee_offset7, restart_begin, restart_end, flags,
-                                      deadline_s, &o, nullptr);
+    const int rc = (flags & OPTIK_HIP_IK_ENGINE)
+                       ? optik_hip_engine_solve(ch, cfg, d_t, d_x0, T, ee_offset7, restart_begin, restart_end,
+                                                flags & ~OPTIK_HIP_IK_ENGINE, deadline_s, &o, nullptr)
+                       : optik_hip_ik_batch(ch, cfg, d_t, d_x0, T, ee_offset7, restart_begin, restart_end, flags,
+                                            deadline_s, &o, nullptr);
     if (rc) return rc;
     double *h_out = ch->hw_pin + n_in;
     HIP_TRY(hipMemcpyAsync(h_out, d_wx, sizeof(double) * n_out, hipMemcpyDeviceToHost, nullptr));
@@ -1983,6 +1987,17 @@ int optik_hip_ik_host(optik_hip_chain *ch, const optik_solver_config *cfg, const
     if (win_key) std::memcpy(win_key, h_out + (size_t)(n + 1) * T, sizeof(double) * (size_t)T);
     if (win_idx) std::memcpy(win_idx, h_out + (size_t)(n + 2) * T, sizeof(uint64_t) * (size_t)T);
     return 0;
+}
+
+int optik_hip_engine_solve(optik_hip_chain *ch, const optik_solver_config *cfg, const double *d_targets,
+                           const double *d_x0, int32_t T, const double *ee_offset7, uint64_t restart_begin,
+                           uint64_t restart_end, uint32_t flags, double deadline_s,
+                           const optik_hip_ik_outputs *out, void *stream) {
+    if (!ch) return fail(OPTIK_HIP_EINVAL, "bad argument");
+    std::lock_guard<std::mutex> session(ch->eng_session_mu);
+    int rc = optik_hip_engine_submit(ch, cfg, d_targets, d_x0, T, ee_offset7, restart_begin, restart_end, flags, out);
+    if (!rc) rc = optik_hip_engine_run_ex(ch, stream, deadline_s);
+    return rc;
 }
 
 int optik_hip_probe(int32_t op, const double *a, const double *b, int64_t count, double *out) {

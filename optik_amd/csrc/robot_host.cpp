@@ -395,8 +395,16 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
     // at once: device g of G takes the g-th contiguous part of the round's index range
     // (lib.rs:297-300 shards the same range over rayon workers) and the host keeps the
     // minimum of the G (key, index) records.
+    // A call that is still running after those two launches (a hard target, or Quality with a large
+    // budget) is throughput-bound: rounds of 1 M restarts per GPU on the streaming engine (46 ms
+    // against 118 on the solve kernel).
     const uint64_t cus = (uint64_t)(c0->num_cus > 0 ? c0->num_cus : 256);
     const uint64_t first_batch = cus * 2, later_batch = cus * 2 * 64 * 2;
+    static const uint64_t engine_batch = [] {
+        const char *e = std::getenv("OPTIK_IK_ENGINE_ROUND");  // restarts per GPU per engine round; 0 = never
+        return e ? (uint64_t)std::atoll(e) : (uint64_t)1 << 20;
+    }();
+    const bool engine_ok = engine_batch > 0 && r->n <= 7;
     const size_t G = device_count(r);
     const uint32_t speed_flags = OPTIK_HIP_IK_EARLY_EXIT | (r->parallelism != 1 ? OPTIK_HIP_IK_FIND_ANY : 0u);
     struct Part {
@@ -419,7 +427,8 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
             if (deadline <= 0.0) break;
         }
         const size_t g_round = begin == 0 ? 1 : G;  // (the latency-sized first launch stays on one GPU)
-        const uint64_t batch = begin == 0 ? first_batch : later_batch;
+        const bool on_engine = engine_ok && begin >= first_batch + later_batch;
+        const uint64_t batch = begin == 0 ? first_batch : on_engine ? engine_batch : later_batch;
         std::vector<Part> parts;
         for (size_t g = 0; g < g_round && begin < max_restarts; ++g) {
             Part p;
@@ -433,8 +442,8 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
         }
         auto run_part = [&](Part &p) {
             p.rc = optik_hip_ik_host(p.ctx->chain, config, tgt7, x0, 1, ee16 ? ee7 : nullptr, p.begin, p.end,
-                                     quality ? 0u : speed_flags, deadline, p.wx.data(), &p.wf, &p.widx,
-                                     &p.wkey);
+                                     (quality ? 0u : speed_flags) | (on_engine ? OPTIK_HIP_IK_ENGINE : 0u), deadline,
+                                     p.wx.data(), &p.wf, &p.widx, &p.wkey);
             if (p.rc) p.err = optik_hip_last_error();
         };
         if (parts.size() == 1) {
@@ -576,8 +585,8 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
                                                mode_flags | OPTIK_HIP_IK_RESTART_MAJOR, deadline, &o, nullptr);
             if (rck) { err = optik_hip_last_error(); return -1; }
         } else {
-            int rc = optik_hip_engine_submit(c->chain, config, d_t, d_x0, (int32_t)L, ee7, begin, end, mode_flags, &o);
-            if (!rc) rc = optik_hip_engine_run_ex(c->chain, nullptr, deadline);
+            const int rc = optik_hip_engine_solve(c->chain, config, d_t, d_x0, (int32_t)L, ee7, begin, end, mode_flags,
+                                                  deadline, &o, nullptr);
             if (rc) { err = optik_hip_last_error(); return -1; }
         }
         if (hipMemcpyAsync(h_out, d_wx, sizeof(double) * (size_t)(n + 3) * L, hipMemcpyDeviceToHost, nullptr) != hipSuccess

@@ -431,6 +431,40 @@ def test_diff_ik_six_dof_solution_is_the_unique_ray(ur3e):
         np.testing.assert_allclose(v, alpha_ref * w, atol=1e-8, rtol=0)
 
 
+def test_long_calls_move_to_the_engine_with_the_same_answer(panda):
+    """A call still running after 512 + 65 536 restarts continues in rounds of 1 M restarts on the
+    streaming engine: Quality over 300 000 restarts returns the restart one solve-kernel launch
+    over the whole range selects; an unreachable Speed target comes back None after all of them;
+    max_time ends an engine round early."""
+    import torch
+    from optik_amd import SolverConfig
+    rng = np.random.default_rng(77)
+    lb, ub = (np.array(v) for v in panda.joint_limits())
+    R = 300_000
+    cfg = SolverConfig(solution_mode="quality", max_time=0.0, max_restarts=R)
+    for _ in range(8):  # (a target whose winner comes from the engine round: 3 of 4 do)
+        tgt = np.array(panda.fk(rng.uniform(lb, ub)))
+        x0 = rng.uniform(lb, ub)
+        x, c, idx = panda.ik(cfg, tgt, x0.tolist(), return_index=True)
+        if idx >= 512 + 65536:
+            break
+    assert idx >= 512 + 65536
+    hc = panda.hip_chain()
+    t7 = torch.tensor(_mat_to_pose7(tgt)[None], dtype=torch.float64, device="cuda")
+    ref = hc.ik_batch(cfg.to_c(), t7, torch.tensor(x0[None], device="cuda"), idx - 2000, idx + 2000,
+                      per_restart=False)
+    torch.cuda.synchronize()
+    # the same restart wins its neighbourhood, with the same numbers up to the 4x4 -> pose conversion
+    assert int(ref["win_idx"][0]) == idx
+    np.testing.assert_allclose(ref["win_x"][0].cpu().numpy(), x, atol=1e-6, rtol=0)
+    far = np.eye(4)
+    far[:3, 3] = 50.0
+    assert panda.ik(SolverConfig(max_time=0.0, max_restarts=200_000), far, x0.tolist()) is None
+    t0 = time.perf_counter()
+    assert panda.ik(SolverConfig(max_time=0.03, max_restarts=50_000_000), far, x0.tolist()) is None
+    assert time.perf_counter() - t0 < 0.13
+
+
 def test_set_parallelism_selects_find_any(oracle, chains):
     """set_parallelism(n > 1): SolutionMode::Speed stops at the first success of ANY restart
     (rayon's find_any with several threads, lib.rs:409-412) -- the returned restart is then not
