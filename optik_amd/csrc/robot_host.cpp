@@ -427,7 +427,8 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
             if (deadline <= 0.0) break;
         }
         const size_t g_round = begin == 0 ? 1 : G;  // (the latency-sized first launch stays on one GPU)
-        const bool on_engine = engine_ok && begin >= first_batch + later_batch;
+        // (what is left must be worth an engine run: below ~100 000 restarts the solve kernel is faster)
+        const bool on_engine = engine_ok && begin >= first_batch + later_batch && max_restarts - begin >= 98304;
         const uint64_t batch = begin == 0 ? first_batch : on_engine ? engine_batch : later_batch;
         std::vector<Part> parts;
         for (size_t g = 0; g < g_round && begin < max_restarts; ++g) {
