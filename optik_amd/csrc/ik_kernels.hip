@@ -1710,11 +1710,12 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
         };
         ch->eng_launches = 0;
         // hand-over to the tail kernel once this few restarts are left in all sub-pools together
-        // (the cooperative tail holds 16 restarts per wave, 16 384 resident at once, at half the time
-        // per iteration of the per-lane one: measured best between 12 k and 24 k, 23.7 against 22.4 M
-        // restarts/s at 4 096 for a 20-step run)
+        // (the cooperative tail holds 16 restarts per wave, 16 384 resident at once -- its waves pull
+        // the rest of the list as groups finish -- at half the time per iteration of the per-lane
+        // one: measured best between 24 k and 48 k since the group evaluation, 24.3 against 23.9 M
+        // restarts/s at 16 k and 22.4 at 4 096 for a 20-step run)
         unsigned long long tail_max = total / 16;
-        const unsigned long long tail_cap = (getenv("OPTIK_SOLVE_KERNEL") && std::strcmp(getenv("OPTIK_SOLVE_KERNEL"), "lane") == 0) ? 4096ull : 16384ull;
+        const unsigned long long tail_cap = (getenv("OPTIK_SOLVE_KERNEL") && std::strcmp(getenv("OPTIK_SOLVE_KERNEL"), "lane") == 0) ? 4096ull : 32768ull;
         if (tail_max > tail_cap) tail_max = tail_cap;
         if (tail_max < 64) tail_max = 64;
         if (getenv("OPTIK_ENG_NO_TAIL")) tail_max = 0;
