@@ -465,6 +465,51 @@ def test_long_calls_move_to_the_engine_with_the_same_answer(panda):
     assert time.perf_counter() - t0 < 0.13
 
 
+def test_robot_is_reentrant(panda):
+    """Robot::ik takes &self and is called from many host threads at once (lib.rs:241; SURVEY 8b
+    "Threading"): concurrent ik / ik_batch / fk calls on ONE robot -- short ones on the solve
+    kernel, a long Quality call that moves to the engine, a batch -- return what they return alone."""
+    import threading
+    from optik_amd import SolverConfig
+    rng = np.random.default_rng(31)
+    lb, ub = (np.array(v) for v in panda.joint_limits())
+    qs = rng.uniform(lb, ub, size=(12, 7))
+    targets = [np.array(panda.fk(q)) for q in qs]
+    x0s = rng.uniform(lb, ub, size=(12, 7))
+    speed = SolverConfig(max_time=0.0, max_restarts=2000)
+    long_q = SolverConfig(solution_mode="quality", max_time=0.0, max_restarts=250_000)
+    batch_cfg = SolverConfig(max_time=0.0, max_restarts=64)
+    want_speed = [panda.ik(speed, targets[t], x0s[t].tolist(), return_index=True) for t in range(12)]
+    want_long = panda.ik(long_q, targets[0], x0s[0].tolist(), return_index=True)
+    want_batch = panda.ik_batch(batch_cfg, targets, x0s)
+    want_fk = [panda.fk(q) for q in qs]
+    errors = []
+
+    def check(name, fn, want, reps):
+        try:
+            for _ in range(reps):
+                got = fn()
+                if got != want:
+                    errors.append(f"{name}: differs")
+                    return
+        except Exception as e:  # noqa: BLE001
+            errors.append(f"{name}: {e!r}")
+
+    threads = [threading.Thread(target=check, args=(f"speed{t}", (lambda t=t: panda.ik(
+        speed, targets[t], x0s[t].tolist(), return_index=True)), want_speed[t], 15)) for t in range(6)]
+    threads.append(threading.Thread(target=check, args=("long", lambda: panda.ik(
+        long_q, targets[0], x0s[0].tolist(), return_index=True), want_long, 3)))
+    threads.append(threading.Thread(target=check, args=("batch", lambda: panda.ik_batch(batch_cfg, targets, x0s),
+                                                        want_batch, 10)))
+    threads.append(threading.Thread(target=check, args=("fk", lambda: [panda.fk(q) for q in qs], want_fk, 10)))
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=120)
+    assert not any(th.is_alive() for th in threads), "deadlock"
+    assert not errors, errors
+
+
 def test_set_parallelism_selects_find_any(oracle, chains):
     """set_parallelism(n > 1): SolutionMode::Speed stops at the first success of ANY restart
     (rayon's find_any with several threads, lib.rs:409-412) -- the returned restart is then not
