@@ -884,21 +884,24 @@ OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a, double *wave_lds) {
             cs.pos[k] = 0;
             const unsigned c = gl * CPL + k;
             if (live && c < (unsigned)n) {
+                // The emitted record is read whether or not the problem turns out to be a suspended
+                // one (8 %: their record is stale but still the slot's memory): these loads then do
+                // not wait for the meta word that says which -- one memory latency less at the head
+                // of every wave.
+                // column c < N: row c of E^-1 on rows c .. N-1, h_lo[c] below; column N + c: its
+                // negation, h_hi[c] below
+                const bool neg = c >= (unsigned)N;
+                const int cc = (int)(neg ? c - N : c);
+                const int off = cc * (N + 2) - (cc * (cc - 1)) / 2 - cc;  // rec_row(cc) - cc
+#pragma unroll
+                for (int r = 0; r < N; ++r) {
+                    const double v = (r >= cc) ? rec[off + r] : 0.0;
+                    col[k][r] = neg ? ((r >= cc) ? -v : 0.0) : v;
+                }
+                col[k][N] = rec[off + N + (neg ? 1 : 0)];  // h_lo / h_hi follow the row
                 if (resume) {
 #pragma unroll
                     for (int r = 0; r < m; ++r) col[k][r] = cmat[(size_t)c * m + r];
-                } else {
-                    // column c < N: row c of E^-1 on rows c .. N-1, h_lo[c] below; column N + c: its
-                    // negation, h_hi[c] below
-                    const bool neg = c >= (unsigned)N;
-                    const int cc = (int)(neg ? c - N : c);
-                    const int off = cc * (N + 2) - (cc * (cc - 1)) / 2 - cc;  // rec_row(cc) - cc
-#pragma unroll
-                    for (int r = 0; r < N; ++r) {
-                        const double v = (r >= cc) ? rec[off + r] : 0.0;
-                        col[k][r] = neg ? ((r >= cc) ? -v : 0.0) : v;
-                    }
-                    col[k][N] = rec[off + N + (neg ? 1 : 0)];  // h_lo / h_hi follow the row
                 }
             }
             if (resume) {
