@@ -365,6 +365,12 @@ def test_multi_device_sharding_gives_the_single_device_answers():
     for mode in ("speed", "quality"):
         cfg = SolverConfig(solution_mode=mode, max_time=0.0, max_restarts=300)
         assert one.ik_batch(cfg, targets, x0s) == two.ik_batch(cfg, targets, x0s)
+    # a long Quality call: after 512 + 65 536 (x 2) restarts on the solve kernel the rounds of 1 M
+    # restarts per context run on each context's own engine; same winner, same numbers
+    cfg = SolverConfig(solution_mode="quality", max_time=0.0, max_restarts=2_400_000)
+    a = one.ik(cfg, targets[1], x0s[1].tolist(), return_index=True)
+    b = two.ik(cfg, targets[1], x0s[1].tolist(), return_index=True)
+    assert a is not None and a == b
     with pytest.raises(RuntimeError):
         two.set_devices([0])  # only before the first GPU call
 
