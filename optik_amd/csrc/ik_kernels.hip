@@ -1094,7 +1094,10 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     // restart-major Speed batch keeps about eight restarts per target in flight: the waves pull
     // the higher indices of the targets still unsolved as they go
     long long resident = (long long)cols;
-    if (coop && early && (flags & OPTIK_HIP_IK_RESTART_MAJOR) && resident > (long long)T * 8) resident = (long long)T * 8;
+    // (but never fewer than one restart per resident wave: a small batch has the chip to itself, and
+    // the more of a target's restarts run at once the sooner its first success comes)
+    if (coop && early && (flags & OPTIK_HIP_IK_RESTART_MAJOR) && resident > (long long)T * 8)
+        resident = std::max((long long)T * 8, std::min(resident, cap));
     long long lanes = (resident + cap - 1) / cap;
     if (lanes < 1) lanes = 1;
     if (lanes > per_wave_max) lanes = per_wave_max;
