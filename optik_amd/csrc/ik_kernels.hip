@@ -1096,8 +1096,12 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     long long resident = (long long)cols;
     // (but never fewer than one restart per resident wave: a small batch has the chip to itself, and
     // the more of a target's restarts run at once the sooner its first success comes)
-    if (coop && early && (flags & OPTIK_HIP_IK_RESTART_MAJOR) && resident > (long long)T * 8)
-        resident = std::max((long long)T * 8, std::min(resident, cap));
+    static const long long inflight = [] {
+        const char *e = std::getenv("OPTIK_IK_BATCH_INFLIGHT");  // restarts per target in flight
+        return e && std::atoll(e) > 0 ? std::atoll(e) : 8ll;
+    }();
+    if (coop && early && (flags & OPTIK_HIP_IK_RESTART_MAJOR) && resident > (long long)T * inflight)
+        resident = std::max((long long)T * inflight, std::min(resident, cap));
     long long lanes = (resident + cap - 1) / cap;
     if (lanes < 1) lanes = 1;
     if (lanes > per_wave_max) lanes = per_wave_max;
