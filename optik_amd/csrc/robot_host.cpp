@@ -548,6 +548,11 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
         uint64_t round = 256;
         if (big_speed)
             while (round > 8 && round * (uint64_t)L > round_items) round >>= 1;
+        // Quality runs every restart of every target to the end: nothing to gain from short rounds,
+        // and an engine run has a ~10 ms floor -- as many indices per round as ~4 M items allow
+        // (288 MB of per-restart keys, points and residuals)
+        if (quality)
+            while (round * 2 * (uint64_t)L <= round_items && round < max_restarts - begin) round <<= 1;
         const uint64_t end = (max_restarts - begin > round) ? begin + round : max_restarts;
         double *h_t = c->h_batch, *h_x0 = h_t + 7 * L, *h_out = h_x0 + (size_t)n * L;
         double *d_t = c->d_batch, *d_x0 = d_t + 7 * L, *d_wx = d_x0 + (size_t)n * L, *d_wf = d_wx + (size_t)n * L,

@@ -240,6 +240,11 @@ def test_ik_batch_equals_individual_calls(panda, oracle, chains, kernel_max, mon
             assert ref["found"] == (batch[t] is not None)
             if ref["found"]:
                 np.testing.assert_allclose(batch[t][0], ref["x"], atol=1e-6, rtol=0)
+    # Quality with thousands of restarts per target: one engine round covers them all
+    cfg = SolverConfig(solution_mode="quality", max_time=0.0, max_restarts=3000)
+    batch = panda.ik_batch(cfg, targets[:20], x0s[:20])
+    for t in (0, 9, 19):
+        assert batch[t] == panda.ik(cfg, targets[t], x0s[t].tolist())
     # a target nobody can reach stays None; the others are unaffected
     far = np.eye(4)
     far[:3, 3] = 50.0
