@@ -134,6 +134,11 @@ int optik_hip_seed_batch(const optik_hip_chain *chain, uint64_t first, int64_t c
  * (optik_hip_engine_solve) instead of the single solve kernel -- same results; faster from
  * ~100 000 restarts (1 M restarts: 46 against 118 ms), slower below (16 384: 9.8 against 3.9 ms). */
 #define OPTIK_HIP_IK_ENGINE 8u
+/* Engine jobs with EARLY_EXIT: a run whose jobs all have early exit uses a pool of about eight
+ * slots per target (most restarts above a target's first success are abandoned, and the phase
+ * kernels cost per slot scanned).  FULL_POOL keeps the whole pool: for jobs whose targets are
+ * known to be hard -- the later rounds of a call, where nearly every restart runs to the end. */
+#define OPTIK_HIP_IK_FULL_POOL 16u
 
 /* Outputs of optik_hip_ik_batch; any pointer may be NULL to skip that output.
  * R = restart_end - restart_begin. */

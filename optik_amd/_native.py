@@ -16,6 +16,8 @@ MAX_DOF = 8
 IK_EARLY_EXIT = 1
 IK_FIND_ANY = 2
 IK_RESTART_MAJOR = 4
+IK_ENGINE = 8      # optik_hip_ik_host only: run the call as one engine job
+IK_FULL_POOL = 16  # engine jobs with early exit: keep the whole slot pool (hard targets)
 UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 
 RES_FAILURE, RES_ROUNDOFF, RES_FORCED_STOP, RES_ITER_CAP = -1, -4, -5, -100

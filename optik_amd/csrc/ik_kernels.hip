@@ -548,6 +548,7 @@ struct optik_hip_chain {
         optik_hip_ik_outputs out;
         double *own_x = nullptr, *own_f = nullptr, *own_key = nullptr;  // scratch when the caller skips them
         unsigned long long *own_fs = nullptr;
+        bool full_pool = false;  // OPTIK_HIP_IK_FULL_POOL
     };
     std::vector<EngineJobHost> eng_jobs;
     optik_solver_config eng_cfg{};
@@ -1235,6 +1236,7 @@ int optik_hip_engine_submit(optik_hip_chain *ch, const optik_solver_config *cfg,
     j.dev.out_x = px; j.dev.out_f = pf; j.dev.out_key = pk;
     j.dev.out_status = out->d_status; j.dev.out_evals = out->d_evals;
     j.dev.first_success = j.own_fs;
+    j.full_pool = (flags & OPTIK_HIP_IK_FULL_POOL) != 0;
     j.dev.quality = (cfg->solution_mode == 1);
     j.dev.restart_major = (early && T > 1) ? 1 : 0;
     j.dev.find_any = (early && (flags & OPTIK_HIP_IK_FIND_ANY)) ? 1 : 0;
@@ -1360,7 +1362,7 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
         unsigned long long targets = 0;
         for (size_t ji = g0; ji < g1; ++ji) {
             const auto &j = ch->eng_jobs[ji];
-            all_early = all_early && j.own_fs != nullptr;
+            all_early = all_early && j.own_fs != nullptr && !j.full_pool;
             targets += (unsigned long long)j.T;
         }
         if (all_early && !std::getenv("OPTIK_ENGINE_SLOTS")) {

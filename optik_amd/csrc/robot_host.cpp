@@ -443,7 +443,7 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
         }
         auto run_part = [&](Part &p) {
             p.rc = optik_hip_ik_host(p.ctx->chain, config, tgt7, x0, 1, ee16 ? ee7 : nullptr, p.begin, p.end,
-                                     (quality ? 0u : speed_flags) | (on_engine ? OPTIK_HIP_IK_ENGINE : 0u), deadline,
+                                     (quality ? 0u : speed_flags) | (on_engine ? (OPTIK_HIP_IK_ENGINE | OPTIK_HIP_IK_FULL_POOL) : 0u), deadline,
                                      p.wx.data(), &p.wf, &p.widx, &p.wkey);
             if (p.rc) p.err = optik_hip_last_error();
         };
@@ -537,6 +537,11 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
         }
         c->batch_cap = n_in + n_out;
     }
+    // Speed: the first round is latency-sized (256 indices: it solves nearly every reachable
+    // target); what is still unsolved after it is hard or unreachable and throughput-bound, so every
+    // later round covers four times as many indices (ten unreachable targets x 100 000 restarts are
+    // 8 rounds instead of 390)
+    uint64_t speed_round = 256;
     for (uint64_t begin = 0; begin < max_restarts && !live.empty();) {
         double deadline = 0.0;
         if (config->max_time > 0.0) {
@@ -545,9 +550,11 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
         }
         const size_t L = live.size();
         const bool big_speed = !quality && L >= engine_min;
-        uint64_t round = 256;
+        uint64_t round = quality ? 256 : speed_round;
+        while (round > 256 && round * (uint64_t)L > round_items) round >>= 1;
         if (big_speed)
             while (round > 8 && round * (uint64_t)L > round_items) round >>= 1;
+        if (speed_round < ((uint64_t)1 << 40)) speed_round *= 4;
         // Quality runs every restart of every target to the end: nothing to gain from short rounds,
         // and an engine run has a ~10 ms floor -- as many indices per round as ~4 M items allow
         // (288 MB of per-restart keys, points and residuals)
@@ -571,28 +578,36 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
         optik_hip_ik_outputs o;
         std::memset(&o, 0, sizeof o);
         o.d_win_x = d_wx; o.d_win_f = d_wf; o.d_win_idx = d_wi; o.d_win_key = d_wk;
-        // Which path.  A Speed batch is latency-bound at any size -- early exit abandons most of its
-        // restarts, what is left is each target's few first restarts run to the end: the cooperative
-        // single-kernel solver with restart-major hand-out (no trips of five dependent launches)
-        // beats the engine from 1 target (0.8 against 2.1 ms) to 131 072 (measured, Panda:
-        // 64 targets 1.2 against 2.9 ms, 4 096: 841 k against 324 k calls/s, 16 384: 1.13 M against
-        // 0.81 M).  A Quality batch runs every restart to the end: throughput-bound, the engine's
-        // domain, unless the whole round is a few launches' worth of restarts.
+        // Which path.  The first round of a Speed batch is latency-bound -- early exit abandons most of
+        // its restarts, what is left is each target's few first restarts run to the end: the
+        // cooperative single-kernel solver with restart-major hand-out (no trips of five dependent
+        // launches) beats the engine from 1 target (0.5 against 2.1 ms) to ~50 000 (measured, Panda:
+        // 64 targets 1.0 against 2.9 ms, 4 096: 1.1 M against 324 k calls/s, 16 384: 1.68 M against
+        // 1.05 M).  Everything else -- a Quality batch, the later rounds of a Speed batch (whatever
+        // 256 restarts did not solve runs nearly all of its restarts) -- is throughput-bound: the
+        // engine's domain, unless the round is a few launches' worth of restarts.
         static const size_t small_batch = [] {
             const char *e = std::getenv("OPTIK_IK_BATCH_KERNEL_MAX");  // targets; 0 = always the engine
             return e ? (size_t)std::atoll(e) : (size_t)-1;
         }();
+        // (one job of ~100 000 restarts is where the engine overtakes the solve kernel: 65 536 take 12.3
+        // against 9.8 ms, 262 144 take 17 against 32 ms)
         const bool kernel_path = r->n <= 7 && !big_speed && L <= small_batch
-                                 && (!quality || (uint64_t)L * (end - begin) <= 32768ull);
+                                 && ((!quality && begin == 0) || (uint64_t)L * (end - begin) < 98304ull);
         const uint32_t mode_flags =
             quality ? 0u : (OPTIK_HIP_IK_EARLY_EXIT | (r->parallelism != 1 ? OPTIK_HIP_IK_FIND_ANY : 0u));
         if (kernel_path) {
+            // (restart-major hand-out keeps only a few restarts per target in flight -- right while
+            // early exit abandons most of them, i.e. in the first round; later rounds fill the chip)
             const int rck = optik_hip_ik_batch(c->chain, config, d_t, d_x0, (int32_t)L, ee7, begin, end,
-                                               mode_flags | OPTIK_HIP_IK_RESTART_MAJOR, deadline, &o, nullptr);
+                                               mode_flags | (begin == 0 ? OPTIK_HIP_IK_RESTART_MAJOR : 0u), deadline,
+                                               &o, nullptr);
             if (rck) { err = optik_hip_last_error(); return -1; }
         } else {
-            const int rc = optik_hip_engine_solve(c->chain, config, d_t, d_x0, (int32_t)L, ee7, begin, end, mode_flags,
-                                                  deadline, &o, nullptr);
+            // (later rounds: the targets still unsolved run nearly all of their restarts -- the whole pool)
+            const int rc = optik_hip_engine_solve(c->chain, config, d_t, d_x0, (int32_t)L, ee7, begin, end,
+                                                  mode_flags | (begin > 0 ? OPTIK_HIP_IK_FULL_POOL : 0u), deadline, &o,
+                                                  nullptr);
             if (rc) { err = optik_hip_last_error(); return -1; }
         }
         if (hipMemcpyAsync(h_out, d_wx, sizeof(double) * (size_t)(n + 3) * L, hipMemcpyDeviceToHost, nullptr) != hipSuccess

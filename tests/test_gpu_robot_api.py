@@ -286,6 +286,32 @@ def test_big_speed_batch_on_the_engine_equals_individual_calls(panda):
         assert single is not None and single[0] == xr[0, t].tolist() and single[1] == fr[0, t]
 
 
+def test_speed_batch_with_hard_targets_runs_growing_rounds(panda):
+    """A Speed batch's first round is 256 restart indices per target; what it leaves unsolved goes
+    through rounds four times as long each (on the engine with the whole pool once a round is
+    ~100 000 restarts): reachable targets keep the answer of ik() alone, unreachable ones come back
+    None after all max_restarts -- in a time that shows the rounds grew (390 rounds of 256 took 0.8 s)."""
+    from optik_amd import SolverConfig
+    rng = np.random.default_rng(61)
+    lb, ub = (np.array(v) for v in panda.joint_limits())
+    T = 12
+    targets = np.array([panda.fk(rng.uniform(lb, ub)) for _ in range(T)])
+    far = np.eye(4)
+    far[:3, 3] = 50.0
+    targets[[2, 7]] = far
+    x0s = rng.uniform(lb, ub, size=(T, 7))
+    cfg = SolverConfig(solution_mode="speed", max_time=0.0, max_restarts=60_000)
+    panda.ik_batch_arrays(cfg, targets, x0s)  # (first engine use of this robot allocates the pool)
+    t0 = time.perf_counter()
+    x, f, ok = panda.ik_batch_arrays(cfg, targets, x0s)
+    dt = time.perf_counter() - t0
+    assert ok.tolist() == [t not in (2, 7) for t in range(T)]
+    for t in (0, 3, 11):
+        single = panda.ik(cfg, targets[t], x0s[t].tolist())
+        assert single is not None and single[0] == x[t].tolist() and single[1] == f[t]
+    assert dt < 0.25, dt
+
+
 def _world_jacobian(robot, x):
     fk = np.array(robot.fk(x))
     J = np.array(robot.joint_jacobian(x))
