@@ -426,17 +426,31 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
             deadline = config->max_time - elapsed();
             if (deadline <= 0.0) break;
         }
-        const size_t g_round = begin == 0 ? 1 : G;  // (the latency-sized first launch stays on one GPU)
+        // Quality with a restart budget and no time budget runs every restart whatever happens: no
+        // latency-sized first launches (each of them waits for its slowest restart -- 1 000 restarts
+        // took two launches of 2.7 ms), the whole range at once: one launch of the solve kernel
+        // below ~100 000 restarts, engine rounds from index 0 above.
+        const bool all_at_once = quality && config->max_time <= 0.0 && config->max_restarts > 0;
+        const size_t g_round = (begin == 0 && !(all_at_once && max_restarts >= 2 * 98304)) ? 1 : G;  // (the latency-sized first launch stays on one GPU)
         // (what is left must be worth an engine run: below ~100 000 restarts the solve kernel is faster)
-        const bool on_engine = engine_ok && begin >= first_batch + later_batch && max_restarts - begin >= 98304;
-        const uint64_t batch = begin == 0 ? first_batch : on_engine ? engine_batch : later_batch;
+        const bool on_engine = engine_ok && max_restarts - begin >= 98304
+                               && (all_at_once || begin >= first_batch + later_batch);
+        const uint64_t batch = on_engine ? engine_batch
+                               : all_at_once ? (uint64_t)98304
+                               : begin == 0 ? first_batch : later_batch;
+        // (several GPUs: what is left is cut evenly when it is less than a full round of each)
+        uint64_t per_part = batch;
+        if (g_round > 1 && max_restarts != UINT64_MAX) {
+            const uint64_t even = (max_restarts - begin + g_round - 1) / g_round;
+            if (even < per_part) per_part = even;
+        }
         std::vector<Part> parts;
         for (size_t g = 0; g < g_round && begin < max_restarts; ++g) {
             Part p;
             p.ctx = g == 0 ? c0 : device_ctx(r, g);
             if (!p.ctx) return -1;
             p.begin = begin;
-            p.end = (max_restarts - begin > batch) ? begin + batch : max_restarts;
+            p.end = (max_restarts - begin > per_part) ? begin + per_part : max_restarts;
             p.wx.resize((size_t)r->n);
             begin = p.end;
             parts.push_back(std::move(p));

@@ -469,17 +469,18 @@ def test_diff_ik_six_dof_solution_is_the_unique_ray(ur3e):
 
 
 def test_long_calls_move_to_the_engine_with_the_same_answer(panda):
-    """A call still running after 512 + 65 536 restarts continues in rounds of 1 M restarts on the
-    streaming engine: Quality over 300 000 restarts returns the restart one solve-kernel launch
-    over the whole range selects; an unreachable Speed target comes back None after all of them;
-    max_time ends an engine round early."""
+    """Throughput-bound calls run on the streaming engine -- Quality with a restart budget of
+    ~100 000 or more from index 0, any call still running after 512 + 65 536 restarts in rounds of
+    1 M: Quality over 300 000 restarts returns the restart a solve-kernel launch around it
+    selects; an unreachable Speed target comes back None after all of them; max_time ends an
+    engine round early."""
     import torch
     from optik_amd import SolverConfig
     rng = np.random.default_rng(77)
     lb, ub = (np.array(v) for v in panda.joint_limits())
     R = 300_000
     cfg = SolverConfig(solution_mode="quality", max_time=0.0, max_restarts=R)
-    for _ in range(8):  # (a target whose winner comes from the engine round: 3 of 4 do)
+    for _ in range(8):  # (a target whose winner lies beyond the first two solve-kernel launches of a timed call)
         tgt = np.array(panda.fk(rng.uniform(lb, ub)))
         x0 = rng.uniform(lb, ub)
         x, c, idx = panda.ik(cfg, tgt, x0.tolist(), return_index=True)
