@@ -1974,12 +1974,17 @@ int optik_hip_ik_host(optik_hip_chain *ch, const optik_solver_config *cfg, const
         HIP_TRY(hipHostMalloc(&ch->hw_pin, sizeof(double) * (n_in + n_out)));
         ch->hw_cap = n_in + n_out;
     }
-    double *d_t = ch->hw_dev, *d_x0 = d_t + (size_t)7 * T;
-    double *d_wx = ch->hw_dev + n_in, *d_wf = d_wx + (size_t)n * T, *d_wk = d_wf + T;
+    // A few targets (Robot::ik: one): the kernels read the inputs from and write the winners to the
+    // pinned block directly -- no copy commands around the launch.
+    const bool zero_copy = T <= 16;
+    double *io = zero_copy ? ch->hw_pin : ch->hw_dev;
+    double *d_t = io, *d_x0 = d_t + (size_t)7 * T;
+    double *d_wx = io + n_in, *d_wf = d_wx + (size_t)n * T, *d_wk = d_wf + T;
     uint64_t *d_wi = reinterpret_cast<uint64_t *>(d_wk + T);
     std::memcpy(ch->hw_pin, targets, sizeof(double) * 7 * (size_t)T);
     std::memcpy(ch->hw_pin + (size_t)7 * T, x0, sizeof(double) * (size_t)n * (size_t)T);
-    HIP_TRY(hipMemcpyAsync(ch->hw_dev, ch->hw_pin, sizeof(double) * n_in, hipMemcpyHostToDevice, nullptr));
+    if (!zero_copy)
+        HIP_TRY(hipMemcpyAsync(ch->hw_dev, ch->hw_pin, sizeof(double) * n_in, hipMemcpyHostToDevice, nullptr));
     optik_hip_ik_outputs o;
     std::memset(&o, 0, sizeof o);
     o.d_win_x = d_wx; o.d_win_f = d_wf; o.d_win_idx = d_wi; o.d_win_key = d_wk;
@@ -1990,7 +1995,7 @@ int optik_hip_ik_host(optik_hip_chain *ch, const optik_solver_config *cfg, const
                                             deadline_s, &o, nullptr);
     if (rc) return rc;
     double *h_out = ch->hw_pin + n_in;
-    HIP_TRY(hipMemcpyAsync(h_out, d_wx, sizeof(double) * n_out, hipMemcpyDeviceToHost, nullptr));
+    if (!zero_copy) HIP_TRY(hipMemcpyAsync(h_out, d_wx, sizeof(double) * n_out, hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
     if (win_x) std::memcpy(win_x, h_out, sizeof(double) * (size_t)n * (size_t)T);
     if (win_f) std::memcpy(win_f, h_out + (size_t)n * T, sizeof(double) * (size_t)T);
