@@ -77,8 +77,11 @@ const char *optik_hip_last_error(void);
 
 /* origins: n_joints x 7 poses (Joint::origin), axes: n_joints x 3 (unit axis of
  * each chain joint, ignored for fixed), types: OPTIK_JOINT_*, lb/ub: n limits
- * (Robot::joint_limits, lib.rs:78-84).  Supported: 2 <= n <= 7 revolute joints plus
- * an optional trailing fixed joint. */
+ * (Robot::joint_limits, lib.rs:78-84).  Supported: 1 <= n <= 8 positional joints plus
+ * an optional trailing fixed joint (what from_urdf's folding produces); the streaming engine
+ * and the cooperative kernels cover n <= 7, an 8-DoF chain runs on the per-lane solve kernel;
+ * prismatic joints: forward kinematics only (the reference's Jacobian is todo!(),
+ * kinematics.rs:185). */
 int optik_hip_chain_create(const double *origins, const double *axes, const int32_t *types,
                            int32_t n_joints, const double *lb, const double *ub, int32_t n,
                            optik_hip_chain **out);
