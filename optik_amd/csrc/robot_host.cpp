@@ -516,6 +516,13 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
         const char *e = std::getenv("OPTIK_IK_BATCH_ROUND_ITEMS");
         return e ? (uint64_t)std::atoll(e) : (uint64_t)4 << 20;
     }();
+    static const uint64_t engine_first_round = [] {
+        // restart indices per target in the first round of a Speed batch on the engine: 16 measured best
+        // at 65 536 / 131 072 / 262 144 targets (8: 30.0 / 43.2 ms, 16: 26.5 / 34.6, 32: 27.0 / 40.1,
+        // 64: 31.0 / - ms); 0.03 % of reachable targets are left for the next round
+        const char *e = std::getenv("OPTIK_IK_BATCH_ENGINE_ROUND");
+        return e && std::atoll(e) > 0 ? (uint64_t)std::atoll(e) : (uint64_t)16;
+    }();
     static const size_t engine_min = [] {
         const char *e = std::getenv("OPTIK_IK_BATCH_ENGINE_MIN");  // Speed batches from this many targets: engine
         return e ? (size_t)std::atoll(e) : (size_t)65536;
@@ -568,9 +575,10 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
         const size_t L = live.size();
         const bool big_speed = !quality && L >= engine_min;
         uint64_t round = quality ? 256 : speed_round;
-        while (round > 256 && round * (uint64_t)L > round_items) round >>= 1;
-        if (big_speed)
-            while (round > 8 && round * (uint64_t)L > round_items) round >>= 1;
+        while (round > (big_speed ? 16u : 256u) && round * (uint64_t)L > round_items) round >>= 1;
+        // (from ~500 000 targets the queue fetches of the abandoned indices outweigh the second round
+        // that 8 indices leave 1.7 % of the targets for: 1 M targets 163 against 194 ms)
+        if (big_speed && begin == 0) round = (L >= 524288 && engine_first_round > 8) ? 8 : engine_first_round;
         if (speed_round < ((uint64_t)1 << 40)) speed_round *= 4;
         // Quality runs every restart of every target to the end: nothing to gain from short rounds,
         // and an engine run has a ~10 ms floor -- as many indices per round as ~4 M items allow
