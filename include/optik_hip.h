@@ -131,7 +131,7 @@ int optik_hip_seed_batch(const optik_hip_chain *chain, uint64_t first, int64_t c
  * restart-major (every target's restart 0, then every target's restart 1, ...) instead of
  * target-major; with EARLY_EXIT about eight restarts per target are kept in flight and most
  * higher indices are never started.  Scheduling only: per-restart results and winners are the
- * same (an abandoned restart's status is FORCED_STOP either way).  n <= 7. */
+ * same (an abandoned restart's status is FORCED_STOP either way). */
 #define OPTIK_HIP_IK_RESTART_MAJOR 4u
 /* optik_hip_ik_host only: run the call as one job of the streaming engine
  * (optik_hip_engine_solve) instead of the single solve kernel -- same results; faster from

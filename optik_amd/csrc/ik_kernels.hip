@@ -1101,7 +1101,7 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         const char *e = std::getenv("OPTIK_IK_BATCH_INFLIGHT");  // restarts per target in flight
         return e && std::atoll(e) > 0 ? std::atoll(e) : 8ll;
     }();
-    if (coop && early && (flags & OPTIK_HIP_IK_RESTART_MAJOR) && resident > (long long)T * inflight)
+    if (early && (flags & OPTIK_HIP_IK_RESTART_MAJOR) && resident > (long long)T * inflight)
         resident = std::max((long long)T * inflight, std::min(resident, cap));
     long long lanes = (resident + cap - 1) / cap;
     if (lanes < 1) lanes = 1;
@@ -1330,7 +1330,8 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
             if (deadline_s > 0.0) { left = deadline_s - since_call(); if (left <= 0.0) left = 1e-9; }
             rc = ik_batch_locked(ch, &cfg, j.dev.targets, j.dev.x0, j.T, ch->eng_has_ee ? ch->eng_ee : nullptr,
                                  j.dev.restart_begin, j.dev.restart_begin + j.dev.n_restarts,
-                                 (j.own_fs ? OPTIK_HIP_IK_EARLY_EXIT : 0u) | (j.dev.find_any ? OPTIK_HIP_IK_FIND_ANY : 0u), left,
+                                 (j.own_fs ? OPTIK_HIP_IK_EARLY_EXIT : 0u) | (j.dev.find_any ? OPTIK_HIP_IK_FIND_ANY : 0u)
+                                     | ((j.dev.restart_major && !j.full_pool) ? OPTIK_HIP_IK_RESTART_MAJOR : 0u), left,
                                  &j.out, stream);
             if (!rc && hipStreamSynchronize(stream) != hipSuccess) rc = fail(OPTIK_HIP_ENODEVICE, "engine job failed");
         }

@@ -231,9 +231,11 @@ OPTIK_DEV void solve_wave(const ChainDev &ch, const EvalParams &ep, const SolveP
             if (want) {
                 want = false;
                 if (it < wq.total_items) {
-                    item = it;
-                    tslot = (unsigned)(it / wq.n_restarts);
-                    index = wq.restart_begin + (it - (unsigned long long)tslot * wq.n_restarts);
+                    unsigned long long r;
+                    if (wq.restart_major) { r = it / wq.n_targets; tslot = (unsigned)(it - r * wq.n_targets); }
+                    else { tslot = (unsigned)(it / wq.n_restarts); r = it - (unsigned long long)tslot * wq.n_restarts; }
+                    item = (unsigned long long)tslot * wq.n_restarts + r;  // output column
+                    index = wq.restart_begin + r;
                     target = load_pose(wq.targets + (size_t)tslot * 7);
                     // lib.rs:366-370: restart 0 starts from the caller's seed
                     restart_seed<N>(key, ch.lb, scale, index, x);

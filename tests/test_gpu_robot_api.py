@@ -312,6 +312,26 @@ def test_speed_batch_with_hard_targets_runs_growing_rounds(panda):
     assert dt < 0.25, dt
 
 
+def test_eight_dof_batch_equals_individual_calls():
+    """n = 8 runs on the per-lane solve kernel (the engine and the cooperative kernels hold n + 1 <= 8
+    rows): a Speed batch is handed out restart-major there too, same answers as ik() alone."""
+    from conftest import TEST_ROBOTS
+    from optik_amd import Robot, SolverConfig
+    r = Robot.from_urdf_file(os.path.join(TEST_ROBOTS, "arm8.urdf"), "l0", "l9")
+    r.set_parallelism(1)
+    assert r.num_positions() == 8
+    rng = np.random.default_rng(5)
+    lb, ub = (np.array(v) for v in r.joint_limits())
+    T = 40
+    targets = np.array([r.fk(rng.uniform(lb, ub)) for _ in range(T)])
+    x0s = rng.uniform(lb, ub, size=(T, 8))
+    for mode in ("speed", "quality"):
+        cfg = SolverConfig(solution_mode=mode, max_time=0.0, max_restarts=48)
+        batch = r.ik_batch(cfg, targets, x0s)
+        for t in (0, 13, 39):
+            assert batch[t] == r.ik(cfg, targets[t], x0s[t].tolist())
+
+
 def _world_jacobian(robot, x):
     fk = np.array(robot.fk(x))
     J = np.array(robot.joint_jacobian(x))
