@@ -494,8 +494,9 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
 namespace {
 
 // optik_robot_ik_batch_ex for the targets of one GPU: rounds of `round` restart indices per
-// target on the streaming engine; targets already solved (Speed) drop out of later rounds;
-// max_time is enforced inside a run (optik_hip_engine_run_ex) and between rounds.
+// target (sizes and the kernel each round runs on: see the loop); targets already solved
+// (Speed) drop out of later rounds; max_time is enforced inside a launch / engine run and
+// between rounds.
 int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *config, int32_t T,
                        const double *targets16, bool row_major, const double *x0, const double *ee7,
                        std::chrono::steady_clock::time_point start, double *x_out, double *f_out,
@@ -674,8 +675,8 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
 // Many independent ik() calls at once (the motion-planning workload of examples/example.rs:
 // a stream of targets, each with its own seed): every target gets the semantics of Robot::ik
 // with the same SolverConfig.  The targets are split into contiguous parts over the robot's
-// GPUs (BASELINE.json config 5: no collective, the host gathers), each part runs on its GPU's
-// streaming engine from its own host thread.
+// GPUs (BASELINE.json config 5: no collective, the host gathers), each part runs on its GPU
+// from its own host thread.
 int optik_robot_ik_batch_ex(const optik_robot *r, const CSolverConfig *config, int32_t T,
                             const double *targets16, const double *x0, const double *ee16, double *x_out,
                             double *f_out, int32_t *found_out) {
