@@ -22,7 +22,7 @@
 //                           (ik_nnls_coop.hpp)
 //       eng_finish_kernel   refill of finished slots from the work queue; LDP tail,
 //                           descent test and next trial point from the NNLS answers
-//     (the last restarts of a run -- up to 16 384 -- are finished by eng_tail_coop_kernel,
+//     (the last restarts of a run -- up to 32 768 -- are finished by eng_tail_coop_kernel,
 //     ik_tail.hpp / ik_coop.hpp, without kernel boundaries; OPTIK_ENG_FUSED=1 runs finish, eval
 //     and update as one launch, eng_slot_kernel);
 //   * jobs (one optik_hip_ik_batch call each) submitted before a run share the pool:
