@@ -22,6 +22,10 @@ namespace optik {
 
 constexpr int COOP_GROUP = COOP_COLS / 4;           // lanes per restart (4 columns per lane)
 constexpr int COOP_GROUPS_PER_WAVE = 64 / COOP_GROUP;
+#ifndef OPTIK_COOP_REFILL_BATCH
+#define OPTIK_COOP_REFILL_BATCH 1
+#endif
+constexpr unsigned COOP_REFILL_BATCH = OPTIK_COOP_REFILL_BATCH;  // idle groups a wave accumulates before it refills
 
 // doubles of the group's LDS window: the problem record, the multipliers, {mode + 8 passes, rnorm}
 // (parking the leader's LSQ factor here across the solve does not help: 396 against 372 B of scratch)
@@ -319,7 +323,10 @@ OPTIK_DEV void coop_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
         OPTIK_PROF_BEGIN();
         // ---- refill: leaders without a restart pull the next work item -----------------
         const unsigned n_want = (unsigned)__popcll(__ballot(want));
-        if (n_want >= (unsigned)(wq.lanes < REFILL_BATCH ? wq.lanes : REFILL_BATCH) || (n_want > 0 && !wave_any(active))) {
+        // (a wave holds at most 16 restarts here: an idle group is 1/16 of it, and drawing a seed costs the
+        // wave ~2 % of a trip -- refill as soon as one group is free; waiting for 8 as the 64-lane kernel
+        // does left a quarter of the groups idle)
+        if (n_want >= COOP_REFILL_BATCH || (n_want > 0 && !wave_any(active))) {
             const unsigned long long it = fetch_items(wq.next_item, want);
             if (want) {
                 want = false;
