@@ -433,7 +433,9 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
         // latency-sized first launches (each of them waits for its slowest restart -- 1 000 restarts
         // took two launches of 2.7 ms), the whole range at once: one launch of the solve kernel
         // below ~100 000 restarts, engine rounds from index 0 above.
-        const bool all_at_once = quality && config->max_time <= 0.0 && config->max_restarts > 0;
+        // (with a time budget too when the whole range is one solve-kernel launch: its waves watch the clock)
+        const bool all_at_once = quality && config->max_restarts > 0
+                                 && (config->max_time <= 0.0 || config->max_restarts < 98304);
         const size_t g_round = (begin == 0 && !(all_at_once && max_restarts >= 2 * 98304)) ? 1 : G;  // (the latency-sized first launch stays on one GPU)
         // (what is left must be worth an engine run: below ~100 000 restarts the solve kernel is faster)
         const bool on_engine = engine_ok && max_restarts - begin >= 98304
