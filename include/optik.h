@@ -62,7 +62,7 @@ int optik_robot_ik_ex(const optik_robot *robot, const CSolverConfig *config, con
  * x0 [T][n] -> x_out [T][n], f_out [T], found_out [T] (0/1).  Every target gets Robot::ik's
  * semantics (config 5 of BASELINE.json: many targets x a few hundred restarts).  Scheduling
  * (robot_host.cpp:ik_batch_on_device): a Speed batch's first round of 256 restart indices per
- * target runs on the cooperative solve kernel, restart-major -- from 65 536 targets on the
+ * target runs on the cooperative solve kernel, restart-major -- from 40 960 targets on the
  * streaming engine, 16 indices per target; what it leaves unsolved runs in rounds four times as
  * long each; Quality batches and rounds of ~100 000 restarts or more run on the engine.
  * rc 0 = ran, < 0 = error. */
