@@ -261,8 +261,8 @@ def test_ik_batch_equals_individual_calls(panda, oracle, chains, kernel_max, mon
 
 
 def test_big_speed_batch_on_the_engine_equals_individual_calls(panda):
-    """From 65 536 targets a Speed batch runs on the streaming engine in short rounds (64 restart
-    indices per round at this size, the unsolved rest goes through later rounds): the answers are
+    """From 40 960 targets a Speed batch runs on the streaming engine in short rounds (16 restart
+    indices in the first, the unsolved rest goes through later rounds): the answers are
     still those of ik() alone -- the lowest successful restart index with set_parallelism(1)."""
     from optik_amd import SolverConfig
     rng = np.random.default_rng(15)
