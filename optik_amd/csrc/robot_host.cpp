@@ -582,7 +582,7 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
         // (from ~500 000 targets the queue fetches of the abandoned indices outweigh the second round
         // that 8 indices leave 1.7 % of the targets for: 1 M targets 163 against 194 ms)
         if (big_speed && begin == 0) round = (L >= 524288 && engine_first_round > 8) ? 8 : engine_first_round;
-        if (speed_round < ((uint64_t)1 << 40)) speed_round *= 4;
+        else if (speed_round < ((uint64_t)1 << 40)) speed_round *= 4;  // (the round after a short engine round is 256 again)
         // Quality runs every restart of every target to the end: nothing to gain from short rounds,
         // and an engine run has a ~10 ms floor -- as many indices per round as ~4 M items allow
         // (288 MB of per-restart keys, points and residuals)
@@ -621,20 +621,21 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
         // (one job of ~100 000 restarts is where the engine overtakes the solve kernel: 65 536 take 12.3
         // against 9.8 ms, 262 144 take 17 against 32 ms)
         const bool kernel_path = r->n <= 7 && !big_speed && L <= small_batch
-                                 && ((!quality && begin == 0) || (uint64_t)L * (end - begin) < 98304ull);
+                                 && ((!quality && begin < 256) || (uint64_t)L * (end - begin) < 98304ull);
         const uint32_t mode_flags =
             quality ? 0u : (OPTIK_HIP_IK_EARLY_EXIT | (r->parallelism != 1 ? OPTIK_HIP_IK_FIND_ANY : 0u));
         if (kernel_path) {
             // (restart-major hand-out keeps only a few restarts per target in flight -- right while
-            // early exit abandons most of them, i.e. in the first round; later rounds fill the chip)
+            // early exit abandons most of them, i.e. for the first 256 indices of a target (the
+            // leftovers of a 16-index engine round are unlucky, not hard); later rounds fill the chip)
             const int rck = optik_hip_ik_batch(c->chain, config, d_t, d_x0, (int32_t)L, ee7, begin, end,
-                                               mode_flags | (begin == 0 ? OPTIK_HIP_IK_RESTART_MAJOR : 0u), deadline,
+                                               mode_flags | (begin < 256 ? OPTIK_HIP_IK_RESTART_MAJOR : 0u), deadline,
                                                &o, nullptr);
             if (rck) { err = optik_hip_last_error(); return -1; }
         } else {
             // (later rounds: the targets still unsolved run nearly all of their restarts -- the whole pool)
             const int rc = optik_hip_engine_solve(c->chain, config, d_t, d_x0, (int32_t)L, ee7, begin, end,
-                                                  mode_flags | (begin > 0 ? OPTIK_HIP_IK_FULL_POOL : 0u), deadline, &o,
+                                                  mode_flags | (begin >= 256 ? OPTIK_HIP_IK_FULL_POOL : 0u), deadline, &o,
                                                   nullptr);
             if (rc) { err = optik_hip_last_error(); return -1; }
         }
