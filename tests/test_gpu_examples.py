@@ -36,3 +36,32 @@ def test_diff_ik_example():
     assert out.startswith("alpha = "), out
     resid = float(out.split("|J v - alpha V| = ")[1].split(";")[0])
     assert resid < 1e-9, out
+
+
+def test_reference_style_script_runs_unchanged(tmp_path):
+    """A script written against the reference's Python module (`from optik import Robot,
+    SolverConfig`; optik.pyi) runs as it is with this repository on PYTHONPATH."""
+    script = tmp_path / "user_script.py"
+    script.write_text(
+        "import sys\n"
+        "import numpy as np\n"
+        "from optik import Robot, SolverConfig\n"
+        "robot = Robot.from_urdf_file(*sys.argv[1:4])\n"
+        "robot.set_parallelism(1)\n"
+        "config = SolverConfig()\n"
+        "rng = np.random.default_rng(0)\n"
+        "ok = 0\n"
+        "for _ in range(20):\n"
+        "    x0 = rng.uniform(*robot.joint_limits())\n"
+        "    q = rng.uniform(*robot.joint_limits())\n"
+        "    target = np.array(robot.fk(q))\n"
+        "    sol = robot.ik(config, target, x0)\n"
+        "    if sol is not None:\n"
+        "        q_opt, c = sol\n"
+        "        assert c < 1e-6 and np.allclose(np.array(robot.fk(q_opt)), target, atol=2e-3)\n"
+        "        ok += 1\n"
+        "print(ok)\n")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    res = subprocess.run([sys.executable, str(script), *PANDA], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-500:] + res.stderr[-2000:]
+    assert int(res.stdout.split()[-1]) >= 19
