@@ -893,12 +893,15 @@ OPTIK_DEV void eng_nnls_coop_body(const EngArgs &a, double *wave_lds) {
                 const bool neg = c >= (unsigned)N;
                 const int cc = (int)(neg ? c - N : c);
                 const int off = cc * (N + 2) - (cc * (cc - 1)) / 2 - cc;  // rec_row(cc) - cc
+                // (unconditional loads of the N + 2 doubles at rec[off ..]: for r < cc they are entries of
+                // earlier rows of the same record, discarded below -- adjacent loads the compiler can pair
+                // into 16-byte accesses instead of N + 1 predicated 8-byte ones)
+                double rowv[N + 2];
 #pragma unroll
-                for (int r = 0; r < N; ++r) {
-                    const double v = (r >= cc) ? rec[off + r] : 0.0;
-                    col[k][r] = neg ? ((r >= cc) ? -v : 0.0) : v;
-                }
-                col[k][N] = rec[off + N + (neg ? 1 : 0)];  // h_lo / h_hi follow the row
+                for (int r = 0; r < N + 2; ++r) rowv[r] = rec[off + r];
+#pragma unroll
+                for (int r = 0; r < N; ++r) col[k][r] = (r >= cc) ? (neg ? -rowv[r] : rowv[r]) : 0.0;
+                col[k][N] = neg ? rowv[N + 1] : rowv[N];  // h_lo / h_hi follow the row
                 if (resume) {
 #pragma unroll
                     for (int r = 0; r < m; ++r) col[k][r] = cmat[(size_t)c * m + r];
