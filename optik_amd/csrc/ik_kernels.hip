@@ -1101,8 +1101,17 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         const char *e = std::getenv("OPTIK_IK_BATCH_INFLIGHT");  // restarts per target in flight
         return e && std::atoll(e) > 0 ? std::atoll(e) : 8ll;
     }();
-    if (early && (flags & OPTIK_HIP_IK_RESTART_MAJOR) && resident > (long long)T * inflight)
-        resident = std::max((long long)T * inflight, std::min(resident, cap));
+    // (a few targets have the chip to themselves: two restarts per resident wave at least, 32 per
+    // target up to 256 targets -- measured: 64 targets 1.01 -> 0.79 ms, 256: 1.66 -> 1.47 ms, and the
+    // few hundred targets a big batch's short engine round leaves over 8 ms sooner)
+    static const long long min_resident = [] {
+        const char *e = std::getenv("OPTIK_IK_BATCH_MIN_RESIDENT");
+        return e && std::atoll(e) > 0 ? std::atoll(e) : 0ll;
+    }();
+    if (early && (flags & OPTIK_HIP_IK_RESTART_MAJOR) && resident > (long long)T * inflight) {
+        const long long floor_res = min_resident > 0 ? min_resident : std::max(2 * cap, (long long)T * 32);
+        resident = std::max((long long)T * inflight, std::min(resident, floor_res));
+    }
     long long lanes = (resident + cap - 1) / cap;
     if (lanes < 1) lanes = 1;
     if (lanes > per_wave_max) lanes = per_wave_max;
