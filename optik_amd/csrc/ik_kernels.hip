@@ -554,7 +554,8 @@ struct optik_hip_chain {
     optik_solver_config eng_cfg{};
     double eng_ee[7] = {0, 0, 0, 0, 0, 0, 1};
     bool eng_has_ee = false;
-    size_t eng_C = 0;
+    bool eng_pool_attached = false;  // counted among the users of its device's EnginePool
+    size_t eng_C = 0;                // the eng_* slot buffers below are views of that pool (engine_reserve)
     double *eng_d = nullptr;
     int32_t *eng_i32 = nullptr;
     unsigned long long *eng_item = nullptr;
@@ -604,6 +605,39 @@ struct optik_hip_chain {
 };
 
 namespace {
+
+// The slot pool of the streaming engine: ONE per device, shared by every chain (robot) of that
+// device -- ~1 GB at the default capacity, sized for n = 7 (a superset of every smaller chain's
+// planes and records).  An engine run owns it from its set-up to its last kernel (run_mu): runs
+// on one GPU gain nothing from overlapping, and a slot's content never outlives a run
+// (eng_init_kernel resets every slot).  Freed when the last chain that used it is destroyed.
+struct EnginePool {
+    std::mutex run_mu;
+    size_t C = 0;
+    double *d = nullptr;
+    int32_t *i32 = nullptr;
+    unsigned long long *item = nullptr;
+    double *prob = nullptr, *y = nullptr, *meta = nullptr, *carry = nullptr;
+    unsigned int *list = nullptr, *refill = nullptr, *cont = nullptr, *order = nullptr, *compact = nullptr;
+    int users = 0;
+};
+constexpr int ENG_MAX_DEVICES = 64;
+static EnginePool g_eng_pools[ENG_MAX_DEVICES];
+static std::mutex g_eng_pools_mu;  // guards `users`
+static EnginePool &engine_pool_of(const optik_hip_chain *ch) {
+    const int d = ch->device_id >= 0 && ch->device_id < ENG_MAX_DEVICES ? ch->device_id : 0;
+    return g_eng_pools[d];
+}
+static void engine_pool_free(EnginePool &P) {
+    (void)hipFree(P.d); (void)hipFree(P.i32); (void)hipFree(P.item); (void)hipFree(P.prob); (void)hipFree(P.y);
+    (void)hipFree(P.meta); (void)hipFree(P.carry); (void)hipFree(P.list); (void)hipFree(P.refill); (void)hipFree(P.cont);
+    (void)hipFree(P.order); (void)hipFree(P.compact);
+    P.d = nullptr; P.i32 = nullptr; P.item = nullptr; P.prob = P.y = P.meta = P.carry = nullptr;
+    P.list = P.refill = P.cont = P.order = P.compact = nullptr;
+    P.C = 0;
+}
+
+
 
 thread_local std::string g_err;
 
@@ -832,23 +866,17 @@ void optik_hip_chain_destroy(optik_hip_chain *ch) {
     if (ch->tmp_f) hipFree(ch->tmp_f);
     if (ch->tmp_key) hipFree(ch->tmp_key);
     if (ch->queue) hipFree(ch->queue);
-    if (ch->eng_d) hipFree(ch->eng_d);
-    if (ch->eng_i32) hipFree(ch->eng_i32);
-    if (ch->eng_item) hipFree(ch->eng_item);
+    if (ch->eng_pool_attached) {  // the slot pool belongs to the device: released with its last user
+        EnginePool &P = engine_pool_of(ch);
+        std::lock_guard<std::mutex> run(P.run_mu);
+        std::lock_guard<std::mutex> g(g_eng_pools_mu);
+        if (--P.users == 0) { (void)hipSetDevice(ch->device_id); (void)hipDeviceSynchronize(); engine_pool_free(P); }
+    }
     if (ch->eng_djobs) hipFree(ch->eng_djobs);
     if (ch->eng_counters) hipFree(ch->eng_counters);
-    if (ch->eng_order) hipFree(ch->eng_order);
-    if (ch->eng_carry) hipFree(ch->eng_carry);
     if (ch->eng_trip_log) hipFree(ch->eng_trip_log);
-    if (ch->eng_compact) hipFree(ch->eng_compact);
-    if (ch->eng_list) hipFree(ch->eng_list);
-    if (ch->eng_refill) hipFree(ch->eng_refill);
-    if (ch->eng_cont) hipFree(ch->eng_cont);
     if (ch->hw_dev) hipFree(ch->hw_dev);
     if (ch->hw_pin) hipHostFree(ch->hw_pin);
-    if (ch->eng_prob) hipFree(ch->eng_prob);
-    if (ch->eng_y) hipFree(ch->eng_y);
-    if (ch->eng_meta) hipFree(ch->eng_meta);
     if (ch->eng_pinned) hipHostFree(ch->eng_pinned);
     for (auto &pe : ch->eng_pool_ev) for (auto &e : pe) if (e) hipEventDestroy(e);
     if (ch->eng_fork_ev) hipEventDestroy(ch->eng_fork_ev);
@@ -1254,53 +1282,51 @@ int optik_hip_engine_submit(optik_hip_chain *ch, const optik_solver_config *cfg,
     return 0;
 }
 
-// Device memory and streams of the streaming engine for a pool of AC slots (no-op when the
-// chain already holds that much).  nd / ni / rec_len: planes and record length of the chain's n.
-static int engine_reserve(optik_hip_chain *ch, size_t AC, int nd, int ni, int rec_len, hipStream_t stream) {
-    if (AC > ch->eng_C) {
-        if (ch->eng_d) HIP_TRY(hipFree(ch->eng_d));
-        if (ch->eng_i32) HIP_TRY(hipFree(ch->eng_i32));
-        if (ch->eng_item) HIP_TRY(hipFree(ch->eng_item));
-        if (ch->eng_prob) HIP_TRY(hipFree(ch->eng_prob));
-        if (ch->eng_y) HIP_TRY(hipFree(ch->eng_y));
-        if (ch->eng_meta) HIP_TRY(hipFree(ch->eng_meta));
-        if (ch->eng_order) HIP_TRY(hipFree(ch->eng_order));
-        if (ch->eng_carry) HIP_TRY(hipFree(ch->eng_carry));
-        if (ch->eng_compact) HIP_TRY(hipFree(ch->eng_compact));
-        if (ch->eng_list) HIP_TRY(hipFree(ch->eng_list));
-        if (ch->eng_refill) HIP_TRY(hipFree(ch->eng_refill));
-        if (ch->eng_cont) HIP_TRY(hipFree(ch->eng_cont));
-        ch->eng_cont = nullptr;
-        ch->eng_compact = nullptr; ch->eng_list = nullptr; ch->eng_refill = nullptr;
-        ch->eng_order = nullptr; ch->eng_carry = nullptr;
-        ch->eng_d = nullptr; ch->eng_i32 = nullptr; ch->eng_item = nullptr;
-        ch->eng_prob = ch->eng_y = ch->eng_meta = nullptr;
-        HIP_TRY(hipMalloc(&ch->eng_d, sizeof(double) * (size_t)((nd + 1) / 2 * 2) * ((AC + 63) / 64 * 64)));  // whole 64-slot tiles of plane pairs
-        HIP_TRY(hipMalloc(&ch->eng_i32, sizeof(int32_t) * (size_t)ni * AC));
-        HIP_TRY(hipMalloc(&ch->eng_item, sizeof(unsigned long long) * AC));
-        const size_t nn = (size_t)ch->n;
-        HIP_TRY(hipMalloc(&ch->eng_prob, sizeof(double) * AC * rec_len));
-        HIP_TRY(hipMalloc(&ch->eng_y, sizeof(double) * AC * (2 * nn)));
-        HIP_TRY(hipMalloc(&ch->eng_meta, sizeof(double) * AC * 2));
-        HIP_TRY(hipMalloc(&ch->eng_list, sizeof(unsigned int) * 2 * AC));
-        HIP_TRY(hipMalloc(&ch->eng_refill, sizeof(unsigned int) * AC));
-        HIP_TRY(hipMalloc(&ch->eng_cont, sizeof(unsigned int) * (AC + ENG_MAX_POOLS * NN_CONT_SHARDS)));
-        HIP_TRY(hipMemsetAsync(ch->eng_cont, 0, sizeof(unsigned int) * (AC + ENG_MAX_POOLS * NN_CONT_SHARDS), stream));
-        HIP_TRY(hipMalloc(&ch->eng_order, sizeof(unsigned int) * 2 * NN_CLASSES * AC));
-        HIP_TRY(hipMalloc(&ch->eng_carry, sizeof(double) * NN_CARRY * AC));
-        HIP_TRY(hipMalloc(&ch->eng_compact, sizeof(unsigned int) * (2 * ENG_MAX_POOLS + 2 * AC)));
-        ch->eng_C = AC;
+// Device memory and streams of the streaming engine for a pool of AC slots: grows the device's
+// shared pool when it holds less and points the chain's eng_* fields at it (the caller holds the
+// pool's run_mu).  ni: int planes (the same for every n).
+static int engine_reserve(optik_hip_chain *ch, size_t AC, int /*nd*/, int ni, int /*rec_len*/, hipStream_t stream) {
+    EnginePool &P = engine_pool_of(ch);
+    constexpr int nd = EngLayout<7>::ND, rec_len = rec_stride<7>();
+    constexpr size_t nn = 7;
+    if (AC > P.C) {
+        HIP_TRY(hipDeviceSynchronize());  // (another chain's last run may still be draining on its streams)
+        engine_pool_free(P);
+        HIP_TRY(hipMalloc(&P.d, sizeof(double) * (size_t)((nd + 1) / 2 * 2) * ((AC + 63) / 64 * 64)));  // whole 64-slot tiles of plane pairs
+        HIP_TRY(hipMalloc(&P.i32, sizeof(int32_t) * (size_t)ni * AC));
+        HIP_TRY(hipMalloc(&P.item, sizeof(unsigned long long) * AC));
+        HIP_TRY(hipMalloc(&P.prob, sizeof(double) * AC * rec_len));
+        HIP_TRY(hipMalloc(&P.y, sizeof(double) * AC * (2 * nn)));
+        HIP_TRY(hipMalloc(&P.meta, sizeof(double) * AC * 2));
+        HIP_TRY(hipMalloc(&P.list, sizeof(unsigned int) * 2 * AC));
+        HIP_TRY(hipMalloc(&P.refill, sizeof(unsigned int) * AC));
+        HIP_TRY(hipMalloc(&P.cont, sizeof(unsigned int) * (AC + ENG_MAX_POOLS * NN_CONT_SHARDS)));
+        HIP_TRY(hipMemsetAsync(P.cont, 0, sizeof(unsigned int) * (AC + ENG_MAX_POOLS * NN_CONT_SHARDS), stream));
+        HIP_TRY(hipMalloc(&P.order, sizeof(unsigned int) * 2 * NN_CLASSES * AC));
+        HIP_TRY(hipMalloc(&P.carry, sizeof(double) * NN_CARRY * AC));
+        HIP_TRY(hipMalloc(&P.compact, sizeof(unsigned int) * (2 * ENG_MAX_POOLS + 2 * AC)));
+        P.C = AC;
         // first touch of the big buffers here, not in the first run that uses the slots (a
         // warm-up of one step followed by a 5-step run paid ~10 ms for it inside the timed run)
-        HIP_TRY(hipMemsetAsync(ch->eng_d, 0, sizeof(double) * (size_t)((nd + 1) / 2 * 2) * ((AC + 63) / 64 * 64), stream));
-        HIP_TRY(hipMemsetAsync(ch->eng_i32, 0, sizeof(int32_t) * (size_t)ni * AC, stream));
-        HIP_TRY(hipMemsetAsync(ch->eng_item, 0, sizeof(unsigned long long) * AC, stream));
-        HIP_TRY(hipMemsetAsync(ch->eng_prob, 0, sizeof(double) * AC * rec_len, stream));
-        HIP_TRY(hipMemsetAsync(ch->eng_y, 0, sizeof(double) * AC * (2 * nn), stream));
-        HIP_TRY(hipMemsetAsync(ch->eng_meta, 0, sizeof(double) * AC * 2, stream));
-        HIP_TRY(hipMemsetAsync(ch->eng_order, 0, sizeof(unsigned int) * 2 * NN_CLASSES * AC, stream));
-        HIP_TRY(hipMemsetAsync(ch->eng_carry, 0, sizeof(double) * NN_CARRY * AC, stream));
+        HIP_TRY(hipMemsetAsync(P.d, 0, sizeof(double) * (size_t)((nd + 1) / 2 * 2) * ((AC + 63) / 64 * 64), stream));
+        HIP_TRY(hipMemsetAsync(P.i32, 0, sizeof(int32_t) * (size_t)ni * AC, stream));
+        HIP_TRY(hipMemsetAsync(P.item, 0, sizeof(unsigned long long) * AC, stream));
+        HIP_TRY(hipMemsetAsync(P.prob, 0, sizeof(double) * AC * rec_len, stream));
+        HIP_TRY(hipMemsetAsync(P.y, 0, sizeof(double) * AC * (2 * nn), stream));
+        HIP_TRY(hipMemsetAsync(P.meta, 0, sizeof(double) * AC * 2, stream));
+        HIP_TRY(hipMemsetAsync(P.order, 0, sizeof(unsigned int) * 2 * NN_CLASSES * AC, stream));
+        HIP_TRY(hipMemsetAsync(P.carry, 0, sizeof(double) * NN_CARRY * AC, stream));
     }
+    if (!ch->eng_pool_attached) {
+        std::lock_guard<std::mutex> g(g_eng_pools_mu);
+        P.users += 1;
+        ch->eng_pool_attached = true;
+    }
+    // the chain's view of the pool (refreshed on every run: another chain may have grown it)
+    ch->eng_C = P.C;
+    ch->eng_d = P.d; ch->eng_i32 = P.i32; ch->eng_item = P.item; ch->eng_prob = P.prob; ch->eng_y = P.y;
+    ch->eng_meta = P.meta; ch->eng_carry = P.carry; ch->eng_list = P.list; ch->eng_refill = P.refill;
+    ch->eng_cont = P.cont; ch->eng_order = P.order; ch->eng_compact = P.compact;
     if (!ch->eng_djobs) HIP_TRY(hipMalloc(&ch->eng_djobs, sizeof(EngJob) * ENG_MAX_JOBS));
     constexpr int PCB = ENG_POOL_COUNTERS;
     if (!ch->eng_counters) HIP_TRY(hipMalloc(&ch->eng_counters, ENG_MAX_POOLS * PCB * sizeof(unsigned int)));
@@ -1353,6 +1379,9 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
         ch->eng_jobs.clear();
         return rc;
     }
+    // the device's slot pool is this run's from here to its last kernel (the runs of other chains of
+    // the device wait: ik_engine.hpp's kernels fill the chip on their own)
+    std::lock_guard<std::mutex> pool_lock(engine_pool_of(ch).run_mu);
     // at most ENG_MAX_JOBS jobs share one run of the pool; more are executed as consecutive runs
     for (size_t g0 = 0; g0 < ch->eng_jobs.size() && rc == 0; g0 += ENG_MAX_JOBS) {
     const size_t g1 = std::min(ch->eng_jobs.size(), g0 + (size_t)ENG_MAX_JOBS);
@@ -1933,6 +1962,7 @@ int optik_hip_engine_reserve(optik_hip_chain *ch, uint64_t slots, void *stream_v
     default: return fail(OPTIK_HIP_EUNSUPPORTED, OPTIK_N_RANGE_MSG);
     }
     hipStream_t stream = (hipStream_t)stream_v;
+    std::lock_guard<std::mutex> pool_lock(engine_pool_of(ch).run_mu);
     const int rc = engine_reserve(ch, AC, nd, ni, rec_len, stream);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(stream));

@@ -568,6 +568,41 @@ def test_robot_is_reentrant(panda):
     assert not errors, errors
 
 
+def test_robots_share_one_engine_pool_per_device():
+    """The streaming engine's slot pool (~1 GB) belongs to the device, not to the robot: several
+    robots -- different chains, used from different threads at once -- take turns on it, return
+    what they return alone, and do not multiply the memory."""
+    import threading
+    import torch
+    from optik_amd import Robot, SolverConfig
+    specs = [("panda.urdf", "panda_link0", "panda_link8"), ("ur10.urdf", "base_link", "ee_link"),
+             ("panda.urdf", "panda_link0", "panda_link5"), ("panda.urdf", "panda_link0", "panda_hand")]
+    robots = [Robot.from_urdf_file(os.path.join(ROBOTS, f), b, e) for f, b, e in specs]
+    rng = np.random.default_rng(9)
+    cfg = SolverConfig(solution_mode="quality", max_time=0.0, max_restarts=150_000)  # an engine run each
+    cases = []
+    for r in robots:
+        lb, ub = (np.array(v) for v in r.joint_limits())
+        cases.append((np.array(r.fk(rng.uniform(lb, ub))), rng.uniform(lb, ub)))
+    free0, _ = torch.cuda.mem_get_info()
+    want = [r.ik(cfg, t, x0, return_index=True) for r, (t, x0) in zip(robots, cases)]
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 2.2 * 2**30, (free0 - free1) / 2**30  # one pool (+ per-robot job buffers), not four
+    got = [None] * len(robots)
+
+    def run(k):
+        for _ in range(3):
+            got[k] = robots[k].ik(cfg, cases[k][0], cases[k][1], return_index=True)
+
+    threads = [threading.Thread(target=run, args=(k,)) for k in range(len(robots))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=120)
+    assert not any(th.is_alive() for th in threads), "deadlock"
+    assert got == want
+
+
 def test_set_parallelism_selects_find_any(oracle, chains):
     """set_parallelism(n > 1): SolutionMode::Speed stops at the first success of ANY restart
     (rayon's find_any with several threads, lib.rs:409-412) -- the returned restart is then not
