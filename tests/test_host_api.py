@@ -158,6 +158,35 @@ def test_no_gpu_means_loud_failure(built):
         device.HipChain(**r.chain_tables())
     with pytest.raises(OptikHipError):
         device.probe(0, np.ones(4), np.ones(4))
+    with pytest.raises(RuntimeError):
+        r.ik_batch_arrays(SolverConfig(max_time=0.0, max_restarts=4), np.tile(np.eye(4), (3, 1, 1)), np.zeros((3, 6)))
+    with pytest.raises(RuntimeError):
+        r.diff_ik([0.0] * 6, [0.1, 0, 0, 0, 0, 0], [1.0] * 6)
+
+
+def test_batch_inputs_are_validated_on_the_host(built):
+    """optik_robot_ik_batch_poses checks every target with parse_pose's isometry test
+    (optik-py/src/lib.rs:8-15) and every seed against the joint limits (lib.rs:251-254) before any
+    GPU work: both errors surface without a device."""
+    from optik_amd import Robot, SolverConfig
+    r = Robot.from_urdf_file(os.path.join(REF_GOLDEN, "ur3e.urdf"), "ur_base_link", "ur_ee_link")
+    lb, ub = (np.array(v) for v in r.joint_limits())
+    good = np.tile(np.eye(4), (4, 1, 1))
+    seeds = np.tile((lb + ub) / 2, (4, 1))
+    for bad_at, edit in ((2, lambda m: m.__setitem__((slice(0, 3), slice(0, 3)), m[:3, :3] * 1.001)),   # not orthonormal
+                         (0, lambda m: m.__setitem__((3, 0), 1e-9)),                                       # bottom row
+                         (3, lambda m: m.__setitem__((slice(0, 3), 0), -m[:3, 0])),                        # det = -1
+                         (1, lambda m: m.__setitem__((0, 3), float("nan")) or m.__setitem__((0, 0), float("nan")))):
+        tg = good.copy()
+        edit(tg[bad_at])
+        with pytest.raises(ValueError, match="invalid target transform"):
+            r.ik_batch_arrays(SolverConfig(), tg, seeds)
+    out_of_limits = seeds.copy()
+    out_of_limits[2, 4] = ub[4] + 1.0
+    with pytest.raises(RuntimeError, match="joint limits"):
+        r.ik_batch_arrays(SolverConfig(), good, out_of_limits)
+    with pytest.raises(ValueError):
+        r.ik_batch_arrays(SolverConfig(), good[:, :3], seeds)
 
 
 def test_headers_compile_as_c_and_link(built, tmp_path):
