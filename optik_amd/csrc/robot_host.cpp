@@ -564,11 +564,18 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
         }
         c->batch_cap = n_in + n_out;
     }
-    // Speed: the first round is latency-sized (256 indices: it solves nearly every reachable
-    // target); what is still unsolved after it is hard or unreachable and throughput-bound, so every
-    // later round covers four times as many indices (ten unreachable targets x 100 000 restarts are
-    // 8 rounds instead of 390)
-    uint64_t speed_round = 256;
+    // Speed: the first round is latency-sized -- 128 indices: with a third of the restarts succeeding
+    // it leaves no reachable target unsolved, and the abandoned indices of a round still cost the
+    // solve kernel's groups a queue fetch each (measured per first-round size 16 / 32 / 64 / 128 / 256:
+    // 1 024 targets 3.7 / 2.0 / 2.1 / 2.2 / 2.2 ms, 16 384 targets 9.8 / 9.5 / 8.7 / 8.3 / 9.4 ms; 32 768
+    // targets 15.9 ms at 64, 13.5 at 128, 16.8 at 256); what is
+    // still unsolved after it is hard or unreachable and throughput-bound, so every later round covers
+    // four times as many indices (ten unreachable targets x 100 000 restarts are 8 rounds instead of 390)
+    static const uint64_t first_round = [] {
+        const char *e = std::getenv("OPTIK_IK_BATCH_FIRST_ROUND");
+        return e && std::atoll(e) > 0 ? (uint64_t)std::atoll(e) : (uint64_t)128;
+    }();
+    uint64_t speed_round = first_round;
     for (uint64_t begin = 0; begin < max_restarts && !live.empty();) {
         double deadline = 0.0;
         if (config->max_time > 0.0) {
@@ -578,7 +585,9 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
         const size_t L = live.size();
         const bool big_speed = !quality && L >= engine_min;
         uint64_t round = quality ? 256 : speed_round;
-        while (round > (big_speed ? 16u : 256u) && round * (uint64_t)L > round_items) round >>= 1;
+        // (~4 M work items per round at most -- 288 MB of per-restart keys, points and residuals --
+        // down to 64 indices per target, which still leave no reachable target unsolved)
+        while (round > (big_speed ? 16u : (first_round < 64 ? first_round : 64u)) && round * (uint64_t)L > round_items) round >>= 1;
         // (from ~500 000 targets the queue fetches of the abandoned indices outweigh the second round
         // that 8 indices leave 1.7 % of the targets for: 1 M targets 163 against 194 ms)
         if (big_speed && begin == 0) round = (L >= 524288 && engine_first_round > 8) ? 8 : engine_first_round;
