@@ -12,7 +12,16 @@ submitted as K jobs and executed by one run of the streaming engine, which keeps
 its slot pool full across step boundaries (continuous batching); --path kernel
 launches one persistent solve kernel per step, back to back.
 
-Multi-GPU (one process per GPU under torch.distributed.run, RCCL over xGMI):
+Multi-GPU.  `python bench.py --gpus N` with no launcher around it starts the N ranks itself: it
+re-executes under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+127.0.0.1` with the same arguments (one process per GPU, RCCL over xGMI); under an outer launcher
+(RANK / WORLD_SIZE in the environment: what the driver uses for N > 1) it is one of the ranks.  The
+line's "n_gpus" is the number of ranks that actually joined the process group, and config carries
+the world size, the backend string and every rank's torch.cuda.current_device(); a --gpus that
+disagrees with WORLD_SIZE is refused.  `--inprocess` drives the other multi-GPU form instead: ONE
+process, N devices behind the C ABI (optik_robot_set_devices: a host thread per device, host min over
+N 16-byte records), through Robot.ik with SolutionMode::Quality and a restart budget of R x N.
+Workload flags (one process per GPU):
   --scaling weak    (default) every rank solves its own contiguous restart range
                     [rank*R, (rank+1)*R) of the step's target: R restarts per GPU per step
   --scaling strong  the step's R restarts are cut into one contiguous range per rank
@@ -37,6 +46,8 @@ The JSON line carries:
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -48,6 +59,9 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F64_VALU_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 16 f64 lanes/clk x 2 (FMA) x 2.4 GHz
+# ... and what this path can reach at best: -ffp-contract=off (rustc never fuses a*b+c, and the
+# bit-exactness contract with the oracle forbids it) makes every f64 instruction ONE flop
+F64_VALU_NOFMA_TFLOPS = 39.3
 PMC_FILE = os.path.join(ROOT, "profiles", "r2_pmc_by_command.json")
 
 ENGINE_POOL = 240  # steps whose restarts share one engine run (the engine pools up to 256 jobs)
@@ -121,9 +135,99 @@ def cpu_baseline(robot_name, chain_tables, target7, x0, mode, seconds_budget=15.
             "winner": winner}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run the N ranks under torch.distributed.run
+    (one process per GPU) with the same arguments and return its exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
+def inprocess_main(args):
+    """One process, G devices behind the C ABI (SURVEY 8e's other form; robot_host.cpp:
+    optik_robot_set_devices): a step is Robot.ik(SolutionMode::Quality, max_restarts = R x G) on one
+    target -- every restart of [0, R x G) runs to termination, device g takes the g-th contiguous
+    part from its own host thread, the host keeps the minimum of the G (key, index) records."""
+    from optik_amd import SolverConfig
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: optik_amd has no CPU fallback")
+    G = args.gpus or 1
+    K, W = args.steps, args.warmup
+    R = args.restarts or 65536
+    have = torch.cuda.device_count()
+    one = os.environ.get("OPTIK_BENCH_ONE_DEVICE") == "1"
+    devices = [0] * G if one else list(range(G))
+    if not one and G > have:
+        raise SystemExit(f"--inprocess --gpus {G}: this node has {have} device(s)")
+    robot = load_chain(args.robot)
+    robot.set_devices(devices)
+    n = robot.num_positions()
+    rng = np.random.default_rng(0)
+    lb, ub = (np.array(v) for v in robot.joint_limits())
+    q_star = rng.uniform(lb, ub, size=(K + W, n))
+    x0 = rng.uniform(lb, ub, size=(K + W, n))
+    targets = [robot.fk(q) for q in q_star]
+    cfg = SolverConfig(solution_mode="quality", max_time=0.0, max_restarts=R * G, tol_f=1e-6)
+
+    def run_steps(first, count):
+        out = []
+        for k in range(first, first + count):
+            r = robot.ik(cfg, targets[k], x0[k], return_index=True)
+            out.append(-1 if r is None else int(r[2]))
+        return out
+
+    if W:
+        run_steps(0, W)
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    rep_elapsed, winners = [], None
+    for _rep in range(max(1, args.reps)):
+        t0 = time.perf_counter()
+        w_rep = run_steps(W, K)  # Robot.ik blocks until the G parts are done and reduced
+        rep_elapsed.append(time.perf_counter() - t0)
+        if winners is not None and winners != w_rep:
+            raise SystemExit("winners differ between repetitions of the same steps")
+        winners = w_rep
+    elapsed = sorted(rep_elapsed)[len(rep_elapsed) // 2]
+    total = float(R) * G * K
+    out_bytes = 8 * n + 8 + 8 + 4 + 4
+    line = {
+        "metric": "random-restart IK solves/sec (Panda 7-DoF, 1e-6 tol)" if args.robot == "panda"
+                  else f"random-restart IK solves/sec ({args.robot}, 1e-6 tol)",
+        "value": total / elapsed, "unit": "restarts/s", "n_gpus": robot.num_devices(), "steps": K, "warmup": W,
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{args.robot} {n}-DoF, {R} random restarts per GPU per step (one Robot.ik call over "
+                               f"[0, {R * G})), one target per step, SolutionMode::Quality, every restart run to termination",
+                   "inprocess": True, "devices": devices, "world": 1, "backend": "host threads + host min (no collective)",
+                   "reps": len(rep_elapsed), "rep_reported": "median", "value_reps": [total / e for e in rep_elapsed],
+                   "restarts_per_gpu": R, "tol_f": 1e-6, "solution_mode": "quality",
+                   "parallelism": f"restart-range x{G} (in-process)", "winner_index_per_step": winners[:64]},
+        # this form goes through the host API, which does not expose per-kernel timers: the boundary view only
+        "roofline": {"bound": "hbm", "achieved": total / elapsed * out_bytes / 1e9, "peak": HBM_PEAK_GBS * G,
+                     "unit": "GB/s", "frac": total / elapsed * out_bytes / 1e9 / (HBM_PEAK_GBS * G), "traffic": None,
+                     "kernel": None, "algorithmic_bytes_per_unit": out_bytes, "unit_name": "restart (path boundary)"},
+        "cpu_baseline": None,
+    }
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="GPUs (= ranks) of this node; without a launcher N > 1 ranks are spawned here")
+    ap.add_argument("--inprocess", action="store_true",
+                    help="one process driving --gpus devices through optik_robot_set_devices (Robot.ik, "
+                         "Quality, restart budget R x N) instead of one process per GPU")
+    ap.add_argument("--reps", type=int, default=5,
+                    help="repetitions of the K-step timed run: value / ms_per_step are the MEDIAN repetition's, "
+                         "config.value_reps lists all of them")
     ap.add_argument("--steps", type=int, default=48,
                     help="timed steps; on the engine path they are pooled into one run (one drain of the slot pool)")
     ap.add_argument("--warmup", type=int, default=3)
@@ -150,9 +254,20 @@ def main():
     if args.restarts is None:
         args.restarts = 256 if args.targets else 65536
 
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.inprocess:
+        if env_world is not None and int(env_world) > 1:
+            raise SystemExit("--inprocess is one process driving every device: do not launch it under a multi-rank launcher")
+        return inprocess_main(args)
+    if env_world is None and (args.gpus or 1) > 1:
+        # no launcher around us: start the ranks ourselves
+        raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
+    if args.gpus is not None and args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to print a "
+                         f"line whose n_gpus is not the number of ranks that ran")
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: optik_amd has no CPU fallback")
@@ -169,6 +284,17 @@ def main():
             dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
         else:
             dist.init_process_group(backend)
+        if dist.get_world_size() != world:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, WORLD_SIZE says {world}")
+        # proof that N ranks joined, each on its own GPU: (rank, current device, device name, pid)
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, {"rank": rank, "device": int(torch.cuda.current_device()),
+                                              "name": torch.cuda.get_device_name(dev_index), "pid": os.getpid()})
+        backend_name = str(dist.get_backend())
+    else:
+        rank_devices = [{"rank": 0, "device": int(torch.cuda.current_device()),
+                         "name": torch.cuda.get_device_name(dev_index), "pid": os.getpid()}]
+        backend_name = None
 
     from optik_amd import _native as nat
     from optik_amd.parallel import shard_range, select_winner
@@ -250,20 +376,35 @@ def main():
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
-    hc.set_timing(True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    winners = run_steps(W, K)
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        from optik_amd.parallel import _all_reduce
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        _all_reduce(tmax, dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    # The K timed steps are repeated `--reps` times (same steps, same buffers); every repetition is
+    # bracketed by a barrier + synchronize on both sides and reduced to the MAX over ranks.  The line
+    # reports the median repetition (ms_per_step x steps = that one repetition), and all of them in
+    # config.value_reps: box-to-box and run-to-run spread is a few percent, more than some rounds move.
+    rep_elapsed = []
+    winners = None
+    for _rep in range(max(1, args.reps)):
+        hc.set_timing(True)
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        w_rep = run_steps(W, K)
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if distributed:
+            from optik_amd.parallel import _all_reduce
+            tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+            _all_reduce(tmax, dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        rep_elapsed.append(el)
+        if winners is not None and not torch.equal(winners, w_rep):
+            raise SystemExit("winners differ between repetitions of the same steps")
+        winners = w_rep
+    elapsed = sorted(rep_elapsed)[len(rep_elapsed) // 2]  # the median repetition (upper median for even counts)
 
     last = bufs[K - 1] if args.path == "engine" else bufs[0]
     solved_targets = int((winners >= 0).logical_and(winners < torch.iinfo(torch.int64).max).sum().item())
@@ -340,6 +481,11 @@ def main():
                 tf = total / elapsed * fl / 1e12
                 roof["secondary"] = {"bound": "valu_f64", "achieved": tf, "peak": F64_VALU_PEAK_TFLOPS,
                                      "unit": "TFLOP/s", "frac": tf / F64_VALU_PEAK_TFLOPS,
+                                     # the ceiling this path can reach: contraction is off by contract, so
+                                     # every f64 instruction is one flop (39.3 = 78.6 / 2)
+                                     "peak_no_fma": F64_VALU_NOFMA_TFLOPS, "frac_no_fma": tf / F64_VALU_NOFMA_TFLOPS,
+                                     "flops_note": "wave-level instruction counts x 64 lanes (EXEC masks not applied): "
+                                                   "an upper bound on the useful flops",
                                      "f64_flops_per_restart": fl, "valu_busy": pmc.get("valu_busy"),
                                      "source": os.path.relpath(PMC_FILE, ROOT) + ": SQ_INSTS_VALU_*_F64 x 64 lanes "
                                      "per restart and SQ_ACTIVE_INST_VALU per kernel of this command"}
@@ -381,6 +527,10 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": workload, "command_key": key,
+                       "world": world, "backend": backend_name, "rank_devices": rank_devices,
+                       "reps": len(rep_elapsed), "rep_reported": "median",
+                       "value_reps": [total / e for e in rep_elapsed],
+                       "value_min": total / max(rep_elapsed), "value_max": total / min(rep_elapsed),
                        "path": args.path, "restarts_per_gpu": cols, "tol_f": 1e-6, "solution_mode": mode,
                        "parallelism": (f"targets x{world}" if T else f"restart-range x{world}"),
                        "success_rate_last_step": (n_success / cols) if n_success is not None else None,

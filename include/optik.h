@@ -100,11 +100,15 @@ int optik_robot_fk_ex(const optik_robot *robot, const double *x, const double *e
 int optik_robot_joint_jacobian_ex(const optik_robot *robot, const double *x,
                                   const double *ee_offset16, double *jac6n_out);
 /* Flat chain table (what KinematicChain::from_urdf produced): n_joints poses, axes, types.
- * Call once with NULL buffers to learn *n_joints, then with buffers of n_joints x 7 / x 3 /
- * x 1 elements; on entry of the second call *n_joints holds the caller's capacity in joints
- * (fewer than the chain has: error, nothing is written). */
+ * optik_robot_chain_tables: *n_joints is written only; non-NULL buffers must hold OPTIK_MAX_JOINTS
+ * joints (x 7 / x 3 / x 1 elements).  optik_robot_chain_tables_n: the same with the caller's buffer
+ * capacity (in joints) passed explicitly -- fewer than the chain has: error, nothing is written;
+ * NULL buffers just report *n_joints. */
+#define OPTIK_MAX_JOINTS 9
 int optik_robot_chain_tables(const optik_robot *robot, int32_t *n_joints, double *origins7,
                              double *axes3, int32_t *types);
+int optik_robot_chain_tables_n(const optik_robot *robot, int32_t capacity, int32_t *n_joints,
+                               double *origins7, double *axes3, int32_t *types);
 /* The device-side chain of this robot on the current HIP device (created on first
  * use; owned by the robot). */
 optik_hip_chain *optik_robot_hip_chain(const optik_robot *robot);

@@ -243,6 +243,11 @@ int optik_hip_ik_host(optik_hip_chain *chain, const optik_solver_config *cfg,
 /* Test hook: elementary functions the kernels use, evaluated on the device.
  * op 0: a/b, 1: sqrt(a), 2: sin(a), 3: cos(a), 4: atan2(a, b) for a > 0, b >= 0. */
 int optik_hip_probe(int32_t op, const double *a, const double *b, int64_t count, double *out);
+/* Test hook: the math.rs functions one at a time on the device (the reference pins them with golden
+ * vectors, crates/optik/tests/test_math.rs:14-61).  poses7 = count x {t[3], quat[i,j,k,w]}; row-major
+ * results, `count` x: op 0 so3::log (3), 1 so3::right_jacobian(so3::log(q)) (9), 2 se3::log (6: linear,
+ * angular), 3 se3::right_jacobian (36). */
+int optik_hip_probe_math(int32_t op, const double *poses7, int64_t count, double *out);
 
 /* Last launch geometry / timing of optik_hip_ik_batch on this chain (for bench.py). */
 typedef struct optik_hip_launch_info {

@@ -100,6 +100,7 @@ def lib():
     L.optik_hip_engine_last_pools.argtypes = [vp, C.POINTER(C.c_int32)]
     L.optik_hip_engine_stats.argtypes = [vp, dp, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
     L.optik_hip_probe.argtypes = [C.c_int32, dp, dp, C.c_int64, dp]
+    L.optik_hip_probe_math.argtypes = [C.c_int32, dp, C.c_int64, dp]
     L.optik_hip_set_timing.argtypes = [vp, C.c_int32]
     L.optik_hip_last_launch.argtypes = [vp, C.POINTER(LaunchInfo)]
     L.optik_hip_timing_mean.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]

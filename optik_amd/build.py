@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "liboptik_amd.so")
 SOURCES = ["ik_kernels.hip", "robot_host.cpp"]
 HEADERS = ["ik_math.hpp", "ik_eval.hpp", "ik_slsqp.hpp", "ik_solve.hpp", "ik_nnls_coop.hpp", "ik_engine.hpp",
-           "ik_tail.hpp", "ik_coop.hpp",
+           "ik_tail.hpp", "ik_coop.hpp", "device_scope.hpp",
            "urdf_chain.hpp",
            os.path.join("..", "..", "include", "optik_hip.h"),
            os.path.join("..", "..", "include", "optik.h")]
@@ -24,7 +24,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
 # headers each translation unit depends on (a source is recompiled when one of them is newer than
 # its object file; the objects are build artefacts, git-ignored like the library)
 DEPS = {"ik_kernels.hip": HEADERS,
-        "robot_host.cpp": ["urdf_chain.hpp", os.path.join("..", "..", "include", "optik_hip.h"),
+        "robot_host.cpp": ["urdf_chain.hpp", "device_scope.hpp", os.path.join("..", "..", "include", "optik_hip.h"),
                            os.path.join("..", "..", "include", "optik.h")]}
 
 

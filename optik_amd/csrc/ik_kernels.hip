@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../include/optik_hip.h"
+#include "device_scope.hpp"
 #include "ik_engine.hpp"
 #include "ik_tail.hpp"
 #include "ik_coop.hpp"
@@ -508,6 +509,37 @@ __global__ void probe_kernel(int op, const double *a, const double *b, long long
     }
 }
 
+// math.rs functions one at a time (test hook: compared with the reference's own golden vectors,
+// /root/reference/crates/optik/tests/test_math.rs:14-61).  pose = t[3], quat[i,j,k,w]; matrices row-major.
+// op 0 so3::log (3), 1 so3::right_jacobian(so3::log(q)) (9), 2 se3::log (6: V^-1 t, w),
+// 3 se3::right_jacobian (36: [[J, Q], [0, J]]).
+__global__ void probe_math_kernel(int op, const double *poses, long long count, double *out, int stride) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (long long)gridDim.x * blockDim.x) {
+        const Pose X = load_pose(poses + i * 7);
+        double *o = out + i * stride;
+        const V3 w = so3_log(X.q);
+        if (op == 0) { o[0] = w.x; o[1] = w.y; o[2] = w.z; continue; }
+        const RotTerms rt = rot_terms(w);
+        const M3 Jr = so3_right_jacobian(rt);
+        if (op == 1) {
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) o[r * 3 + c] = Jr.m[r][c];
+        } else if (op == 2) {
+            const V3 lin = se3_log_linear(rt, X.t);
+            o[0] = lin.x; o[1] = lin.y; o[2] = lin.z; o[3] = w.x; o[4] = w.y; o[5] = w.z;
+        } else {
+            const M3 Q = se3_q_matrix(rt, X.t, Jr);
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) {
+                    o[r * 6 + c] = Jr.m[r][c];
+                    o[r * 6 + 3 + c] = Q.m[r][c];
+                    o[(r + 3) * 6 + c] = 0.0;
+                    o[(r + 3) * 6 + 3 + c] = Jr.m[r][c];
+                }
+        }
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -744,9 +776,12 @@ int ensure_device() {
 }
 
 // A chain lives on the device that was current when it was created; its entry points make that
-// device current for the calling thread (a host that drives several GPUs from one process
-// calls them from one thread per device, or in turn).
-#define BIND_DEVICE(CH) HIP_TRY(hipSetDevice((CH)->device_id))
+// device current for the calling thread for the duration of the call and restore the caller's
+// device on every exit path (device_scope.hpp) -- a host that also drives torch / RCCL on the
+// thread finds its own device current again.
+#define BIND_DEVICE(CH)                                                                 \
+    optik::DeviceScope dev_scope_((CH)->device_id);                                     \
+    if (!dev_scope_.ok()) return fail(OPTIK_HIP_ENODEVICE, "hipSetDevice(" + std::to_string((CH)->device_id) + ") failed")
 
 // Dispatch on (n, trailing fixed joint).
 // Kernels are instantiated for 1 <= n <= 8 revolute joints, each with and without a trailing
@@ -859,6 +894,7 @@ int optik_hip_chain_create(const double *origins, const double *axes, const int3
 
 void optik_hip_chain_destroy(optik_hip_chain *ch) {
     if (!ch) return;
+    optik::DeviceScope dev_scope(ch->device_id);  // frees and the pool's last sync run on the chain's device
     if (ch->dev) hipFree(ch->dev);
     if (ch->tile_recs) hipFree(ch->tile_recs);
     if (ch->first_success) hipFree(ch->first_success);
@@ -870,7 +906,7 @@ void optik_hip_chain_destroy(optik_hip_chain *ch) {
         EnginePool &P = engine_pool_of(ch);
         std::lock_guard<std::mutex> run(P.run_mu);
         std::lock_guard<std::mutex> g(g_eng_pools_mu);
-        if (--P.users == 0) { (void)hipSetDevice(ch->device_id); (void)hipDeviceSynchronize(); engine_pool_free(P); }
+        if (--P.users == 0) { (void)hipDeviceSynchronize(); engine_pool_free(P); }
     }
     if (ch->eng_djobs) hipFree(ch->eng_djobs);
     if (ch->eng_counters) hipFree(ch->eng_counters);
@@ -1027,8 +1063,9 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     constexpr int SEL_TILE = 4096;
     const uint64_t tiles_per_target = (R + SEL_TILE - 1) / SEL_TILE;
     const uint64_t n_tiles64 = tiles_per_target * (uint64_t)T;
-    if (n_tiles64 > 0x7fffffffull)
-        return fail(OPTIK_HIP_EINVAL, "too many restarts / targets in one launch (more than 2^31 selection tiles)");
+    // (HIP rejects a launch whose grid.x * block.x reaches 2^32: 256-thread tile blocks cap the tiles at 2^24 - 1)
+    if (n_tiles64 * 256ull >= (1ull << 32))
+        return fail(OPTIK_HIP_EINVAL, "too many restarts / targets in one launch (2^24 or more selection tiles)");
     const int n_tiles = (int)n_tiles64;
     const size_t cols = (size_t)T * (size_t)R;
 
@@ -1234,8 +1271,8 @@ int optik_hip_engine_submit(optik_hip_chain *ch, const optik_solver_config *cfg,
         if (!same) return fail(OPTIK_HIP_EINVAL, "jobs pooled in one engine run must share tolerances, weights and ee_offset");
     }
     const uint64_t R = restart_end - restart_begin;
-    if (((R + 4095) / 4096) * (uint64_t)T > 0x7fffffffull)
-        return fail(OPTIK_HIP_EINVAL, "too many restarts / targets in one job (more than 2^31 selection tiles)");
+    if (((R + 4095) / 4096) * (uint64_t)T * 256ull >= (1ull << 32))
+        return fail(OPTIK_HIP_EINVAL, "too many restarts / targets in one job (2^24 or more selection tiles)");
     optik_hip_chain::EngineJobHost j;
     std::memset(&j.dev, 0, sizeof j.dev);
     j.T = T;
@@ -1255,7 +1292,8 @@ int optik_hip_engine_submit(optik_hip_chain *ch, const optik_solver_config *cfg,
             return fail(OPTIK_HIP_ENOMEM, std::string(#expr) + ": " + hipGetErrorString(e_)); \
         }                                                                                    \
     } while (0)
-    if (want_win) {
+    // (an 8-DoF chain's jobs run through ik_batch_locked, which brings its own scratch)
+    if (want_win && ch->n <= 7) {
         JOB_TRY(hipMalloc(&j.own_key, sizeof(double) * cols));
         pk = j.own_key;
         if (!px && out->d_win_x) { JOB_TRY(hipMalloc(&j.own_x, sizeof(double) * cols * (size_t)ch->n)); px = j.own_x; }
@@ -2075,6 +2113,22 @@ int optik_hip_probe(int32_t op, const double *a, const double *b, int64_t count,
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out, d_o, bytes, hipMemcpyDeviceToHost));
     hipFree(d_a); hipFree(d_b); hipFree(d_o);
+    return 0;
+}
+
+int optik_hip_probe_math(int32_t op, const double *poses7, int64_t count, double *out) {
+    if (!poses7 || !out || count < 0 || op < 0 || op > 3) return fail(OPTIK_HIP_EINVAL, "bad argument");
+    if (int rc = ensure_device()) return rc;
+    if (count == 0) return 0;
+    const int stride = op == 0 ? 3 : (op == 1 ? 9 : (op == 2 ? 6 : 36));
+    double *d_p = nullptr, *d_o = nullptr;
+    HIP_TRY(hipMalloc(&d_p, sizeof(double) * 7 * (size_t)count));
+    HIP_TRY(hipMalloc(&d_o, sizeof(double) * (size_t)stride * (size_t)count));
+    HIP_TRY(hipMemcpy(d_p, poses7, sizeof(double) * 7 * (size_t)count, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(probe_math_kernel, dim3(64), dim3(64), 0, nullptr, op, d_p, (long long)count, d_o, stride);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d_o, sizeof(double) * (size_t)stride * (size_t)count, hipMemcpyDeviceToHost));
+    hipFree(d_p); hipFree(d_o);
     return 0;
 }
 

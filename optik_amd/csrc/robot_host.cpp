@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "../../include/optik.h"
+#include "device_scope.hpp"
 #include "urdf_chain.hpp"
 
 using optik_host::Chain;
@@ -147,7 +148,9 @@ DeviceCtx *device_ctx(const optik_robot *r, size_t k = 0) {
     int devid = 0;
     if (r->device_ids.empty()) (void)hipGetDevice(&devid);
     else devid = r->device_ids[k];
-    if (hipSetDevice(devid) != hipSuccess) {
+    // (the caller's device is current again when this returns, also when the set-up fails)
+    optik::DeviceScope dev_scope(devid);
+    if (!dev_scope.ok()) {
         g_robot_err = "hipSetDevice(" + std::to_string(devid) + ") failed";
         return nullptr;
     }
@@ -242,7 +245,8 @@ int fk_on_device(const optik_robot *r, const double *x, const double *ee16, doub
     double ee7[7];
     if (ee16) pose7_from_mat16(ee16, ee7);
     std::lock_guard<std::mutex> lock(r->mu);
-    if (hipSetDevice(c->device) != hipSuccess) return set_err(-1, "hipSetDevice failed");
+    optik::DeviceScope dev_scope(c->device);
+    if (!dev_scope.ok()) return set_err(-1, "hipSetDevice failed");
     // one configuration: the kernel reads q from and writes the pose / Jacobian to pinned host
     // memory (one launch and one wait instead of three copies around them: 43 -> ~20 us per call)
     double *p_q = c->h_scratch, *p_pose = p_q + r->n, *p_jac = p_pose + 7;
@@ -297,7 +301,7 @@ void optik_robot_free(optik_robot *r) {
     if (!r) return;
     for (auto &c : r->devs) {
         if (!c->chain) continue;
-        (void)hipSetDevice(c->device);
+        optik::DeviceScope dev_scope(c->device);  // the caller's device is current again afterwards
         optik_hip_chain_destroy(c->chain);
         if (c->d_scratch) (void)hipFree(c->d_scratch);
         if (c->h_scratch) (void)hipHostFree(c->h_scratch);
@@ -531,7 +535,8 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
         return e ? (size_t)std::atoll(e) : (size_t)40960;  // 32 768 targets: 16.8 (kernel) against 18.5 ms, 49 152: 24.7 against 22.7
     }();
     std::lock_guard<std::mutex> lock(c->batch_mu);
-    if (hipSetDevice(c->device) != hipSuccess) { err = "hipSetDevice failed"; return -1; }
+    optik::DeviceScope dev_scope(c->device);
+    if (!dev_scope.ok()) { err = "hipSetDevice failed"; return -1; }
 
     std::vector<double> tgt7((size_t)T * 7), best_key((size_t)T, 0.0);
     std::vector<uint64_t> best_idx((size_t)T, UINT64_MAX);
@@ -946,17 +951,22 @@ const double *optik_robot_diff_ik(const optik_robot *r, const double *x0, const 
     return malloc_copy(v.data(), v.size());
 }
 
-int optik_robot_chain_tables(const optik_robot *r, int32_t *n_joints, double *origins7, double *axes3,
-                             int32_t *types) {
+int optik_robot_chain_tables_n(const optik_robot *r, int32_t capacity, int32_t *n_joints, double *origins7,
+                               double *axes3, int32_t *types) {
     if (!r || !n_joints) return set_err(-1, "null argument");
-    const int32_t cap = *n_joints;
     *n_joints = (int32_t)r->types.size();
-    if ((origins7 || axes3 || types) && cap < *n_joints)
+    if ((origins7 || axes3 || types) && capacity < *n_joints)
         return set_err(-1, "chain_tables: buffers too small for the chain's joints");
     if (origins7) std::memcpy(origins7, r->origins.data(), sizeof(double) * r->origins.size());
     if (axes3) std::memcpy(axes3, r->axes.data(), sizeof(double) * r->axes.size());
     if (types) std::memcpy(types, r->types.data(), sizeof(int32_t) * r->types.size());
     return 0;
+}
+
+// (the original contract: *n_joints is an out-parameter only, the buffers hold OPTIK_MAX_JOINTS joints)
+int optik_robot_chain_tables(const optik_robot *r, int32_t *n_joints, double *origins7, double *axes3,
+                             int32_t *types) {
+    return optik_robot_chain_tables_n(r, OPTIK_MAX_JOINTS, n_joints, origins7, axes3, types);
 }
 
 optik_hip_chain *optik_robot_hip_chain(const optik_robot *r) {

@@ -208,3 +208,20 @@ def probe(op, a, b=None):
     out = np.empty_like(a)
     nat.check(nat.lib().optik_hip_probe(int(op), _dp(a), _dp(b), a.size, _dp(out)))
     return out
+
+
+_MATH_STRIDE = {0: 3, 1: 9, 2: 6, 3: 36}
+
+
+def probe_math(op, poses7):
+    """math.rs functions on the device (test hook): poses7 [count, 7] = t[3], quat[i,j,k,w].
+    op 0 so3::log -> [count, 3]; 1 so3::right_jacobian(so3::log(q)) -> [count, 3, 3]; 2 se3::log ->
+    [count, 6]; 3 se3::right_jacobian -> [count, 6, 6] (row-major matrices)."""
+    p = np.ascontiguousarray(poses7, dtype=np.float64).reshape(-1, 7)
+    out = np.empty((p.shape[0], _MATH_STRIDE[int(op)]), dtype=np.float64)
+    nat.check(nat.lib().optik_hip_probe_math(int(op), _dp(p), p.shape[0], _dp(out)))
+    if op == 1:
+        return out.reshape(-1, 3, 3)
+    if op == 3:
+        return out.reshape(-1, 6, 6)
+    return out

@@ -39,6 +39,7 @@ def _bind(L):
     L.optik_robot_set_devices.argtypes = [vp, C.POINTER(C.c_int32), C.c_int32]
     L.optik_robot_num_devices.argtypes = [vp]
     L.optik_robot_chain_tables.argtypes = [vp, C.POINTER(C.c_int32), dp, dp, C.POINTER(C.c_int32)]
+    L.optik_robot_chain_tables_n.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), dp, dp, C.POINTER(C.c_int32)]
     L.optik_robot_hip_chain.argtypes = [vp]
     L.optik_robot_hip_chain.restype = vp
     L.optik_robot_joint_limits.argtypes = [vp]
@@ -241,15 +242,10 @@ class Robot:
     def ik_batch(self, config: SolverConfig, targets, x0s, ee_offset=None):
         """ik_batch_arrays as a list: (x, c) or None per target, like T calls of ik()."""
         x, f, found = self.ik_batch_arrays(config, targets, x0s, ee_offset)
-        import gc
-        collecting = gc.isenabled()
-        gc.disable()  # ~10 objects per target are born here; none of them is garbage
-        try:
-            xs, fs = x.tolist(), f.tolist()
-            return [(xs[t], fs[t]) if ok else None for t, ok in enumerate(found.tolist())]
-        finally:
-            if collecting:
-                gc.enable()
+        # (no gc toggling here: the collector's state is process-global and other threads may own it;
+        # callers who want arrays without the ~10 Python objects per target use ik_batch_arrays)
+        xs, fs = x.tolist(), f.tolist()
+        return [(xs[t], fs[t]) if ok else None for t, ok in enumerate(found.tolist())]
 
     def diff_ik(self, x0, V_WE, v_max, ee_offset=None):
         """Returns (alpha, v) or None (optik.pyi:43-49; lib.rs:123-239): the joint velocities
@@ -273,12 +269,12 @@ class Robot:
         """Flat chain (types, origins[J,7], axes[J,3], lb, ub) as loaded by the C++ URDF loader."""
         nj = C.c_int32(0)
         # first call: joint count only (NULL buffers), then buffers of exactly that size
-        if self._L.optik_robot_chain_tables(self._h, C.byref(nj), None, None, None):
+        if self._L.optik_robot_chain_tables_n(self._h, 0, C.byref(nj), None, None, None):
             raise RuntimeError(_err(self._L))
         origins, axes = np.zeros(nj.value * 7), np.zeros(nj.value * 3)
         types = np.zeros(nj.value, dtype=np.int32)
-        if self._L.optik_robot_chain_tables(self._h, C.byref(nj), _dp(origins), _dp(axes),
-                                            types.ctypes.data_as(C.POINTER(C.c_int32))):
+        if self._L.optik_robot_chain_tables_n(self._h, nj.value, C.byref(nj), _dp(origins), _dp(axes),
+                                              types.ctypes.data_as(C.POINTER(C.c_int32))):
             raise RuntimeError(_err(self._L))
         J = nj.value
         lb, ub = self.joint_limits()

@@ -1,0 +1,41 @@
+"""bench.py's rank accounting, without a GPU: `--gpus N` must either BE N ranks or refuse.  (The
+runs themselves are -m gpu: tests/test_gpu_bench_ranks.py.)"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def test_gpus_flag_disagreeing_with_the_launcher_is_refused():
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2"], cwd=ROOT, capture_output=True, text=True,
+                       env=_clean_env(WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"), timeout=300)
+    assert r.returncode != 0
+    assert "refusing" in r.stderr and "WORLD_SIZE=3" in r.stderr
+    assert '{"metric"' not in r.stdout
+
+
+def test_gpus_flag_without_a_launcher_spawns_that_many_ranks():
+    """No GPU here: every spawned rank must stop at 'needs a GPU' -- two of them, from one command."""
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT,
+                       capture_output=True, text=True, env=_clean_env(), timeout=600)
+    import torch
+    if torch.cuda.is_available():  # on a GPU box the run simply succeeds with two ranks
+        assert r.returncode == 0 and '"n_gpus": 2' in r.stdout
+        return
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-3000:]
+    assert '{"metric"' not in r.stdout
+
+
+def test_inprocess_refuses_a_multi_rank_launcher():
+    r = subprocess.run([sys.executable, "bench.py", "--inprocess", "--gpus", "2"], cwd=ROOT, capture_output=True,
+                       text=True, env=_clean_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=300)
+    assert r.returncode != 0 and "one process" in r.stderr

@@ -86,3 +86,43 @@ def test_config5_targets_sharded_two_ranks():
     # rank 0 reports its own targets: the first 32 of every step
     assert b["config"]["winner_index_per_step"] == a["config"]["winner_index_per_step"]
     assert a["config"]["solved_targets"] >= 3 * 60 and b["config"]["solved_targets"] >= 3 * 30
+
+
+@pytest.mark.gpu
+def test_plain_gpus_flag_spawns_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it must run TWO ranks (it re-executes under
+    torch.distributed.run) and say so: n_gpus == 2, both ranks listed, the 1-rank winners."""
+    common = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--reps", "2"]
+    one = subprocess.run([sys.executable, "bench.py", "--restarts", "4096", *common], cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(OPTIK_BENCH_BACKEND="gloo", OPTIK_BENCH_ONE_DEVICE="1")
+    two = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--restarts", "2048", *common], cwd=ROOT,
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a, b = _line(one.stdout), _line(two.stdout)
+    assert a["n_gpus"] == 1 and b["n_gpus"] == 2
+    assert b["config"]["world"] == 2 and b["config"]["backend"] == "gloo"
+    assert sorted(d["rank"] for d in b["config"]["rank_devices"]) == [0, 1]
+    assert len({d["pid"] for d in b["config"]["rank_devices"]}) == 2
+    assert b["config"]["winner_index_per_step"] == a["config"]["winner_index_per_step"]
+    assert len(b["config"]["value_reps"]) == 2 and b["config"]["value_min"] <= b["value"] <= b["config"]["value_max"]
+
+
+@pytest.mark.gpu
+def test_inprocess_two_devices_reports_two_gpus():
+    """`--inprocess --gpus 2`: one process, two device contexts (the test box's GPU listed twice)
+    behind optik_robot_set_devices; the winner is the one a single device finds in the same range."""
+    common = ["--inprocess", "--steps", "2", "--warmup", "1", "--reps", "1", "--restarts", "4096"]
+    env = dict(os.environ, OPTIK_BENCH_ONE_DEVICE="1")
+    two = subprocess.run([sys.executable, "bench.py", "--gpus", "2", *common], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    common[-1] = "8192"
+    one = subprocess.run([sys.executable, "bench.py", "--gpus", "1", *common], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    a, b = _line(one.stdout), _line(two.stdout)
+    assert b["n_gpus"] == 2 and b["config"]["inprocess"] and b["config"]["devices"] == [0, 0]
+    assert a["config"]["winner_index_per_step"] == b["config"]["winner_index_per_step"]

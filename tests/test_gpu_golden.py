@@ -75,3 +75,59 @@ def test_restarts_and_winners_match_fixture(hip_chains, robot, rule, path):
                 assert_bit_equal(out["win_f"].cpu().numpy(), [w["f"]], "winner f vs fixture")
     finally:
         hc.set_range_rule(nat.RANGE_SINGLE_INCLUSIVE)
+
+
+# ---- the HIP math functions against the reference's OWN golden vectors (a6-a9), directly ----------
+# /root/reference/crates/optik/tests/test_math.rs:14-61 (ground truth from Pinocchio), abs 1e-6 as
+# there; the fixtures are the reference's data files (tests/golden/reference/README.md).
+
+REF_TOL = 1e-6
+
+
+def _ref(name):
+    from conftest import REF_GOLDEN
+    with open(os.path.join(REF_GOLDEN, name)) as fh:
+        return json.load(fh)
+
+
+def _math_inputs():
+    inp = _ref("test_math_inputs.json")
+    return np.array([list(i["translation"]) + list(i["rotation"]) for i in inp], dtype=np.float64)
+
+
+def test_hip_so3_log_vs_reference_fixture():
+    from optik_amd import device
+    want = np.array([np.ravel(o) for o in _ref("test_math_outputs_so3_log.json")])
+    np.testing.assert_allclose(device.probe_math(0, _math_inputs()), want, atol=REF_TOL, rtol=0)
+    # test_math.rs:24-30: the zero rotation
+    z = device.probe_math(0, np.array([[0, 0, 0, 0, 0, 0, 1.0]]))
+    np.testing.assert_allclose(z, np.zeros((1, 3)), atol=REF_TOL, rtol=0)
+
+
+def test_hip_so3_right_jacobian_vs_reference_fixture():
+    from optik_amd import device
+    want = np.array([np.array(o).reshape(3, 3).T for o in _ref("test_math_outputs_so3_right_jacobian.json")])
+    np.testing.assert_allclose(device.probe_math(1, _math_inputs()), want, atol=REF_TOL, rtol=0)
+
+
+def test_hip_se3_log_vs_reference_fixture():
+    from optik_amd import device
+    want = np.array([np.ravel(o) for o in _ref("test_math_outputs_se3_log.json")])
+    np.testing.assert_allclose(device.probe_math(2, _math_inputs()), want, atol=REF_TOL, rtol=0)
+
+
+def test_hip_se3_right_jacobian_vs_reference_fixture():
+    from optik_amd import device
+    want = np.array([np.array(o).reshape(6, 6).T for o in _ref("test_math_outputs_se3_right_jacobian.json")])
+    np.testing.assert_allclose(device.probe_math(3, _math_inputs()), want, atol=REF_TOL, rtol=0)
+
+
+def test_hip_math_probes_equal_the_oracle_bit_for_bit(oracle):
+    from optik_amd import device
+    p = _math_inputs()
+    assert_bit_equal(device.probe_math(0, p), np.array([oracle.so3_log(r[3:]) for r in p]), "so3::log")
+    assert_bit_equal(device.probe_math(1, p), np.array([oracle.so3_right_jacobian(oracle.so3_log(r[3:])) for r in p]),
+                     "so3::right_jacobian")
+    assert_bit_equal(device.probe_math(2, p), np.array([oracle.se3_log(r[:3], r[3:]) for r in p]), "se3::log")
+    assert_bit_equal(device.probe_math(3, p), np.array([oracle.se3_right_jacobian(r[:3], r[3:]) for r in p]),
+                     "se3::right_jacobian")
