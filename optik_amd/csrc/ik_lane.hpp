@@ -1,0 +1,62 @@
+// ik_lane.hpp -- cross-lane primitives of a QUAD: four adjacent lanes that share one restart.
+//
+// gfx950: a value moves between the lanes of a quad with DPP quad_perm row moves -- two
+// v_mov_b32_dpp per double, no LDS round trip (ds_bpermute costs an LDS issue and ~60 cycles of
+// latency per value).  The source lane must be a compile-time constant for DPP; every call site
+// has one after unrolling (joint k lives in lane k & 3).
+#pragma once
+
+#include "ik_math.hpp"
+
+namespace optik {
+
+constexpr int QUAD = 4;
+
+OPTIK_DEV int quad_lane() { return (int)(threadIdx.x & 3u); }
+OPTIK_DEV int quad_base() { return (int)(threadIdx.x & 63u) & ~3; }
+
+#ifdef OPTIK_LANE_EMU
+OPTIK_DEV double quad_get(double v, int k) { return __shfl(v, quad_base() + (k & 3), 64); }
+OPTIK_DEV int quad_get(int v, int k) { return __shfl(v, quad_base() + (k & 3), 64); }
+#else
+template <int K>
+OPTIK_DEV double quad_get_c(double v) {
+    return __builtin_amdgcn_update_dpp(0.0, v, K * 0x55, 0xf, 0xf, false);  // quad_perm:[K,K,K,K]
+}
+template <int K>
+OPTIK_DEV int quad_get_c(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, K * 0x55, 0xf, 0xf, false);
+}
+// value held by lane k & 3 of the caller's quad (k: a constant after unrolling)
+OPTIK_DEV double quad_get(double v, int k) {
+    switch (k & 3) {
+    case 0: return quad_get_c<0>(v);
+    case 1: return quad_get_c<1>(v);
+    case 2: return quad_get_c<2>(v);
+    default: return quad_get_c<3>(v);
+    }
+}
+OPTIK_DEV int quad_get(int v, int k) {
+    switch (k & 3) {
+    case 0: return quad_get_c<0>(v);
+    case 1: return quad_get_c<1>(v);
+    case 2: return quad_get_c<2>(v);
+    default: return quad_get_c<3>(v);
+    }
+}
+#endif
+
+// does p hold in some / every lane of the caller's quad
+OPTIK_DEV bool quad_any(bool p) {
+    const unsigned long long m = __ballot(p);
+    return ((m >> quad_base()) & 0xfull) != 0ull;
+}
+OPTIK_DEV bool quad_all(bool p) { return !quad_any(!p); }
+
+// LDS written by some lanes of the wave is about to be read by others
+OPTIK_DEV void lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+}  // namespace optik

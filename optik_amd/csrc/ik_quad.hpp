@@ -1,0 +1,910 @@
+// ik_quad.hpp -- the restart solver with one restart per QUAD and its state SPREAD over the quad.
+//
+// ik_coop.hpp (round 2) already gives a restart four lanes, but keeps the whole SLSQP state in the
+// quad's leader: 512 registers + 428 B of scratch, one wave per SIMD, three lanes idle outside the
+// NNLS and the Jacobian columns.  Here lane q of a quad owns joints / rows / columns q and q + 4:
+//
+//   by joint (2 doubles per lane each)   x, x0, g, s, x_best, x_prev, lb, ub, f (LSQ right-hand side)
+//   row j of the packed LDL' factor      l(i, j), i < j, and the diagonal l(j, j)       (11 doubles, n = 7)
+//   column j of E = D^1/2 L'             E[i][j], i < j, and E[j][j]                     (same shape)
+//   rows q, q + 4 of E^-1                = NNLS columns q, q + 4 (lower bounds), n + q, n + q + 4 (upper)
+//   Jacobian columns q, q + 4            -> gradient components q, q + 4
+//
+// and every scalar of Kraft's / NLopt's state machine is replicated in the four lanes.  Values move
+// between the lanes of a quad with DPP quad_perm moves (ik_lane.hpp), never through LDS; the only
+// LDS of the solver is the NNLS window of ik_nnls_coop.hpp.
+//
+// Bit-exactness (the contract of DESIGN.md section 2): every sum the reference / oracle forms
+// sequentially is formed here in the SAME ORDER from the same products -- either inside one lane
+// (column j of E holds all the terms of f_j's recurrence, row j of L all the terms of (L' v)_j) or,
+// where the terms live in different lanes, by fetching them one at a time in index order into an
+// accumulator every lane carries (quad_dot).  What is spread over the lanes is work whose pieces
+// are independent: sin / cos and local frames of different joints, Jacobian columns, rows of E^-1,
+// the row updates of a rank-one LDL' modification, the three quotients of one of its pivots.
+//
+// Restates, per quad: /root/reference/crates/optik/src/lib.rs:301-391 (the restart closure) with
+// NLopt's SLSQP (un-vendored; oracle/optik_oracle.c is the CPU statement of the same arithmetic).
+#pragma once
+
+#include "ik_lane.hpp"
+#include "ik_solve.hpp"
+#include "ik_nnls_coop.hpp"
+
+namespace optik {
+
+template <int N>
+struct QuadDims {
+    static constexpr int NS = (N > 4) ? 2 : 1;       // joints (rows, columns) a lane owns: q and q + 4
+    static constexpr int NM = (N > 1) ? N - 1 : 1;   // entries below the diagonal a row can have
+};
+
+// can a row of slot s (rows 4 s .. 4 s + 3) have an entry in column i (i.e. some row > i, row < N)
+template <int N>
+OPTIK_DEV constexpr bool slot_has(int s, int i) { return i < N - 1 && (s == 1 || i < 3); }
+
+OPTIK_DEV unsigned long long quad_get_u64(unsigned long long v, int k) {
+    const int lo = quad_get((int)(unsigned)(v & 0xffffffffull), k);
+    const int hi = quad_get((int)(unsigned)(v >> 32), k);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
+}
+
+// sum_k a_k b_k over the joints in index order, starting from +0.0 (the oracle's `acc = 0; acc += ...`):
+// products where the operands live, one fetch per term.  Same value in every lane of the quad.
+template <int N, int NS>
+OPTIK_DEV double quad_dot(const double (&a)[NS], const double (&b)[NS]) {
+    double p[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) p[s] = a[s] * b[s];
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc += quad_get(p[k >> 2], k);
+    return acc;
+}
+
+OPTIK_DEV Pose pose_sel(bool c, const Pose a, const Pose b) {
+    Pose o;
+    o.t = V3{c ? a.t.x : b.t.x, c ? a.t.y : b.t.y, c ? a.t.z : b.t.z};
+    o.q = Q4{c ? a.q.i : b.q.i, c ? a.q.j : b.q.j, c ? a.q.k : b.q.k, c ? a.q.w : b.q.w};
+    return o;
+}
+
+// ---- objective + gradient (ik_eval.hpp:eval_fg_stream, spread over the quad) ---------------------
+// x by joint in, gradient by joint out; f in every lane.  sin / cos and origin * local of a joint
+// are computed by its owner (kinematics.rs:142-158 forms `joint.origin * local_transform(q)` before
+// multiplying it onto the chain: independent per joint); the chain product itself is sequential
+// and every lane walks it, keeping the frames of its own joints; the error terms are formed by all
+// four lanes alike; each lane then does the Jacobian columns of its joints.
+template <int N, bool TIP>
+OPTIK_DEV double eval_quad(const ChainDev &ch, const EvalParams &ep, const Pose target,
+                           const double (&x)[QuadDims<N>::NS], double (&gout)[QuadDims<N>::NS]) {
+    constexpr int NS = QuadDims<N>::NS;
+    const int q = quad_lane();
+    Q4 jq[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int j = (q + 4 * s < N) ? q + 4 * s : N - 1;
+        double sn, cs;
+        sincos_dev(x[s] / 2.0, sn, cs);  // UnitQuaternion::from_axis_angle
+        const Q4 local{ch.axis[j][0] * sn, ch.axis[j][1] * sn, ch.axis[j][2] * sn, cs};
+        jq[s] = qmul(Q4{ch.origin[j][3], ch.origin[j][4], ch.origin[j][5], ch.origin[j][6]}, local);
+        OPTIK_SCHED_FENCE();
+    }
+    Pose tf[NS];  // T_w_j after joint j's own rotation, for the lane's joints (kinematics.rs:153-156)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { tf[s].t = V3{0, 0, 0}; tf[s].q = Q4{0, 0, 0, 1}; }
+    Pose state;
+    state.t = V3{0, 0, 0};
+    state.q = Q4{0, 0, 0, 1};
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int sk = k >> 2;
+        Pose jt;  // joint.origin * local_transform(q): the translation part is exact
+        jt.t = V3{ch.origin[k][0], ch.origin[k][1], ch.origin[k][2]};
+        jt.q = Q4{quad_get(jq[sk].i, k), quad_get(jq[sk].j, k), quad_get(jq[sk].k, k), quad_get(jq[sk].w, k)};
+        state = (k == 0) ? jt : pose_mul(state, jt);  // identity * jt is exact
+        tf[sk] = pose_sel(q == (k & 3), state, tf[sk]);
+        OPTIK_SCHED_FENCE();
+    }
+    if (TIP) state = pose_mul(state, load_pose(ch.origin[N]));
+    const Pose ee = ep.has_ee_offset ? pose_mul(state, load_pose(ep.ee_offset)) : state;  // kinematics.rs:163
+
+    // X = T_target^-1 T_ee  (objective.rs:69-70)
+    const Pose X = pose_inv_mul(target, ee);
+    const V3 w = so3_log(X.q);
+    const RotTerms rt = rot_terms(w);
+    const M3 Jr = so3_right_jacobian(rt);          // math.rs:195
+    const M3 Qm = se3_q_matrix(rt, X.t, Jr);       // math.rs:196 (E = Jr, math.rs:167)
+    const V3 elin = se3_log_linear(rt, X.t);       // math.rs:120-122
+
+    // weighted error for the value (objective.rs:52) and for the gradient (:104)
+    V3 fl = elin, fa = w;
+    if (!ep.skip_lin) fl = weight_block(target.q, elin, ep.w_lin);
+    if (!ep.skip_ang) fa = weight_block(target.q, w, ep.w_ang);
+    V3 gl = fl, ga = fa;
+    if (!ep.grad_same_as_value) {
+        gl = elin; ga = w;
+        if (!ep.skip_lin2) gl = weight_block(target.q, elin, ep.w_lin2);
+        if (!ep.skip_ang2) ga = weight_block(target.q, w, ep.w_ang2);
+    }
+    const double e2[6] = {2.0 * gl.x, 2.0 * gl.y, 2.0 * gl.z, 2.0 * ga.x, 2.0 * ga.y, 2.0 * ga.z};
+    // f = ||e||^2 (objective.rs:56)
+    const double ef[6] = {fl.x, fl.y, fl.z, fa.x, fa.y, fa.z};
+    double f = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) f += ef[i] * ef[i];
+    OPTIK_SCHED_FENCE();
+
+    // the lane's joints: body-frame Jacobian column (kinematics.rs:173-184), then
+    // Jtask = Jlog6 * J (objective.rs:81) and g = (2 e') Jtask (objective.rs:106-109)
+    const Q4 eeqc = qconj(ee.q);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int k = (q + 4 * s < N) ? q + 4 * s : N - 1;
+        const V3 tk = tf[s].t;
+        const Q4 tq = tf[s].q;
+        const V3 ax{ch.axis[k][0], ch.axis[k][1], ch.axis[k][2]};
+        const V3 angular = qrot(tq, ax);
+        const V3 d{ee.t.x - tk.x, ee.t.y - tk.y, ee.t.z - tk.z};
+        const V3 linear = cross(angular, d);
+        const V3 al = qrot(eeqc, angular);
+        const V3 ll = qrot(eeqc, linear);
+        const double lin[3] = {ll.x, ll.y, ll.z};
+        const double ang[3] = {al.x, al.y, al.z};
+        double jt[6];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            double acc = 0.0;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) acc += Jr.m[r][m] * lin[m];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) acc += Qm.m[r][m] * ang[m];
+            jt[r] = acc;
+            double acc2 = 0.0;  // lower-left block of Jlog6 is zero
+#pragma unroll
+            for (int m = 0; m < 3; ++m) acc2 += Jr.m[r][m] * ang[m];
+            jt[r + 3] = acc2;
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) acc += e2[r] * jt[r];
+        gout[s] = acc;
+        OPTIK_SCHED_FENCE();
+    }
+    return f;
+}
+
+// nlopt_stop_x (ik_solve.hpp:stop_x) on by-joint vectors: the per-joint tests, then "all of them" over the quad
+template <int N>
+OPTIK_DEV bool stop_x_quad(const SolveParams &sp, const double (&x)[QuadDims<N>::NS],
+                           const double (&oldx)[QuadDims<N>::NS]) {
+    constexpr int NS = QuadDims<N>::NS;
+    const int q = quad_lane();
+    bool zero = true, allx = true;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const bool val = q + 4 * s < N;
+        zero = zero && (!val || x[s] == oldx[s]);
+        allx = allx && (!val || !(__builtin_fabs(x[s] - oldx[s]) >= sp.xtol_abs));
+    }
+    const bool zero_q = quad_all(zero), allx_q = quad_all(allx);
+    return (sp.stop_x_zero != 0 && zero_q) || allx_q;
+}
+
+// ---- Fletcher-Powell composite-t update LDL' += sigma z z' (ik_slsqp.hpp:ldl_update) -----------
+// Row j of the factor and z_j live with joint j's owner.  Per pivot i: z_i and l(i,i) are fetched
+// from the owner, the pivot's scalars are formed by every lane, the three quotients tp/t, delta/tp,
+// t/tp by lanes 0, 1, 2 at once (one division's time), and every lane updates its own rows j > i.
+// `live`: the quad really performs the update (the others run the same instructions on whatever
+// they hold and keep their state).
+template <int N>
+OPTIK_DEV void ldl_quad(bool live, double (&Lr)[QuadDims<N>::NS][QuadDims<N>::NM], double (&dg)[QuadDims<N>::NS],
+                        double (&z)[QuadDims<N>::NS], double sigma) {
+    constexpr int NS = QuadDims<N>::NS;
+    const int q = quad_lane();
+    live = live && sigma != 0.0;
+    const bool neg = sigma < 0.0;
+    double w[NS];
+    double t = 1.0 / sigma;
+    if (wave_any(live && neg)) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) w[s] = z[s];
+        double tn = t;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double v = quad_get(w[i >> 2], i);
+            const double aii = quad_get(dg[i >> 2], i);
+            tn += v * v / aii;
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                if (slot_has<N>(s, i)) w[s] = (q + 4 * s > i) ? w[s] - v * Lr[s][i] : w[s];
+            OPTIK_SCHED_FENCE();
+        }
+        if (tn >= 0.0) tn = EPMACH / sigma;
+        // t_j = t_(j+1) - w_j^2 / l(j,j): the quotients are independent, each owner forms its own
+        double c[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) c[s] = w[s] * w[s] / dg[s];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int j = N - 1 - i;
+            w[j >> 2] = (q == (j & 3)) ? tn : w[j >> 2];
+            tn -= quad_get(c[j >> 2], j);
+        }
+        t = neg ? tn : t;
+    } else {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) w[s] = 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int si = i >> 2;
+        const double v = quad_get(z[si], i);
+        const double aii = quad_get(dg[si], i);
+        const double wi = quad_get(w[si], i);
+        const double delta = v / aii;
+        const double tp = neg ? wi : t + delta * v;
+        // alpha = tp / t (lane 0), beta = delta / tp (lane 1), gamma = t / tp (lane 2)
+        const double num = (q == 0) ? tp : ((q == 1) ? delta : t);
+        const double den = (q == 0) ? t : tp;
+        const double quo = num / den;
+        const double alpha = quad_get(quo, 0);
+        dg[si] = (live && q == (i & 3)) ? alpha * aii : dg[si];
+        if (i < N - 1) {
+            const double beta = quad_get(quo, 1), gamma = quad_get(quo, 2);
+            const bool big = alpha > 4.0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (!slot_has<N>(s, i)) continue;
+                const bool below = live && (q + 4 * s > i) && (q + 4 * s < N);
+                const double u = Lr[s][i];
+                const double zn = z[s] - v * u;
+                const double a_big = gamma * u + beta * z[s];
+                const double a_small = u + beta * zn;
+                Lr[s][i] = below ? (big ? a_big : a_small) : u;
+                z[s] = below ? zn : z[s];
+            }
+            t = tp;
+        }
+        OPTIK_SCHED_FENCE();
+    }
+}
+
+// BFGS update of the LDL' factor with Powell damping (ik_slsqp.hpp:bfgs_update); u = g_new - g_old on
+// entry (destroyed), s = the accepted step, both by joint.
+template <int N>
+OPTIK_DEV void bfgs_quad(bool live, double (&Lr)[QuadDims<N>::NS][QuadDims<N>::NM], double (&dg)[QuadDims<N>::NS],
+                         const double (&sv)[QuadDims<N>::NS], double (&u)[QuadDims<N>::NS]) {
+    constexpr int NS = QuadDims<N>::NS;
+    const int q = quad_lane();
+    double v[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) v[s] = 0.0;
+    // v = L' s: v_i = s_i + sum_{j > i} l(i,j) s_j -- the terms of one sum live with the owners of rows j
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double p[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) p[s] = slot_has<N>(s, i) ? Lr[s][i] * sv[s] : 0.0;
+        double h = 0.0;
+#pragma unroll
+        for (int j = i + 1; j < N; ++j) h += quad_get(p[j >> 2], j);
+        const double vi = sv[i >> 2] + h;
+        v[i >> 2] = (q == (i & 3)) ? vi : v[i >> 2];
+    }
+    // v = D v
+#pragma unroll
+    for (int s = 0; s < NS; ++s) v[s] = dg[s] * v[s];
+    // v = L v: v_i += sum_{j < i} l(j,i) v_j with the v_j of before this pass -- row i holds every factor
+    {
+        double vb[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) vb[j] = quad_get(v[j >> 2], j);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            double h = 0.0;
+#pragma unroll
+            for (int j = 0; j < N - 1; ++j)
+                if (slot_has<N>(s, j)) h = (j < q + 4 * s) ? h + Lr[s][j] * vb[j] : h;
+            v[s] += h;
+        }
+    }
+    double h1 = quad_dot<N, NS>(sv, u);
+    const double h2 = quad_dot<N, NS>(sv, v);
+    const double h3 = h2 * 0.2;
+    {
+        const bool damp = h1 < h3;
+        const double h4 = (h2 - h3) / (h2 - h1);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const double ud = u[s] * h4 + (1.0 - h4) * v[s];
+            u[s] = damp ? ud : u[s];
+        }
+        h1 = damp ? h3 : h1;
+    }
+    OPTIK_SCHED_FENCE();
+    ldl_quad<N>(live, Lr, dg, u, 1.0 / h1);
+    OPTIK_SCHED_FENCE();
+    ldl_quad<N>(live, Lr, dg, v, -1.0 / h2);
+    OPTIK_SCHED_FENCE();
+}
+
+// ---- Kraft LSQ pieces (ik_slsqp.hpp: lsq_factor, lsq_bound_rows, ldp tail, lsq_finish) ------------
+
+// E = D^1/2 L' by column (column j with joint j's owner: Ec[s][i] = E[i][row], i < row; Ed = E[row][row]),
+// f = -E^-T g by joint, then Kraft's LSI Householder pass.  Returns 1, or 5 (E numerically singular);
+// the same value in every lane of the quad.
+template <int N>
+OPTIK_DEV int lsq_factor_quad(const double (&Lr)[QuadDims<N>::NS][QuadDims<N>::NM], const double (&dg)[QuadDims<N>::NS],
+                              const double (&g)[QuadDims<N>::NS], double (&Ec)[QuadDims<N>::NS][QuadDims<N>::NM],
+                              double (&Ed)[QuadDims<N>::NS], double (&fv)[QuadDims<N>::NS]) {
+    constexpr int NS = QuadDims<N>::NS;
+    const int q = quad_lane();
+    double sd[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) sd[s] = __builtin_sqrt(dg[s]);
+#pragma unroll
+    for (int i = 0; i < N - 1; ++i) {
+        const double sdi = quad_get(sd[i >> 2], i);
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            if (slot_has<N>(s, i)) Ec[s][i] = Lr[s][i] * sdi;
+    }
+    // f_i = (g_i - sum_{k < i} E[k][i] f_k) / E[i][i]: column i holds every factor of its sum
+    double acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { Ed[s] = sd[s]; acc[s] = 0.0; }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int si = i >> 2;
+        const double fi = quad_get((g[si] - acc[si]) / sd[si], i);
+        fv[si] = (q == (i & 3)) ? fi : fv[si];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            if (slot_has<N>(s, i)) acc[s] = (q + 4 * s > i) ? acc[s] + Ec[s][i] * fi : acc[s];
+        OPTIK_SCHED_FENCE();
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) fv[s] = -fv[s];
+
+    // LSI: "QR" of the already-triangular E: row i's reflection depends on E[i][i] only, so every
+    // owner prepares the reflections of its own rows (rows 0 .. N-2 have one) ...
+    double up[NS], binv[NS];
+    int act[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int r = q + 4 * s;
+        const double p = Ed[s];
+        double cl = __builtin_fabs(p);
+        const bool nz = !(cl <= 0.0) && r < N - 1;
+        const double clinv = 1.0 / cl;
+        const double d = p * clinv;
+        const double sm0 = d * d;
+        cl *= __builtin_sqrt(sm0);
+        if (p > 0.0) cl = -cl;
+        up[s] = p - cl;
+        Ed[s] = nz ? cl : Ed[s];
+        const double b = up[s] * cl;
+        const bool a = nz && !(b >= 0.0);
+        act[s] = a ? 1 : 0;
+        binv[s] = 1.0 / b;
+        const double sm = fv[s] * up[s];
+        if (a && sm != 0.0) fv[s] += (sm * binv[s]) * up[s];
+    }
+    // ... and row i's reflection is applied to E[i][j], j > i, by the owners of the columns j
+#pragma unroll
+    for (int i = 0; i < N - 1; ++i) {
+        const double upi = quad_get(up[i >> 2], i), bi = quad_get(binv[i >> 2], i);
+        const bool ai = quad_get(act[i >> 2], i) != 0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (!slot_has<N>(s, i)) continue;
+            const double sm = Ec[s][i] * upi;
+            const bool on = ai && (q + 4 * s > i) && sm != 0.0;
+            Ec[s][i] = on ? Ec[s][i] + (sm * bi) * upi : Ec[s][i];
+        }
+    }
+    bool singular = false;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) singular = singular || (q + 4 * s < N && !(__builtin_fabs(Ed[s]) >= EPMACH));
+    return quad_any(singular) ? 5 : 1;
+}
+
+// Rows q, q + 4 of E^-1 (row[s][j], j >= the row; zero before it) and the two bound rows each gives
+// (ik_slsqp.hpp:lsq_bound_rows).  The rows are independent recurrences: one or two per lane, all at
+// once; E's entries come from their column owners.  Returns whether some h > 0 in the quad.
+template <int N>
+OPTIK_DEV bool bound_rows_quad(const double (&Ec)[QuadDims<N>::NS][QuadDims<N>::NM], const double (&Ed)[QuadDims<N>::NS],
+                               const double (&fv)[QuadDims<N>::NS], const double (&lo)[QuadDims<N>::NS],
+                               const double (&hi)[QuadDims<N>::NS], double (&row)[QuadDims<N>::NS][N],
+                               double (&h_lo)[QuadDims<N>::NS], double (&h_hi)[QuadDims<N>::NS]) {
+    constexpr int NS = QuadDims<N>::NS;
+    const int q = quad_lane();
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const double ejj = quad_get(Ed[j >> 2], j);
+        double acc[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] = 0.0;
+#pragma unroll
+        for (int k = 0; k < j; ++k) {
+            const double ekj = quad_get(Ec[j >> 2][k], j);  // E[k][j]: entry k of column j
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (s == 1 && k < 4) continue;  // rows 4.. start at column >= 4
+                acc[s] = (k >= q + 4 * s) ? acc[s] + row[s][k] * ekj : acc[s];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (s == 1 && j < 4) { row[s][j] = 0.0; continue; }
+            const int r = q + 4 * s;
+            const double v = (((j == r) ? 1.0 : 0.0) - acc[s]) / ejj;
+            row[s][j] = (j >= r) ? v : 0.0;
+        }
+        OPTIK_SCHED_FENCE();
+    }
+    bool need = false;
+    double acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const double fj = quad_get(fv[j >> 2], j);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (s == 1 && j < 4) continue;
+            acc[s] = (j >= q + 4 * s) ? acc[s] + row[s][j] * fj : acc[s];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        h_lo[s] = lo[s] - acc[s];
+        h_hi[s] = (-hi[s]) - (-acc[s]);
+        need = need || (q + 4 * s < N && (h_lo[s] > 0.0 || h_hi[s] > 0.0));
+    }
+    return quad_any(need);
+}
+
+// LDP tail from the NNLS multipliers (ik_engine.hpp:ldp_from_record): the transformed-space step,
+// by joint.  ylo / yhi: multipliers of the lane's lower- / upper-bound columns.  Returns the mode.
+template <int N>
+OPTIK_DEV int ldp_quad(int mode, double rnorm, const double (&row)[QuadDims<N>::NS][N], const double (&h_lo)[QuadDims<N>::NS],
+                       const double (&h_hi)[QuadDims<N>::NS], const double (&ylo)[QuadDims<N>::NS],
+                       const double (&yhi)[QuadDims<N>::NS], double (&sv)[QuadDims<N>::NS]) {
+    constexpr int NS = QuadDims<N>::NS;
+    const int q = quad_lane();
+    if (mode == 1 && rnorm <= 0.0) mode = 4;
+    double plo[NS], phi[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { plo[s] = h_lo[s] * ylo[s]; phi[s] = h_hi[s] * yhi[s]; }
+    double hy = 0.0;
+#pragma unroll
+    for (int r = 0; r < N; ++r) hy += quad_get(plo[r >> 2], r);
+#pragma unroll
+    for (int r = 0; r < N; ++r) hy += quad_get(phi[r >> 2], r);
+    double fac = 1.0 - hy;
+    const double d1 = 1.0 + fac;
+    if (mode == 1 && d1 - 1.0 <= 0.0) mode = 4;
+    fac = 1.0 / fac;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double a[NS], b[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { a[s] = row[s][j] * ylo[s]; b[s] = (-row[s][j]) * yhi[s]; }
+        double acc = 0.0;
+#pragma unroll
+        for (int r = 0; r <= j; ++r) acc += quad_get(a[r >> 2], r);
+#pragma unroll
+        for (int r = 0; r <= j; ++r) acc += quad_get(b[r >> 2], r);
+        const double sj = fac * acc;
+        sv[j >> 2] = (q == (j & 3)) ? sj : sv[j >> 2];
+        OPTIK_SCHED_FENCE();
+    }
+    return mode;
+}
+
+// s (transformed space) -> s = E^-1 (s + f), clipped into [lo, hi] (ik_slsqp.hpp:lsq_finish).
+template <int N>
+OPTIK_DEV void lsq_finish_quad(const double (&Ec)[QuadDims<N>::NS][QuadDims<N>::NM], const double (&Ed)[QuadDims<N>::NS],
+                               const double (&fv)[QuadDims<N>::NS], const double (&lo)[QuadDims<N>::NS],
+                               const double (&hi)[QuadDims<N>::NS], double (&sv)[QuadDims<N>::NS]) {
+    constexpr int NS = QuadDims<N>::NS;
+    const int q = quad_lane();
+#pragma unroll
+    for (int s = 0; s < NS; ++s) sv[s] += fv[s];
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+        double p[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) p[s] = slot_has<N>(s, i) ? Ec[s][i] * sv[s] : 0.0;  // E[i][row] s_row
+        double acc = 0.0;
+#pragma unroll
+        for (int j = i + 1; j < N; ++j) acc += quad_get(p[j >> 2], j);
+        const int si = i >> 2;
+        const double t = (sv[si] - acc) / Ed[si];
+        sv[si] = (q == (i & 3)) ? t : sv[si];
+        OPTIK_SCHED_FENCE();
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (sv[s] < lo[s]) sv[s] = lo[s];
+        else if (sv[s] > hi[s]) sv[s] = hi[s];
+    }
+}
+
+// ---- the wave: 16 quads, each solving restarts until the queue is dry ----------------------------
+
+constexpr int QUADS_PER_WAVE = 64 / QUAD;
+
+// doubles of LDS per wave: the NNLS windows of its quads and the column of zeros (ik_nnls_coop.hpp)
+constexpr int quad_wave_lds() { return QUADS_PER_WAVE * COOP_WIN + 8; }
+
+template <int N, bool TIP>
+OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolveParams &sp, const uint32_t (&key)[8],
+                         const double (&scale)[MAX_DOF], const WorkQueue &wq,
+                         double *nnls_lds /* quad_wave_lds() doubles, the last 8 zero */) {
+    constexpr int NS = QuadDims<N>::NS, NM = QuadDims<N>::NM;
+    constexpr int CPL = 4;
+    const unsigned lane = threadIdx.x & 63u;
+    const int q = quad_lane();
+    const unsigned quad = lane / QUAD;
+    const bool member = (int)quad < wq.lanes;  // wq.lanes = restarts (quads) a wave holds at a time
+    const double alfmin = 0.1;
+
+    // the lane's joints
+    int jc[NS];
+    bool val[NS];
+    double lb[NS], ub[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        val[s] = q + 4 * s < N;
+        jc[s] = val[s] ? q + 4 * s : N - 1;
+        lb[s] = ch.lb[jc[s]];
+        ub[s] = ch.ub[jc[s]];
+    }
+
+    // SLSQP state of the quad's restart: by joint, by row, and the replicated scalars (names as in solve_wave)
+    double x[NS], x0[NS], g[NS], sv[NS], xb[NS], xp[NS];
+    double Lr[NS][NM], dg[NS];
+    double f = 0.0, f0 = 0.0, t0 = 0.0, h3 = 0.0, alpha = 1.0;
+    double minf = __builtin_huge_val(), fprev = __builtin_huge_val();
+    int ireset = 0, line = 0, nevals = 0;
+    bool first = true;
+    Pose target;
+    unsigned long long item = 0, index = 0;
+    unsigned tslot = 0;
+    bool active = false, want = member;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        x[s] = 0.0; x0[s] = 0.0; g[s] = 0.0; sv[s] = 0.0; xb[s] = 0.0; xp[s] = 0.0; dg[s] = 1.0;
+#pragma unroll
+        for (int i = 0; i < NM; ++i) Lr[s][i] = 0.0;
+    }
+    target.t = V3{0, 0, 0};
+    target.q = Q4{0, 0, 0, 1};
+    OPTIK_PROF_DECL;  // (-DOPTIK_PROFILE: slots 0 refill, 1 eval, 4 bookkeeping + BFGS, 5 direction, 6 NNLS of it, 3 publish, 7 trips)
+
+    for (;;) {
+        OPTIK_PROF_BEGIN();
+        // ---- refill: quads without a restart pull the next work item (the leader fetches) ----------
+        if (wave_any(want)) {
+            unsigned long long it = fetch_items(wq.next_item, want && q == 0);
+            it = quad_get_u64(it, 0);
+            if (want) {
+                want = false;
+                if (it < wq.total_items) {
+                    unsigned long long r;
+                    if (wq.restart_major) { r = it / wq.n_targets; tslot = (unsigned)(it - r * wq.n_targets); }
+                    else { tslot = (unsigned)(it / wq.n_restarts); r = it - (unsigned long long)tslot * wq.n_restarts; }
+                    item = (unsigned long long)tslot * wq.n_restarts + r;  // output column
+                    index = wq.restart_begin + r;
+                    target = load_pose(wq.targets + (size_t)tslot * 7);
+                    // lib.rs:366-370: restart 0 starts from the caller's seed
+                    double xs[N];
+                    restart_seed<N>(key, ch.lb, scale, index, xs);
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        double v = xs[4 * s];
+#pragma unroll
+                        for (int j = 4 * s + 1; j < N && j < 4 * s + 4; ++j) v = (jc[s] == j) ? xs[j] : v;
+                        if (index == 0) v = wq.x0[(size_t)tslot * N + jc[s]];
+                        x[s] = v; xb[s] = v; xp[s] = v; x0[s] = v; sv[s] = 0.0; g[s] = 0.0;
+                    }
+                    f = 0.0; f0 = 0.0; t0 = 0.0; h3 = 0.0; alpha = 1.0;
+                    minf = __builtin_huge_val(); fprev = __builtin_huge_val();
+                    ireset = 0; line = 0; nevals = 0;
+                    first = true;
+                    active = true;
+                }
+            }
+        }
+        OPTIK_PROF_END(0);
+        if (!wave_any(active)) break;
+        OPTIK_PROF_COUNT(7, 1);
+
+        int32_t ret = 0;
+        if (active) {
+            // lib.rs:308: abandon when timed out or another restart of the target succeeded
+            bool stop = false;
+            if (wq.first_success) {
+                const unsigned long long fs = __hip_atomic_load(wq.first_success + tslot, __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_AGENT);
+                stop = wq.find_any ? (fs != ~0ull) : (fs < index);
+            }
+            if (wq.deadline && (unsigned long long)wall_clock64() > wq.deadline) stop = true;
+            if (stop) ret = RES_FORCED_STOP;
+        }
+        // (the four lanes may have read first_success / the clock at different moments: the leader decides)
+        ret = quad_get(ret, 0);
+        const bool do_eval = active && ret == 0;
+        double gn[NS];
+        double fn = 0.0;
+        OPTIK_SCHED_FENCE();
+        OPTIK_PROF_BEGIN();
+        fn = eval_quad<N, TIP>(ch, ep, target, x, gn);
+        OPTIK_PROF_END(1);
+        OPTIK_SCHED_FENCE();
+
+        // ---- NLopt bookkeeping and Kraft's line search (labels 100 / 220), replicated scalars ------
+        OPTIK_PROF_BEGIN();
+        bool need_dir = false, reset = false, do_bfgs = false;
+        double u[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) u[s] = 0.0;
+        const bool sx_prev = (xprev_live(sp) && wave_any(do_eval && !first)) ? stop_x_quad<N>(sp, x, xp) : false;
+        if (do_eval) {
+            f = fn;
+            ++nevals;
+            // NLopt: update best point so far; stopval is tested after every evaluation
+            if (f < minf) {
+                minf = f;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) xb[s] = x[s];
+            }
+            if (minf < sp.stopval) {
+                ret = RES_STOPVAL_REACHED;
+            } else if (nevals >= MAX_EVALS_CAP) {
+                ret = RES_ITER_CAP;
+            } else if (first) {
+                // SLSQPB label 100/110: initialise, reset the BFGS matrix
+                first = false;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) g[s] = gn[s];
+                need_dir = true;
+                reset = true;
+            } else {
+                // label 220: L1 merit (m = 0: the objective itself)
+                const double h1 = f - t0;
+                bool accept = false;
+                if (__builtin_isfinite(h1)) {
+                    if (h1 <= h3 / 10.0 || line > 10) accept = true;
+                    else {
+                        const double a = h3 / ((h3 - h1) * 2.0);
+                        alpha = (a > alfmin) ? a : alfmin;
+                    }
+                } else {
+                    const double a = alpha * 0.5;
+                    alpha = (a > alfmin) ? a : alfmin;
+                }
+                if (accept) {
+                    // line search complete (mode -1): NLopt re-evaluates f and the gradient there
+                    // unless the accepted trial was the first one
+                    if (line > 1) ++nevals;
+                    if (!__builtin_isinf(fprev)) {
+                        if (__builtin_fabs(f - fprev) < sp.ftol_abs) ret = RES_FTOL_REACHED;
+                        else if (xprev_live(sp) && sx_prev) ret = RES_XTOL_REACHED;
+                    }
+                    fprev = f;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) xp[s] = x[s];
+                    if (ret == 0 && nevals >= MAX_EVALS_CAP) ret = RES_ITER_CAP;
+                    if (ret == 0) {
+                        // label 260: BFGS update with u = g_new - g_old
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) { u[s] = gn[s] - g[s]; g[s] = gn[s]; }
+                        do_bfgs = true;
+                        need_dir = true;
+                    }
+                }
+            }
+        }
+        OPTIK_SCHED_FENCE();
+        if (wave_any(do_bfgs)) bfgs_quad<N>(do_bfgs, Lr, dg, sv, u);
+        OPTIK_SCHED_FENCE();
+        OPTIK_PROF_END(4);
+
+        // ---- labels 110/130: (reset,) search direction, descent test: a wave-uniform loop, every
+        // quad that needs a direction takes part in every step of a round (ik_coop.hpp:coop_direction)
+        OPTIK_PROF_BEGIN();
+        while (wave_any(need_dir)) {
+            bool pass = need_dir;
+            const bool sx0 = stop_x_quad<N>(sp, x, x0);
+            if (pass && reset) {
+                ++ireset;
+                if (ireset > 5) {
+                    // label 255 with acc = 0 -> mode 8; NLopt's relaxed test vs (f0, x0)
+                    ret = RES_ROUNDOFF_LIMITED;
+                    if (__builtin_fabs(f - f0) < sp.ftol_abs && !__builtin_isinf(f0)) ret = RES_FTOL_REACHED;
+                    else if (sx0) ret = RES_XTOL_REACHED;
+                    need_dir = false;
+                    pass = false;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        dg[s] = 1.0;
+#pragma unroll
+                        for (int i = 0; i < NM; ++i) Lr[s][i] = 0.0;
+                    }
+                }
+            }
+            double Ec[NS][NM], Ed[NS], fv[NS], lo[NS], hi[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                lo[s] = lb[s] - x[s];
+                hi[s] = ub[s] - x[s];
+                fv[s] = 0.0;
+                Ed[s] = 1.0;
+#pragma unroll
+                for (int i = 0; i < NM; ++i) Ec[s][i] = 0.0;
+            }
+            OPTIK_SCHED_FENCE();
+            int lmode = lsq_factor_quad<N>(Lr, dg, g, Ec, Ed, fv);
+            OPTIK_SCHED_FENCE();
+            double row[NS][N], h_lo[NS], h_hi[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int j = 0; j < N; ++j) row[s][j] = 0.0;
+            bool need_nnls = bound_rows_quad<N>(Ec, Ed, fv, lo, hi, row, h_lo, h_hi);
+            need_nnls = need_nnls && pass && lmode == 1;
+            OPTIK_SCHED_FENCE();
+            // ---- the bounded dual problems of this round, one per quad, all 64 lanes -----------
+            double ylo[NS], yhi[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { ylo[s] = 0.0; yhi[s] = 0.0; }
+            int nmode = 1;
+            double rnorm = 1.0;
+            if (wave_any(need_nnls)) {
+#ifdef OPTIK_PROFILE
+                const unsigned long long t_nn = __builtin_readcyclecounter();
+#endif
+                dvec8 col[CPL];
+                int ids[CPL];
+                CoopCarry<CPL> cs;
+                cs.b = 0.0;
+                cs.up = 0.0;
+                cs.nsetp = 0;
+                cs.iter = 0;
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) {
+                    // column of row r = q + 4 s: k = s (lower bound, id r + 1), k = 2 + s (upper bound, id N + r + 1)
+                    const int s = k & 1;
+                    const bool neg = k >= 2;
+                    col[k] = 0.0;
+                    cs.xv[k] = 0.0;
+                    cs.pos[k] = 0;
+                    ids[k] = 0x7fff;
+                    if (s < NS) {
+                        const int r = q + 4 * s;
+                        ids[k] = (r < N) ? (neg ? N : 0) + r + 1 : 0x7fff;
+#pragma unroll
+                        for (int j = 0; j < N; ++j) {
+                            const double v = row[s][j];
+                            col[k][j] = neg ? ((j >= r) ? -v : 0.0) : v;
+                        }
+                        col[k][N] = neg ? h_hi[s] : h_lo[s];
+                    }
+                }
+                int iters;
+                auto park = [&](const dvec8 (&)[CPL], const CoopCarry<CPL> &) {};  // (never suspended: no budget)
+                nnls_coop_ids<N, CPL>(need_nnls, false, 0x3fffffff, ids, col, cs, nmode, rnorm, iters,
+                                      nnls_lds + quad * COOP_WIN, nnls_lds + QUADS_PER_WAVE * COOP_WIN, park);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) { ylo[s] = cs.xv[s]; yhi[s] = cs.xv[2 + s]; }
+#ifdef OPTIK_PROFILE
+                OPTIK_PROF_COUNT(6, __builtin_readcyclecounter() - t_nn);
+#endif
+            }
+            OPTIK_SCHED_FENCE();
+            double sn[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) sn[s] = 0.0;
+            if (wave_any(need_nnls)) {
+                const int m2 = ldp_quad<N>(nmode, rnorm, row, h_lo, h_hi, ylo, yhi, sn);
+                if (need_nnls) lmode = m2;
+                else {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) sn[s] = 0.0;
+                }
+            }
+            lsq_finish_quad<N>(Ec, Ed, fv, lo, hi, sn);
+            OPTIK_SCHED_FENCE();
+            const double gs = quad_dot<N, NS>(g, sn);
+            if (pass) {
+                if (lmode != 1) {
+                    // NLopt: modes 5,6,7 -> ROUNDOFF_LIMITED; 3,4,9 -> FAILURE
+                    ret = (lmode == 5 || lmode == 6 || lmode == 7) ? RES_ROUNDOFF_LIMITED : RES_FAILURE;
+                    need_dir = false;
+                } else {
+                    // (g is also Kraft's v: the gradient at the start of the line search)
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) { sv[s] = sn[s]; x0[s] = x[s]; }
+                    f0 = f;
+                    t0 = f;
+                    h3 = gs;  // h3 = gs - h1 * h4 with h1 = 0 (no constraints)
+                    if (h3 >= 0.0) {
+                        reset = true;  // not a descent direction: reset B and repeat
+                    } else {
+                        line = 0;
+                        alpha = 1.0;
+                        need_dir = false;
+                    }
+                }
+            }
+        }
+        OPTIK_PROF_END(5);
+        OPTIK_PROF_BEGIN();
+        if (do_eval && ret == 0) {
+            // label 190: next trial point x = x0 + alpha * s, clipped (NLopt)
+            ++line;
+            h3 = alpha * h3;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                sv[s] *= alpha;
+                double xi = x0[s];
+                xi += sv[s];
+                if (xi < lb[s]) xi = lb[s];
+                else if (xi > ub[s]) xi = ub[s];
+                x[s] = xi;
+            }
+        }
+        // ---- a restart ended: classify (lib.rs:376-379), publish, free the quad -------------------
+        const bool ended = active && ret != 0;
+        if (wave_any(ended)) {
+            const bool success = (sp.ok_stopval && ret == RES_STOPVAL_REACHED)
+                                 || (sp.ok_ftol && ret == RES_FTOL_REACHED)
+                                 || (sp.ok_xtol && ret == RES_XTOL_REACHED);
+            // selection key (lib.rs:402-407): Quality = ||x - x0||_2, Speed = index
+            double kq = 0.0;
+            if (wq.quality) {
+                double d2[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const double d = xb[s] - ((ended && val[s]) ? wq.x0[(size_t)tslot * N + jc[s]] : 0.0);
+                    d2[s] = d * d;
+                }
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) acc += quad_get(d2[i >> 2], i);
+                kq = __builtin_sqrt(acc);
+            }
+            if (ended) {
+                if (wq.out_x) {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s)
+                        if (val[s]) wq.out_x[(size_t)jc[s] * wq.total_items + item] = xb[s];
+                }
+                if (q == 0) {
+                    if (wq.out_f) wq.out_f[item] = minf;
+                    if (wq.out_status) wq.out_status[item] = ret;
+                    if (wq.out_evals) wq.out_evals[item] = nevals;
+                    double k = __builtin_huge_val();
+                    if (success) {
+                        if (wq.quality) k = kq;
+                        else {
+                            k = (double)index;
+                            if (wq.first_success) atomicMin(wq.first_success + tslot, index);
+                        }
+                    }
+                    if (wq.out_key) wq.out_key[item] = k;
+                }
+                active = false;
+                want = true;
+            }
+        }
+        OPTIK_PROF_END(3);
+    }
+    OPTIK_PROF_FLUSH(wq.prof);
+}
+
+}  // namespace optik

@@ -1,0 +1,100 @@
+// quad_emu.cpp -- TEST INFRASTRUCTURE: runs the quad-distributed restart solver of
+// optik_amd/csrc/ik_quad.hpp on the HOST (one thread per emulated lane, tests/emu/lane_emu.hpp) so
+// that tests/test_quad_emulation.py can compare every restart with the C oracle bit for bit without
+// a GPU.  The device headers are compiled as they are (only the cross-lane primitives and the HIP
+// intrinsics are swapped for their emulation), with -ffp-contract=off like the kernels.
+//
+// Not part of the product: nothing under optik_amd/ or bench.py builds, loads or calls this.
+#define OPTIK_LANE_EMU 1
+#include <thread>
+#include <vector>
+
+#include "ik_quad.hpp"
+#include "ik_host_params.hpp"
+
+using namespace optik;
+
+namespace {
+
+template <int N, bool TIP>
+void run_wave(const ChainDev &ch, const EvalParams &ep, const SolveParams &sp, const uint32_t (&key)[8],
+              const double (&scale)[MAX_DOF], const WorkQueue &wq, int quads) {
+    optik_emu::Wave wave;
+    wave.lanes = 4 * quads;
+    std::vector<double> lds((size_t)quad_wave_lds(), 0.0);
+    std::vector<std::thread> th;
+    for (int lane = 0; lane < wave.lanes; ++lane) {
+        th.emplace_back([&, lane]() {
+            optik_emu::t_wave = &wave;
+            threadIdx.x = (unsigned)lane;
+            quad_wave<N, TIP>(ch, ep, sp, key, scale, wq, lds.data());
+        });
+    }
+    for (auto &t : th) t.join();
+}
+
+}  // namespace
+
+extern "C" {
+
+// origins [J][7] (t, quat ijkw), axes [n][3], J = n or n + 1; restarts [begin, end) of ONE target.
+// out_x [n][R], out_f / out_key [R], out_status / out_evals [R].  quads: restarts in flight (1 .. 16).
+int quad_emu_solve(const double *origins, const double *axes, int n, int n_joints, const double *lb, const double *ub,
+                   const optik_solver_config *cfg, const double *target7, const double *x0, const double *ee_offset7,
+                   uint64_t restart_begin, uint64_t restart_end, int quads, int range_rule, double *out_x, double *out_f,
+                   double *out_key, int32_t *out_status, int32_t *out_evals) {
+    if (n < 1 || n > 7 || quads < 1 || quads > 16 || restart_end <= restart_begin) return -1;
+    ChainDev ch;
+    std::memset(&ch, 0, sizeof ch);
+    ch.n_pos = n;
+    ch.has_tip = n_joints == n + 1;
+    for (int j = 0; j < n_joints; ++j)
+        for (int c = 0; c < 7; ++c) ch.origin[j][c] = origins[j * 7 + c];
+    for (int j = 0; j < n; ++j) {
+        for (int c = 0; c < 3; ++c) ch.axis[j][c] = axes[j * 3 + c];
+        ch.lb[j] = lb[j];
+        ch.ub[j] = ub[j];
+    }
+    EvalParams ep;
+    hostparams::make_eval_params(cfg->linear_weight, cfg->angular_weight, ee_offset7, ep);
+    SolveParams sp;
+    hostparams::fill_solve_params(cfg, sp);
+    uint32_t key[8];
+    hostparams::seed_from_u64(42, key);
+    double scale[MAX_DOF] = {0};
+    for (int j = 0; j < n; ++j) scale[j] = hostparams::uniform_scale(lb[j], ub[j], range_rule);
+
+    unsigned long long counter = 0;
+    WorkQueue wq;
+    std::memset(&wq, 0, sizeof wq);
+    const uint64_t R = restart_end - restart_begin;
+    wq.next_item = &counter;
+    wq.total_items = R;
+    wq.n_restarts = R;
+    wq.restart_begin = restart_begin;
+    wq.targets = target7;
+    wq.x0 = x0;
+    wq.first_success = nullptr;
+    wq.n_targets = 1;
+    wq.quality = cfg->solution_mode == 1;
+    wq.lanes = quads;
+    wq.out_x = out_x;
+    wq.out_f = out_f;
+    wq.out_key = out_key;
+    wq.out_status = out_status;
+    wq.out_evals = out_evals;
+
+#define RUN(NN)                                                                              \
+    case NN:                                                                                 \
+        if (ch.has_tip) run_wave<NN, true>(ch, ep, sp, key, scale, wq, quads);               \
+        else run_wave<NN, false>(ch, ep, sp, key, scale, wq, quads);                         \
+        break;
+    switch (n) {
+        RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7)
+    default: return -1;
+    }
+#undef RUN
+    return 0;
+}
+
+}  // extern "C"
