@@ -13,9 +13,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "liboptik_amd.so")
-SOURCES = ["ik_kernels.hip", "robot_host.cpp"]
+SOURCES = ["ik_kernels.hip", "ik_quad_kernel.hip", "robot_host.cpp"]
 HEADERS = ["ik_math.hpp", "ik_eval.hpp", "ik_slsqp.hpp", "ik_solve.hpp", "ik_nnls_coop.hpp", "ik_engine.hpp",
-           "ik_tail.hpp", "ik_coop.hpp", "device_scope.hpp",
+           "ik_tail.hpp", "ik_coop.hpp", "device_scope.hpp", "ik_host_params.hpp", "ik_launch.hpp",
            "urdf_chain.hpp",
            os.path.join("..", "..", "include", "optik_hip.h"),
            os.path.join("..", "..", "include", "optik.h")]
@@ -23,9 +23,15 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
          "-Wno-unused-value", "-pthread"]
 # headers each translation unit depends on (a source is recompiled when one of them is newer than
 # its object file; the objects are build artefacts, git-ignored like the library)
+QUAD_HEADERS = ["ik_math.hpp", "ik_eval.hpp", "ik_slsqp.hpp", "ik_solve.hpp", "ik_nnls_coop.hpp", "ik_nnls_quad.hpp", "ik_lane.hpp",
+                "ik_quad.hpp", "ik_launch.hpp"]
 DEPS = {"ik_kernels.hip": HEADERS,
+        "ik_quad_kernel.hip": QUAD_HEADERS,
         "robot_host.cpp": ["urdf_chain.hpp", "device_scope.hpp", os.path.join("..", "..", "include", "optik_hip.h"),
                            os.path.join("..", "..", "include", "optik.h")]}
+
+
+EXTRA_FLAGS = {"ik_quad_kernel.hip": ["-DOPTIK_QUAD_WAVES=1"]}
 
 
 def _hipcc():
@@ -39,7 +45,7 @@ def is_stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS + QUAD_HEADERS]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
@@ -60,7 +66,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         t = os.path.getmtime(obj) if os.path.exists(obj) else -1.0
         deps = [sp] + [os.path.join(CSRC, d) for d in DEPS.get(src, HEADERS)]
         if force or t < 0 or any(_newer(d, t) for d in deps):
-            cmd = [hipcc, *FLAGS, "-x", "hip", "-c", sp, "-o", obj]
+            cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", sp, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd, cwd=CSRC)

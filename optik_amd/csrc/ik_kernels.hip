@@ -24,6 +24,7 @@
 #include "../../include/optik_hip.h"
 #include "device_scope.hpp"
 #include "ik_host_params.hpp"
+#include "ik_launch.hpp"
 #include "ik_engine.hpp"
 #include "ik_tail.hpp"
 #include "ik_coop.hpp"
@@ -43,25 +44,6 @@ struct TileRec {
     unsigned long long idx;  // winning restart index in the tile, ~0 if none
     double key;
 };
-
-struct SolveLaunch {
-    const ChainDev *chain;
-    EvalParams ep;
-    SolveParams sp;
-    uint32_t key[8];        // ChaCha key = seed_from_u64(42)
-    double scale[MAX_DOF];  // rand UniformFloat scale per joint
-    WorkQueue wq;
-    unsigned long long deadline_ticks;  // relative to kernel start, 0 = none
-};
-
-__device__ __forceinline__ void stage_chain(ChainDev &dst, const ChainDev *src) {
-    constexpr int ND = (int)(sizeof(ChainDev) / sizeof(double));
-    static_assert(sizeof(ChainDev) % sizeof(double) == 0, "ChainDev is a whole number of doubles");
-    const double *s = reinterpret_cast<const double *>(src);
-    double *d = reinterpret_cast<double *>(&dst);
-    for (int i = threadIdx.x; i < ND; i += blockDim.x) d[i] = s[i];
-    __syncthreads();
-}
 
 // (key, idx) argmin across the wave: smaller key wins, ties -> smaller idx; idx ~0 = none.
 __device__ __forceinline__ void wave_argmin(double &key, unsigned long long &idx) {
@@ -1070,15 +1052,19 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         if (a.deadline_ticks == 0) a.deadline_ticks = 1;
     }
 
-    // Which solver: the cooperative one (ik_coop.hpp, a restart per group of four lanes, NNLS in
-    // registers; n <= 7) unless OPTIK_SOLVE_KERNEL=lane asks for round 1's one-restart-per-lane
-    // kernel with its per-lane LDS NNLS (the only one for n = 8).
-    bool coop = ch->n <= 7;
-    if (const char *e = std::getenv("OPTIK_SOLVE_KERNEL")) coop = coop && std::strcmp(e, "lane") != 0;
+    // Which solver (n <= 7): the quad solver of ik_quad.hpp (a restart per quad of lanes, its state spread
+    // over the quad; the default), round 2's cooperative one (OPTIK_SOLVE_KERNEL=coop: the state in the
+    // quad's leader, ik_coop.hpp) or round 1's one-restart-per-lane kernel with its per-lane LDS NNLS
+    // (OPTIK_SOLVE_KERNEL=lane; the only one for n = 8).  Same results, bit for bit.
+    bool coop = ch->n <= 7, quadk = ch->n <= 7;
+    if (const char *e = std::getenv("OPTIK_SOLVE_KERNEL")) {
+        coop = coop && std::strcmp(e, "lane") != 0;
+        quadk = coop && std::strcmp(e, "coop") != 0;
+    }
     // Persistent waves, each pulling work items until the queue is dry: as many as a CU holds
     // (lane kernel: 2 workgroups, LDS-bound; cooperative kernel: 4, one per SIMD), times the CU count.
     const int cus = ch->num_cus > 0 ? ch->num_cus : 256;
-    const long long cap = (long long)cus * (coop ? 4 : ch->waves_per_cu);
+    const long long cap = (long long)cus * (quadk ? quad_solve_waves_per_cu() : (coop ? 4 : ch->waves_per_cu));
     const long long per_wave_max = coop ? COOP_GROUPS_PER_WAVE : WAVE;
     // fewer work items than the chip holds: one restart per wave (or as few as fit).  A
     // restart-major Speed batch keeps about eight restarts per target in flight: the waves pull
@@ -1115,7 +1101,9 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         HIP_TRY(hipEventRecord(ch->ev0[ev_slot], stream));
     }
     int lds = 0;
-    if (coop) {
+    if (quadk) {
+        HIP_TRY(quad_solve_launch(ch->n, ch->tip, grid, stream, a, &lds));
+    } else if (coop) {
 #define CALL_COOP(NN, TT)                                                                            \
     lds = (int)(sizeof(ChainDev) + sizeof(double) * (coop_wave_lds<4>() + COOP_GROUPS_PER_WAVE * coop_rec_lds<NN>())); \
     hipLaunchKernelGGL((ik_coop_kernel<NN, TT>), dim3(grid), dim3(WAVE), 0, stream, a)

@@ -100,14 +100,10 @@ __device__ unsigned long long g_nnls_prof[8];
 // past the loop just to store it costs ~280 B of scratch per lane).
 //
 // `win` = the group's LDS window, `zeros` = eight doubles of +0.0 in LDS (read only).
-//
-// nnls_coop_ids takes the 1-based id of each of the lane's columns explicitly (any assignment of
-// the 2N columns to the lanes of the group: the quad solver of ik_quad.hpp gives a lane the columns
-// of the rows of E^-1 it computed); nnls_coop is the contiguous case ids = cid0 + 1 .. cid0 + CPL.
 template <int N, int CPL, class Park>
-OPTIK_DEV void nnls_coop_ids(bool live, bool resume, int budget, const int (&ids)[CPL], dvec8 (&col)[CPL],
-                             CoopCarry<CPL> &cs, int &mode_out, double &rnorm_out, int &iters_out, double *win,
-                             const double *zeros, Park &&park) {
+OPTIK_DEV void nnls_coop(bool live, bool resume, int budget, int cid0, dvec8 (&col)[CPL], CoopCarry<CPL> &cs,
+                         int &mode_out, double &rnorm_out, int &iters_out, double *win, const double *zeros,
+                         Park &&park) {
     constexpr int m = N + 1, n = 2 * N;
     constexpr int G = COOP_COLS / CPL;
     static_assert(m <= 8, "a column is one dvec8");
@@ -130,8 +126,8 @@ OPTIK_DEV void nnls_coop_ids(bool live, bool resume, int budget, const int (&ids
     double wv[CPL];
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
-        isc[k] = ids[k] <= n;
-        pos[k] = resume ? cs.pos[k] : ids[k];
+        isc[k] = cid0 + k + 1 <= n;
+        pos[k] = resume ? cs.pos[k] : cid0 + k + 1;
         inZ[k] = isc[k] && pos[k] > nsetp;  // set P holds positions 1 .. nsetp
         wv[k] = 0.0;
         xv[k] = resume ? xv[k] : 0.0;
@@ -522,10 +518,8 @@ OPTIK_DEV void nnls_coop_ids(bool live, bool resume, int budget, const int (&ids
                 if (nsetp <= 0) { mode = 3; phase = 4; }
             }
             mirror(run);  // the columns left in P moved and were rotated
-            {
+            if (phase == 3) {
                 // is every coefficient left in P feasible?  first offending position, in order
-                // (the exchange runs for every lane of the wave -- cross-lane moves stay in wave-uniform
-                // control flow -- and only the groups still removing use its result)
                 int bad = 0x7fffffff;
 #pragma unroll
                 for (int k = 0; k < CPL; ++k) {
@@ -534,12 +528,10 @@ OPTIK_DEV void nnls_coop_ids(bool live, bool resume, int budget, const int (&ids
                 }
 #pragma unroll
                 for (int off = G / 2; off >= 1; off >>= 1) { const int o = __shfl_xor(bad, off, 64); bad = o < bad ? o : bad; }
-                if (phase == 3) {
-                    if (bad != 0x7fffffff) {
-                        rem_jj = bad;  // again
-                    } else {
-                        phase = 2;
-                    }
+                if (bad != 0x7fffffff) {
+                    rem_jj = bad;  // again
+                } else {
+                    phase = 2;
                 }
             }
             NNLS_PROBE(5);
@@ -574,16 +566,6 @@ OPTIK_DEV void nnls_coop_ids(bool live, bool resume, int budget, const int (&ids
     }
     mode_out = phase == 5 ? NNLS_SUSPENDED : mode;
     iters_out = iter;
-}
-
-template <int N, int CPL, class Park>
-OPTIK_DEV void nnls_coop(bool live, bool resume, int budget, int cid0, dvec8 (&col)[CPL], CoopCarry<CPL> &cs,
-                         int &mode_out, double &rnorm_out, int &iters_out, double *win, const double *zeros,
-                         Park &&park) {
-    int ids[CPL];
-#pragma unroll
-    for (int k = 0; k < CPL; ++k) ids[k] = cid0 + k + 1;
-    nnls_coop_ids<N, CPL>(live, resume, budget, ids, col, cs, mode_out, rnorm_out, iters_out, win, zeros, park);
 }
 
 }  // namespace optik

@@ -1,0 +1,430 @@
+// ik_nnls_quad.hpp -- Lawson-Hanson NNLS of the LSQ dual for the quad solver: matrix in LDS.
+//
+// ik_nnls_coop.hpp keeps the (n+1) x 2n matrix in REGISTERS, four columns per lane (64 VGPRs) plus
+// ~120 more for the masked copies of the Householder vector: 242 VGPRs on its own, which is what
+// holds every kernel that contains it at two waves per SIMD at best -- and the quad solver, whose
+// own state lives next to it, at one.  A register file cannot be indexed per lane; LDS can.  Here
+// the quad's matrix lives in a 1 KB block of LDS, column-major (column id c at doubles [8 (c-1),
+// 8 c)), next to the multipliers x by column id:
+//
+//   * a lane still OWNS four columns (any assignment; the quad solver gives it the rows of E^-1 it
+//     computed) and does everything "for each column" on them: it loads one column at a time
+//     (4 x ds_read_b128), works on it, stores the rows that changed;
+//   * reads whose column differs from problem to problem -- the chosen column of step five, the
+//     columns of set P by position in the triangular solve, the pivot pair of a Givens step --
+//     are plain LDS reads at a per-quad address, all four lanes the same one (broadcast);
+//   * the permutation (position -> column id) is a 64-bit nibble vector replicated in every lane.
+//
+// Layout: quad g at doubles [g * NNLS_QUAD_STRIDE, ...).  The stride (130 doubles = 65 16-byte
+// granules, odd) puts the 16 quads of a wave on distinct granules, and consecutive columns are 4
+// granules apart, so a wave-wide ds_read_b128 of "my k-th column" (lanes of a quad on four
+// consecutive columns) touches 64 distinct granules of every 256-byte row: conflict-free.
+//
+// Arithmetic per matrix element, its order, and every decision are those of nnls_coop and of
+// oracle/optik_oracle.c:nnls: same bits.  Control flow around every cross-lane move and LDS
+// hand-over is wave-uniform (tests/emu runs this file on the host).
+#pragma once
+
+#include "ik_lane.hpp"
+#include "ik_slsqp.hpp"
+
+namespace optik {
+
+constexpr int NNLS_QUAD_STRIDE = 130;              // doubles per quad
+constexpr int NNLS_QUAD_XS = 14 * 8;               // multipliers by column id, after the 14 columns
+// doubles of LDS per wave: the blocks of its 16 quads, then eight doubles of +0.0 (read only)
+constexpr int nnls_quad_wave_lds() { return 16 * NNLS_QUAD_STRIDE + 8; }
+
+OPTIK_DEV dvec8 lds_col_load(const double *p) {
+    const double *a = (const double *)__builtin_assume_aligned(p, 16);
+    dvec8 v;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = a[r];
+    return v;
+}
+
+// min over the quad of an int / (w, pos) argmax helper moves: lane ^ 1, lane ^ 2
+OPTIK_DEV int quad_xor_get(int v, int mask) { return __shfl_xor(v, mask, 64); }
+OPTIK_DEV double quad_xor_get(double v, int mask) { return __shfl_xor(v, mask, 64); }
+
+// Solves the quad's problem.  On entry the owners have written the columns to `blk` (column id c at
+// blk + 8 (c - 1), rows 0 .. N) and an lds_sync() has made them visible; ids[k] = 1-based id of the
+// lane's k-th column (> 2N: padding).  `live` = the quad has a problem.  On return xv[k] = the
+// multiplier of the lane's k-th column; quad-uniform: mode (1 ok, 3 iteration cap), rnorm, and the
+// number of solve passes.
+template <int N>
+OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const double *zeros, double (&xv)[4], int &mode_out,
+                         double &rnorm_out, int &iters_out) {
+    constexpr int m = N + 1, n = 2 * N;
+    constexpr int CPL = 4;
+    static_assert(m <= 8 && n <= 14, "a column is eight doubles, the block holds fourteen");
+    const double factor = 0.01;
+    const int itmax = 3 * n;
+    const int ql = quad_lane();
+    double *const xs = blk + NNLS_QUAD_XS;
+    // quad-uniform state (replicated in every lane of the quad)
+    dvec8 b = 0.0;
+    b[m - 1] = 1.0;
+    PackedIndex indx;
+    indx.v = 0xFEDCBA9876543210ull;  // indx[pos] = pos
+    int nsetp = 0, npp1 = 1, iter = 0, mode = 1;
+    double up = 0.0;
+    // per-column state of the lane's columns
+    int pos[CPL];
+    bool inZ[CPL], isc[CPL];
+    double wv[CPL];
+    double *colp[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        isc[k] = ids[k] <= n;
+        pos[k] = ids[k];
+        inZ[k] = isc[k];
+        wv[k] = 0.0;
+        xv[k] = 0.0;
+        colp[k] = blk + 8 * ((isc[k] ? ids[k] : 1) - 1);
+        if (live && isc[k]) xs[ids[k] - 1] = 0.0;
+    }
+    int rem_jj = 0;  // step eleven: position being removed
+    // phases: 0 = step two (recompute duals, then choose), 1 = step three (choose again),
+    // 2 = step six (solve), 3 = step eleven (remove), 4 = done
+    int phase = live ? 0 : 4;
+    lds_sync();
+
+    while (wave_any(phase < 4)) {
+        // ---------------- steps two .. five --------------------------------------------
+        if (wave_any(phase == 0 || phase == 1)) {
+            const bool inA = (phase == 0 || phase == 1);
+            if (inA && (nsetp + 1 > n || nsetp >= m)) phase = 4;  // iz1 > iz2 || nsetp >= m
+            const bool run = (phase == 0 || phase == 1);
+            if (wave_any(phase == 0)) {
+                // step two: duals of the columns in Z over rows npp1 .. m
+                dvec8 bm = 0.0;
+#pragma unroll
+                for (int r = 1; r <= m; ++r) bm[r - 1] = (r >= npp1) ? b[r - 1] : 0.0;
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) {
+                    const dvec8 cv = lds_col_load(colp[k]);
+                    double sdot = 0.0;
+#pragma unroll
+                    for (int r = 1; r <= m; ++r) sdot += cv[r - 1] * bm[r - 1];
+                    wv[k] = (phase == 0 && inZ[k]) ? sdot : wv[k];
+                }
+            }
+            // step three: largest positive dual among Z, ties to the smallest position
+            double bw = 0.0;
+            int bp = 0x7fffffff;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const bool c = run && inZ[k] && wv[k] > 0.0;
+                const double w = c ? wv[k] : 0.0;
+                const int p = c ? pos[k] : 0x7fffffff;
+                const bool better = (w > bw) || (w == bw && p < bp);
+                bw = better ? w : bw;
+                bp = better ? p : bp;
+            }
+#pragma unroll
+            for (int off = 2; off >= 1; off >>= 1) {
+                const double ow = quad_xor_get(bw, off);
+                const int op = quad_xor_get(bp, off);
+                const bool better = (ow > bw) || (ow == bw && op < bp);
+                bw = better ? ow : bw;
+                bp = better ? op : bp;
+            }
+            const bool none = !(bw > 0.0);
+            if (run && none) phase = 4;  // step four: every dual <= 0 -> done
+            const bool cand = run && !none;
+            // (the last trip of most waves: every problem left has just finished)
+            if (wave_any(cand)) {
+                // step five: Householder construction on the chosen column j (position bp)
+                const int j = cand ? indx.get(bp) : 1;
+                const dvec8 u = lds_col_load(blk + 8 * (j - 1));
+                lds_sync();  // (every lane has the column before its pivot rows are rewritten below)
+                bool hitk[CPL];
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) hitk[k] = cand && inZ[k] && pos[k] == bp;
+                // (all lanes run the construction; only `cand` quads keep its results)
+                const double asave = vpick(u, npp1);
+                const bool h12_live = npp1 < m;
+                double cl = __builtin_fabs(asave);
+#pragma unroll
+                for (int r = 1; r <= m; ++r) {
+                    const double sm = (r > npp1) ? __builtin_fabs(u[r - 1]) : 0.0;
+                    cl = (sm > cl) ? sm : cl;
+                }
+                const bool pivot = h12_live && !(cl <= 0.0);
+                double ulp = asave;
+                {
+                    const double clinv = 1.0 / cl;
+                    double d = asave * clinv;
+                    double sm = d * d;
+#pragma unroll
+                    for (int r = 1; r <= m; ++r) {
+                        d = ((r > npp1) ? u[r - 1] : 0.0) * clinv;
+                        sm += d * d;
+                    }
+                    double c2 = cl * __builtin_sqrt(sm);
+                    c2 = (asave > 0.0) ? -c2 : c2;
+                    up = (cand && pivot) ? asave - c2 : up;
+                    ulp = pivot ? c2 : ulp;
+                }
+                // Lawson-Hanson's independence test diff(unorm + factor |ulp|, unorm) > 0 (see nnls_coop: decided
+                // by t > 3 * 2^-52 * xmax whenever that holds, by the norm itself otherwise)
+                double xmax = 0.0;
+#pragma unroll
+                for (int r = 1; r <= m; ++r) {
+                    const double av = (r <= nsetp) ? __builtin_fabs(u[r - 1]) : 0.0;
+                    xmax = (av > xmax) ? av : xmax;
+                }
+                const double t = factor * __builtin_fabs(ulp);
+                bool ok1 = t > 6.7e-16 * xmax;
+                if (wave_any(cand && !ok1)) {
+                    const double scale = 1.0 / xmax;
+                    double sum = 0.0;
+#pragma unroll
+                    for (int r = 1; r <= m; ++r) {
+                        const double xsr = scale * ((r <= nsetp) ? u[r - 1] : 0.0);
+                        sum += xsr * xsr;
+                    }
+                    const double unorm = (xmax != 0.0) ? xmax * __builtin_sqrt(sum) : 0.0;
+                    const double d1 = unorm + t;
+                    ok1 = d1 - unorm > 0.0;
+                }
+                const double hprod = up * ulp;
+                const bool apply_live = cand && h12_live && !(__builtin_fabs(ulp) <= 0.0) && !(hprod >= 0.0);
+                const double hb = apply_live ? 1.0 / hprod : 0.0;
+                // the transformation as a weight per row: up at the pivot row, u below, 0 above -- formed in
+                // place of u (the column's own new content needs nothing of it: unchanged above the pivot
+                // row, ulp on it, zeros below)
+                dvec8 w = u;
+#pragma unroll
+                for (int r = 1; r <= m; ++r) w[r - 1] = (r == npp1) ? up : ((r > npp1) ? w[r - 1] : 0.0);
+                // b := Q b: first the scalar and the pivot entry (they decide whether the column enters), then
+                // b itself, in place, only if it does
+                double smb = 0.0;
+#pragma unroll
+                for (int r = 1; r <= m; ++r) {
+                    const double pr = b[r - 1] * w[r - 1];
+                    smb = (r == 1) ? pr : smb + pr;
+                }
+                const bool actb = apply_live && ok1 && smb != 0.0;
+                const double smhb = actb ? smb * hb : 0.0;
+                const double bpiv = vpick(b, npp1);
+                const double ztp = actb ? bpiv + smhb * up : bpiv;
+                const bool found = cand && ok1 && (ztp / ulp > 0.0);
+#pragma unroll
+                for (int r = 1; r <= m; ++r) {
+                    const double add = smhb * w[r - 1];
+                    b[r - 1] = (found && actb && r >= npp1) ? b[r - 1] + add : b[r - 1];
+                }
+                // column j takes position iz1 = nsetp + 1, the column there takes j's
+                {
+                    const int iz1 = nsetp + 1;
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k) {
+                        const bool me = found && hitk[k];
+                        const bool other = found && isc[k] && pos[k] == iz1 && !hitk[k];
+                        pos[k] = other ? bp : pos[k];
+                        pos[k] = me ? iz1 : pos[k];
+                        inZ[k] = me ? false : inZ[k];
+                    }
+                    if (found) {
+                        indx.set(bp, indx.get(iz1));
+                        indx.set(iz1, j);
+                    }
+                }
+                nsetp = found ? npp1 : nsetp;
+                npp1 = nsetp + 1;
+                // the column that entered P: untouched above the pivot row, ulp on it, zeros below
+                if (found && ql == 0) {
+                    double *d = blk + 8 * (j - 1);
+#pragma unroll
+                    for (int r = 1; r <= m; ++r)
+                        if (r >= nsetp) d[r - 1] = (r == nsetp) ? ulp : 0.0;
+                }
+                // the transformation applied to the lane's columns still in Z (pivot row nsetp, rows below)
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) {
+                    const dvec8 cv = lds_col_load(colp[k]);
+                    double sm = 0.0;
+#pragma unroll
+                    for (int r = 1; r <= m; ++r) {
+                        const double pr = cv[r - 1] * w[r - 1];
+                        sm = (r == 1) ? pr : sm + pr;
+                    }
+                    const bool act = found && apply_live && inZ[k] && sm != 0.0;
+                    const double smh = act ? sm * hb : 0.0;
+                    if (act) {
+#pragma unroll
+                        for (int r = 1; r <= m; ++r)
+                            if (r >= nsetp) colp[k][r - 1] = cv[r - 1] + smh * w[r - 1];
+                    }
+                    wv[k] = (cand && hitk[k]) ? 0.0 : wv[k];
+                }
+                // found: solve (step six); else choose again without recomputing the duals
+                phase = cand ? (found ? 2 : 1) : phase;
+                lds_sync();
+            }
+        }
+        // ---------------- steps six .. ten ---------------------------------------------
+        if (wave_any(phase == 2)) {
+            const bool run = phase == 2;
+            dvec8 zz = b;  // (steps five / eleven leave z := b)
+            int nmax = 0;
+#pragma unroll
+            for (int v = 1; v <= m; ++v)
+                if (wave_any(run && nsetp >= v)) nmax = v;
+            // step six: solve the triangular system on set P (positions nsetp .. 1); the column at position ip
+            // is read from the block.  A quad whose set P ends below ip reads the zeros instead and
+            // subtracts 0 * 0 = +0, which changes nothing (x - (+0) == x bit for bit).
+#pragma unroll
+            for (int ip = m; ip >= 1; --ip) {
+                if (ip > nmax) continue;
+                const bool step = run && ip <= nsetp;
+                const double *cp = step ? blk + 8 * (indx.get(ip) - 1) : zeros;
+                dvec8 cv = 0.0;
+#pragma unroll
+                for (int r = 1; r <= ip; ++r) cv[r - 1] = cp[r - 1];
+                const double zi = zz[ip - 1] / cv[ip - 1];
+                const double zie = step ? zi : 0.0;
+                zz[ip - 1] = step ? zi : zz[ip - 1];
+#pragma unroll
+                for (int r = 1; r < ip; ++r) zz[r - 1] = zz[r - 1] - zie * cv[r - 1];
+            }
+            if (run) {
+                ++iter;
+                if (iter > itmax) { mode = 3; phase = 4; }
+            }
+            const bool go = phase == 2;
+            // steps seven..ten: step length; scan the positions in order, as the serial code does
+            double alpha = 1.0;
+            int jj = 0;
+#pragma unroll
+            for (int ip = 1; ip <= m; ++ip) {
+                if (ip > nmax) continue;
+                const bool step = go && ip <= nsetp;
+                // only positions whose z is not positive limit the step: most have none in the whole wave
+                if (!wave_any(step && !(zz[ip - 1] > 0.0))) continue;
+                const double xp = xs[(step ? indx.get(ip) : 1) - 1];
+                const double zp = zz[ip - 1];
+                const double tq = -xp / (zp - xp);
+                const bool take = step && !(zp > 0.0) && !(alpha < tq);
+                alpha = take ? tq : alpha;
+                jj = take ? ip : jj;
+            }
+            lds_sync();  // (the scan has read the multipliers: now their owners may rewrite them)
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const bool mine = go && isc[k] && !inZ[k];
+                const double zown = vpick(zz, mine ? pos[k] : 1);
+                const double nx = (1.0 - alpha) * xv[k] + alpha * zown;
+                xv[k] = mine ? nx : xv[k];
+                if (mine) xs[ids[k] - 1] = nx;
+            }
+            rem_jj = (go && jj != 0) ? jj : rem_jj;
+            phase = go ? (jj == 0 ? 0 : 3) : phase;  // back to step two, or remove position jj
+            lds_sync();
+        }
+        // ---------------- step eleven ----------------------------------------------------
+        if (wave_any(phase == 3)) {
+            const bool run = phase == 3;
+            // move the coefficient at position rem_jj from set P to set Z
+            bool leaving[CPL];
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                leaving[k] = run && isc[k] && !inZ[k] && pos[k] == rem_jj;
+                if (leaving[k]) { xv[k] = 0.0; xs[ids[k] - 1] = 0.0; }
+            }
+            const int id_out = run ? indx.get(rem_jj) : 1;
+            const int jlo = run ? rem_jj + 1 : 0x7fffffff, jhi = run ? nsetp : 0;
+            int wlo = jlo, whi = jhi;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const int a0 = __shfl_xor(wlo, off, 64), a1 = __shfl_xor(whi, off, 64);
+                wlo = a0 < wlo ? a0 : wlo;
+                whi = a1 > whi ? a1 : whi;
+            }
+            for (int j = wlo; j <= whi; ++j) {
+                const bool step = run && j >= jlo && j <= jhi;
+                const int jm1 = j - 1 < 1 ? 1 : (j - 1 > m ? m : j - 1), jc = j > m ? m : (j < 1 ? 1 : j);
+                // the column at position j moves to position j-1; Givens on its rows j-1, j
+                const int ii = step ? indx.get(jc) : 1;
+                double a0 = blk[8 * (ii - 1) + jm1 - 1], a1 = blk[8 * (ii - 1) + jc - 1];
+                lds_sync();  // (the pivot pair is read before the owners rewrite rows j-1, j)
+                double c = 1.0, s = 0.0;
+                rotg(a0, a1, c, s);
+                const double t = a0;
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) {
+                    if (!(step && isc[k])) continue;
+                    const bool is_ii = ids[k] == ii;
+                    double *p0 = colp[k] + (jm1 - 1), *p1 = colp[k] + (jc - 1);
+                    const double xi = *p0, yi = *p1;
+                    const double nx = c * xi + s * yi;
+                    const double ny = c * yi - s * xi;
+                    *p0 = is_ii ? t : nx;
+                    *p1 = is_ii ? 0.0 : ny;
+                    if (is_ii) pos[k] = j - 1;
+                }
+                if (step) {
+                    indx.set(jm1, ii);
+                    const double bx = vpick(b, j - 1), by = vpick(b, j);
+                    vput(b, j - 1, c * bx + s * by);
+                    vput(b, j, c * by - s * bx);
+                }
+                lds_sync();
+            }
+            if (run) {
+                npp1 = nsetp;
+                --nsetp;
+#pragma unroll
+                for (int k = 0; k < CPL; ++k)
+                    if (leaving[k]) { pos[k] = nsetp + 1; inZ[k] = true; }  // --iz1; indx[iz1] = i
+                indx.set(nsetp + 1 < 1 ? 1 : nsetp + 1, id_out);
+                if (nsetp <= 0) { mode = 3; phase = 4; }
+            }
+            {
+                // is every coefficient left in P feasible?  first offending position, in order
+                int bad = 0x7fffffff;
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) {
+                    const int p = (isc[k] && !inZ[k] && xv[k] <= 0.0) ? pos[k] : 0x7fffffff;
+                    bad = p < bad ? p : bad;
+                }
+#pragma unroll
+                for (int off = 2; off >= 1; off >>= 1) { const int o = quad_xor_get(bad, off); bad = o < bad ? o : bad; }
+                if (phase == 3) {
+                    if (bad != 0x7fffffff) rem_jj = bad;  // again
+                    else phase = 2;
+                }
+            }
+            lds_sync();
+        }
+    }
+    // rnorm = ||b(npp1..m)||
+    {
+        const int k0 = (npp1 < m) ? npp1 : m;
+        const int cnt = m - nsetp;
+        double xmax = 0.0;
+#pragma unroll
+        for (int r = 1; r <= m; ++r) {
+            const double av = __builtin_fabs(b[r - 1]);
+            if (r >= k0 && r < k0 + cnt && av > xmax) xmax = av;
+        }
+        double rn = 0.0;
+        if (xmax != 0.0) {
+            const double scale = 1.0 / xmax;
+            double sum = 0.0;
+#pragma unroll
+            for (int r = 1; r <= m; ++r) {
+                const double xsr = scale * b[r - 1];
+                if (r >= k0 && r < k0 + cnt) sum += xsr * xsr;
+            }
+            rn = xmax * __builtin_sqrt(sum);
+        }
+        rnorm_out = rn;
+    }
+    mode_out = mode;
+    iters_out = iter;
+}
+
+}  // namespace optik

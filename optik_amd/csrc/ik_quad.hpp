@@ -12,7 +12,8 @@
 //
 // and every scalar of Kraft's / NLopt's state machine is replicated in the four lanes.  Values move
 // between the lanes of a quad with DPP quad_perm moves (ik_lane.hpp), never through LDS; the only
-// LDS of the solver is the NNLS window of ik_nnls_coop.hpp.
+// LDS of the solver is the 1 KB block per quad that holds the matrix of the bounded dual problem
+// while ik_nnls_quad.hpp solves it.
 //
 // Bit-exactness (the contract of DESIGN.md section 2): every sum the reference / oracle forms
 // sequentially is formed here in the SAME ORDER from the same products -- either inside one lane
@@ -28,7 +29,7 @@
 
 #include "ik_lane.hpp"
 #include "ik_solve.hpp"
-#include "ik_nnls_coop.hpp"
+#include "ik_nnls_quad.hpp"
 
 namespace optik {
 
@@ -536,13 +537,18 @@ OPTIK_DEV void lsq_finish_quad(const double (&Ec)[QuadDims<N>::NS][QuadDims<N>::
 
 constexpr int QUADS_PER_WAVE = 64 / QUAD;
 
-// doubles of LDS per wave: the NNLS windows of its quads and the column of zeros (ik_nnls_coop.hpp)
-constexpr int quad_wave_lds() { return QUADS_PER_WAVE * COOP_WIN + 8; }
+// doubles of LDS per wave: the NNLS blocks of its quads and the column of zeros (ik_nnls_quad.hpp) ...
+constexpr int quad_wave_lds() { return nnls_quad_wave_lds(); }
+// ... and the best point so far / the previous iterate of every lane's joints ([slot][lane]: they are
+// written when f improves / a line search ends and read when a restart is published -- not worth
+// eight registers for the whole life of the kernel)
+constexpr int quad_lane_lds() { return 4 * 64; }
 
 template <int N, bool TIP>
 OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolveParams &sp, const uint32_t (&key)[8],
                          const double (&scale)[MAX_DOF], const WorkQueue &wq,
-                         double *nnls_lds /* quad_wave_lds() doubles, the last 8 zero */) {
+                         double *nnls_lds /* quad_wave_lds() doubles, the last 8 zero */,
+                         double *lane_lds /* quad_lane_lds() doubles: x_best, x_prev of every lane */) {
     constexpr int NS = QuadDims<N>::NS, NM = QuadDims<N>::NM;
     constexpr int CPL = 4;
     const unsigned lane = threadIdx.x & 63u;
@@ -554,34 +560,33 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
     // the lane's joints
     int jc[NS];
     bool val[NS];
-    double lb[NS], ub[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         val[s] = q + 4 * s < N;
         jc[s] = val[s] ? q + 4 * s : N - 1;
-        lb[s] = ch.lb[jc[s]];
-        ub[s] = ch.ub[jc[s]];
     }
+    double *const xb = lane_lds + lane;        // xb[s * 64]: best point so far
+    double *const xp = lane_lds + 128 + lane;  // xp[s * 64]: iterate of the last completed line search
+    // the quad's block of LDS: the NNLS matrix during a direction search, and during an evaluation the
+    // parking place of what the evaluation does not touch (lane ql's i-th double at [4 i + ql])
+    double *const blk = nnls_lds + quad * NNLS_QUAD_STRIDE;
 
     // SLSQP state of the quad's restart: by joint, by row, and the replicated scalars (names as in solve_wave)
-    double x[NS], x0[NS], g[NS], sv[NS], xb[NS], xp[NS];
+    double x[NS], x0[NS], g[NS], sv[NS];
     double Lr[NS][NM], dg[NS];
     double f = 0.0, f0 = 0.0, t0 = 0.0, h3 = 0.0, alpha = 1.0;
     double minf = __builtin_huge_val(), fprev = __builtin_huge_val();
     int ireset = 0, line = 0, nevals = 0;
     bool first = true;
-    Pose target;
     unsigned long long item = 0, index = 0;
     unsigned tslot = 0;
     bool active = false, want = member;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        x[s] = 0.0; x0[s] = 0.0; g[s] = 0.0; sv[s] = 0.0; xb[s] = 0.0; xp[s] = 0.0; dg[s] = 1.0;
+        x[s] = 0.0; x0[s] = 0.0; g[s] = 0.0; sv[s] = 0.0; xb[s * 64] = 0.0; xp[s * 64] = 0.0; dg[s] = 1.0;
 #pragma unroll
         for (int i = 0; i < NM; ++i) Lr[s][i] = 0.0;
     }
-    target.t = V3{0, 0, 0};
-    target.q = Q4{0, 0, 0, 1};
     OPTIK_PROF_DECL;  // (-DOPTIK_PROFILE: slots 0 refill, 1 eval, 4 bookkeeping + BFGS, 5 direction, 6 NNLS of it, 3 publish, 7 trips)
 
     for (;;) {
@@ -598,7 +603,6 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
                     else { tslot = (unsigned)(it / wq.n_restarts); r = it - (unsigned long long)tslot * wq.n_restarts; }
                     item = (unsigned long long)tslot * wq.n_restarts + r;  // output column
                     index = wq.restart_begin + r;
-                    target = load_pose(wq.targets + (size_t)tslot * 7);
                     // lib.rs:366-370: restart 0 starts from the caller's seed
                     double xs[N];
                     restart_seed<N>(key, ch.lb, scale, index, xs);
@@ -608,7 +612,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
 #pragma unroll
                         for (int j = 4 * s + 1; j < N && j < 4 * s + 4; ++j) v = (jc[s] == j) ? xs[j] : v;
                         if (index == 0) v = wq.x0[(size_t)tslot * N + jc[s]];
-                        x[s] = v; xb[s] = v; xp[s] = v; x0[s] = v; sv[s] = 0.0; g[s] = 0.0;
+                        x[s] = v; xb[s * 64] = v; xp[s * 64] = v; x0[s] = v; sv[s] = 0.0; g[s] = 0.0;
                     }
                     f = 0.0; f0 = 0.0; t0 = 0.0; h3 = 0.0; alpha = 1.0;
                     minf = __builtin_huge_val(); fprev = __builtin_huge_val();
@@ -641,7 +645,35 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
         double fn = 0.0;
         OPTIK_SCHED_FENCE();
         OPTIK_PROF_BEGIN();
-        fn = eval_quad<N, TIP>(ch, ep, target, x, gn);
+        {
+            // what the evaluation does not touch waits in the quad's (idle) block of LDS: the evaluation is
+            // the register peak of the loop (~200 VGPRs on its own)
+            int pi = 0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                blk[4 * pi++ + q] = x0[s]; blk[4 * pi++ + q] = g[s]; blk[4 * pi++ + q] = sv[s]; blk[4 * pi++ + q] = dg[s];
+#pragma unroll
+                for (int i = 0; i < NM; ++i)
+                    if (slot_has<N>(s, i)) blk[4 * pi++ + q] = Lr[s][i];
+            }
+            OPTIK_SCHED_FENCE();
+            // (the target pose is re-read for every evaluation: seven L1 / L2 hits instead of 14 registers)
+            const Pose target = load_pose(wq.targets + (size_t)tslot * 7);
+#ifndef OPTIK_QUAD_EXP_NO_EVAL
+            fn = eval_quad<N, TIP>(ch, ep, target, x, gn);
+#else
+            fn = target.t.x; gn[0] = x[0]; if (NS > 1) gn[NS - 1] = x[NS - 1];
+#endif
+            OPTIK_SCHED_FENCE();
+            pi = 0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                x0[s] = blk[4 * pi++ + q]; g[s] = blk[4 * pi++ + q]; sv[s] = blk[4 * pi++ + q]; dg[s] = blk[4 * pi++ + q];
+#pragma unroll
+                for (int i = 0; i < NM; ++i)
+                    if (slot_has<N>(s, i)) Lr[s][i] = blk[4 * pi++ + q];
+            }
+        }
         OPTIK_PROF_END(1);
         OPTIK_SCHED_FENCE();
 
@@ -651,7 +683,13 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
         double u[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) u[s] = 0.0;
-        const bool sx_prev = (xprev_live(sp) && wave_any(do_eval && !first)) ? stop_x_quad<N>(sp, x, xp) : false;
+        bool sx_prev = false;
+        if (xprev_live(sp) && wave_any(do_eval && !first)) {
+            double xpv[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) xpv[s] = xp[s * 64];
+            sx_prev = stop_x_quad<N>(sp, x, xpv);
+        }
         if (do_eval) {
             f = fn;
             ++nevals;
@@ -659,7 +697,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
             if (f < minf) {
                 minf = f;
 #pragma unroll
-                for (int s = 0; s < NS; ++s) xb[s] = x[s];
+                for (int s = 0; s < NS; ++s) xb[s * 64] = x[s];
             }
             if (minf < sp.stopval) {
                 ret = RES_STOPVAL_REACHED;
@@ -696,7 +734,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
                     }
                     fprev = f;
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) xp[s] = x[s];
+                    for (int s = 0; s < NS; ++s) xp[s * 64] = x[s];
                     if (ret == 0 && nevals >= MAX_EVALS_CAP) ret = RES_ITER_CAP;
                     if (ret == 0) {
                         // label 260: BFGS update with u = g_new - g_old
@@ -709,7 +747,9 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
             }
         }
         OPTIK_SCHED_FENCE();
+#ifndef OPTIK_QUAD_EXP_NO_BFGS
         if (wave_any(do_bfgs)) bfgs_quad<N>(do_bfgs, Lr, dg, sv, u);
+#endif
         OPTIK_SCHED_FENCE();
         OPTIK_PROF_END(4);
 
@@ -740,8 +780,8 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
             double Ec[NS][NM], Ed[NS], fv[NS], lo[NS], hi[NS];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                lo[s] = lb[s] - x[s];
-                hi[s] = ub[s] - x[s];
+                lo[s] = ch.lb[jc[s]] - x[s];
+                hi[s] = ch.ub[jc[s]] - x[s];
                 fv[s] = 0.0;
                 Ed[s] = 1.0;
 #pragma unroll
@@ -768,39 +808,37 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
 #ifdef OPTIK_PROFILE
                 const unsigned long long t_nn = __builtin_readcyclecounter();
 #endif
-                dvec8 col[CPL];
+                // the lane's columns go to the quad's block: row r = q + 4 s of E^-1 is column r + 1 (lower
+                // bound, h_lo below it) and, negated, column N + r + 1 (upper bound, h_hi below it)
                 int ids[CPL];
-                CoopCarry<CPL> cs;
-                cs.b = 0.0;
-                cs.up = 0.0;
-                cs.nsetp = 0;
-                cs.iter = 0;
 #pragma unroll
                 for (int k = 0; k < CPL; ++k) {
-                    // column of row r = q + 4 s: k = s (lower bound, id r + 1), k = 2 + s (upper bound, id N + r + 1)
                     const int s = k & 1;
                     const bool neg = k >= 2;
-                    col[k] = 0.0;
-                    cs.xv[k] = 0.0;
-                    cs.pos[k] = 0;
                     ids[k] = 0x7fff;
                     if (s < NS) {
                         const int r = q + 4 * s;
                         ids[k] = (r < N) ? (neg ? N : 0) + r + 1 : 0x7fff;
+                        if (need_nnls && r < N) {
+                            double *c = blk + 8 * (ids[k] - 1);
 #pragma unroll
-                        for (int j = 0; j < N; ++j) {
-                            const double v = row[s][j];
-                            col[k][j] = neg ? ((j >= r) ? -v : 0.0) : v;
+                            for (int j = 0; j < N; ++j) {
+                                const double v = row[s][j];
+                                c[j] = neg ? ((j >= r) ? -v : 0.0) : v;
+                            }
+                            c[N] = neg ? h_hi[s] : h_lo[s];
                         }
-                        col[k][N] = neg ? h_hi[s] : h_lo[s];
                     }
                 }
                 int iters;
-                auto park = [&](const dvec8 (&)[CPL], const CoopCarry<CPL> &) {};  // (never suspended: no budget)
-                nnls_coop_ids<N, CPL>(need_nnls, false, 0x3fffffff, ids, col, cs, nmode, rnorm, iters,
-                                      nnls_lds + quad * COOP_WIN, nnls_lds + QUADS_PER_WAVE * COOP_WIN, park);
+                double xv[CPL];
+#ifndef OPTIK_QUAD_EXP_NO_NNLS
+                nnls_quad<N>(need_nnls, ids, blk, nnls_lds + QUADS_PER_WAVE * NNLS_QUAD_STRIDE, xv, nmode, rnorm, iters);
+#else
+                for (int k = 0; k < CPL; ++k) xv[k] = blk[k]; iters = 0;
+#endif
 #pragma unroll
-                for (int s = 0; s < NS; ++s) { ylo[s] = cs.xv[s]; yhi[s] = cs.xv[2 + s]; }
+                for (int s = 0; s < NS; ++s) { ylo[s] = xv[s]; yhi[s] = xv[2 + s]; }
 #ifdef OPTIK_PROFILE
                 OPTIK_PROF_COUNT(6, __builtin_readcyclecounter() - t_nn);
 #endif
@@ -853,8 +891,9 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
                 sv[s] *= alpha;
                 double xi = x0[s];
                 xi += sv[s];
-                if (xi < lb[s]) xi = lb[s];
-                else if (xi > ub[s]) xi = ub[s];
+                const double lbs = ch.lb[jc[s]], ubs = ch.ub[jc[s]];
+                if (xi < lbs) xi = lbs;
+                else if (xi > ubs) xi = ubs;
                 x[s] = xi;
             }
         }
@@ -870,7 +909,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
                 double d2[NS];
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
-                    const double d = xb[s] - ((ended && val[s]) ? wq.x0[(size_t)tslot * N + jc[s]] : 0.0);
+                    const double d = xb[s * 64] - ((ended && val[s]) ? wq.x0[(size_t)tslot * N + jc[s]] : 0.0);
                     d2[s] = d * d;
                 }
                 double acc = 0.0;
@@ -882,7 +921,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
                 if (wq.out_x) {
 #pragma unroll
                     for (int s = 0; s < NS; ++s)
-                        if (val[s]) wq.out_x[(size_t)jc[s] * wq.total_items + item] = xb[s];
+                        if (val[s]) wq.out_x[(size_t)jc[s] * wq.total_items + item] = xb[s * 64];
                 }
                 if (q == 0) {
                     if (wq.out_f) wq.out_f[item] = minf;

@@ -19,17 +19,18 @@ template <int N, bool TIP>
 __global__ __launch_bounds__(64, OPTIK_QUAD_WAVES) void ik_quad_kernel(const SolveLaunch a) {
     __shared__ ChainDev sch;
     __shared__ __attribute__((aligned(16))) double nnls_lds[quad_wave_lds()];
+    __shared__ double lane_lds[quad_lane_lds()];
     if (threadIdx.x < 8) nnls_lds[quad_wave_lds() - 8 + threadIdx.x] = 0.0;  // the column of zeros
     stage_chain(sch, a.chain);
     WorkQueue wq = a.wq;
     wq.deadline = a.deadline_ticks ? wall_clock64() + a.deadline_ticks : 0ull;
-    quad_wave<N, TIP>(sch, a.ep, a.sp, a.key, a.scale, wq, nnls_lds);
+    quad_wave<N, TIP>(sch, a.ep, a.sp, a.key, a.scale, wq, nnls_lds, lane_lds);
 }
 
 int quad_solve_waves_per_cu() { return 4 * OPTIK_QUAD_WAVES; }
 
 hipError_t quad_solve_launch(int n, bool tip, int grid, hipStream_t stream, const SolveLaunch &a, int *lds_bytes) {
-    if (lds_bytes) *lds_bytes = (int)(sizeof(ChainDev) + sizeof(double) * quad_wave_lds());
+    if (lds_bytes) *lds_bytes = (int)(sizeof(ChainDev) + sizeof(double) * (quad_wave_lds() + quad_lane_lds()));
 #define CALL_QUAD(NN)                                                                                   \
     case NN:                                                                                            \
         if (tip) hipLaunchKernelGGL((ik_quad_kernel<NN, true>), dim3(grid), dim3(64), 0, stream, a);    \

@@ -21,13 +21,13 @@ void run_wave(const ChainDev &ch, const EvalParams &ep, const SolveParams &sp, c
               const double (&scale)[MAX_DOF], const WorkQueue &wq, int quads) {
     optik_emu::Wave wave;
     wave.lanes = 4 * quads;
-    std::vector<double> lds((size_t)quad_wave_lds(), 0.0);
+    std::vector<double> lds((size_t)quad_wave_lds(), 0.0), lane_lds((size_t)quad_lane_lds(), 0.0);
     std::vector<std::thread> th;
     for (int lane = 0; lane < wave.lanes; ++lane) {
         th.emplace_back([&, lane]() {
             optik_emu::t_wave = &wave;
             threadIdx.x = (unsigned)lane;
-            quad_wave<N, TIP>(ch, ep, sp, key, scale, wq, lds.data());
+            quad_wave<N, TIP>(ch, ep, sp, key, scale, wq, lds.data(), lane_lds.data());
         });
     }
     for (auto &t : th) t.join();

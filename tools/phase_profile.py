@@ -20,11 +20,15 @@ def main():
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     robot = sys.argv[1] if len(sys.argv) > 1 else "panda"
     R = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-                           "-shared", "-Wno-unused-value", "-pthread", "-DOPTIK_PROFILE", "-x", "hip",
-                           os.path.join(CSRC, "ik_kernels.hip"), os.path.join(CSRC, "robot_host.cpp"), "-o", LIB])
+    lib = os.environ.get("OPTIK_PROF_LIB")  # a -DOPTIK_PROFILE build made beforehand (hipcc cross-compiles without a GPU)
+    if not lib:
+        lib = LIB
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+                               "-shared", "-Wno-unused-value", "-pthread", "-DOPTIK_PROFILE", "-x", "hip",
+                               os.path.join(CSRC, "ik_kernels.hip"), os.path.join(CSRC, "ik_quad_kernel.hip"),
+                               os.path.join(CSRC, "robot_host.cpp"), "-o", lib])
     from optik_amd import _native as nat
-    nat.LIB_PATH = LIB
+    nat.LIB_PATH = os.path.abspath(lib)
     import numpy as np
     import torch
     from optik_amd import Robot
