@@ -330,7 +330,14 @@ def main():
     if T_loc < 1 or cols < 1:
         raise SystemExit("more ranks than work items: nothing to do on this rank")
     n_buf = max(K, W) if args.path == "engine" else 1
+    # kernel path: the steps of a run are the targets of ONE launch of the solve kernel (each step its own
+    # target, seed and output columns) -- the persistent waves pull (step, restart) items from one queue,
+    # so the run pays one fill and one drain of the chip instead of one per step (the engine path pools
+    # its steps the same way: one run of the slot pool)
+    pooled_kernel = args.path == "kernel" and not T
     bufs = [hc.alloc_ik_buffers(T_loc, cols, per_restart=not T) for _ in range(n_buf)]
+    # (one set of output buffers per run length: the timed run of K steps and the warm-up run of W)
+    kbufs = {c: hc.alloc_ik_buffers(c, cols) for c in {K, W} if c} if pooled_kernel else {}
     # the per-step winner records are rows of two tensors, so that the winners of a whole run are
     # selected (and, with several ranks, reduced) in one piece without gathering them first
     win_idx_all = torch.zeros((n_buf, T_loc), dtype=torch.int64, device=dev)
@@ -363,6 +370,11 @@ def main():
             stacked = {"win_idx": win_idx_all[:count].reshape(-1), "win_key": win_key_all[:count].reshape(-1)}
             # config 5: every rank owns its targets outright -- no collective
             return select_winner(stacked, mode, distributed and not T).reshape(count, T_loc)
+        if pooled_kernel:
+            i = first + t_lo
+            kb = kbufs[count]
+            hc.ik_batch(cfg, targets[i:i + count], x0[i:i + count], begin, end, flags=flags, bufs=kb, per_restart=True)
+            return select_winner(kb, mode, distributed).clone().reshape(count, 1)
         winners = []
         for k in range(count):
             i = (first + k) * per_step + t_lo
@@ -407,6 +419,8 @@ def main():
     elapsed = sorted(rep_elapsed)[len(rep_elapsed) // 2]  # the median repetition (upper median for even counts)
 
     last = bufs[K - 1] if args.path == "engine" else bufs[0]
+    if pooled_kernel:  # the last timed step's columns of the pooled launch
+        last = dict(status=kbufs[K]["status"][(K - 1) * cols:K * cols], evals=kbufs[K]["evals"])
     solved_targets = int((winners >= 0).logical_and(winners < torch.iinfo(torch.int64).max).sum().item())
     if T:
         n_success, mean_evals, mean_exec = None, None, None
@@ -414,7 +428,10 @@ def main():
         n_success = int((last["status"] == nat.RES_STOPVAL).sum().item())
         # NLopt's count over every restart of the timed steps (the population the executed count covers)
         timed = bufs[:K] if args.path == "engine" else bufs
-        mean_evals = float(sum(b["evals"].double().sum().item() for b in timed) / (len(timed) * cols))
+        if pooled_kernel:
+            mean_evals = float(last["evals"].double().mean().item())
+        else:
+            mean_evals = float(sum(b["evals"].double().sum().item() for b in timed) / (len(timed) * cols))
         mean_exec = None
 
     if rank == 0:
@@ -495,11 +512,16 @@ def main():
         else:
             kernel_ms, launches = hc.timing_mean()
             info = hc.last_launch()
-            achieved = out_bytes * cols / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+            per_launch = cols * (K if pooled_kernel else 1)
+            achieved = out_bytes * per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+            kname = {"coop": "ik_coop_kernel", "lane": "ik_solve_kernel"}.get(os.environ.get("OPTIK_SOLVE_KERNEL", ""),
+                                                                                "ik_quad_kernel" if n <= 7 else "ik_solve_kernel")
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "ik_coop_kernel",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
                     "kernel_ms": kernel_ms, "launches_timed": launches,
-                    "algorithmic_bytes_per_unit": out_bytes, "units_per_launch": cols, "secondary": None}
+                    "algorithmic_bytes_per_unit": out_bytes, "unit_name": "restart (seeds are generated in-kernel: "
+                    "the outputs are the whole per-restart traffic of this path)", "units_per_launch": per_launch,
+                    "secondary": None}
         if T:
             metric = f"ik() calls/sec ({args.robot}, {T} targets x {R} restarts per step, 1e-6 tol; BASELINE.json config 5)"
             unit = "ik calls/s"

@@ -11,6 +11,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liboptik_amd.so")
+# diagnostics only (tools/: tuning variants and -DOPTIK_PROFILE builds of the same sources)
+if os.environ.get("OPTIK_AMD_LIB"):
+    LIB_PATH = os.path.abspath(os.environ["OPTIK_AMD_LIB"])
 
 MAX_DOF = 8
 IK_EARLY_EXIT = 1

@@ -31,7 +31,7 @@ DEPS = {"ik_kernels.hip": HEADERS,
                            os.path.join("..", "..", "include", "optik.h")]}
 
 
-EXTRA_FLAGS = {"ik_quad_kernel.hip": ["-DOPTIK_QUAD_WAVES=1"]}
+EXTRA_FLAGS = {"ik_quad_kernel.hip": ["-DOPTIK_QUAD_WAVES=2"]}
 
 
 def _hipcc():
@@ -45,7 +45,7 @@ def is_stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS + QUAD_HEADERS]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS + QUAD_HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
@@ -65,11 +65,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         t = os.path.getmtime(obj) if os.path.exists(obj) else -1.0
         deps = [sp] + [os.path.join(CSRC, d) for d in DEPS.get(src, HEADERS)]
-        if force or t < 0 or any(_newer(d, t) for d in deps):
-            cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", sp, "-o", obj]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", sp, "-o", obj]
+        # (an object is also stale when it was compiled with other flags: they are kept next to it)
+        flags_file = obj + ".flags"
+        same_flags = os.path.exists(flags_file) and open(flags_file).read() == " ".join(cmd[1:])
+        if force or t < 0 or not same_flags or any(_newer(d, t) for d in deps):
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd, cwd=CSRC)
+            with open(flags_file, "w") as fh:
+                fh.write(" ".join(cmd[1:]))
         objs.append(obj)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", *objs, "-o", LIB]
     if verbose:

@@ -46,6 +46,22 @@ OPTIK_DEV int quad_get(int v, int k) {
 }
 #endif
 
+// value held by lane (own ^ mask) of the caller's quad, mask = 1 or 2: the butterflies of a quad-wide
+// min / argmax.  DPP quad_perm [1,0,3,2] / [2,3,0,1] on the device (ds_bpermute costs an LDS round trip).
+#ifdef OPTIK_LANE_EMU
+OPTIK_DEV double quad_xor(double v, int mask) { return __shfl_xor(v, mask, 64); }
+OPTIK_DEV int quad_xor(int v, int mask) { return __shfl_xor(v, mask, 64); }
+#else
+OPTIK_DEV double quad_xor(double v, int mask) {
+    return mask == 1 ? __builtin_amdgcn_update_dpp(0.0, v, 0xB1, 0xf, 0xf, false)
+                     : __builtin_amdgcn_update_dpp(0.0, v, 0x4E, 0xf, 0xf, false);
+}
+OPTIK_DEV int quad_xor(int v, int mask) {
+    return mask == 1 ? __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false)
+                     : __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+}
+#endif
+
 // does p hold in some / every lane of the caller's quad
 OPTIK_DEV bool quad_any(bool p) {
     const unsigned long long m = __ballot(p);

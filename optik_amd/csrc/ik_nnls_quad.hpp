@@ -35,6 +35,18 @@ constexpr int NNLS_QUAD_XS = 14 * 8;               // multipliers by column id, 
 // doubles of LDS per wave: the blocks of its 16 quads, then eight doubles of +0.0 (read only)
 constexpr int nnls_quad_wave_lds() { return 16 * NNLS_QUAD_STRIDE + 8; }
 
+// -DOPTIK_PROFILE: wave cycles per part of the loop below, summed over all waves into g_quad_nnls_prof
+// (tools/phase_profile.py): 0 steps two-four, 1 step five, 2 steps six-ten, 3 step eleven, 4 loop trips,
+// 5 calls, 6 Givens steps
+#if defined(OPTIK_PROFILE) && !defined(OPTIK_LANE_EMU)
+__device__ unsigned long long g_quad_nnls_prof[8];
+#define QNNLS_PROBE(slot) do { const unsigned long long now_ = __builtin_readcyclecounter(); np_[slot] += now_ - nt_; nt_ = now_; } while (0)
+#define QNNLS_COUNT(slot, n) np_[slot] += (n)
+#else
+#define QNNLS_PROBE(slot)
+#define QNNLS_COUNT(slot, n)
+#endif
+
 OPTIK_DEV dvec8 lds_col_load(const double *p) {
     const double *a = (const double *)__builtin_assume_aligned(p, 16);
     dvec8 v;
@@ -43,9 +55,11 @@ OPTIK_DEV dvec8 lds_col_load(const double *p) {
     return v;
 }
 
-// min over the quad of an int / (w, pos) argmax helper moves: lane ^ 1, lane ^ 2
-OPTIK_DEV int quad_xor_get(int v, int mask) { return __shfl_xor(v, mask, 64); }
-OPTIK_DEV double quad_xor_get(double v, int mask) { return __shfl_xor(v, mask, 64); }
+OPTIK_DEV void lds_col_store(double *p, const dvec8 v) {
+    double *a = (double *)__builtin_assume_aligned(p, 16);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a[r] = v[r];
+}
 
 // Solves the quad's problem.  On entry the owners have written the columns to `blk` (column id c at
 // blk + 8 (c - 1), rows 0 .. N) and an lds_sync() has made them visible; ids[k] = 1-based id of the
@@ -89,8 +103,14 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
     // 2 = step six (solve), 3 = step eleven (remove), 4 = done
     int phase = live ? 0 : 4;
     lds_sync();
+#if defined(OPTIK_PROFILE) && !defined(OPTIK_LANE_EMU)
+    unsigned long long np_[8] = {0, 0, 0, 0, 0, 1, 0, 0};
+    unsigned long long nt_ = __builtin_readcyclecounter();
+#endif
 
     while (wave_any(phase < 4)) {
+        QNNLS_COUNT(4, 1);
+        QNNLS_PROBE(7);
         // ---------------- steps two .. five --------------------------------------------
         if (wave_any(phase == 0 || phase == 1)) {
             const bool inA = (phase == 0 || phase == 1);
@@ -124,8 +144,8 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
             }
 #pragma unroll
             for (int off = 2; off >= 1; off >>= 1) {
-                const double ow = quad_xor_get(bw, off);
-                const int op = quad_xor_get(bp, off);
+                const double ow = quad_xor(bw, off);
+                const int op = quad_xor(bp, off);
                 const bool better = (ow > bw) || (ow == bw && op < bp);
                 bw = better ? ow : bw;
                 bp = better ? op : bp;
@@ -133,6 +153,7 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
             const bool none = !(bw > 0.0);
             if (run && none) phase = 4;  // step four: every dual <= 0 -> done
             const bool cand = run && !none;
+            QNNLS_PROBE(0);
             // (the last trip of most waves: every problem left has just finished)
             if (wave_any(cand)) {
                 // step five: Householder construction on the chosen column j (position bp)
@@ -210,7 +231,14 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
                 const double smhb = actb ? smb * hb : 0.0;
                 const double bpiv = vpick(b, npp1);
                 const double ztp = actb ? bpiv + smhb * up : bpiv;
-                const bool found = cand && ok1 && (ztp / ulp > 0.0);
+                // Lawson-Hanson's test z(npp1) / A(npp1, j) > 0.  The quotient of two finite numbers is positive
+                // exactly when they have the same sign and it does not underflow to zero: with both magnitudes
+                // in [2^-500, 2^500] it cannot, so the signs decide; anything else takes the division itself.
+                const double aztp = __builtin_fabs(ztp), aulp = __builtin_fabs(ulp);
+                const bool tame = aztp >= 0x1p-500 && aztp <= 0x1p500 && aulp >= 0x1p-500 && aulp <= 0x1p500;
+                bool quo_pos = (ztp > 0.0) == (ulp > 0.0);
+                if (wave_any(cand && ok1 && !tame)) quo_pos = tame ? quo_pos : (ztp / ulp > 0.0);
+                const bool found = cand && ok1 && quo_pos;
 #pragma unroll
                 for (int r = 1; r <= m; ++r) {
                     const double add = smhb * w[r - 1];
@@ -236,10 +264,10 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
                 npp1 = nsetp + 1;
                 // the column that entered P: untouched above the pivot row, ulp on it, zeros below
                 if (found && ql == 0) {
-                    double *d = blk + 8 * (j - 1);
+                    dvec8 nc = 0.0;
 #pragma unroll
-                    for (int r = 1; r <= m; ++r)
-                        if (r >= nsetp) d[r - 1] = (r == nsetp) ? ulp : 0.0;
+                    for (int r = 1; r <= m; ++r) nc[r - 1] = (r < nsetp) ? u[r - 1] : ((r == nsetp) ? ulp : 0.0);
+                    lds_col_store(blk + 8 * (j - 1), nc);
                 }
                 // the transformation applied to the lane's columns still in Z (pivot row nsetp, rows below)
 #pragma unroll
@@ -254,15 +282,20 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
                     const bool act = found && apply_live && inZ[k] && sm != 0.0;
                     const double smh = act ? sm * hb : 0.0;
                     if (act) {
+                        dvec8 nc = cv;
 #pragma unroll
-                        for (int r = 1; r <= m; ++r)
-                            if (r >= nsetp) colp[k][r - 1] = cv[r - 1] + smh * w[r - 1];
+                        for (int r = 1; r <= m; ++r) {
+                            const double v = cv[r - 1] + smh * w[r - 1];
+                            nc[r - 1] = (r >= nsetp) ? v : cv[r - 1];
+                        }
+                        lds_col_store(colp[k], nc);
                     }
                     wv[k] = (cand && hitk[k]) ? 0.0 : wv[k];
                 }
                 // found: solve (step six); else choose again without recomputing the duals
                 phase = cand ? (found ? 2 : 1) : phase;
                 lds_sync();
+                QNNLS_PROBE(1);
             }
         }
         // ---------------- steps six .. ten ---------------------------------------------
@@ -323,6 +356,7 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
             rem_jj = (go && jj != 0) ? jj : rem_jj;
             phase = go ? (jj == 0 ? 0 : 3) : phase;  // back to step two, or remove position jj
             lds_sync();
+            QNNLS_PROBE(2);
         }
         // ---------------- step eleven ----------------------------------------------------
         if (wave_any(phase == 3)) {
@@ -336,14 +370,17 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
             }
             const int id_out = run ? indx.get(rem_jj) : 1;
             const int jlo = run ? rem_jj + 1 : 0x7fffffff, jhi = run ? nsetp : 0;
-            int wlo = jlo, whi = jhi;
+            // (the positions some quad of the wave has to move: m ballots instead of a wave-wide min / max butterfly)
+            int wlo = 0x7fffffff, whi = 0;
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const int a0 = __shfl_xor(wlo, off, 64), a1 = __shfl_xor(whi, off, 64);
-                wlo = a0 < wlo ? a0 : wlo;
-                whi = a1 > whi ? a1 : whi;
+            for (int v = 2; v <= m; ++v) {
+                if (wave_any(run && v >= jlo && v <= jhi)) {
+                    wlo = wlo < v ? wlo : v;
+                    whi = v;
+                }
             }
             for (int j = wlo; j <= whi; ++j) {
+                QNNLS_COUNT(6, 1);
                 const bool step = run && j >= jlo && j <= jhi;
                 const int jm1 = j - 1 < 1 ? 1 : (j - 1 > m ? m : j - 1), jc = j > m ? m : (j < 1 ? 1 : j);
                 // the column at position j moves to position j-1; Givens on its rows j-1, j
@@ -391,15 +428,20 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
                     bad = p < bad ? p : bad;
                 }
 #pragma unroll
-                for (int off = 2; off >= 1; off >>= 1) { const int o = quad_xor_get(bad, off); bad = o < bad ? o : bad; }
+                for (int off = 2; off >= 1; off >>= 1) { const int o = quad_xor(bad, off); bad = o < bad ? o : bad; }
                 if (phase == 3) {
                     if (bad != 0x7fffffff) rem_jj = bad;  // again
                     else phase = 2;
                 }
             }
             lds_sync();
+            QNNLS_PROBE(3);
         }
     }
+#if defined(OPTIK_PROFILE) && !defined(OPTIK_LANE_EMU)
+    if ((threadIdx.x & 63u) == 0)
+        for (int i_ = 0; i_ < 7; ++i_) atomicAdd(&g_quad_nnls_prof[i_], np_[i_]);
+#endif
     // rnorm = ||b(npp1..m)||
     {
         const int k0 = (npp1 < m) ? npp1 : m;

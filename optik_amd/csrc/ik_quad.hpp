@@ -75,8 +75,20 @@ OPTIK_DEV Pose pose_sel(bool c, const Pose a, const Pose b) {
 // multiplying it onto the chain: independent per joint); the chain product itself is sequential
 // and every lane walks it, keeping the frames of its own joints; the error terms are formed by all
 // four lanes alike; each lane then does the Jacobian columns of its joints.
+// (makes the compiler forget what it knows about a pointer: a later load through it is issued again
+// instead of keeping the first load's registers alive in between)
+template <class T>
+OPTIK_DEV const T *reload_barrier(const T *p) {
+#ifdef OPTIK_LANE_EMU
+    asm volatile("" : "+r"(p));
+#else
+    asm volatile("" : "+v"(p));
+#endif
+    return p;
+}
+
 template <int N, bool TIP>
-OPTIK_DEV double eval_quad(const ChainDev &ch, const EvalParams &ep, const Pose target,
+OPTIK_DEV double eval_quad(const ChainDev &ch, const EvalParams &ep, const double *target7,
                            const double (&x)[QuadDims<N>::NS], double (&gout)[QuadDims<N>::NS]) {
     constexpr int NS = QuadDims<N>::NS;
     const int q = quad_lane();
@@ -109,23 +121,47 @@ OPTIK_DEV double eval_quad(const ChainDev &ch, const EvalParams &ep, const Pose 
     if (TIP) state = pose_mul(state, load_pose(ch.origin[N]));
     const Pose ee = ep.has_ee_offset ? pose_mul(state, load_pose(ep.ee_offset)) : state;  // kinematics.rs:163
 
+    // the lane's joints: body-frame Jacobian column (kinematics.rs:173-184) -- formed here, while the
+    // joint frames are at hand: six doubles per joint stay, the frames (fourteen) go
+    double lin[NS][3], ang[NS][3];
+    {
+        const Q4 eeqc = qconj(ee.q);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int k = (q + 4 * s < N) ? q + 4 * s : N - 1;
+            const V3 ax{ch.axis[k][0], ch.axis[k][1], ch.axis[k][2]};
+            const V3 angular = qrot(tf[s].q, ax);
+            const V3 d{ee.t.x - tf[s].t.x, ee.t.y - tf[s].t.y, ee.t.z - tf[s].t.z};
+            const V3 linear = cross(angular, d);
+            const V3 al = qrot(eeqc, angular);
+            const V3 ll = qrot(eeqc, linear);
+            lin[s][0] = ll.x; lin[s][1] = ll.y; lin[s][2] = ll.z;
+            ang[s][0] = al.x; ang[s][1] = al.y; ang[s][2] = al.z;
+            OPTIK_SCHED_FENCE();
+        }
+    }
+
     // X = T_target^-1 T_ee  (objective.rs:69-70)
-    const Pose X = pose_inv_mul(target, ee);
+    const Pose X = pose_inv_mul(load_pose(target7), ee);
+    OPTIK_SCHED_FENCE();
     const V3 w = so3_log(X.q);
     const RotTerms rt = rot_terms(w);
     const M3 Jr = so3_right_jacobian(rt);          // math.rs:195
     const M3 Qm = se3_q_matrix(rt, X.t, Jr);       // math.rs:196 (E = Jr, math.rs:167)
     const V3 elin = se3_log_linear(rt, X.t);       // math.rs:120-122
+    OPTIK_SCHED_FENCE();
 
     // weighted error for the value (objective.rs:52) and for the gradient (:104)
+    const double *tq7 = reload_barrier(target7);
+    const Q4 tq{tq7[3], tq7[4], tq7[5], tq7[6]};
     V3 fl = elin, fa = w;
-    if (!ep.skip_lin) fl = weight_block(target.q, elin, ep.w_lin);
-    if (!ep.skip_ang) fa = weight_block(target.q, w, ep.w_ang);
+    if (!ep.skip_lin) fl = weight_block(tq, elin, ep.w_lin);
+    if (!ep.skip_ang) fa = weight_block(tq, w, ep.w_ang);
     V3 gl = fl, ga = fa;
     if (!ep.grad_same_as_value) {
         gl = elin; ga = w;
-        if (!ep.skip_lin2) gl = weight_block(target.q, elin, ep.w_lin2);
-        if (!ep.skip_ang2) ga = weight_block(target.q, w, ep.w_ang2);
+        if (!ep.skip_lin2) gl = weight_block(tq, elin, ep.w_lin2);
+        if (!ep.skip_ang2) ga = weight_block(tq, w, ep.w_ang2);
     }
     const double e2[6] = {2.0 * gl.x, 2.0 * gl.y, 2.0 * gl.z, 2.0 * ga.x, 2.0 * ga.y, 2.0 * ga.z};
     // f = ||e||^2 (objective.rs:56)
@@ -135,34 +171,21 @@ OPTIK_DEV double eval_quad(const ChainDev &ch, const EvalParams &ep, const Pose 
     for (int i = 0; i < 6; ++i) f += ef[i] * ef[i];
     OPTIK_SCHED_FENCE();
 
-    // the lane's joints: body-frame Jacobian column (kinematics.rs:173-184), then
-    // Jtask = Jlog6 * J (objective.rs:81) and g = (2 e') Jtask (objective.rs:106-109)
-    const Q4 eeqc = qconj(ee.q);
+    // Jtask = Jlog6 * J (objective.rs:81) and g = (2 e') Jtask (objective.rs:106-109) for the lane's columns
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        const int k = (q + 4 * s < N) ? q + 4 * s : N - 1;
-        const V3 tk = tf[s].t;
-        const Q4 tq = tf[s].q;
-        const V3 ax{ch.axis[k][0], ch.axis[k][1], ch.axis[k][2]};
-        const V3 angular = qrot(tq, ax);
-        const V3 d{ee.t.x - tk.x, ee.t.y - tk.y, ee.t.z - tk.z};
-        const V3 linear = cross(angular, d);
-        const V3 al = qrot(eeqc, angular);
-        const V3 ll = qrot(eeqc, linear);
-        const double lin[3] = {ll.x, ll.y, ll.z};
-        const double ang[3] = {al.x, al.y, al.z};
         double jt[6];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             double acc = 0.0;
 #pragma unroll
-            for (int m = 0; m < 3; ++m) acc += Jr.m[r][m] * lin[m];
+            for (int m = 0; m < 3; ++m) acc += Jr.m[r][m] * lin[s][m];
 #pragma unroll
-            for (int m = 0; m < 3; ++m) acc += Qm.m[r][m] * ang[m];
+            for (int m = 0; m < 3; ++m) acc += Qm.m[r][m] * ang[s][m];
             jt[r] = acc;
             double acc2 = 0.0;  // lower-left block of Jlog6 is zero
 #pragma unroll
-            for (int m = 0; m < 3; ++m) acc2 += Jr.m[r][m] * ang[m];
+            for (int m = 0; m < 3; ++m) acc2 += Jr.m[r][m] * ang[s][m];
             jt[r + 3] = acc2;
         }
         double acc = 0.0;
@@ -658,20 +681,23 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
             }
             OPTIK_SCHED_FENCE();
             // (the target pose is re-read for every evaluation: seven L1 / L2 hits instead of 14 registers)
-            const Pose target = load_pose(wq.targets + (size_t)tslot * 7);
+            const double *target7 = wq.targets + (size_t)tslot * 7;
 #ifndef OPTIK_QUAD_EXP_NO_EVAL
-            fn = eval_quad<N, TIP>(ch, ep, target, x, gn);
+            fn = eval_quad<N, TIP>(ch, ep, target7, x, gn);
 #else
-            fn = target.t.x; gn[0] = x[0]; if (NS > 1) gn[NS - 1] = x[NS - 1];
+            fn = target7[0]; gn[0] = x[0]; if (NS > 1) gn[NS - 1] = x[NS - 1];
 #endif
             OPTIK_SCHED_FENCE();
+            // (through a pointer the compiler knows nothing about: otherwise it forwards the stored values to
+            // these loads, i.e. keeps them in registers across the evaluation after all)
+            const double *pk = reload_barrier((const double *)blk);
             pi = 0;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                x0[s] = blk[4 * pi++ + q]; g[s] = blk[4 * pi++ + q]; sv[s] = blk[4 * pi++ + q]; dg[s] = blk[4 * pi++ + q];
+                x0[s] = pk[4 * pi++ + q]; g[s] = pk[4 * pi++ + q]; sv[s] = pk[4 * pi++ + q]; dg[s] = pk[4 * pi++ + q];
 #pragma unroll
                 for (int i = 0; i < NM; ++i)
-                    if (slot_has<N>(s, i)) Lr[s][i] = blk[4 * pi++ + q];
+                    if (slot_has<N>(s, i)) Lr[s][i] = pk[4 * pi++ + q];
             }
         }
         OPTIK_PROF_END(1);

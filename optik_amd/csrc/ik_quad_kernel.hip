@@ -20,17 +20,28 @@ __global__ __launch_bounds__(64, OPTIK_QUAD_WAVES) void ik_quad_kernel(const Sol
     __shared__ ChainDev sch;
     __shared__ __attribute__((aligned(16))) double nnls_lds[quad_wave_lds()];
     __shared__ double lane_lds[quad_lane_lds()];
+    // The launch parameters (~540 bytes: weights, ChaCha key, scales, queue and output pointers) are
+    // copied from the kernel-argument segment to LDS once and read from there: as kernel arguments
+    // they would sit in ~125 SGPRs for the whole kernel, next to the ~60 double constants of
+    // sin / cos / atan2 the compiler hoists out of the solver loop -- more than the 102 a wave has;
+    // the overflow spills into VGPR lanes, and those VGPRs into scratch.
+    __shared__ __attribute__((aligned(8))) uint32_t launch_lds[(sizeof(SolveLaunch) + 3) / 4];
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(&a);
+        for (unsigned i = threadIdx.x; i < sizeof(SolveLaunch) / 4; i += 64) launch_lds[i] = src[i];
+    }
     if (threadIdx.x < 8) nnls_lds[quad_wave_lds() - 8 + threadIdx.x] = 0.0;  // the column of zeros
     stage_chain(sch, a.chain);
-    WorkQueue wq = a.wq;
-    wq.deadline = a.deadline_ticks ? wall_clock64() + a.deadline_ticks : 0ull;
-    quad_wave<N, TIP>(sch, a.ep, a.sp, a.key, a.scale, wq, nnls_lds, lane_lds);
+    SolveLaunch &L = *reinterpret_cast<SolveLaunch *>(launch_lds);
+    if (threadIdx.x == 0) L.wq.deadline = L.deadline_ticks ? wall_clock64() + L.deadline_ticks : 0ull;
+    __syncthreads();
+    quad_wave<N, TIP>(sch, L.ep, L.sp, L.key, L.scale, L.wq, nnls_lds, lane_lds);
 }
 
 int quad_solve_waves_per_cu() { return 4 * OPTIK_QUAD_WAVES; }
 
 hipError_t quad_solve_launch(int n, bool tip, int grid, hipStream_t stream, const SolveLaunch &a, int *lds_bytes) {
-    if (lds_bytes) *lds_bytes = (int)(sizeof(ChainDev) + sizeof(double) * (quad_wave_lds() + quad_lane_lds()));
+    if (lds_bytes) *lds_bytes = (int)(sizeof(ChainDev) + sizeof(SolveLaunch) + sizeof(double) * (quad_wave_lds() + quad_lane_lds()));
 #define CALL_QUAD(NN)                                                                                   \
     case NN:                                                                                            \
         if (tip) hipLaunchKernelGGL((ik_quad_kernel<NN, true>), dim3(grid), dim3(64), 0, stream, a);    \
@@ -49,3 +60,13 @@ hipError_t quad_solve_launch(int n, bool tip, int grid, hipStream_t stream, cons
 }
 
 }  // namespace optik
+
+#ifdef OPTIK_PROFILE
+// diagnostic builds: cycles per part of the quad NNLS since the last call (ik_nnls_quad.hpp), then reset
+extern "C" int optik_hip_quad_nnls_profile(unsigned long long *out8) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(optik::g_quad_nnls_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[8] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(optik::g_quad_nnls_prof), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#endif

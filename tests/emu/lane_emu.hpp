@@ -61,8 +61,8 @@ inline void barrier() {
                 std::this_thread::yield();
                 spins = 0;
                 if ((++yields & 1023) == 0
-                    && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 20.0) {
-                    std::fprintf(stderr, "lane_emu: lane %u waited 20 s at a barrier: a collective was called under "
+                    && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) {
+                    std::fprintf(stderr, "lane_emu: lane %u waited 120 s at a barrier: a collective was called under "
                                          "lane-divergent control flow\n", threadIdx_x());
                     std::abort();
                 }

@@ -41,7 +41,11 @@ def main():
     x0 = torch.tensor(rng.uniform(lb, ub, size=(1, len(lb))), device="cuda:0")
     cfg = nat.make_config("speed")
     bufs = hc.alloc_ik_buffers(1, R)
+    qn = (C.c_ulonglong * 8)()
+    have_qn = hasattr(nat.lib(), "optik_hip_quad_nnls_profile")
     for _ in range(2):
+        if have_qn:
+            nat.lib().optik_hip_quad_nnls_profile(qn)  # (reset)
         hc.ik_batch(cfg, tgt, x0, 0, R, bufs=bufs)
     torch.cuda.synchronize()
     out = (C.c_ulonglong * 8)()
@@ -56,6 +60,14 @@ def main():
     for n_, c in zip(names[:7], v[:7]):
         print(f"  {n_:16s} {c / trips:10.0f} cycles/trip  {100.0 * c / total:5.1f} %")
     print(f"  total            {total / trips:10.0f} cycles/trip")
+    if have_qn and os.environ.get("OPTIK_SOLVE_KERNEL") in (None, "quad"):
+        nat.lib().optik_hip_quad_nnls_profile(qn)
+        q = list(qn)
+        calls, loops = max(q[5], 1), max(q[4], 1)
+        print(f"  quad NNLS: {calls} wave-level calls ({calls / trips:.2f} per trip), {loops / calls:.2f} loop trips per call, "
+              f"{q[6] / calls:.2f} Givens steps per call")
+        for n_, c in zip(["steps 2-4 (duals, argmax)", "step 5 (Householder)", "steps 6-10 (solve, step)", "step 11 (remove)"], q[:4]):
+            print(f"    {n_:26s} {c / calls:9.0f} cycles/call {c / loops:9.0f} cycles/loop trip")
 
 
 def engine_profile():
