@@ -19,13 +19,15 @@ OPTIK_DEV int quad_base() { return (int)(threadIdx.x & 63u) & ~3; }
 OPTIK_DEV double quad_get(double v, int k) { return __shfl(v, quad_base() + (k & 3), 64); }
 OPTIK_DEV int quad_get(int v, int k) { return __shfl(v, quad_base() + (k & 3), 64); }
 #else
+// (bound_ctrl = true: every lane of a full wave has a valid source, so no "old" value has to be
+// materialised in the destination first -- with false the compiler emits a v_mov 0 before every DPP move)
 template <int K>
 OPTIK_DEV double quad_get_c(double v) {
-    return __builtin_amdgcn_update_dpp(0.0, v, K * 0x55, 0xf, 0xf, false);  // quad_perm:[K,K,K,K]
+    return __builtin_amdgcn_update_dpp(0.0, v, K * 0x55, 0xf, 0xf, true);  // quad_perm:[K,K,K,K]
 }
 template <int K>
 OPTIK_DEV int quad_get_c(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, K * 0x55, 0xf, 0xf, false);
+    return __builtin_amdgcn_update_dpp(0, v, K * 0x55, 0xf, 0xf, true);
 }
 // value held by lane k & 3 of the caller's quad (k: a constant after unrolling)
 OPTIK_DEV double quad_get(double v, int k) {
@@ -53,12 +55,12 @@ OPTIK_DEV double quad_xor(double v, int mask) { return __shfl_xor(v, mask, 64); 
 OPTIK_DEV int quad_xor(int v, int mask) { return __shfl_xor(v, mask, 64); }
 #else
 OPTIK_DEV double quad_xor(double v, int mask) {
-    return mask == 1 ? __builtin_amdgcn_update_dpp(0.0, v, 0xB1, 0xf, 0xf, false)
-                     : __builtin_amdgcn_update_dpp(0.0, v, 0x4E, 0xf, 0xf, false);
+    return mask == 1 ? __builtin_amdgcn_update_dpp(0.0, v, 0xB1, 0xf, 0xf, true)
+                     : __builtin_amdgcn_update_dpp(0.0, v, 0x4E, 0xf, 0xf, true);
 }
 OPTIK_DEV int quad_xor(int v, int mask) {
-    return mask == 1 ? __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false)
-                     : __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+    return mask == 1 ? __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true)
+                     : __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);
 }
 #endif
 

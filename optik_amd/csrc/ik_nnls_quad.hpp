@@ -158,18 +158,28 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
             if (wave_any(cand)) {
                 // step five: Householder construction on the chosen column j (position bp)
                 const int j = cand ? indx.get(bp) : 1;
-                const dvec8 u = lds_col_load(blk + 8 * (j - 1));
+                // (w: the column, soon the transformation's weights -- u below the pivot row, up on it, 0 above)
+                dvec8 w = lds_col_load(blk + 8 * (j - 1));
                 lds_sync();  // (every lane has the column before its pivot rows are rewritten below)
                 bool hitk[CPL];
 #pragma unroll
                 for (int k = 0; k < CPL; ++k) hitk[k] = cand && inZ[k] && pos[k] == bp;
                 // (all lanes run the construction; only `cand` quads keep its results)
-                const double asave = vpick(u, npp1);
+                const double asave = vpick(w, npp1);
                 const bool h12_live = npp1 < m;
+                // the part of the column above the pivot row only feeds Lawson-Hanson's independence test (below)
+                double xmax = 0.0;
+#pragma unroll
+                for (int r = 1; r <= m; ++r) {
+                    const double av = (r <= nsetp) ? __builtin_fabs(w[r - 1]) : 0.0;
+                    xmax = (av > xmax) ? av : xmax;
+                }
+#pragma unroll
+                for (int r = 1; r <= m; ++r) w[r - 1] = (r > npp1) ? w[r - 1] : 0.0;
                 double cl = __builtin_fabs(asave);
 #pragma unroll
                 for (int r = 1; r <= m; ++r) {
-                    const double sm = (r > npp1) ? __builtin_fabs(u[r - 1]) : 0.0;
+                    const double sm = __builtin_fabs(w[r - 1]);
                     cl = (sm > cl) ? sm : cl;
                 }
                 const bool pivot = h12_live && !(cl <= 0.0);
@@ -180,7 +190,7 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
                     double sm = d * d;
 #pragma unroll
                     for (int r = 1; r <= m; ++r) {
-                        d = ((r > npp1) ? u[r - 1] : 0.0) * clinv;
+                        d = w[r - 1] * clinv;
                         sm += d * d;
                     }
                     double c2 = cl * __builtin_sqrt(sm);
@@ -188,22 +198,17 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
                     up = (cand && pivot) ? asave - c2 : up;
                     ulp = pivot ? c2 : ulp;
                 }
-                // Lawson-Hanson's independence test diff(unorm + factor |ulp|, unorm) > 0 (see nnls_coop: decided
-                // by t > 3 * 2^-52 * xmax whenever that holds, by the norm itself otherwise)
-                double xmax = 0.0;
-#pragma unroll
-                for (int r = 1; r <= m; ++r) {
-                    const double av = (r <= nsetp) ? __builtin_fabs(u[r - 1]) : 0.0;
-                    xmax = (av > xmax) ? av : xmax;
-                }
+                // diff(unorm + factor |ulp|, unorm) > 0 (see nnls_coop: decided by t > 3 * 2^-52 * xmax whenever
+                // that holds; otherwise by the norm of the column above the pivot row, re-read from the block)
                 const double t = factor * __builtin_fabs(ulp);
                 bool ok1 = t > 6.7e-16 * xmax;
                 if (wave_any(cand && !ok1)) {
+                    const dvec8 uu = lds_col_load(blk + 8 * (j - 1));
                     const double scale = 1.0 / xmax;
                     double sum = 0.0;
 #pragma unroll
                     for (int r = 1; r <= m; ++r) {
-                        const double xsr = scale * ((r <= nsetp) ? u[r - 1] : 0.0);
+                        const double xsr = scale * ((r <= nsetp) ? uu[r - 1] : 0.0);
                         sum += xsr * xsr;
                     }
                     const double unorm = (xmax != 0.0) ? xmax * __builtin_sqrt(sum) : 0.0;
@@ -213,12 +218,8 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
                 const double hprod = up * ulp;
                 const bool apply_live = cand && h12_live && !(__builtin_fabs(ulp) <= 0.0) && !(hprod >= 0.0);
                 const double hb = apply_live ? 1.0 / hprod : 0.0;
-                // the transformation as a weight per row: up at the pivot row, u below, 0 above -- formed in
-                // place of u (the column's own new content needs nothing of it: unchanged above the pivot
-                // row, ulp on it, zeros below)
-                dvec8 w = u;
 #pragma unroll
-                for (int r = 1; r <= m; ++r) w[r - 1] = (r == npp1) ? up : ((r > npp1) ? w[r - 1] : 0.0);
+                for (int r = 1; r <= m; ++r) w[r - 1] = (r == npp1) ? up : w[r - 1];
                 // b := Q b: first the scalar and the pivot entry (they decide whether the column enters), then
                 // b itself, in place, only if it does
                 double smb = 0.0;
@@ -239,10 +240,21 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
                 bool quo_pos = (ztp > 0.0) == (ulp > 0.0);
                 if (wave_any(cand && ok1 && !tame)) quo_pos = tame ? quo_pos : (ztp / ulp > 0.0);
                 const bool found = cand && ok1 && quo_pos;
+                // Rows the transformation leaves alone (above the pivot row) get -0.0 added: their weight is
+                // an exact zero, the product a signed zero, and with the sign bit forced x + (-0.0) == x bit for
+                // bit -- one OR per element instead of a select.  The same OR neutralises a whole vector.
+                unsigned rowkeep[8];
 #pragma unroll
-                for (int r = 1; r <= m; ++r) {
-                    const double add = smhb * w[r - 1];
-                    b[r - 1] = (found && actb && r >= npp1) ? b[r - 1] + add : b[r - 1];
+                for (int r = 1; r <= m; ++r) rowkeep[r - 1] = (r < npp1) ? 0x80000000u : 0u;
+                {
+                    const unsigned allkeep = (found && actb) ? 0u : 0x80000000u;
+#pragma unroll
+                    for (int r = 1; r <= m; ++r) {
+                        const double add = smhb * w[r - 1];
+                        const double addz = __hiloint2double((int)((unsigned)__double2hiint(add) | rowkeep[r - 1] | allkeep),
+                                                             __double2loint(add));
+                        b[r - 1] = b[r - 1] + addz;
+                    }
                 }
                 // column j takes position iz1 = nsetp + 1, the column there takes j's
                 {
@@ -263,16 +275,17 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
                 nsetp = found ? npp1 : nsetp;
                 npp1 = nsetp + 1;
                 // the column that entered P: untouched above the pivot row, ulp on it, zeros below
-                if (found && ql == 0) {
-                    dvec8 nc = 0.0;
+                {
+                    dvec8 nc = lds_col_load(blk + 8 * (j - 1));
 #pragma unroll
-                    for (int r = 1; r <= m; ++r) nc[r - 1] = (r < nsetp) ? u[r - 1] : ((r == nsetp) ? ulp : 0.0);
-                    lds_col_store(blk + 8 * (j - 1), nc);
+                    for (int r = 1; r <= m; ++r) nc[r - 1] = (r < nsetp) ? nc[r - 1] : ((r == nsetp) ? ulp : 0.0);
+                    lds_sync();  // (every lane has re-read it)
+                    if (found && ql == 0) lds_col_store(blk + 8 * (j - 1), nc);
                 }
                 // the transformation applied to the lane's columns still in Z (pivot row nsetp, rows below)
 #pragma unroll
                 for (int k = 0; k < CPL; ++k) {
-                    const dvec8 cv = lds_col_load(colp[k]);
+                    dvec8 cv = lds_col_load(colp[k]);
                     double sm = 0.0;
 #pragma unroll
                     for (int r = 1; r <= m; ++r) {
@@ -281,15 +294,14 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
                     }
                     const bool act = found && apply_live && inZ[k] && sm != 0.0;
                     const double smh = act ? sm * hb : 0.0;
-                    if (act) {
-                        dvec8 nc = cv;
 #pragma unroll
-                        for (int r = 1; r <= m; ++r) {
-                            const double v = cv[r - 1] + smh * w[r - 1];
-                            nc[r - 1] = (r >= nsetp) ? v : cv[r - 1];
-                        }
-                        lds_col_store(colp[k], nc);
+                    for (int r = 1; r <= m; ++r) {
+                        const double add = smh * w[r - 1];
+                        const double addz = __hiloint2double((int)((unsigned)__double2hiint(add) | rowkeep[r - 1]),
+                                                             __double2loint(add));
+                        cv[r - 1] = cv[r - 1] + addz;
                     }
+                    if (act) lds_col_store(colp[k], cv);
                     wv[k] = (cand && hitk[k]) ? 0.0 : wv[k];
                 }
                 // found: solve (step six); else choose again without recomputing the duals
