@@ -62,7 +62,9 @@ F64_VALU_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 16 f64 lanes/clk x 2 (FMA) x 
 # ... and what this path can reach at best: -ffp-contract=off (rustc never fuses a*b+c, and the
 # bit-exactness contract with the oracle forbids it) makes every f64 instruction ONE flop
 F64_VALU_NOFMA_TFLOPS = 39.3
-PMC_FILE = os.path.join(ROOT, "profiles", "r2_pmc_by_command.json")
+PMC_FILES = [os.path.join(ROOT, "profiles", "r3_pmc_by_command.json"),
+             os.path.join(ROOT, "profiles", "r2_pmc_by_command.json")]
+PMC_FILE = PMC_FILES[0]
 
 ENGINE_POOL = 240  # steps whose restarts share one engine run (the engine pools up to 256 jobs)
 
@@ -74,18 +76,27 @@ def command_key(args, world):
 
 
 def pmc_for(key):
-    try:
-        with open(PMC_FILE) as fh:
-            return json.load(fh)["commands"].get(key)
-    except (OSError, KeyError, ValueError):
-        return None
+    """The PMC record of this exact command (newest profile file first), with the file it came from."""
+    global PMC_FILE
+    for f in PMC_FILES:
+        try:
+            with open(f) as fh:
+                rec = json.load(fh)["commands"].get(key)
+        except (OSError, KeyError, ValueError):
+            rec = None
+        if rec:
+            PMC_FILE = f
+            return rec
+    return None
 
 
 def load_chain(robot):
     """Flat chain table through the product's own URDF loader (C++, optik_robot_*)."""
     from optik_amd import Robot
     spec = {"panda": ("panda.urdf", "panda_link0", "panda_link8"),
-            "ur10": ("ur10.urdf", "base_link", "ee_link")}[robot]
+            "ur10": ("ur10.urdf", "base_link", "ee_link"),
+            # a synthetic 8-DoF chain (tests/golden/robots/): the largest n the kernels are built for
+            "arm8": (os.path.join("..", "..", "tests", "golden", "robots", "arm8.urdf"), "l0", "l9")}[robot]
     path = os.path.join(ROOT, "optik_amd", "robots", spec[0])
     return Robot.from_urdf_file(path, spec[1], spec[2])
 
@@ -234,7 +245,7 @@ def main():
     ap.add_argument("--restarts", type=int, default=None,
                     help="restarts per step: per GPU (weak) or in total (strong); per target with --targets; "
                          "default 65536 (256 with --targets)")
-    ap.add_argument("--robot", default="panda", choices=["panda", "ur10"])
+    ap.add_argument("--robot", default="panda", choices=["panda", "ur10", "arm8"])
     ap.add_argument("--mode", default="speed", choices=["speed", "quality"], help="SolutionMode (config.rs:3-8)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--targets", type=int, default=0,
@@ -516,12 +527,30 @@ def main():
             achieved = out_bytes * per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
             kname = {"coop": "ik_coop_kernel", "lane": "ik_solve_kernel"}.get(os.environ.get("OPTIK_SOLVE_KERNEL", ""),
                                                                                 "ik_quad_kernel" if n <= 7 else "ik_solve_kernel")
+            kp = (pmc or {}).get("kernel_path")
+            traffic, traffic_note, secondary = None, f"no PMC pass of this command under profiles/ (key: {key})", None
+            if kp:
+                traffic = kp["hbm_bytes_per_restart"] * per_launch
+                traffic_note = (f"{os.path.relpath(PMC_FILE, ROOT)}: separate FETCH_SIZE / WRITE_SIZE passes of this command "
+                                f"(2 x FETCH + WRITE), the {kp['launches']} launches of the timed repetitions: "
+                                f"{kp['hbm_bytes_per_restart']:.0f} B per restart at the fabric counters against "
+                                f"{out_bytes} B of outputs -- the difference is the kernel's register spills (scratch: "
+                                "per-wave private memory, Infinity-Cache resident), not restart state")
+                tf = total / elapsed * kp["f64_flops_per_restart"] / 1e12
+                secondary = {"bound": "valu_f64", "achieved": tf, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": tf / F64_VALU_PEAK_TFLOPS, "peak_no_fma": F64_VALU_NOFMA_TFLOPS,
+                             "frac_no_fma": tf / F64_VALU_NOFMA_TFLOPS,
+                             "flops_note": "wave-level instruction counts x 64 lanes (EXEC masks not applied; the four "
+                                           "lanes of a quad repeat the scalar parts): an upper bound on the useful flops",
+                             "f64_flops_per_restart": kp["f64_flops_per_restart"], "valu_busy": kp.get("valu_busy"),
+                             "source": os.path.relpath(PMC_FILE, ROOT)}
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note, "kernel": kname,
                     "kernel_ms": kernel_ms, "launches_timed": launches,
+                    "algorithmic_bytes_per_launch": out_bytes * per_launch,
                     "algorithmic_bytes_per_unit": out_bytes, "unit_name": "restart (seeds are generated in-kernel: "
                     "the outputs are the whole per-restart traffic of this path)", "units_per_launch": per_launch,
-                    "secondary": None}
+                    "secondary": secondary}
         if T:
             metric = f"ik() calls/sec ({args.robot}, {T} targets x {R} restarts per step, 1e-6 tol; BASELINE.json config 5)"
             unit = "ik calls/s"

@@ -31,7 +31,7 @@ DEPS = {"ik_kernels.hip": HEADERS,
                            os.path.join("..", "..", "include", "optik.h")]}
 
 
-EXTRA_FLAGS = {"ik_quad_kernel.hip": ["-DOPTIK_QUAD_WAVES=2"]}
+EXTRA_FLAGS = {}
 
 
 def _hipcc():

@@ -1052,20 +1052,25 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         if (a.deadline_ticks == 0) a.deadline_ticks = 1;
     }
 
-    // Which solver (n <= 7): the quad solver of ik_quad.hpp (a restart per quad of lanes, its state spread
-    // over the quad; the default), round 2's cooperative one (OPTIK_SOLVE_KERNEL=coop: the state in the
-    // quad's leader, ik_coop.hpp) or round 1's one-restart-per-lane kernel with its per-lane LDS NNLS
-    // (OPTIK_SOLVE_KERNEL=lane; the only one for n = 8).  Same results, bit for bit.
-    bool coop = ch->n <= 7, quadk = ch->n <= 7;
+    // Which solver: the quad solver of ik_quad.hpp (a restart per quad of lanes, its state spread over the
+    // quad, NNLS matrix in LDS; the default, n <= 8), round 2's cooperative one (OPTIK_SOLVE_KERNEL=coop:
+    // the state in the quad's leader, ik_coop.hpp; n <= 7) or round 1's one-restart-per-lane kernel with
+    // its per-lane LDS NNLS (OPTIK_SOLVE_KERNEL=lane).  Same results, bit for bit.
+    bool coop = ch->n <= 7, quadk = true;
     if (const char *e = std::getenv("OPTIK_SOLVE_KERNEL")) {
         coop = coop && std::strcmp(e, "lane") != 0;
-        quadk = coop && std::strcmp(e, "coop") != 0;
+        quadk = std::strcmp(e, "lane") != 0 && std::strcmp(e, "coop") != 0;
     }
+    coop = coop && !quadk;
     // Persistent waves, each pulling work items until the queue is dry: as many as a CU holds
     // (lane kernel: 2 workgroups, LDS-bound; cooperative kernel: 4, one per SIMD), times the CU count.
     const int cus = ch->num_cus > 0 ? ch->num_cus : 256;
-    const long long cap = (long long)cus * (quadk ? quad_solve_waves_per_cu() : (coop ? 4 : ch->waves_per_cu));
-    const long long per_wave_max = coop ? COOP_GROUPS_PER_WAVE : WAVE;
+    // (quad solver: a launch with no more work items than the chip has SIMDs runs one restart per wave on the
+    // one-wave-per-SIMD build -- no scratch, the lowest latency per iteration; anything bigger on the
+    // two-waves-per-SIMD build)
+    const bool quad_latency = quadk && (long long)cols <= (long long)cus * 4;
+    const long long cap = (long long)cus * (quadk ? (quad_latency ? 4 : quad_solve_waves_per_cu(ch->n)) : (coop ? 4 : ch->waves_per_cu));
+    const long long per_wave_max = (coop || quadk) ? COOP_GROUPS_PER_WAVE : WAVE;
     // fewer work items than the chip holds: one restart per wave (or as few as fit).  A
     // restart-major Speed batch keeps about eight restarts per target in flight: the waves pull
     // the higher indices of the targets still unsolved as they go
@@ -1102,7 +1107,7 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     }
     int lds = 0;
     if (quadk) {
-        HIP_TRY(quad_solve_launch(ch->n, ch->tip, grid, stream, a, &lds));
+        HIP_TRY(quad_solve_launch(ch->n, ch->tip, grid, stream, a, &lds, quad_latency));
     } else if (coop) {
 #define CALL_COOP(NN, TT)                                                                            \
     lds = (int)(sizeof(ChainDev) + sizeof(double) * (coop_wave_lds<4>() + COOP_GROUPS_PER_WAVE * coop_rec_lds<NN>())); \

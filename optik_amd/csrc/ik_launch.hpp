@@ -27,10 +27,12 @@ __device__ __forceinline__ void stage_chain(ChainDev &dst, const ChainDev *src) 
     __syncthreads();
 }
 
-// ik_quad_kernel.hip: the quad-distributed solver (ik_quad.hpp), n <= 7.  Launches `grid` single-wave
-// workgroups on `stream`; *lds_bytes = static LDS of the kernel.  Returns the hipGetLastError of the launch.
-hipError_t quad_solve_launch(int n, bool tip, int grid, hipStream_t stream, const SolveLaunch &a, int *lds_bytes);
+// ik_quad_kernel.hip: the quad-distributed solver (ik_quad.hpp), n <= 8.  Launches `grid` single-wave
+// workgroups on `stream`; *lds_bytes = static LDS of the kernel.  latency_form: the one-wave-per-SIMD
+// build without scratch (grids of at most 4 waves per CU).  Returns the hipGetLastError of the launch.
+hipError_t quad_solve_launch(int n, bool tip, int grid, hipStream_t stream, const SolveLaunch &a, int *lds_bytes,
+                             bool latency_form);
 // resident single-wave workgroups per CU the kernel is built for (registers and LDS)
-int quad_solve_waves_per_cu();
+int quad_solve_waves_per_cu(int n);
 
 }  // namespace optik

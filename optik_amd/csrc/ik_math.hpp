@@ -109,6 +109,18 @@ OPTIK_DEV double vpick(const dvec16 a, int idx) {
     return v;
 }
 
+OPTIK_DEV void vput(dvec16 &a, int idx, double v) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = (idx == i + 1) ? v : a[i];
+}
+
+OPTIK_DEV dvec16 vsel(bool c, const dvec16 a, const dvec16 b) {
+    dvec16 o;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] = c ? a[i] : b[i];
+    return o;
+}
+
 template <bool SMALL> struct RowVecOf { typedef dvec8 type; };
 template <> struct RowVecOf<false> { typedef dvec16 type; };
 

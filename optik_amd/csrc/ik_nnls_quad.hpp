@@ -30,10 +30,20 @@
 
 namespace optik {
 
-constexpr int NNLS_QUAD_STRIDE = 130;              // doubles per quad
-constexpr int NNLS_QUAD_XS = 14 * 8;               // multipliers by column id, after the 14 columns
-// doubles of LDS per wave: the blocks of its 16 quads, then eight doubles of +0.0 (read only)
-constexpr int nnls_quad_wave_lds() { return 16 * NNLS_QUAD_STRIDE + 8; }
+// Geometry of a quad's block for an N-joint chain: 2N columns of CS doubles (m = N + 1 rows: eight
+// doubles up to N = 7, ten -- 16-byte aligned -- for the nine rows of N = 8, whose row vectors are
+// dvec16), then the 2N multipliers.  STRIDE: doubles per quad, an odd number of 16-byte granules.
+template <int N>
+struct NnlsQuadGeom {
+    static constexpr int CS = (N + 1 <= 8) ? 8 : 10;
+    static constexpr int XS = (N <= 7 ? 14 : 2 * N) * CS;                    // (one block geometry for every N <= 7)
+    static constexpr int STRIDE = (N <= 7) ? 130 : ((XS + 2 * N + 1) / 2 * 2 + 2);  // N = 8: 160 + 16 -> 178 = 89 granules
+    typedef typename RowVecOf<(N + 1 <= 8)>::type rowvec;
+};
+static_assert(NnlsQuadGeom<8>::STRIDE == 178, "N = 8: 89 granules per quad");
+// doubles of LDS per wave: the blocks of its 16 quads, then sixteen doubles of +0.0 (read only)
+template <int N>
+constexpr int nnls_quad_wave_lds() { return 16 * NnlsQuadGeom<N>::STRIDE + 16; }
 
 // -DOPTIK_PROFILE: wave cycles per part of the loop below, summed over all waves into g_quad_nnls_prof
 // (tools/phase_profile.py): 0 steps two-four, 1 step five, 2 steps six-ten, 3 step eleven, 4 loop trips,
@@ -47,18 +57,20 @@ __device__ unsigned long long g_quad_nnls_prof[8];
 #define QNNLS_COUNT(slot, n)
 #endif
 
-OPTIK_DEV dvec8 lds_col_load(const double *p) {
+template <int N>
+OPTIK_DEV typename NnlsQuadGeom<N>::rowvec lds_col_load(const double *p) {
     const double *a = (const double *)__builtin_assume_aligned(p, 16);
-    dvec8 v;
+    typename NnlsQuadGeom<N>::rowvec v = 0.0;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = a[r];
+    for (int r = 0; r < NnlsQuadGeom<N>::CS; ++r) v[r] = a[r];
     return v;
 }
 
-OPTIK_DEV void lds_col_store(double *p, const dvec8 v) {
+template <int N>
+OPTIK_DEV void lds_col_store(double *p, const typename NnlsQuadGeom<N>::rowvec v) {
     double *a = (double *)__builtin_assume_aligned(p, 16);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) a[r] = v[r];
+    for (int r = 0; r < NnlsQuadGeom<N>::CS; ++r) a[r] = v[r];
 }
 
 // Solves the quad's problem.  On entry the owners have written the columns to `blk` (column id c at
@@ -71,13 +83,15 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
                          double &rnorm_out, int &iters_out) {
     constexpr int m = N + 1, n = 2 * N;
     constexpr int CPL = 4;
-    static_assert(m <= 8 && n <= 14, "a column is eight doubles, the block holds fourteen");
+    static_assert(m <= 9 && n <= 16, "row vectors hold up to sixteen entries, the permutation sixteen nibbles");
+    constexpr int CS = NnlsQuadGeom<N>::CS;
+    typedef typename NnlsQuadGeom<N>::rowvec dvecm;
     const double factor = 0.01;
     const int itmax = 3 * n;
     const int ql = quad_lane();
-    double *const xs = blk + NNLS_QUAD_XS;
+    double *const xs = blk + NnlsQuadGeom<N>::XS;
     // quad-uniform state (replicated in every lane of the quad)
-    dvec8 b = 0.0;
+    dvecm b = 0.0;
     b[m - 1] = 1.0;
     PackedIndex indx;
     indx.v = 0xFEDCBA9876543210ull;  // indx[pos] = pos
@@ -95,7 +109,7 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
         inZ[k] = isc[k];
         wv[k] = 0.0;
         xv[k] = 0.0;
-        colp[k] = blk + 8 * ((isc[k] ? ids[k] : 1) - 1);
+        colp[k] = blk + CS * ((isc[k] ? ids[k] : 1) - 1);
         if (live && isc[k]) xs[ids[k] - 1] = 0.0;
     }
     int rem_jj = 0;  // step eleven: position being removed
@@ -118,12 +132,12 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
             const bool run = (phase == 0 || phase == 1);
             if (wave_any(phase == 0)) {
                 // step two: duals of the columns in Z over rows npp1 .. m
-                dvec8 bm = 0.0;
+                dvecm bm = 0.0;
 #pragma unroll
                 for (int r = 1; r <= m; ++r) bm[r - 1] = (r >= npp1) ? b[r - 1] : 0.0;
 #pragma unroll
                 for (int k = 0; k < CPL; ++k) {
-                    const dvec8 cv = lds_col_load(colp[k]);
+                    const dvecm cv = lds_col_load<N>(colp[k]);
                     double sdot = 0.0;
 #pragma unroll
                     for (int r = 1; r <= m; ++r) sdot += cv[r - 1] * bm[r - 1];
@@ -159,7 +173,7 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
                 // step five: Householder construction on the chosen column j (position bp)
                 const int j = cand ? indx.get(bp) : 1;
                 // (w: the column, soon the transformation's weights -- u below the pivot row, up on it, 0 above)
-                dvec8 w = lds_col_load(blk + 8 * (j - 1));
+                dvecm w = lds_col_load<N>(blk + CS * (j - 1));
                 lds_sync();  // (every lane has the column before its pivot rows are rewritten below)
                 bool hitk[CPL];
 #pragma unroll
@@ -203,7 +217,7 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
                 const double t = factor * __builtin_fabs(ulp);
                 bool ok1 = t > 6.7e-16 * xmax;
                 if (wave_any(cand && !ok1)) {
-                    const dvec8 uu = lds_col_load(blk + 8 * (j - 1));
+                    const dvecm uu = lds_col_load<N>(blk + CS * (j - 1));
                     const double scale = 1.0 / xmax;
                     double sum = 0.0;
 #pragma unroll
@@ -243,7 +257,7 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
                 // Rows the transformation leaves alone (above the pivot row) get -0.0 added: their weight is
                 // an exact zero, the product a signed zero, and with the sign bit forced x + (-0.0) == x bit for
                 // bit -- one OR per element instead of a select.  The same OR neutralises a whole vector.
-                unsigned rowkeep[8];
+                unsigned rowkeep[m];
 #pragma unroll
                 for (int r = 1; r <= m; ++r) rowkeep[r - 1] = (r < npp1) ? 0x80000000u : 0u;
                 {
@@ -276,16 +290,16 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
                 npp1 = nsetp + 1;
                 // the column that entered P: untouched above the pivot row, ulp on it, zeros below
                 {
-                    dvec8 nc = lds_col_load(blk + 8 * (j - 1));
+                    dvecm nc = lds_col_load<N>(blk + CS * (j - 1));
 #pragma unroll
                     for (int r = 1; r <= m; ++r) nc[r - 1] = (r < nsetp) ? nc[r - 1] : ((r == nsetp) ? ulp : 0.0);
                     lds_sync();  // (every lane has re-read it)
-                    if (found && ql == 0) lds_col_store(blk + 8 * (j - 1), nc);
+                    if (found && ql == 0) lds_col_store<N>(blk + CS * (j - 1), nc);
                 }
                 // the transformation applied to the lane's columns still in Z (pivot row nsetp, rows below)
 #pragma unroll
                 for (int k = 0; k < CPL; ++k) {
-                    dvec8 cv = lds_col_load(colp[k]);
+                    dvecm cv = lds_col_load<N>(colp[k]);
                     double sm = 0.0;
 #pragma unroll
                     for (int r = 1; r <= m; ++r) {
@@ -301,7 +315,7 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
                                                              __double2loint(add));
                         cv[r - 1] = cv[r - 1] + addz;
                     }
-                    if (act) lds_col_store(colp[k], cv);
+                    if (act) lds_col_store<N>(colp[k], cv);
                     wv[k] = (cand && hitk[k]) ? 0.0 : wv[k];
                 }
                 // found: solve (step six); else choose again without recomputing the duals
@@ -313,7 +327,7 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
         // ---------------- steps six .. ten ---------------------------------------------
         if (wave_any(phase == 2)) {
             const bool run = phase == 2;
-            dvec8 zz = b;  // (steps five / eleven leave z := b)
+            dvecm zz = b;  // (steps five / eleven leave z := b)
             int nmax = 0;
 #pragma unroll
             for (int v = 1; v <= m; ++v)
@@ -325,8 +339,8 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
             for (int ip = m; ip >= 1; --ip) {
                 if (ip > nmax) continue;
                 const bool step = run && ip <= nsetp;
-                const double *cp = step ? blk + 8 * (indx.get(ip) - 1) : zeros;
-                dvec8 cv = 0.0;
+                const double *cp = step ? blk + CS * (indx.get(ip) - 1) : zeros;
+                dvecm cv = 0.0;
 #pragma unroll
                 for (int r = 1; r <= ip; ++r) cv[r - 1] = cp[r - 1];
                 const double zi = zz[ip - 1] / cv[ip - 1];
@@ -397,7 +411,7 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
                 const int jm1 = j - 1 < 1 ? 1 : (j - 1 > m ? m : j - 1), jc = j > m ? m : (j < 1 ? 1 : j);
                 // the column at position j moves to position j-1; Givens on its rows j-1, j
                 const int ii = step ? indx.get(jc) : 1;
-                double a0 = blk[8 * (ii - 1) + jm1 - 1], a1 = blk[8 * (ii - 1) + jc - 1];
+                double a0 = blk[CS * (ii - 1) + jm1 - 1], a1 = blk[CS * (ii - 1) + jc - 1];
                 lds_sync();  // (the pivot pair is read before the owners rewrite rows j-1, j)
                 double c = 1.0, s = 0.0;
                 rotg(a0, a1, c, s);

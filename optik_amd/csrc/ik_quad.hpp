@@ -561,7 +561,8 @@ OPTIK_DEV void lsq_finish_quad(const double (&Ec)[QuadDims<N>::NS][QuadDims<N>::
 constexpr int QUADS_PER_WAVE = 64 / QUAD;
 
 // doubles of LDS per wave: the NNLS blocks of its quads and the column of zeros (ik_nnls_quad.hpp) ...
-constexpr int quad_wave_lds() { return nnls_quad_wave_lds(); }
+template <int N>
+constexpr int quad_wave_lds() { return nnls_quad_wave_lds<N>(); }
 // ... and the best point so far / the previous iterate of every lane's joints ([slot][lane]: they are
 // written when f improves / a line search ends and read when a restart is published -- not worth
 // eight registers for the whole life of the kernel)
@@ -570,7 +571,7 @@ constexpr int quad_lane_lds() { return 4 * 64; }
 template <int N, bool TIP>
 OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolveParams &sp, const uint32_t (&key)[8],
                          const double (&scale)[MAX_DOF], const WorkQueue &wq,
-                         double *nnls_lds /* quad_wave_lds() doubles, the last 8 zero */,
+                         double *nnls_lds /* quad_wave_lds<N>() doubles, the last 16 zero */,
                          double *lane_lds /* quad_lane_lds() doubles: x_best, x_prev of every lane */) {
     constexpr int NS = QuadDims<N>::NS, NM = QuadDims<N>::NM;
     constexpr int CPL = 4;
@@ -592,7 +593,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
     double *const xp = lane_lds + 128 + lane;  // xp[s * 64]: iterate of the last completed line search
     // the quad's block of LDS: the NNLS matrix during a direction search, and during an evaluation the
     // parking place of what the evaluation does not touch (lane ql's i-th double at [4 i + ql])
-    double *const blk = nnls_lds + quad * NNLS_QUAD_STRIDE;
+    double *const blk = nnls_lds + quad * NnlsQuadGeom<N>::STRIDE;
 
     // SLSQP state of the quad's restart: by joint, by row, and the replicated scalars (names as in solve_wave)
     double x[NS], x0[NS], g[NS], sv[NS];
@@ -846,7 +847,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
                         const int r = q + 4 * s;
                         ids[k] = (r < N) ? (neg ? N : 0) + r + 1 : 0x7fff;
                         if (need_nnls && r < N) {
-                            double *c = blk + 8 * (ids[k] - 1);
+                            double *c = blk + NnlsQuadGeom<N>::CS * (ids[k] - 1);
 #pragma unroll
                             for (int j = 0; j < N; ++j) {
                                 const double v = row[s][j];
@@ -859,7 +860,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
                 int iters;
                 double xv[CPL];
 #ifndef OPTIK_QUAD_EXP_NO_NNLS
-                nnls_quad<N>(need_nnls, ids, blk, nnls_lds + QUADS_PER_WAVE * NNLS_QUAD_STRIDE, xv, nmode, rnorm, iters);
+                nnls_quad<N>(need_nnls, ids, blk, nnls_lds + QUADS_PER_WAVE * NnlsQuadGeom<N>::STRIDE, xv, nmode, rnorm, iters);
 #else
                 for (int k = 0; k < CPL; ++k) xv[k] = blk[k]; iters = 0;
 #endif

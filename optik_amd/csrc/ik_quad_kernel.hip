@@ -12,13 +12,17 @@
 namespace optik {
 
 #ifndef OPTIK_QUAD_WAVES
-#define OPTIK_QUAD_WAVES 2  // waves per SIMD the register allocator must leave room for
+#define OPTIK_QUAD_WAVES 2  // waves per SIMD of the throughput build (LDS allows two)
 #endif
 
-template <int N, bool TIP>
-__global__ __launch_bounds__(64, OPTIK_QUAD_WAVES) void ik_quad_kernel(const SolveLaunch a) {
+// Two builds of the same body: W = waves per SIMD the register allocator leaves room for.  W = 2
+// (256 registers, some cold spills; 8 waves per CU) is the throughput form; W = 1 (all 512
+// registers, no scratch) the latency form for launches that cannot fill even one wave per SIMD
+// with restarts -- a single ik() call's first rounds.
+template <int N, bool TIP, int W>
+__global__ __launch_bounds__(64, W) void ik_quad_kernel(const SolveLaunch a) {
     __shared__ ChainDev sch;
-    __shared__ __attribute__((aligned(16))) double nnls_lds[quad_wave_lds()];
+    __shared__ __attribute__((aligned(16))) double nnls_lds[quad_wave_lds<N>()];
     __shared__ double lane_lds[quad_lane_lds()];
     // The launch parameters (~540 bytes: weights, ChaCha key, scales, queue and output pointers) are
     // copied from the kernel-argument segment to LDS once and read from there: as kernel arguments
@@ -30,7 +34,7 @@ __global__ __launch_bounds__(64, OPTIK_QUAD_WAVES) void ik_quad_kernel(const Sol
         const uint32_t *src = reinterpret_cast<const uint32_t *>(&a);
         for (unsigned i = threadIdx.x; i < sizeof(SolveLaunch) / 4; i += 64) launch_lds[i] = src[i];
     }
-    if (threadIdx.x < 8) nnls_lds[quad_wave_lds() - 8 + threadIdx.x] = 0.0;  // the column of zeros
+    if (threadIdx.x < 16) nnls_lds[quad_wave_lds<N>() - 16 + threadIdx.x] = 0.0;  // the column of zeros
     stage_chain(sch, a.chain);
     SolveLaunch &L = *reinterpret_cast<SolveLaunch *>(launch_lds);
     if (threadIdx.x == 0) L.wq.deadline = L.deadline_ticks ? wall_clock64() + L.deadline_ticks : 0ull;
@@ -38,20 +42,33 @@ __global__ __launch_bounds__(64, OPTIK_QUAD_WAVES) void ik_quad_kernel(const Sol
     quad_wave<N, TIP>(sch, L.ep, L.sp, L.key, L.scale, L.wq, nnls_lds, lane_lds);
 }
 
-int quad_solve_waves_per_cu() { return 4 * OPTIK_QUAD_WAVES; }
+// (n = 8: nine-row columns make the blocks 22 KB per wave -- one wave per SIMD)
+int quad_solve_waves_per_cu(int n) { return n <= 7 ? 4 * OPTIK_QUAD_WAVES : 4; }
 
-hipError_t quad_solve_launch(int n, bool tip, int grid, hipStream_t stream, const SolveLaunch &a, int *lds_bytes) {
-    if (lds_bytes) *lds_bytes = (int)(sizeof(ChainDev) + sizeof(SolveLaunch) + sizeof(double) * (quad_wave_lds() + quad_lane_lds()));
+hipError_t quad_solve_launch(int n, bool tip, int grid, hipStream_t stream, const SolveLaunch &a, int *lds_bytes,
+                             bool latency_form) {
+    if (lds_bytes)
+        *lds_bytes = (int)(sizeof(ChainDev) + sizeof(SolveLaunch)
+                           + sizeof(double) * ((n <= 7 ? quad_wave_lds<7>() : quad_wave_lds<8>()) + quad_lane_lds()));
 #define CALL_QUAD(NN)                                                                                   \
     case NN:                                                                                            \
-        if (tip) hipLaunchKernelGGL((ik_quad_kernel<NN, true>), dim3(grid), dim3(64), 0, stream, a);    \
-        else hipLaunchKernelGGL((ik_quad_kernel<NN, false>), dim3(grid), dim3(64), 0, stream, a);       \
+        if (latency_form) {                                                                             \
+            if (tip) hipLaunchKernelGGL((ik_quad_kernel<NN, true, 1>), dim3(grid), dim3(64), 0, stream, a);  \
+            else hipLaunchKernelGGL((ik_quad_kernel<NN, false, 1>), dim3(grid), dim3(64), 0, stream, a);     \
+        } else {                                                                                        \
+            if (tip) hipLaunchKernelGGL((ik_quad_kernel<NN, true, OPTIK_QUAD_WAVES>), dim3(grid), dim3(64), 0, stream, a);  \
+            else hipLaunchKernelGGL((ik_quad_kernel<NN, false, OPTIK_QUAD_WAVES>), dim3(grid), dim3(64), 0, stream, a);     \
+        }                                                                                               \
         break;
     switch (n) {
 #ifdef OPTIK_QUAD_ONLY_N
         CALL_QUAD(OPTIK_QUAD_ONLY_N)
 #else
         CALL_QUAD(1) CALL_QUAD(2) CALL_QUAD(3) CALL_QUAD(4) CALL_QUAD(5) CALL_QUAD(6) CALL_QUAD(7)
+    case 8:
+        if (tip) hipLaunchKernelGGL((ik_quad_kernel<8, true, 1>), dim3(grid), dim3(64), 0, stream, a);
+        else hipLaunchKernelGGL((ik_quad_kernel<8, false, 1>), dim3(grid), dim3(64), 0, stream, a);
+        break;
 #endif
     default: return hipErrorInvalidValue;
     }

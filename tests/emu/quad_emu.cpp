@@ -21,7 +21,7 @@ void run_wave(const ChainDev &ch, const EvalParams &ep, const SolveParams &sp, c
               const double (&scale)[MAX_DOF], const WorkQueue &wq, int quads) {
     optik_emu::Wave wave;
     wave.lanes = 4 * quads;
-    std::vector<double> lds((size_t)quad_wave_lds(), 0.0), lane_lds((size_t)quad_lane_lds(), 0.0);
+    std::vector<double> lds((size_t)quad_wave_lds<N>(), 0.0), lane_lds((size_t)quad_lane_lds(), 0.0);
     std::vector<std::thread> th;
     for (int lane = 0; lane < wave.lanes; ++lane) {
         th.emplace_back([&, lane]() {
@@ -43,7 +43,7 @@ int quad_emu_solve(const double *origins, const double *axes, int n, int n_joint
                    const optik_solver_config *cfg, const double *target7, const double *x0, const double *ee_offset7,
                    uint64_t restart_begin, uint64_t restart_end, int quads, int range_rule, double *out_x, double *out_f,
                    double *out_key, int32_t *out_status, int32_t *out_evals) {
-    if (n < 1 || n > 7 || quads < 1 || quads > 16 || restart_end <= restart_begin) return -1;
+    if (n < 1 || n > 8 || quads < 1 || quads > 16 || restart_end <= restart_begin) return -1;
     ChainDev ch;
     std::memset(&ch, 0, sizeof ch);
     ch.n_pos = n;
@@ -90,7 +90,7 @@ int quad_emu_solve(const double *origins, const double *axes, int n, int n_joint
         else run_wave<NN, false>(ch, ep, sp, key, scale, wq, quads);                         \
         break;
     switch (n) {
-        RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7)
+        RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8)
     default: return -1;
     }
 #undef RUN

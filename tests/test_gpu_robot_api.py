@@ -313,8 +313,9 @@ def test_speed_batch_with_hard_targets_runs_growing_rounds(panda):
 
 
 def test_eight_dof_batch_equals_individual_calls():
-    """n = 8 runs on the per-lane solve kernel (the engine and the cooperative kernels hold n + 1 <= 8
-    rows): a Speed batch is handed out restart-major there too, same answers as ik() alone."""
+    """n = 8 runs on the quad solve kernel (nine-row NNLS columns in LDS; the engine's register NNLS holds
+    n + 1 <= 8 rows, so engine jobs of such a chain go there too): a Speed batch is handed out
+    restart-major, same answers as ik() alone."""
     from conftest import TEST_ROBOTS
     from optik_amd import Robot, SolverConfig
     r = Robot.from_urdf_file(os.path.join(TEST_ROBOTS, "arm8.urdf"), "l0", "l9")

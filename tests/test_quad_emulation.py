@@ -37,7 +37,7 @@ def _assert_same(got, ref, n):
 
 @pytest.mark.parametrize("robot,R,quads", [("panda", 24, 1), ("panda", 12, 2), ("ur10", 24, 2), ("ur3e", 16, 1),
                                            ("panda_hand", 12, 1), ("panda5", 16, 2), ("panda4", 16, 1),
-                                           ("panda3", 16, 2), ("panda2", 16, 1), ("panda1", 8, 2)])
+                                           ("panda3", 16, 2), ("panda2", 16, 1), ("panda1", 8, 2), ("arm8", 10, 1)])
 def test_every_restart_bit_equal_to_the_oracle(emu, oracle, chains, robot, R, quads):
     from optik_amd import _native as nat
     d, ch, tgt, x0 = _case(oracle, chains, robot, 5)
