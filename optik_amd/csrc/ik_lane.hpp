@@ -64,6 +64,20 @@ OPTIK_DEV int quad_xor(int v, int mask) {
 }
 #endif
 
+// value held by lane (own + r) & 3 of the caller's quad, r = 1, 2, 3 (a rotation of the quad): the
+// diagonal rounds of a ChaCha block whose columns live in the four lanes.  quad_perm [1,2,3,0] /
+// [2,3,0,1] / [3,0,1,2].
+#ifdef OPTIK_LANE_EMU
+OPTIK_DEV uint32_t quad_rot(uint32_t v, int r) { return (uint32_t)__shfl((int)v, quad_base() + ((quad_lane() + r) & 3), 64); }
+#else
+OPTIK_DEV uint32_t quad_rot(uint32_t v, int r) {
+    const int i = (int)v;
+    return (uint32_t)(r == 1 ? __builtin_amdgcn_update_dpp(0, i, 0x39, 0xf, 0xf, true)
+                             : (r == 2 ? __builtin_amdgcn_update_dpp(0, i, 0x4E, 0xf, 0xf, true)
+                                       : __builtin_amdgcn_update_dpp(0, i, 0x93, 0xf, 0xf, true)));
+}
+#endif
+
 // does p hold in some / every lane of the caller's quad
 OPTIK_DEV bool quad_any(bool p) {
     const unsigned long long m = __ballot(p);

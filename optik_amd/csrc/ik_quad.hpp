@@ -62,6 +62,40 @@ OPTIK_DEV double quad_dot(const double (&a)[NS], const double (&b)[NS]) {
     return acc;
 }
 
+// Random configuration of restart `index` (ik_solve.hpp:restart_seed; lib.rs:86-91, 366-370) with the
+// ChaCha8 block spread over the quad: lane q holds column q of the 4 x 4 state, a column round is the
+// lane's own quarter round, a diagonal round the same after rotating rows 1, 2, 3 by one, two, three
+// lanes (DPP) -- a quarter of the integer work of the block per lane.  Joint k's 64 bits are words
+// 2k, 2k + 1: row k / 2, lanes 2 (k & 1) and 2 (k & 1) + 1.  Writes the lane's joints' components.
+template <int N>
+OPTIK_DEV void restart_seed_quad(const uint32_t (&key)[8], const double *lb, const double *scale, uint64_t index,
+                                 double (&xq)[QuadDims<N>::NS]) {
+    static_assert(N <= 8, "one ChaCha block per restart");
+    constexpr int NS = QuadDims<N>::NS;
+    const int q = quad_lane();
+    const uint32_t cst = (q == 0) ? 0x61707865u : ((q == 1) ? 0x3320646eu : ((q == 2) ? 0x79622d32u : 0x6b206574u));
+    const uint32_t s1 = key[q], s2 = key[4 + q];
+    // words 12-13: block counter (0), 14-15: stream id
+    const uint32_t s3 = (q == 2) ? (uint32_t)index : ((q == 3) ? (uint32_t)(index >> 32) : 0u);
+    uint32_t a = cst, b = s1, c = s2, d = s3;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        OPTIK_QR(a, b, c, d)
+        b = quad_rot(b, 1); c = quad_rot(c, 2); d = quad_rot(d, 3);
+        OPTIK_QR(a, b, c, d)
+        b = quad_rot(b, 3); c = quad_rot(c, 2); d = quad_rot(d, 1);
+    }
+    const uint32_t row[4] = {a + cst, b + s1, c + s2, d + s3};
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const uint32_t lo = (uint32_t)quad_get((int)row[k >> 1], 2 * (k & 1));
+        const uint32_t hi = (uint32_t)quad_get((int)row[k >> 1], 2 * (k & 1) + 1);
+        const uint64_t bits = (uint64_t)lo | ((uint64_t)hi << 32);
+        const double v = uniform_inclusive(lb[k], scale[k], bits);
+        xq[k >> 2] = (q == (k & 3)) ? v : xq[k >> 2];
+    }
+}
+
 OPTIK_DEV Pose pose_sel(bool c, const Pose a, const Pose b) {
     Pose o;
     o.t = V3{c ? a.t.x : b.t.x, c ? a.t.y : b.t.y, c ? a.t.z : b.t.z};
@@ -619,6 +653,17 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
         if (wave_any(want)) {
             unsigned long long it = fetch_items(wq.next_item, want && q == 0);
             it = quad_get_u64(it, 0);
+            // (the seed of the item's restart index, by every quad alike: the block's rounds move values
+            // between the lanes of a quad, so they sit outside the per-quad branch)
+            double seedq[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) seedq[s] = 0.0;
+            {
+                unsigned long long rr = 0;
+                if (want && it < wq.total_items)
+                    rr = wq.restart_major ? it / wq.n_targets : it - (it / wq.n_restarts) * wq.n_restarts;
+                restart_seed_quad<N>(key, ch.lb, scale, wq.restart_begin + rr, seedq);
+            }
             if (want) {
                 want = false;
                 if (it < wq.total_items) {
@@ -627,14 +672,10 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
                     else { tslot = (unsigned)(it / wq.n_restarts); r = it - (unsigned long long)tslot * wq.n_restarts; }
                     item = (unsigned long long)tslot * wq.n_restarts + r;  // output column
                     index = wq.restart_begin + r;
-                    // lib.rs:366-370: restart 0 starts from the caller's seed
-                    double xs[N];
-                    restart_seed<N>(key, ch.lb, scale, index, xs);
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {
-                        double v = xs[4 * s];
-#pragma unroll
-                        for (int j = 4 * s + 1; j < N && j < 4 * s + 4; ++j) v = (jc[s] == j) ? xs[j] : v;
+                        // lib.rs:366-370: restart 0 starts from the caller's seed
+                        double v = seedq[s];
                         if (index == 0) v = wq.x0[(size_t)tslot * N + jc[s]];
                         x[s] = v; xb[s * 64] = v; xp[s * 64] = v; x0[s] = v; sv[s] = 0.0; g[s] = 0.0;
                     }
