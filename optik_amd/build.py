@@ -14,6 +14,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "liboptik_amd.so")
 SOURCES = ["ik_kernels.hip", "ik_quad_kernel.hip", "robot_host.cpp"]
+# translation units: (source, object, extra flags).  ik_quad_kernel.hip is compiled twice -- its
+# throughput form (two waves per SIMD) without the machine-LICM pass, which otherwise hoists constants and
+# LDS addresses out of the solver loop only for the register allocator to spill them to scratch
+# (csrc/ik_quad_kernel.hip), its latency forms and the launch function with the default pipeline.
+UNITS = [("ik_kernels.hip", "ik_kernels.o", []),
+         ("ik_quad_kernel.hip", "ik_quad_latency.o", ["-DOPTIK_QUAD_PART=1"]),
+         ("ik_quad_kernel.hip", "ik_quad_throughput.o",
+          ["-DOPTIK_QUAD_PART=2", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-use-amdgpu-trackers=1"]),
+         ("robot_host.cpp", "robot_host.o", [])]
 HEADERS = ["ik_math.hpp", "ik_eval.hpp", "ik_slsqp.hpp", "ik_solve.hpp", "ik_nnls_coop.hpp", "ik_engine.hpp",
            "ik_tail.hpp", "ik_coop.hpp", "device_scope.hpp", "ik_host_params.hpp", "ik_launch.hpp",
            "urdf_chain.hpp",
@@ -29,9 +38,6 @@ DEPS = {"ik_kernels.hip": HEADERS,
         "ik_quad_kernel.hip": QUAD_HEADERS,
         "robot_host.cpp": ["urdf_chain.hpp", "device_scope.hpp", os.path.join("..", "..", "include", "optik_hip.h"),
                            os.path.join("..", "..", "include", "optik.h")]}
-
-
-EXTRA_FLAGS = {}
 
 
 def _hipcc():
@@ -58,14 +64,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     hipcc = _hipcc()
     objs = []
-    for src in SOURCES:
+    for src, objname, extra in UNITS:
         sp = os.path.join(CSRC, src)
         if not os.path.exists(sp):
             continue
-        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        obj = os.path.join(CSRC, objname)
         t = os.path.getmtime(obj) if os.path.exists(obj) else -1.0
         deps = [sp] + [os.path.join(CSRC, d) for d in DEPS.get(src, HEADERS)]
-        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", sp, "-o", obj]
+        cmd = [hipcc, *FLAGS, *extra, "-x", "hip", "-c", sp, "-o", obj]
         # (an object is also stale when it was compiled with other flags: they are kept next to it)
         flags_file = obj + ".flags"
         same_flags = os.path.exists(flags_file) and open(flags_file).read() == " ".join(cmd[1:])

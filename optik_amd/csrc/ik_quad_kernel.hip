@@ -14,6 +14,16 @@ namespace optik {
 #ifndef OPTIK_QUAD_WAVES
 #define OPTIK_QUAD_WAVES 2  // waves per SIMD of the throughput build (LDS allows two)
 #endif
+// This file is compiled TWICE (optik_amd/build.py): OPTIK_QUAD_PART = 2 holds the throughput form
+// (n <= 7, W = OPTIK_QUAD_WAVES) and is built with `-mllvm -disable-machine-licm -mllvm
+// -amdgpu-use-amdgpu-trackers=1` -- the machine-LICM pass hoists the ~60 double constants of sin / cos /
+// atan2 and LDS address variants out of the solver loop, and at 256 registers the allocator then spills
+// those loop invariants to scratch and reloads them every trip (412 -> 280 B of scratch, +4-5 %
+// restarts/s); OPTIK_QUAD_PART = 1 holds the latency forms (W = 1: no scratch either way, and the
+// default pipeline is the faster one there) and the launch function.
+#ifndef OPTIK_QUAD_PART
+#define OPTIK_QUAD_PART 0  // 0: everything in one object (tools/, experiments)
+#endif
 
 // Two builds of the same body: W = waves per SIMD the register allocator leaves room for.  W = 2
 // (256 registers, some cold spills; 8 waves per CU) is the throughput form; W = 1 (all 512
@@ -43,6 +53,30 @@ __global__ __launch_bounds__(64, W) void ik_quad_kernel(const SolveLaunch a) {
 }
 
 // (n = 8: nine-row columns make the blocks 22 KB per wave -- one wave per SIMD)
+#if OPTIK_QUAD_PART != 1
+// the throughput form, reached through one entry point per (n, tip) so that it can live in its own object
+hipError_t quad_solve_launch_w2(int n, bool tip, int grid, hipStream_t stream, const SolveLaunch &a) {
+#define CALL_QUAD2(NN)                                                                                  \
+    case NN:                                                                                            \
+        if (tip) hipLaunchKernelGGL((ik_quad_kernel<NN, true, OPTIK_QUAD_WAVES>), dim3(grid), dim3(64), 0, stream, a);  \
+        else hipLaunchKernelGGL((ik_quad_kernel<NN, false, OPTIK_QUAD_WAVES>), dim3(grid), dim3(64), 0, stream, a);     \
+        break;
+    switch (n) {
+#ifdef OPTIK_QUAD_ONLY_N
+        CALL_QUAD2(OPTIK_QUAD_ONLY_N)
+#else
+        CALL_QUAD2(1) CALL_QUAD2(2) CALL_QUAD2(3) CALL_QUAD2(4) CALL_QUAD2(5) CALL_QUAD2(6) CALL_QUAD2(7)
+#endif
+    default: return hipErrorInvalidValue;
+    }
+#undef CALL_QUAD2
+    return hipGetLastError();
+}
+#else
+hipError_t quad_solve_launch_w2(int n, bool tip, int grid, hipStream_t stream, const SolveLaunch &a);
+#endif
+
+#if OPTIK_QUAD_PART != 2
 int quad_solve_waves_per_cu(int n) { return n <= 7 ? 4 * OPTIK_QUAD_WAVES : 4; }
 
 hipError_t quad_solve_launch(int n, bool tip, int grid, hipStream_t stream, const SolveLaunch &a, int *lds_bytes,
@@ -56,8 +90,7 @@ hipError_t quad_solve_launch(int n, bool tip, int grid, hipStream_t stream, cons
             if (tip) hipLaunchKernelGGL((ik_quad_kernel<NN, true, 1>), dim3(grid), dim3(64), 0, stream, a);  \
             else hipLaunchKernelGGL((ik_quad_kernel<NN, false, 1>), dim3(grid), dim3(64), 0, stream, a);     \
         } else {                                                                                        \
-            if (tip) hipLaunchKernelGGL((ik_quad_kernel<NN, true, OPTIK_QUAD_WAVES>), dim3(grid), dim3(64), 0, stream, a);  \
-            else hipLaunchKernelGGL((ik_quad_kernel<NN, false, OPTIK_QUAD_WAVES>), dim3(grid), dim3(64), 0, stream, a);     \
+            return quad_solve_launch_w2(n, tip, grid, stream, a);                                       \
         }                                                                                               \
         break;
     switch (n) {
@@ -76,9 +109,11 @@ hipError_t quad_solve_launch(int n, bool tip, int grid, hipStream_t stream, cons
     return hipGetLastError();
 }
 
+#endif  // OPTIK_QUAD_PART != 2
+
 }  // namespace optik
 
-#ifdef OPTIK_PROFILE
+#if defined(OPTIK_PROFILE) && OPTIK_QUAD_PART != 2
 // diagnostic builds: cycles per part of the quad NNLS since the last call (ik_nnls_quad.hpp), then reset
 extern "C" int optik_hip_quad_nnls_profile(unsigned long long *out8) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;

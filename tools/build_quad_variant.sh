@@ -8,4 +8,4 @@ name=$1; shift
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-value -pthread $* \
   -Rpass-analysis=kernel-resource-usage -x hip -c ik_quad_kernel.hip -o variants/$name.quad.o 2> variants/$name.log || { echo "FAILED $name"; exit 1; }
 hipcc --offload-arch=gfx950 -shared -fPIC -pthread ik_kernels.o variants/$name.quad.o robot_host.o -o variants/$name.so
-grep -A10 "ik_quad_kernelILi7ELb1" variants/$name.log | grep "VGPRs:\|AGPRs:\|Scratch\|Occupancy" | sed 's/.*remark: *//; s/\[-Rpass.*//' | paste - - - -
+grep -A10 "ik_quad_kernelILi7ELb1ELi2" variants/$name.log | grep "VGPRs:\|AGPRs:\|Scratch\|Occupancy" | sed 's/.*remark: *//; s/\[-Rpass.*//' | paste - - - -
