@@ -398,7 +398,6 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
             const int jlo = run ? rem_jj + 1 : 0x7fffffff, jhi = run ? nsetp : 0;
             // (the positions some quad of the wave has to move: m ballots instead of a wave-wide min / max butterfly)
             int wlo = 0x7fffffff, whi = 0;
-#pragma unroll
             for (int v = 2; v <= m; ++v) {
                 if (wave_any(run && v >= jlo && v <= jhi)) {
                     wlo = wlo < v ? wlo : v;

@@ -121,9 +121,21 @@ OPTIK_DEV const T *reload_barrier(const T *p) {
     return p;
 }
 
+// (the same for an integer: what is computed from the result is computed where it is used, not hoisted out
+// of the solver loop as an invariant -- and then spilled for the whole loop)
+OPTIK_DEV int opaque_int(int v) {
+#ifdef OPTIK_LANE_EMU
+    asm volatile("" : "+r"(v));
+#else
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
+
 template <int N, bool TIP>
 OPTIK_DEV double eval_quad(const ChainDev &ch, const EvalParams &ep, const double *target7,
-                           const double (&x)[QuadDims<N>::NS], double (&gout)[QuadDims<N>::NS]) {
+                           const double (&x)[QuadDims<N>::NS], double (&gout)[QuadDims<N>::NS],
+                           double *park /* the lane's parking doubles in the quad's block: park[4 i], i < 12 */) {
     constexpr int NS = QuadDims<N>::NS;
     const int q = quad_lane();
     Q4 jq[NS];
@@ -177,6 +189,11 @@ OPTIK_DEV double eval_quad(const ChainDev &ch, const EvalParams &ep, const doubl
 
     // X = T_target^-1 T_ee  (objective.rs:69-70)
     const Pose X = pose_inv_mul(load_pose(target7), ee);
+    // (the columns' geometry waits in LDS while the error terms -- the register peak of the kernel -- are formed)
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { park[4 * (6 * s + c)] = lin[s][c]; park[4 * (6 * s + 3 + c)] = ang[s][c]; }
     OPTIK_SCHED_FENCE();
     const V3 w = so3_log(X.q);
     const RotTerms rt = rot_terms(w);
@@ -206,8 +223,11 @@ OPTIK_DEV double eval_quad(const ChainDev &ch, const EvalParams &ep, const doubl
     OPTIK_SCHED_FENCE();
 
     // Jtask = Jlog6 * J (objective.rs:81) and g = (2 e') Jtask (objective.rs:106-109) for the lane's columns
+    const double *pk = reload_barrier((const double *)park);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { lin[s][c] = pk[4 * (6 * s + c)]; ang[s][c] = pk[4 * (6 * s + 3 + c)]; }
         double jt[6];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -603,8 +623,8 @@ constexpr int quad_wave_lds() { return nnls_quad_wave_lds<N>(); }
 constexpr int quad_lane_lds() { return 4 * 64; }
 
 template <int N, bool TIP>
-OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolveParams &sp, const uint32_t (&key)[8],
-                         const double (&scale)[MAX_DOF], const WorkQueue &wq,
+OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const SolveParams &sp_in, const uint32_t (&key)[8],
+                         const double (&scale)[MAX_DOF], const WorkQueue &wq_in,
                          double *nnls_lds /* quad_wave_lds<N>() doubles, the last 16 zero */,
                          double *lane_lds /* quad_lane_lds() doubles: x_best, x_prev of every lane */) {
     constexpr int NS = QuadDims<N>::NS, NM = QuadDims<N>::NM;
@@ -612,7 +632,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
     const unsigned lane = threadIdx.x & 63u;
     const int q = quad_lane();
     const unsigned quad = lane / QUAD;
-    const bool member = (int)quad < wq.lanes;  // wq.lanes = restarts (quads) a wave holds at a time
+    const bool member = (int)quad < wq_in.lanes;  // wq.lanes = restarts (quads) a wave holds at a time
     const double alfmin = 0.1;
 
     // the lane's joints
@@ -651,6 +671,9 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
         OPTIK_PROF_BEGIN();
         // ---- refill: quads without a restart pull the next work item (the leader fetches) ----------
         if (wave_any(want)) {
+            // (the launch parameters live in LDS: every region of a trip re-reads what it needs through a
+            // laundered pointer, so that none of them is carried -- and spilled -- across the other regions)
+            const WorkQueue &wq = *reload_barrier(&wq_in);
             unsigned long long it = fetch_items(wq.next_item, want && q == 0);
             it = quad_get_u64(it, 0);
             // (the seed of the item's restart index, by every quad alike: the block's rounds move values
@@ -693,6 +716,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
 
         int32_t ret = 0;
         if (active) {
+            const WorkQueue &wq = *reload_barrier(&wq_in);
             // lib.rs:308: abandon when timed out or another restart of the target succeeded
             bool stop = false;
             if (wq.first_success) {
@@ -723,9 +747,10 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
             }
             OPTIK_SCHED_FENCE();
             // (the target pose is re-read for every evaluation: seven L1 / L2 hits instead of 14 registers)
-            const double *target7 = wq.targets + (size_t)tslot * 7;
+            const double *target7 = (*reload_barrier(&wq_in)).targets + (size_t)tslot * 7;
+            const EvalParams &ep = *reload_barrier(&ep_in);
 #ifndef OPTIK_QUAD_EXP_NO_EVAL
-            fn = eval_quad<N, TIP>(ch, ep, target7, x, gn);
+            fn = eval_quad<N, TIP>(ch, ep, target7, x, gn, blk + 4 * pi + q);
 #else
             fn = target7[0]; gn[0] = x[0]; if (NS > 1) gn[NS - 1] = x[NS - 1];
 #endif
@@ -748,6 +773,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
         // ---- NLopt bookkeeping and Kraft's line search (labels 100 / 220), replicated scalars ------
         OPTIK_PROF_BEGIN();
         bool need_dir = false, reset = false, do_bfgs = false;
+        const SolveParams &sp = *reload_barrier(&sp_in);
         double u[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) u[s] = 0.0;
@@ -825,6 +851,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
         // quad that needs a direction takes part in every step of a round (ik_coop.hpp:coop_direction)
         OPTIK_PROF_BEGIN();
         while (wave_any(need_dir)) {
+            const SolveParams &sp = *reload_barrier(&sp_in);
             bool pass = need_dir;
             const bool sx0 = stop_x_quad<N>(sp, x, x0);
             if (pass && reset) {
@@ -878,6 +905,9 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
 #endif
                 // the lane's columns go to the quad's block: row r = q + 4 s of E^-1 is column r + 1 (lower
                 // bound, h_lo below it) and, negated, column N + r + 1 (upper bound, h_hi below it)
+                // (the lane number is made opaque here: the column ids and the dozen LDS addresses
+                // derived from them are loop invariants the compiler would otherwise hoist and spill)
+                const int qn = opaque_int(q);
                 int ids[CPL];
 #pragma unroll
                 for (int k = 0; k < CPL; ++k) {
@@ -885,7 +915,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
                     const bool neg = k >= 2;
                     ids[k] = 0x7fff;
                     if (s < NS) {
-                        const int r = q + 4 * s;
+                        const int r = qn + 4 * s;
                         ids[k] = (r < N) ? (neg ? N : 0) + r + 1 : 0x7fff;
                         if (need_nnls && r < N) {
                             double *c = blk + NnlsQuadGeom<N>::CS * (ids[k] - 1);
@@ -968,6 +998,8 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
         // ---- a restart ended: classify (lib.rs:376-379), publish, free the quad -------------------
         const bool ended = active && ret != 0;
         if (wave_any(ended)) {
+            const WorkQueue &wq = *reload_barrier(&wq_in);
+            const SolveParams &sp = *reload_barrier(&sp_in);
             const bool success = (sp.ok_stopval && ret == RES_STOPVAL_REACHED)
                                  || (sp.ok_ftol && ret == RES_FTOL_REACHED)
                                  || (sp.ok_xtol && ret == RES_XTOL_REACHED);
@@ -1011,7 +1043,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep, const SolvePa
         }
         OPTIK_PROF_END(3);
     }
-    OPTIK_PROF_FLUSH(wq.prof);
+    OPTIK_PROF_FLUSH(wq_in.prof);
 }
 
 }  // namespace optik
