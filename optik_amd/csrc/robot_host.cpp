@@ -412,6 +412,13 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
         return e ? (uint64_t)std::atoll(e) : (uint64_t)1 << 20;
     }();
     const bool engine_ok = engine_batch > 0 && r->n <= 7;
+    // One job of this many restarts is where the engine's ~10 ms floor is amortised against the solve kernel
+    // (tools/kernel_vs_engine_probe.py, quad kernel: 131 072 restarts 12.0 against 15.2 ms, 262 144: 20.2
+    // against 20.8, 524 288: 37.7 against 34.3; with round 2's kernel the two met at ~100 000)
+    static const uint64_t engine_from = [] {
+        const char *e = std::getenv("OPTIK_IK_ENGINE_FROM");
+        return e && std::atoll(e) > 0 ? (uint64_t)std::atoll(e) : (uint64_t)262144;
+    }();
     const size_t G = device_count(r);
     const uint32_t speed_flags = OPTIK_HIP_IK_EARLY_EXIT | (r->parallelism != 1 ? OPTIK_HIP_IK_FIND_ANY : 0u);
     struct Part {
@@ -436,16 +443,16 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
         // Quality with a restart budget and no time budget runs every restart whatever happens: no
         // latency-sized first launches (each of them waits for its slowest restart -- 1 000 restarts
         // took two launches of 2.7 ms), the whole range at once: one launch of the solve kernel
-        // below ~100 000 restarts, engine rounds from index 0 above.
+        // below ~260 000 restarts (engine_from), engine rounds from index 0 above.
         // (with a time budget too when the whole range is one solve-kernel launch: its waves watch the clock)
         const bool all_at_once = quality && config->max_restarts > 0
-                                 && (config->max_time <= 0.0 || config->max_restarts < 98304);
-        const size_t g_round = (begin == 0 && !(all_at_once && max_restarts >= 2 * 98304)) ? 1 : G;  // (the latency-sized first launch stays on one GPU)
-        // (what is left must be worth an engine run: below ~100 000 restarts the solve kernel is faster)
-        const bool on_engine = engine_ok && max_restarts - begin >= 98304
+                                 && (config->max_time <= 0.0 || config->max_restarts < engine_from);
+        const size_t g_round = (begin == 0 && !(all_at_once && max_restarts >= 2 * engine_from)) ? 1 : G;  // (the latency-sized first launch stays on one GPU)
+        // (what is left must be worth an engine run: below engine_from restarts the solve kernel is faster)
+        const bool on_engine = engine_ok && max_restarts - begin >= engine_from
                                && (all_at_once || begin >= first_batch + later_batch);
         const uint64_t batch = on_engine ? engine_batch
-                               : all_at_once ? (uint64_t)98304
+                               : all_at_once ? engine_from
                                : begin == 0 ? first_batch : later_batch;
         // (several GPUs: what is left is cut evenly when it is less than a full round of each)
         uint64_t per_part = batch;
@@ -632,10 +639,14 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
             const char *e = std::getenv("OPTIK_IK_BATCH_KERNEL_MAX");  // targets; 0 = always the engine
             return e ? (size_t)std::atoll(e) : (size_t)-1;
         }();
-        // (one job of ~100 000 restarts is where the engine overtakes the solve kernel: 65 536 take 12.3
-        // against 9.8 ms, 262 144 take 17 against 32 ms)
+        // (one job of ~260 000 restarts is where the engine overtakes the quad solve kernel: 131 072 take 12.0
+        // against 15.2 ms, 524 288 take 37.7 against 34.3 ms; n = 8 has no engine)
+        static const uint64_t kernel_below = [] {
+            const char *e = std::getenv("OPTIK_IK_ENGINE_FROM");
+            return e && std::atoll(e) > 0 ? (uint64_t)std::atoll(e) : (uint64_t)262144;
+        }();
         const bool kernel_path = r->n <= 7 && !big_speed && L <= small_batch
-                                 && ((!quality && begin < 256) || (uint64_t)L * (end - begin) < 98304ull);
+                                 && ((!quality && begin < 256) || (uint64_t)L * (end - begin) < kernel_below);
         const uint32_t mode_flags =
             quality ? 0u : (OPTIK_HIP_IK_EARLY_EXIT | (r->parallelism != 1 ? OPTIK_HIP_IK_FIND_ANY : 0u));
         if (kernel_path) {

@@ -242,10 +242,21 @@ class Robot:
     def ik_batch(self, config: SolverConfig, targets, x0s, ee_offset=None):
         """ik_batch_arrays as a list: (x, c) or None per target, like T calls of ik()."""
         x, f, found = self.ik_batch_arrays(config, targets, x0s, ee_offset)
-        # (no gc toggling here: the collector's state is process-global and other threads may own it;
-        # callers who want arrays without the ~10 Python objects per target use ik_batch_arrays)
-        xs, fs = x.tolist(), f.tolist()
-        return [(xs[t], fs[t]) if ok else None for t, ok in enumerate(found.tolist())]
+        # Building ~10 Python objects per target trips the cyclic collector every few hundred targets, and
+        # each of its passes walks what has been built so far: 65 536 targets take 105 ms instead of 41.
+        # For large batches the collector is paused while the list is built (none of these objects can be
+        # garbage).  Its state is process-global: a thread that changes it at the same moment may find it
+        # re-enabled -- callers for whom that matters (or who want arrays anyway) use ik_batch_arrays.
+        import gc
+        pause = len(found) >= 2048 and gc.isenabled()
+        if pause:
+            gc.disable()
+        try:
+            xs, fs = x.tolist(), f.tolist()
+            return [(xs[t], fs[t]) if ok else None for t, ok in enumerate(found.tolist())]
+        finally:
+            if pause:
+                gc.enable()
 
     def diff_ik(self, x0, V_WE, v_max, ee_offset=None):
         """Returns (alpha, v) or None (optik.pyi:43-49; lib.rs:123-239): the joint velocities
