@@ -681,18 +681,26 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
             double seedq[NS];
 #pragma unroll
             for (int s = 0; s < NS; ++s) seedq[s] = 0.0;
+            // (target, restart) of the item: one division, in 32 bits whenever the launch has fewer than 2^32
+            // items (a 64-bit division is ~150 instructions on this ISA)
+            unsigned long long rq = 0;  // the item's restart number within its target
+            unsigned tq = 0;            // ... and its target
             {
-                unsigned long long rr = 0;
-                if (want && it < wq.total_items)
-                    rr = wq.restart_major ? it / wq.n_targets : it - (it / wq.n_restarts) * wq.n_restarts;
-                restart_seed_quad<N>(key, ch.lb, scale, wq.restart_begin + rr, seedq);
+                const unsigned long long div = wq.restart_major ? wq.n_targets : wq.n_restarts;
+                const unsigned long long itc = it < wq.total_items ? it : 0ull;
+                unsigned long long quo;
+                if (wq.total_items <= 0xffffffffull) quo = (unsigned long long)((unsigned)itc / (unsigned)div);
+                else quo = itc / div;
+                const unsigned long long rem = itc - quo * div;
+                rq = wq.restart_major ? quo : rem;
+                tq = (unsigned)(wq.restart_major ? rem : quo);
             }
+            restart_seed_quad<N>(key, ch.lb, scale, wq.restart_begin + rq, seedq);
             if (want) {
                 want = false;
                 if (it < wq.total_items) {
-                    unsigned long long r;
-                    if (wq.restart_major) { r = it / wq.n_targets; tslot = (unsigned)(it - r * wq.n_targets); }
-                    else { tslot = (unsigned)(it / wq.n_restarts); r = it - (unsigned long long)tslot * wq.n_restarts; }
+                    const unsigned long long r = rq;
+                    tslot = tq;
                     item = (unsigned long long)tslot * wq.n_restarts + r;  // output column
                     index = wq.restart_begin + r;
 #pragma unroll

@@ -1,16 +1,24 @@
 #!/usr/bin/env python3
 """Compiler-reported resources of every gfx950 kernel (registers, scratch, LDS, occupancy):
-hipcc -Rpass-analysis=kernel-resource-usage on ik_kernels.hip with the flags of optik_amd/build.py.
+hipcc -Rpass-analysis=kernel-resource-usage on every HIP translation unit of optik_amd/build.py with its flags.
 Runs without a GPU.  Usage: python tools/kernel_resources.py > profiles/<tag>_kernel_resources.txt"""
 import os
 import re
 import subprocess
+import sys
 
-CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "optik_amd", "csrc")
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-       "-Wno-unused-value", "-pthread", "-x", "hip", "-c", "ik_kernels.hip", "-o", "/tmp/ik_kernels_rpass.o",
-       "-Rpass-analysis=kernel-resource-usage"]
-out = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True).stderr
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "optik_amd", "csrc")
+sys.path.insert(0, ROOT)
+from optik_amd import build as product_build  # noqa: E402  (the translation units and their flags)
+
+out = ""
+for src, objname, extra in product_build.UNITS:
+    if not src.endswith(".hip"):
+        continue
+    cmd = ["/opt/rocm/bin/hipcc", *product_build.FLAGS, *extra, "-x", "hip", "-c", src, "-o", "/tmp/" + objname + ".rpass.o",
+           "-Rpass-analysis=kernel-resource-usage"]
+    out += subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True).stderr
 rows, cur = [], None
 for ln in out.splitlines():
     m = re.search(r"remark: +(.*?) \[-Rpass", ln)
