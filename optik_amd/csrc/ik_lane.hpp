@@ -15,6 +15,22 @@ constexpr int QUAD = 4;
 OPTIK_DEV int quad_lane() { return (int)(threadIdx.x & 3u); }
 OPTIK_DEV int quad_base() { return (int)(threadIdx.x & 63u) & ~3; }
 
+// The lane's number within its wave, produced where it is wanted (two mbcnt instructions) instead of
+// being carried from the kernel's entry: what a region of the solver loop derives from it -- joint
+// numbers, masks, LDS addresses -- is then computed in that region, not hoisted out of the loop as
+// an invariant and spilled for its whole length.
+OPTIK_DEV int wave_lane_now() {
+#ifdef OPTIK_LANE_EMU
+    int v = (int)(threadIdx.x & 63u);
+    asm volatile("" : "+r"(v));
+#else
+    int v = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
+OPTIK_DEV int quad_lane_now() { return wave_lane_now() & 3; }
+
 #ifdef OPTIK_LANE_EMU
 OPTIK_DEV double quad_get(double v, int k) { return __shfl(v, quad_base() + (k & 3), 64); }
 OPTIK_DEV int quad_get(int v, int k) { return __shfl(v, quad_base() + (k & 3), 64); }

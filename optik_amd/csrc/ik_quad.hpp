@@ -72,7 +72,7 @@ OPTIK_DEV void restart_seed_quad(const uint32_t (&key)[8], const double *lb, con
                                  double (&xq)[QuadDims<N>::NS]) {
     static_assert(N <= 8, "one ChaCha block per restart");
     constexpr int NS = QuadDims<N>::NS;
-    const int q = quad_lane();
+    const int q = quad_lane_now();
     const uint32_t cst = (q == 0) ? 0x61707865u : ((q == 1) ? 0x3320646eu : ((q == 2) ? 0x79622d32u : 0x6b206574u));
     const uint32_t s1 = key[q], s2 = key[4 + q];
     // words 12-13: block counter (0), 14-15: stream id
@@ -137,7 +137,7 @@ OPTIK_DEV double eval_quad(const ChainDev &ch, const EvalParams &ep, const doubl
                            const double (&x)[QuadDims<N>::NS], double (&gout)[QuadDims<N>::NS],
                            double *park /* the lane's parking doubles in the quad's block: park[4 i], i < 12 */) {
     constexpr int NS = QuadDims<N>::NS;
-    const int q = quad_lane();
+    const int q = quad_lane_now();
     Q4 jq[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -629,35 +629,28 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                          double *lane_lds /* quad_lane_lds() doubles: x_best, x_prev of every lane */) {
     constexpr int NS = QuadDims<N>::NS, NM = QuadDims<N>::NM;
     constexpr int CPL = 4;
-    const unsigned lane = threadIdx.x & 63u;
-    const int q = quad_lane();
-    const unsigned quad = lane / QUAD;
-    const bool member = (int)quad < wq_in.lanes;  // wq.lanes = restarts (quads) a wave holds at a time
+    const bool member = (int)((threadIdx.x & 63u) / QUAD) < wq_in.lanes;  // wq.lanes = restarts (quads) a wave holds at a time
     const double alfmin = 0.1;
 
-    // the lane's joints
-    int jc[NS];
-    bool val[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        val[s] = q + 4 * s < N;
-        jc[s] = val[s] ? q + 4 * s : N - 1;
-    }
-    double *const xb = lane_lds + lane;        // xb[s * 64]: best point so far
-    double *const xp = lane_lds + 128 + lane;  // xp[s * 64]: iterate of the last completed line search
+    // xb[s * 64]: best point so far, xp[s * 64]: iterate of the last completed line search (the addresses
+    // are formed where they are used, see wave_lane_now)
+#define xb (lane_lds + wave_lane_now())
+#define xp (lane_lds + 128 + wave_lane_now())
     // the quad's block of LDS: the NNLS matrix during a direction search, and during an evaluation the
     // parking place of what the evaluation does not touch (lane ql's i-th double at [4 i + ql])
-    double *const blk = nnls_lds + quad * NnlsQuadGeom<N>::STRIDE;
+#define blk (nnls_lds + (unsigned)(wave_lane_now() >> 2) * NnlsQuadGeom<N>::STRIDE)
 
     // SLSQP state of the quad's restart: by joint, by row, and the replicated scalars (names as in solve_wave)
     double x[NS], x0[NS], g[NS], sv[NS];
     double Lr[NS][NM], dg[NS];
-    double f = 0.0, f0 = 0.0, t0 = 0.0, h3 = 0.0, alpha = 1.0;
-    double minf = __builtin_huge_val(), fprev = __builtin_huge_val();
-    int ireset = 0, line = 0, nevals = 0;
+    // The replicated scalars of the restart are the same in the four lanes of the quad, so each is kept
+    // by ONE of them and fetched (a DPP move) by the region of a trip that uses it -- four registers
+    // across the evaluation and the direction search instead of twenty-two:
+    //   pa: f0 | t0 | h3 | alpha      pb: minf | fprev | f | --
+    //   ia: ireset | line | nevals | target slot      ib: restart number within the target, low | high | -- | --
+    double pa = 0.0, pb = 0.0;
+    int ia = 0, ib = 0;
     bool first = true;
-    unsigned long long item = 0, index = 0;
-    unsigned tslot = 0;
     bool active = false, want = member;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -674,7 +667,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
             // (the launch parameters live in LDS: every region of a trip re-reads what it needs through a
             // laundered pointer, so that none of them is carried -- and spilled -- across the other regions)
             const WorkQueue &wq = *reload_barrier(&wq_in);
-            unsigned long long it = fetch_items(wq.next_item, want && q == 0);
+            unsigned long long it = fetch_items(wq.next_item, want && quad_lane_now() == 0);
             it = quad_get_u64(it, 0);
             // (the seed of the item's restart index, by every quad alike: the block's rounds move values
             // between the lanes of a quad, so they sit outside the per-quad branch)
@@ -699,20 +692,21 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
             if (want) {
                 want = false;
                 if (it < wq.total_items) {
-                    const unsigned long long r = rq;
-                    tslot = tq;
-                    item = (unsigned long long)tslot * wq.n_restarts + r;  // output column
-                    index = wq.restart_begin + r;
+                    const int qr = quad_lane_now();
+                    const unsigned long long index = wq.restart_begin + rq;
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {
                         // lib.rs:366-370: restart 0 starts from the caller's seed
                         double v = seedq[s];
-                        if (index == 0) v = wq.x0[(size_t)tslot * N + jc[s]];
+                        const int jc = (qr + 4 * s < N) ? qr + 4 * s : N - 1;
+                        if (index == 0) v = wq.x0[(size_t)tq * N + jc];
                         x[s] = v; xb[s * 64] = v; xp[s * 64] = v; x0[s] = v; sv[s] = 0.0; g[s] = 0.0;
                     }
-                    f = 0.0; f0 = 0.0; t0 = 0.0; h3 = 0.0; alpha = 1.0;
-                    minf = __builtin_huge_val(); fprev = __builtin_huge_val();
-                    ireset = 0; line = 0; nevals = 0;
+                    // f = f0 = t0 = h3 = 0, alpha = 1, minf = fprev = inf, ireset = line = nevals = 0
+                    pa = (qr == 3) ? 1.0 : 0.0;
+                    pb = (qr < 2) ? __builtin_huge_val() : 0.0;
+                    ia = (qr == 3) ? (int)tq : 0;
+                    ib = (qr == 0) ? (int)(unsigned)(rq & 0xffffffffull) : ((qr == 1) ? (int)(unsigned)(rq >> 32) : 0);
                     first = true;
                     active = true;
                 }
@@ -723,17 +717,22 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
         OPTIK_PROF_COUNT(7, 1);
 
         int32_t ret = 0;
-        if (active) {
-            const WorkQueue &wq = *reload_barrier(&wq_in);
-            // lib.rs:308: abandon when timed out or another restart of the target succeeded
-            bool stop = false;
-            if (wq.first_success) {
-                const unsigned long long fs = __hip_atomic_load(wq.first_success + tslot, __ATOMIC_RELAXED,
-                                                                __HIP_MEMORY_SCOPE_AGENT);
-                stop = wq.find_any ? (fs != ~0ull) : (fs < index);
+        const unsigned tslot = (unsigned)quad_get(ia, 3);
+        {
+            const unsigned rlo = (unsigned)quad_get(ib, 0), rhi = (unsigned)quad_get(ib, 1);
+            if (active) {
+                const WorkQueue &wq = *reload_barrier(&wq_in);
+                const unsigned long long index = wq.restart_begin + (((unsigned long long)rhi << 32) | rlo);
+                // lib.rs:308: abandon when timed out or another restart of the target succeeded
+                bool stop = false;
+                if (wq.first_success) {
+                    const unsigned long long fs = __hip_atomic_load(wq.first_success + tslot, __ATOMIC_RELAXED,
+                                                                    __HIP_MEMORY_SCOPE_AGENT);
+                    stop = wq.find_any ? (fs != ~0ull) : (fs < index);
+                }
+                if (wq.deadline && (unsigned long long)wall_clock64() > wq.deadline) stop = true;
+                if (stop) ret = RES_FORCED_STOP;
             }
-            if (wq.deadline && (unsigned long long)wall_clock64() > wq.deadline) stop = true;
-            if (stop) ret = RES_FORCED_STOP;
         }
         // (the four lanes may have read first_success / the clock at different moments: the leader decides)
         ret = quad_get(ret, 0);
@@ -746,33 +745,34 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
             // what the evaluation does not touch waits in the quad's (idle) block of LDS: the evaluation is
             // the register peak of the loop (~200 VGPRs on its own)
             int pi = 0;
+            double *const bp = blk + quad_lane_now();  // the lane's i-th parked double: bp[4 i]
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                blk[4 * pi++ + q] = x0[s]; blk[4 * pi++ + q] = g[s]; blk[4 * pi++ + q] = sv[s]; blk[4 * pi++ + q] = dg[s];
+                bp[4 * pi++] = x0[s]; bp[4 * pi++] = g[s]; bp[4 * pi++] = sv[s]; bp[4 * pi++] = dg[s];
 #pragma unroll
                 for (int i = 0; i < NM; ++i)
-                    if (slot_has<N>(s, i)) blk[4 * pi++ + q] = Lr[s][i];
+                    if (slot_has<N>(s, i)) bp[4 * pi++] = Lr[s][i];
             }
             OPTIK_SCHED_FENCE();
             // (the target pose is re-read for every evaluation: seven L1 / L2 hits instead of 14 registers)
             const double *target7 = (*reload_barrier(&wq_in)).targets + (size_t)tslot * 7;
             const EvalParams &ep = *reload_barrier(&ep_in);
 #ifndef OPTIK_QUAD_EXP_NO_EVAL
-            fn = eval_quad<N, TIP>(ch, ep, target7, x, gn, blk + 4 * pi + q);
+            fn = eval_quad<N, TIP>(ch, ep, target7, x, gn, bp + 4 * pi);
 #else
             fn = target7[0]; gn[0] = x[0]; if (NS > 1) gn[NS - 1] = x[NS - 1];
 #endif
             OPTIK_SCHED_FENCE();
             // (through a pointer the compiler knows nothing about: otherwise it forwards the stored values to
             // these loads, i.e. keeps them in registers across the evaluation after all)
-            const double *pk = reload_barrier((const double *)blk);
+            const double *pk = reload_barrier((const double *)bp);
             pi = 0;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                x0[s] = pk[4 * pi++ + q]; g[s] = pk[4 * pi++ + q]; sv[s] = pk[4 * pi++ + q]; dg[s] = pk[4 * pi++ + q];
+                x0[s] = pk[4 * pi++]; g[s] = pk[4 * pi++]; sv[s] = pk[4 * pi++]; dg[s] = pk[4 * pi++];
 #pragma unroll
                 for (int i = 0; i < NM; ++i)
-                    if (slot_has<N>(s, i)) Lr[s][i] = pk[4 * pi++ + q];
+                    if (slot_has<N>(s, i)) Lr[s][i] = pk[4 * pi++];
             }
         }
         OPTIK_PROF_END(1);
@@ -792,6 +792,12 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
             for (int s = 0; s < NS; ++s) xpv[s] = xp[s * 64];
             sx_prev = stop_x_quad<N>(sp, x, xpv);
         }
+        // (this region's scalars, fetched from their keepers)
+        double f = quad_get(pb, 2), minf = quad_get(pb, 0), fprev = quad_get(pb, 1);
+        double alpha = quad_get(pa, 3);
+        const double t0 = quad_get(pa, 1), h3 = quad_get(pa, 2);
+        int nevals = quad_get(ia, 2);
+        const int line = quad_get(ia, 1);
         if (do_eval) {
             f = fn;
             ++nevals;
@@ -848,6 +854,12 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                 }
             }
         }
+        {
+            const int qr = quad_lane_now();
+            pb = (qr == 0) ? minf : ((qr == 1) ? fprev : ((qr == 2) ? f : pb));
+            pa = (qr == 3) ? alpha : pa;
+            ia = (qr == 2) ? nevals : ia;
+        }
         OPTIK_SCHED_FENCE();
 #ifndef OPTIK_QUAD_EXP_NO_BFGS
         if (wave_any(do_bfgs)) bfgs_quad<N>(do_bfgs, Lr, dg, sv, u);
@@ -862,29 +874,36 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
             const SolveParams &sp = *reload_barrier(&sp_in);
             bool pass = need_dir;
             const bool sx0 = stop_x_quad<N>(sp, x, x0);
-            if (pass && reset) {
-                ++ireset;
-                if (ireset > 5) {
-                    // label 255 with acc = 0 -> mode 8; NLopt's relaxed test vs (f0, x0)
-                    ret = RES_ROUNDOFF_LIMITED;
-                    if (__builtin_fabs(f - f0) < sp.ftol_abs && !__builtin_isinf(f0)) ret = RES_FTOL_REACHED;
-                    else if (sx0) ret = RES_XTOL_REACHED;
-                    need_dir = false;
-                    pass = false;
-                } else {
+            const int qd = quad_lane_now();
+            if (wave_any(pass && reset)) {
+                const double fd = quad_get(pb, 2), f0 = quad_get(pa, 0);
+                int ireset = quad_get(ia, 0);
+                if (pass && reset) ++ireset;
+                ia = (qd == 0) ? ireset : ia;
+                if (pass && reset) {
+                    if (ireset > 5) {
+                        // label 255 with acc = 0 -> mode 8; NLopt's relaxed test vs (f0, x0)
+                        ret = RES_ROUNDOFF_LIMITED;
+                        if (__builtin_fabs(fd - f0) < sp.ftol_abs && !__builtin_isinf(f0)) ret = RES_FTOL_REACHED;
+                        else if (sx0) ret = RES_XTOL_REACHED;
+                        need_dir = false;
+                        pass = false;
+                    } else {
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) {
-                        dg[s] = 1.0;
+                        for (int s = 0; s < NS; ++s) {
+                            dg[s] = 1.0;
 #pragma unroll
-                        for (int i = 0; i < NM; ++i) Lr[s][i] = 0.0;
+                            for (int i = 0; i < NM; ++i) Lr[s][i] = 0.0;
+                        }
                     }
                 }
             }
             double Ec[NS][NM], Ed[NS], fv[NS], lo[NS], hi[NS];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                lo[s] = ch.lb[jc[s]] - x[s];
-                hi[s] = ch.ub[jc[s]] - x[s];
+                const int jc = (qd + 4 * s < N) ? qd + 4 * s : N - 1;
+                lo[s] = ch.lb[jc] - x[s];
+                hi[s] = ch.ub[jc] - x[s];
                 fv[s] = 0.0;
                 Ed[s] = 1.0;
 #pragma unroll
@@ -915,7 +934,8 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                 // bound, h_lo below it) and, negated, column N + r + 1 (upper bound, h_hi below it)
                 // (the lane number is made opaque here: the column ids and the dozen LDS addresses
                 // derived from them are loop invariants the compiler would otherwise hoist and spill)
-                const int qn = opaque_int(q);
+                const int qn = quad_lane_now();
+                double *const bk = blk;
                 int ids[CPL];
 #pragma unroll
                 for (int k = 0; k < CPL; ++k) {
@@ -926,7 +946,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                         const int r = qn + 4 * s;
                         ids[k] = (r < N) ? (neg ? N : 0) + r + 1 : 0x7fff;
                         if (need_nnls && r < N) {
-                            double *c = blk + NnlsQuadGeom<N>::CS * (ids[k] - 1);
+                            double *c = bk + NnlsQuadGeom<N>::CS * (ids[k] - 1);
 #pragma unroll
                             for (int j = 0; j < N; ++j) {
                                 const double v = row[s][j];
@@ -939,9 +959,9 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                 int iters;
                 double xv[CPL];
 #ifndef OPTIK_QUAD_EXP_NO_NNLS
-                nnls_quad<N>(need_nnls, ids, blk, nnls_lds + QUADS_PER_WAVE * NnlsQuadGeom<N>::STRIDE, xv, nmode, rnorm, iters);
+                nnls_quad<N>(need_nnls, ids, bk, nnls_lds + QUADS_PER_WAVE * NnlsQuadGeom<N>::STRIDE, xv, nmode, rnorm, iters);
 #else
-                for (int k = 0; k < CPL; ++k) xv[k] = blk[k]; iters = 0;
+                for (int k = 0; k < CPL; ++k) xv[k] = bk[k]; iters = 0;
 #endif
 #pragma unroll
                 for (int s = 0; s < NS; ++s) { ylo[s] = xv[s]; yhi[s] = xv[2 + s]; }
@@ -964,6 +984,8 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
             lsq_finish_quad<N>(Ec, Ed, fv, lo, hi, sn);
             OPTIK_SCHED_FENCE();
             const double gs = quad_dot<N, NS>(g, sn);
+            const double fq = quad_get(pb, 2);
+            const int qe = quad_lane_now();
             if (pass) {
                 if (lmode != 1) {
                     // NLopt: modes 5,6,7 -> ROUNDOFF_LIMITED; 3,4,9 -> FAILURE
@@ -973,14 +995,13 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                     // (g is also Kraft's v: the gradient at the start of the line search)
 #pragma unroll
                     for (int s = 0; s < NS; ++s) { sv[s] = sn[s]; x0[s] = x[s]; }
-                    f0 = f;
-                    t0 = f;
-                    h3 = gs;  // h3 = gs - h1 * h4 with h1 = 0 (no constraints)
-                    if (h3 >= 0.0) {
+                    // f0 = t0 = f; h3 = gs - h1 * h4 with h1 = 0 (no constraints)
+                    pa = (qe < 2) ? fq : ((qe == 2) ? gs : pa);
+                    if (gs >= 0.0) {
                         reset = true;  // not a descent direction: reset B and repeat
                     } else {
-                        line = 0;
-                        alpha = 1.0;
+                        ia = (qe == 1) ? 0 : ia;       // line = 0
+                        pa = (qe == 3) ? 1.0 : pa;     // alpha = 1
                         need_dir = false;
                     }
                 }
@@ -988,16 +1009,19 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
         }
         OPTIK_PROF_END(5);
         OPTIK_PROF_BEGIN();
+        const int qf = quad_lane_now();
+        const double alpha_t = quad_get(pa, 3);
         if (do_eval && ret == 0) {
             // label 190: next trial point x = x0 + alpha * s, clipped (NLopt)
-            ++line;
-            h3 = alpha * h3;
+            ia = (qf == 1) ? ia + 1 : ia;           // ++line
+            pa = (qf == 2) ? alpha_t * pa : pa;     // h3 = alpha * h3
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                sv[s] *= alpha;
+                const int jc = (qf + 4 * s < N) ? qf + 4 * s : N - 1;
+                sv[s] *= alpha_t;
                 double xi = x0[s];
                 xi += sv[s];
-                const double lbs = ch.lb[jc[s]], ubs = ch.ub[jc[s]];
+                const double lbs = ch.lb[jc], ubs = ch.ub[jc];
                 if (xi < lbs) xi = lbs;
                 else if (xi > ubs) xi = ubs;
                 x[s] = xi;
@@ -1008,6 +1032,18 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
         if (wave_any(ended)) {
             const WorkQueue &wq = *reload_barrier(&wq_in);
             const SolveParams &sp = *reload_barrier(&sp_in);
+            const double minf = quad_get(pb, 0);
+            const int nevals = quad_get(ia, 2);
+            const unsigned long long rr = ((unsigned long long)(unsigned)quad_get(ib, 1) << 32) | (unsigned)quad_get(ib, 0);
+            const unsigned long long item = (unsigned long long)tslot * wq.n_restarts + rr;  // output column
+            const unsigned long long index = wq.restart_begin + rr;
+            bool val[NS];
+            int jc[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                val[s] = qf + 4 * s < N;
+                jc[s] = val[s] ? qf + 4 * s : N - 1;
+            }
             const bool success = (sp.ok_stopval && ret == RES_STOPVAL_REACHED)
                                  || (sp.ok_ftol && ret == RES_FTOL_REACHED)
                                  || (sp.ok_xtol && ret == RES_XTOL_REACHED);
@@ -1031,7 +1067,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                     for (int s = 0; s < NS; ++s)
                         if (val[s]) wq.out_x[(size_t)jc[s] * wq.total_items + item] = xb[s * 64];
                 }
-                if (q == 0) {
+                if (qf == 0) {
                     if (wq.out_f) wq.out_f[item] = minf;
                     if (wq.out_status) wq.out_status[item] = ret;
                     if (wq.out_evals) wq.out_evals[item] = nevals;
@@ -1052,6 +1088,9 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
         OPTIK_PROF_END(3);
     }
     OPTIK_PROF_FLUSH(wq_in.prof);
+#undef xb
+#undef xp
+#undef blk
 }
 
 }  // namespace optik
