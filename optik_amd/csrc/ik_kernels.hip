@@ -1069,7 +1069,12 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     // one-wave-per-SIMD build -- no scratch, the lowest latency per iteration; anything bigger on the
     // two-waves-per-SIMD build)
     const bool quad_latency = quadk && (long long)cols <= (long long)cus * 4;
-    const long long cap = (long long)cus * (quadk ? (quad_latency ? 4 : quad_solve_waves_per_cu(ch->n)) : (coop ? 4 : ch->waves_per_cu));
+    long long cap = (long long)cus * (quadk ? (quad_latency ? 4 : quad_solve_waves_per_cu(ch->n)) : (coop ? 4 : ch->waves_per_cu));
+    // (experiments: fewer resident waves per CU than the kernel could have, e.g. to share the chip with another stream's kernels)
+    if (const char *e = std::getenv("OPTIK_SOLVE_WAVES_PER_CU")) {
+        const long long v = std::atoll(e);
+        if (v >= 1 && v * cus < cap) cap = v * cus;
+    }
     const long long per_wave_max = (coop || quadk) ? COOP_GROUPS_PER_WAVE : WAVE;
     // fewer work items than the chip holds: one restart per wave (or as few as fit).  A
     // restart-major Speed batch keeps about eight restarts per target in flight: the waves pull

@@ -179,7 +179,7 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
 #pragma unroll
                 for (int k = 0; k < CPL; ++k) hitk[k] = cand && inZ[k] && pos[k] == bp;
                 // (all lanes run the construction; only `cand` quads keep its results)
-                const double asave = vpick(w, npp1);
+                const double asave = blk[CS * (j - 1) + (npp1 <= m ? npp1 : m) - 1];  // w[npp1 - 1]: one read instead of a select chain
                 const bool h12_live = npp1 < m;
                 // the part of the column above the pivot row only feeds Lawson-Hanson's independence test (below)
                 double xmax = 0.0;
@@ -346,6 +346,10 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
                 const double zi = zz[ip - 1] / cv[ip - 1];
                 const double zie = step ? zi : 0.0;
                 zz[ip - 1] = step ? zi : zz[ip - 1];
+                // (the solution component travels to the column's owner through the column's last double: padding
+                // for m < CS, and for m == CS the last row -- an exact +0.0 in every column of set P, which no step
+                // reads while the column is there; restored when the column leaves)
+                if (step && ql == 0) const_cast<double *>(cp)[CS - 1] = zi;
 #pragma unroll
                 for (int r = 1; r < ip; ++r) zz[r - 1] = zz[r - 1] - zie * cv[r - 1];
             }
@@ -374,7 +378,7 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
 #pragma unroll
             for (int k = 0; k < CPL; ++k) {
                 const bool mine = go && isc[k] && !inZ[k];
-                const double zown = vpick(zz, mine ? pos[k] : 1);
+                const double zown = colp[k][CS - 1];  // z at the column's position (written in step six)
                 const double nx = (1.0 - alpha) * xv[k] + alpha * zown;
                 xv[k] = mine ? nx : xv[k];
                 if (mine) xs[ids[k] - 1] = nx;
@@ -392,7 +396,7 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
 #pragma unroll
             for (int k = 0; k < CPL; ++k) {
                 leaving[k] = run && isc[k] && !inZ[k] && pos[k] == rem_jj;
-                if (leaving[k]) { xv[k] = 0.0; xs[ids[k] - 1] = 0.0; }
+                if (leaving[k]) { xv[k] = 0.0; xs[ids[k] - 1] = 0.0; colp[k][CS - 1] = 0.0; }
             }
             const int id_out = run ? indx.get(rem_jj) : 1;
             const int jlo = run ? rem_jj + 1 : 0x7fffffff, jhi = run ? nsetp : 0;
