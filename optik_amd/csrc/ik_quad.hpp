@@ -281,27 +281,31 @@ OPTIK_DEV void ldl_quad(bool live, double (&Lr)[QuadDims<N>::NS][QuadDims<N>::NM
     const int q = quad_lane();
     live = live && sigma != 0.0;
     const bool neg = sigma < 0.0;
-    double w[NS];
+    double w[NS], dl[NS];
     double t = 1.0 / sigma;
-    if (wave_any(live && neg)) {
+    const bool any_neg = wave_any(live && neg), any_pos = wave_any(live && !neg);
+    if (any_neg) {
+        // forward substitution w = L^-1 z first (no quotient in it) ...
 #pragma unroll
         for (int s = 0; s < NS; ++s) w[s] = z[s];
-        double tn = t;
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
+        for (int i = 0; i < N - 1; ++i) {
             const double v = quad_get(w[i >> 2], i);
-            const double aii = quad_get(dg[i >> 2], i);
-            tn += v * v / aii;
 #pragma unroll
             for (int s = 0; s < NS; ++s)
                 if (slot_has<N>(s, i)) w[s] = (q + 4 * s > i) ? w[s] - v * Lr[s][i] : w[s];
             OPTIK_SCHED_FENCE();
         }
-        if (tn >= 0.0) tn = EPMACH / sigma;
-        // t_j = t_(j+1) - w_j^2 / l(j,j): the quotients are independent, each owner forms its own
+        // ... then the quotients w_j^2 / l(j,j) and w_j / l(j,j), each by its owner, all at once: they feed
+        // the sum t + sum_j w_j^2 / l(j,j) (in j order), t_j = t_(j+1) - w_j^2 / l(j,j), and -- the main
+        // loop below repeats this very substitution on z, so its v is w_j -- that loop's delta = v / l(j,j)
         double c[NS];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) c[s] = w[s] * w[s] / dg[s];
+        for (int s = 0; s < NS; ++s) { c[s] = w[s] * w[s] / dg[s]; dl[s] = w[s] / dg[s]; }
+        double tn = t;
+#pragma unroll
+        for (int i = 0; i < N; ++i) tn += quad_get(c[i >> 2], i);
+        if (tn >= 0.0) tn = EPMACH / sigma;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const int j = N - 1 - i;
@@ -311,7 +315,7 @@ OPTIK_DEV void ldl_quad(bool live, double (&Lr)[QuadDims<N>::NS][QuadDims<N>::NM
         t = neg ? tn : t;
     } else {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) w[s] = 0.0;
+        for (int s = 0; s < NS; ++s) { w[s] = 0.0; dl[s] = 0.0; }
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -319,7 +323,8 @@ OPTIK_DEV void ldl_quad(bool live, double (&Lr)[QuadDims<N>::NS][QuadDims<N>::NM
         const double v = quad_get(z[si], i);
         const double aii = quad_get(dg[si], i);
         const double wi = quad_get(w[si], i);
-        const double delta = v / aii;
+        double delta = quad_get(dl[si], i);  // (sigma < 0: formed above)
+        if (any_pos) delta = neg ? delta : v / aii;
         const double tp = neg ? wi : t + delta * v;
         // alpha = tp / t (lane 0), beta = delta / tp (lane 1), gamma = t / tp (lane 2)
         const double num = (q == 0) ? tp : ((q == 1) ? delta : t);
