@@ -526,7 +526,7 @@ def main():
             per_launch = cols * (K if pooled_kernel else 1)
             achieved = out_bytes * per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
             kname = {"coop": "ik_coop_kernel", "lane": "ik_solve_kernel"}.get(os.environ.get("OPTIK_SOLVE_KERNEL", ""),
-                                                                                "ik_quad_kernel" if n <= 7 else "ik_solve_kernel")
+                                                                                "ik_quad_kernel")
             kp = (pmc or {}).get("kernel_path")
             traffic, traffic_note, secondary = None, f"no PMC pass of this command under profiles/ (key: {key})", None
             if kp:
@@ -534,8 +534,8 @@ def main():
                 traffic_note = (f"{os.path.relpath(PMC_FILE, ROOT)}: separate FETCH_SIZE / WRITE_SIZE passes of this command "
                                 f"(2 x FETCH + WRITE), the {kp['launches']} launches of the timed repetitions: "
                                 f"{kp['hbm_bytes_per_restart']:.0f} B per restart at the fabric counters against "
-                                f"{out_bytes} B of outputs -- the difference is the kernel's register spills (scratch: "
-                                "per-wave private memory, Infinity-Cache resident), not restart state")
+                                f"{out_bytes} B of outputs -- the difference is the kernel's few register spills (scratch: "
+                                "per-wave private memory) and the targets / launch parameters it re-reads, not restart state")
                 tf = total / elapsed * kp["f64_flops_per_restart"] / 1e12
                 secondary = {"bound": "valu_f64", "achieved": tf, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": tf / F64_VALU_PEAK_TFLOPS, "peak_no_fma": F64_VALU_NOFMA_TFLOPS,
