@@ -1727,8 +1727,15 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
         // the rest of the list as groups finish -- at half the time per iteration of the per-lane
         // one: measured best between 24 k and 48 k since the group evaluation, 24.3 against 23.9 M
         // restarts/s at 16 k and 22.4 at 4 096 for a 20-step run)
+        // Which tail: the quad solver (ik_quad_tail.hpp; default), round 2's cooperative kernel
+        // (OPTIK_ENG_TAIL=coop or OPTIK_SOLVE_KERNEL=coop) or round 1's per-lane one (OPTIK_SOLVE_KERNEL=lane).
+        // The quad solver runs a restart ~2.7 times as fast as the cooperative kernel, so it takes over earlier.
+        bool tail_quad = true;
+        if (const char *e = getenv("OPTIK_ENG_TAIL")) tail_quad = std::strcmp(e, "coop") != 0 && std::strcmp(e, "lane") != 0;
+        if (const char *e = getenv("OPTIK_SOLVE_KERNEL")) tail_quad = tail_quad && std::strcmp(e, "lane") != 0 && std::strcmp(e, "coop") != 0;
         unsigned long long tail_max = total / 16;
-        const unsigned long long tail_cap = (getenv("OPTIK_SOLVE_KERNEL") && std::strcmp(getenv("OPTIK_SOLVE_KERNEL"), "lane") == 0) ? 4096ull : 32768ull;
+        unsigned long long tail_cap = (getenv("OPTIK_SOLVE_KERNEL") && std::strcmp(getenv("OPTIK_SOLVE_KERNEL"), "lane") == 0) ? 4096ull : 32768ull;
+        if (tail_quad) { tail_max = total / 8; tail_cap = 131072ull; }
         if (tail_max > tail_cap) tail_max = tail_cap;
         if (tail_max < 64) tail_max = 64;
         if (getenv("OPTIK_ENG_NO_TAIL")) tail_max = 0;
@@ -1764,6 +1771,40 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
             HIP_TRY(hipMemsetAsync(t_count, 0, sizeof(unsigned int), stream));
             hipLaunchKernelGGL(eng_tail_list_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream,
                                ch->eng_i32, (unsigned long long)C, t_count, t_list);
+            if (tail_quad) {
+                // persistent waves of the quad solver, each quad pulling the next live slot of the list
+                TailLaunch tq;
+                std::memset(&tq, 0, sizeof tq);
+                const EngArgs &pa0 = pools[0].a;
+                tq.base.chain = pa0.chain;
+                tq.base.ep = pa0.ep;
+                tq.base.sp = pa0.sp;
+                const long long capq = (long long)cus * quad_solve_waves_per_cu(ch->n);
+                long long lq = ((long long)left + capq - 1) / capq;
+                if (lq < 1) lq = 1;
+                if (lq > COOP_GROUPS_PER_WAVE) lq = COOP_GROUPS_PER_WAVE;
+                tq.base.wq.lanes = (int)lq;
+                long long gq = ((long long)left + lq - 1) / lq;
+                if (gq > capq) gq = capq;
+                if (gq < 1) gq = 1;
+                if (deadline_s > 0.0) {
+                    const double left_s = deadline_s - since_call();
+                    const double khz = ch->wall_clock_khz > 0 ? (double)ch->wall_clock_khz : 100000.0;
+                    tq.base.deadline_ticks = left_s > 0.0 ? (unsigned long long)(left_s * khz * 1e3) + 1ull : 1ull;
+                }
+                tq.tail.d = pa0.d; tq.tail.i32 = pa0.i32; tq.tail.item = pa0.item; tq.tail.C = pa0.C;
+                tq.tail.jobs = pa0.jobs;
+                tq.tail.list = t_list;
+                tq.tail.count = t_count;
+                tq.tail.cursor = reinterpret_cast<unsigned long long *>(t_count + 2);  // (8-byte aligned word of the same scratch)
+                tq.tail.exec_evals = pa0.exec_evals;
+                HIP_TRY(hipMemsetAsync(t_count + 2, 0, sizeof(unsigned long long), stream));
+                HIP_TRY(quad_tail_launch(ch->n, tip, (int)gq, stream, tq));
+                ch->eng_tail_restarts = (int)left;
+                for (int p2 = 0; p2 < n_pools; ++p2) pools[p2].done = true;
+                all_done = true;
+                continue;
+            }
             bool tail_coop = true;  // (n <= 7 always here) the cooperative tail, unless the per-lane one is asked for
             if (const char *e = getenv("OPTIK_SOLVE_KERNEL")) tail_coop = std::strcmp(e, "lane") != 0;
             const unsigned long long cap_waves = (unsigned long long)cus * (unsigned long long)(tail_coop ? 4 : ch->waves_per_cu);

@@ -18,6 +18,27 @@ struct SolveLaunch {
     unsigned long long deadline_ticks;  // relative to kernel start, 0 = none
 };
 
+// The engine's drain handed to the quad solver (ik_quad_tail.hpp): the slot planes of the pool, the
+// run's job table and the list of slots that still hold a restart.  Plain data: filled by the host
+// (ik_kernels.hip), read by eng_tail_quad_kernel (ik_quad_kernel.hip).
+struct EngJob;
+struct EngTailData {
+    double *d;                      // slot planes (EngArgs::d / i32 / item / C)
+    int32_t *i32;
+    unsigned long long *item;
+    unsigned long long C;
+    const EngJob *jobs;
+    const unsigned int *list;       // slots holding a restart ...
+    const unsigned int *count;      // ... how many (written by eng_tail_list_kernel)
+    unsigned long long *cursor;     // next list entry to hand out, zeroed before the launch
+    unsigned long long *exec_evals; // [ENG_EXEC_SHARDS] or null
+    unsigned long long deadline;    // wall_clock64() ticks (set by the kernel from SolveLaunch::deadline_ticks), 0 = none
+};
+struct TailLaunch {
+    SolveLaunch base;               // chain, weights, tolerances; wq.lanes = restarts (quads) a wave holds at a time
+    EngTailData tail;
+};
+
 __device__ __forceinline__ void stage_chain(ChainDev &dst, const ChainDev *src) {
     constexpr int ND = (int)(sizeof(ChainDev) / sizeof(double));
     static_assert(sizeof(ChainDev) % sizeof(double) == 0, "ChainDev is a whole number of doubles");
@@ -34,5 +55,7 @@ hipError_t quad_solve_launch(int n, bool tip, int grid, hipStream_t stream, cons
                              bool latency_form);
 // resident single-wave workgroups per CU the kernel is built for (registers and LDS)
 int quad_solve_waves_per_cu(int n);
+// the engine's tail on the quad solver (n <= 7, the two-waves-per-SIMD build)
+hipError_t quad_tail_launch(int n, bool tip, int grid, hipStream_t stream, const TailLaunch &a);
 
 }  // namespace optik

@@ -627,11 +627,18 @@ constexpr int quad_wave_lds() { return nnls_quad_wave_lds<N>(); }
 // eight registers for the whole life of the kernel)
 constexpr int quad_lane_lds() { return 4 * 64; }
 
-template <int N, bool TIP>
+// Where the restarts come from: the work queue of a launch (NoTail: seeds drawn in the kernel), or the slot
+// pool of an engine run that is draining (ik_quad_tail.hpp: restarts taken over mid-flight).
+struct NoTail {
+    static constexpr bool on = false;
+};
+
+template <int N, bool TIP, class Tail = NoTail>
 OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const SolveParams &sp_in, const uint32_t (&key)[8],
                          const double (&scale)[MAX_DOF], const WorkQueue &wq_in,
                          double *nnls_lds /* quad_wave_lds<N>() doubles, the last 16 zero */,
-                         double *lane_lds /* quad_lane_lds() doubles: x_best, x_prev of every lane */) {
+                         double *lane_lds /* quad_lane_lds() doubles: x_best, x_prev of every lane */,
+                         const Tail *tail_in = nullptr) {
     constexpr int NS = QuadDims<N>::NS, NM = QuadDims<N>::NM;
     constexpr int CPL = 4;
     const bool member = (int)((threadIdx.x & 63u) / QUAD) < wq_in.lanes;  // wq.lanes = restarts (quads) a wave holds at a time
@@ -665,10 +672,28 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
     }
     OPTIK_PROF_DECL;  // (-DOPTIK_PROFILE: slots 0 refill, 1 eval, 4 bookkeeping + BFGS, 5 direction, 6 NNLS of it, 3 publish, 7 trips)
 
+    unsigned n_exec = 0;  // (Tail) evaluations the wave's quads executed
     for (;;) {
         OPTIK_PROF_BEGIN();
+        int32_t ret = 0;
+        bool pending = false;  // (Tail) the restart resumes at a deferred direction search, not at an evaluation
         // ---- refill: quads without a restart pull the next work item (the leader fetches) ----------
-        if (wave_any(want)) {
+        if constexpr (Tail::on) {
+            if (wave_any(want)) {
+                const Tail &tl = *reload_barrier(tail_in);
+                const int qr = quad_lane_now();
+                unsigned long long e = fetch_items(tl.cursor, want && qr == 0);
+                e = quad_get_u64(e, 0);
+                if (want) {
+                    want = false;
+                    if (e < (unsigned long long)*tl.count) {
+                        active = tl.template import<N>(tl.list[e], qr, x, x0, g, sv, Lr, dg, pa, pb, ia, ib, first, pending, ret,
+                                                       xb, xp);
+                        want = !active;  // (an empty slot in the list: take the next entry)
+                    }
+                }
+            }
+        } else if (wave_any(want)) {
             // (the launch parameters live in LDS: every region of a trip re-reads what it needs through a
             // laundered pointer, so that none of them is carried -- and spilled -- across the other regions)
             const WorkQueue &wq = *reload_barrier(&wq_in);
@@ -718,12 +743,28 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
             }
         }
         OPTIK_PROF_END(0);
-        if (!wave_any(active)) break;
+        if (!wave_any(active || want)) break;
         OPTIK_PROF_COUNT(7, 1);
 
-        int32_t ret = 0;
         const unsigned tslot = (unsigned)quad_get(ia, 3);
-        {
+        const int job = Tail::on ? quad_get(ib, 3) : 0;
+        if constexpr (Tail::on) {
+            const unsigned rlo = (unsigned)quad_get(ib, 0), rhi = (unsigned)quad_get(ib, 1);
+            if (active && ret == 0) {
+                const Tail &tl = *reload_barrier(tail_in);
+                const auto &J = tl.jobs[job];
+                const unsigned long long index = J.restart_begin + (((unsigned long long)rhi << 32) | rlo);
+                // lib.rs:308: abandon when timed out or another restart of the target succeeded
+                bool stop = false;
+                if (J.first_success) {
+                    const unsigned long long fs = __hip_atomic_load(J.first_success + tslot, __ATOMIC_RELAXED,
+                                                                    __HIP_MEMORY_SCOPE_AGENT);
+                    stop = J.find_any ? (fs != ~0ull) : (fs < index);
+                }
+                if (tl.deadline && (unsigned long long)wall_clock64() > tl.deadline) stop = true;
+                if (stop) ret = RES_FORCED_STOP;
+            }
+        } else {
             const unsigned rlo = (unsigned)quad_get(ib, 0), rhi = (unsigned)quad_get(ib, 1);
             if (active) {
                 const WorkQueue &wq = *reload_barrier(&wq_in);
@@ -741,7 +782,9 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
         }
         // (the four lanes may have read first_success / the clock at different moments: the leader decides)
         ret = quad_get(ret, 0);
-        const bool do_eval = active && ret == 0;
+        const bool stepping = active && ret == 0;
+        const bool do_eval = stepping && !pending;
+        if constexpr (Tail::on) n_exec += (unsigned)__popcll(__ballot(do_eval)) / QUAD;
         double gn[NS];
         double fn = 0.0;
         OPTIK_SCHED_FENCE();
@@ -760,7 +803,9 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
             }
             OPTIK_SCHED_FENCE();
             // (the target pose is re-read for every evaluation: seven L1 / L2 hits instead of 14 registers)
-            const double *target7 = (*reload_barrier(&wq_in)).targets + (size_t)tslot * 7;
+            const double *target7;
+            if constexpr (Tail::on) target7 = (*reload_barrier(tail_in)).jobs[job].targets + (size_t)tslot * 7;
+            else target7 = (*reload_barrier(&wq_in)).targets + (size_t)tslot * 7;
             const EvalParams &ep = *reload_barrier(&ep_in);
 #ifndef OPTIK_QUAD_EXP_NO_EVAL
             fn = eval_quad<N, TIP>(ch, ep, target7, x, gn, bp + 4 * pi);
@@ -785,7 +830,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
 
         // ---- NLopt bookkeeping and Kraft's line search (labels 100 / 220), replicated scalars ------
         OPTIK_PROF_BEGIN();
-        bool need_dir = false, reset = false, do_bfgs = false;
+        bool need_dir = stepping && pending, reset = false, do_bfgs = false;  // (a deferred direction resumes at its LSQ call)
         const SolveParams &sp = *reload_barrier(&sp_in);
         double u[NS];
 #pragma unroll
@@ -1016,7 +1061,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
         OPTIK_PROF_BEGIN();
         const int qf = quad_lane_now();
         const double alpha_t = quad_get(pa, 3);
-        if (do_eval && ret == 0) {
+        if (stepping && ret == 0) {
             // label 190: next trial point x = x0 + alpha * s, clipped (NLopt)
             ia = (qf == 1) ? ia + 1 : ia;           // ++line
             pa = (qf == 2) ? alpha_t * pa : pa;     // h3 = alpha * h3
@@ -1035,13 +1080,30 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
         // ---- a restart ended: classify (lib.rs:376-379), publish, free the quad -------------------
         const bool ended = active && ret != 0;
         if (wave_any(ended)) {
-            const WorkQueue &wq = *reload_barrier(&wq_in);
             const SolveParams &sp = *reload_barrier(&sp_in);
             const double minf = quad_get(pb, 0);
             const int nevals = quad_get(ia, 2);
             const unsigned long long rr = ((unsigned long long)(unsigned)quad_get(ib, 1) << 32) | (unsigned)quad_get(ib, 0);
-            const unsigned long long item = (unsigned long long)tslot * wq.n_restarts + rr;  // output column
-            const unsigned long long index = wq.restart_begin + rr;
+            // where the restart's results go: the launch's outputs, or (Tail) those of the restart's job
+            const double *o_x0;
+            double *o_x, *o_f, *o_key;
+            int32_t *o_status, *o_evals;
+            unsigned long long *o_fs;
+            unsigned long long o_restarts, o_begin, o_stride;
+            bool o_quality;
+            if constexpr (Tail::on) {
+                const auto &J = (*reload_barrier(tail_in)).jobs[job];
+                o_x0 = J.x0; o_x = J.out_x; o_f = J.out_f; o_key = J.out_key; o_status = J.out_status; o_evals = J.out_evals;
+                o_fs = J.first_success; o_restarts = J.n_restarts; o_begin = J.restart_begin; o_stride = J.n_items;
+                o_quality = J.quality != 0;
+            } else {
+                const WorkQueue &wq = *reload_barrier(&wq_in);
+                o_x0 = wq.x0; o_x = wq.out_x; o_f = wq.out_f; o_key = wq.out_key; o_status = wq.out_status; o_evals = wq.out_evals;
+                o_fs = wq.first_success; o_restarts = wq.n_restarts; o_begin = wq.restart_begin; o_stride = wq.total_items;
+                o_quality = wq.quality != 0;
+            }
+            const unsigned long long item = (unsigned long long)tslot * o_restarts + rr;  // output column
+            const unsigned long long index = o_begin + rr;
             bool val[NS];
             int jc[NS];
 #pragma unroll
@@ -1054,11 +1116,11 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                                  || (sp.ok_xtol && ret == RES_XTOL_REACHED);
             // selection key (lib.rs:402-407): Quality = ||x - x0||_2, Speed = index
             double kq = 0.0;
-            if (wq.quality) {
+            if (wave_any(ended && o_quality)) {
                 double d2[NS];
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
-                    const double d = xb[s * 64] - ((ended && val[s]) ? wq.x0[(size_t)tslot * N + jc[s]] : 0.0);
+                    const double d = xb[s * 64] - ((ended && o_quality && val[s]) ? o_x0[(size_t)tslot * N + jc[s]] : 0.0);
                     d2[s] = d * d;
                 }
                 double acc = 0.0;
@@ -1066,25 +1128,27 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                 for (int i = 0; i < N; ++i) acc += quad_get(d2[i >> 2], i);
                 kq = __builtin_sqrt(acc);
             }
+            const unsigned slot_u = Tail::on ? (unsigned)quad_get(ib, 2) : 0u;
             if (ended) {
-                if (wq.out_x) {
+                if (o_x) {
 #pragma unroll
                     for (int s = 0; s < NS; ++s)
-                        if (val[s]) wq.out_x[(size_t)jc[s] * wq.total_items + item] = xb[s * 64];
+                        if (val[s]) o_x[(size_t)jc[s] * o_stride + item] = xb[s * 64];
                 }
                 if (qf == 0) {
-                    if (wq.out_f) wq.out_f[item] = minf;
-                    if (wq.out_status) wq.out_status[item] = ret;
-                    if (wq.out_evals) wq.out_evals[item] = nevals;
+                    if (o_f) o_f[item] = minf;
+                    if (o_status) o_status[item] = ret;
+                    if (o_evals) o_evals[item] = nevals;
                     double k = __builtin_huge_val();
                     if (success) {
-                        if (wq.quality) k = kq;
+                        if (o_quality) k = kq;
                         else {
                             k = (double)index;
-                            if (wq.first_success) atomicMin(wq.first_success + tslot, index);
+                            if (o_fs) atomicMin(o_fs + tslot, index);
                         }
                     }
-                    if (wq.out_key) wq.out_key[item] = k;
+                    if (o_key) o_key[item] = k;
+                    if constexpr (Tail::on) (*reload_barrier(tail_in)).template release<N>(slot_u);
                 }
                 active = false;
                 want = true;
@@ -1093,6 +1157,10 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
         OPTIK_PROF_END(3);
     }
     OPTIK_PROF_FLUSH(wq_in.prof);
+    if constexpr (Tail::on) {
+        const Tail &tl = *reload_barrier(tail_in);
+        if (tl.exec_evals && n_exec && (threadIdx.x & 63u) == 0) atomicAdd(tl.exec_evals + (blockIdx.x % 64u), (unsigned long long)n_exec);
+    }
 #undef xb
 #undef xp
 #undef blk

@@ -273,6 +273,9 @@ def test_engine_pools_jobs_and_matches_the_single_kernel_path(dev, oracle, chain
     {"OPTIK_ENG_NO_TAIL": "1"},                                                    # the engine finishes every restart itself
     {"OPTIK_ENG_TAIL_MAX": "100000", "OPTIK_ENGINE_SLOTS": "4096"},                # tail kernel takes over as soon as the queue is empty
     {"OPTIK_ENG_TAIL_MAX": "7", "OPTIK_ENG_POOLS": "2"},                           # ... or only for the last handful
+    {"OPTIK_ENG_TAIL": "coop", "OPTIK_ENG_TAIL_MAX": "100000", "OPTIK_ENGINE_SLOTS": "4096"},  # round 2's cooperative tail instead of the quad solver's
+    {"OPTIK_ENG_TAIL": "coop"},
+    {"OPTIK_ENG_TAIL_MAX": "100000", "OPTIK_ENGINE_SLOTS": "4096", "OPTIK_ENG_NNLS_BUDGET": "1"},  # quad tail taking over slots with suspended solves
     {"OPTIK_ENG_FUSED": "1"},                                                      # fused trips: bucket -> NNLS -> slot kernel
     {"OPTIK_ENG_FUSED": "1", "OPTIK_ENGINE_SLOTS": "3072", "OPTIK_ENG_POOLS": "3", "OPTIK_ENG_NNLS_BUDGET": "2"},
     {"OPTIK_ENG_FUSED": "1", "OPTIK_ENG_NO_TAIL": "1", "OPTIK_ENGINE_SLOTS": "2048"},
