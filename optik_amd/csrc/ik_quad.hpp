@@ -921,6 +921,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
         // quad that needs a direction takes part in every step of a round (ik_coop.hpp:coop_direction)
         OPTIK_PROF_BEGIN();
         while (wave_any(need_dir)) {
+            OPTIK_PROF_COUNT(2, 1);  // (direction passes: more than one per trip when some quad has to reset and search again)
             const SolveParams &sp = *reload_barrier(&sp_in);
             bool pass = need_dir;
             const bool sx0 = stop_x_quad<N>(sp, x, x0);
