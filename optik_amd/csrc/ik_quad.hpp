@@ -10,10 +10,14 @@
 //   rows q, q + 4 of E^-1                = NNLS columns q, q + 4 (lower bounds), n + q, n + q + 4 (upper)
 //   Jacobian columns q, q + 4            -> gradient components q, q + 4
 //
-// and every scalar of Kraft's / NLopt's state machine is replicated in the four lanes.  Values move
-// between the lanes of a quad with DPP quad_perm moves (ik_lane.hpp), never through LDS; the only
-// LDS of the solver is the 1 KB block per quad that holds the matrix of the bounded dual problem
-// while ik_nnls_quad.hpp solves it.
+// and every scalar of Kraft's / NLopt's state machine is the same in the four lanes: inside a region
+// of a trip it is replicated, ACROSS the regions each scalar is kept by one lane (pa / pb / ia / ib in
+// quad_wave) and fetched where it is used.  Values move between the lanes of a quad with DPP
+// quad_perm moves (ik_lane.hpp), never through LDS; the LDS of the solver is the 1 KB block per quad
+// that holds the matrix of the bounded dual problem while ik_nnls_quad.hpp solves it -- and, while
+// the quad evaluates, what the evaluation does not touch -- plus x_best / x_prev of every lane.
+// The restarts come from the launch's work queue, or (ik_quad_tail.hpp) mid-flight from the slot pool
+// of an engine run that is draining.
 //
 // Bit-exactness (the contract of DESIGN.md section 2): every sum the reference / oracle forms
 // sequentially is formed here in the SAME ORDER from the same products -- either inside one lane
