@@ -496,8 +496,9 @@ def main():
                     "unit_name": "bounded sub-problem" if dom == "nnls" else "slot-trip",
                     "all_kernels_ms": per_kernel, "trips": trips, "sub_pools": st["pools"],
                     # who finishes the run's last restarts once the queue is dry (ik_quad_tail.hpp / ik_tail.hpp)
-                    "tail": ("none" if os.environ.get("OPTIK_ENG_NO_TAIL") else
-                             "cooperative kernel" if os.environ.get("OPTIK_ENG_TAIL") in ("coop", "lane") else "quad solver"),
+                    "tail": dict(zip(("solver", "restarts_taken_over"),
+                                     (lambda sv, nr: ({0: "none", 1: "per-lane kernel", 2: "cooperative kernel", 3: "quad solver"}[sv], nr))(
+                                         *hc.engine_last_tail()))),
                     "launches": st["launches"], "restart_output_bytes": out_bytes,
                     # the whole path at its boundary: SURVEY 8d's per-restart figure with in-kernel
                     # seeds (outputs only) and with the seeds counted as read (16n + 16)

@@ -206,6 +206,11 @@ int optik_hip_engine_solve(optik_hip_chain *chain, const optik_solver_config *cf
  * demand otherwise. */
 int optik_hip_engine_reserve(optik_hip_chain *chain, uint64_t slots, void *stream);
 int optik_hip_engine_last_trips(const optik_hip_chain *chain);
+/* Who finished the last run's final restarts once its queue was dry: *restarts = how many (an upper bound:
+ * the host's lagging count) were handed over from the slot pool; returns the solver -- 0 none (the
+ * phase kernels ran every restart to its end), 1 the per-lane kernel, 2 the cooperative kernel, 3 the
+ * quad solver (the default). */
+int optik_hip_engine_last_tail(const optik_hip_chain *chain, int32_t *restarts);
 /* The slot pool of a run is split into sub-pools (OPTIK_ENG_POOLS, default 3; at most 4),
  * each with its own HIP stream, so that kernels of different sub-pools overlap.  Returns
  * the number of sub-pools of the last run; *launches = launches of each phase kernel,

@@ -100,6 +100,7 @@ def lib():
     L.optik_hip_engine_last_fused.argtypes = [vp]
     L.optik_hip_engine_reserve.argtypes = [vp, C.c_uint64, vp]
     L.optik_hip_engine_last_trips.argtypes = [vp]
+    L.optik_hip_engine_last_tail.argtypes = [vp, C.POINTER(C.c_int32)]
     L.optik_hip_engine_last_pools.argtypes = [vp, C.POINTER(C.c_int32)]
     L.optik_hip_engine_stats.argtypes = [vp, dp, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
     L.optik_hip_probe.argtypes = [C.c_int32, dp, dp, C.c_int64, dp]

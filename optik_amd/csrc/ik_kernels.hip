@@ -594,6 +594,7 @@ struct optik_hip_chain {
     int eng_fused = 0;                         // the last run used fused trips (eng_kernel_ms = {slot, bucket, nnls, -})
     int eng_launches = 0;                      // NNLS launches of the last run, all sub-pools
     int eng_tail_restarts = 0;                 // restarts (upper bound) the tail kernel took over in the last run
+    int eng_tail_solver = 0;                   // ... and on which solver: 0 none, 1 per-lane, 2 cooperative, 3 quad
     int eng_compactions = 0;
     double *eng_prob = nullptr;            // 2 x [C][2n][n+1]
     double *eng_y = nullptr;               // 2 x [C][2n]
@@ -1741,6 +1742,7 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
         if (getenv("OPTIK_ENG_NO_TAIL")) tail_max = 0;
         if (const char *e = getenv("OPTIK_ENG_TAIL_MAX")) tail_max = (unsigned long long)atoll(e);
         ch->eng_tail_restarts = 0;
+        ch->eng_tail_solver = 0;
         for (bool all_done = false; !all_done;) {
             all_done = true;
             for (int p2 = 0; p2 < n_pools; ++p2) {
@@ -1779,7 +1781,11 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
                 tq.base.chain = pa0.chain;
                 tq.base.ep = pa0.ep;
                 tq.base.sp = pa0.sp;
-                const long long capq = (long long)cus * quad_solve_waves_per_cu(ch->n);
+                long long capq = (long long)cus * quad_solve_waves_per_cu(ch->n);
+                if (const char *e = getenv("OPTIK_ENG_TAIL_WAVES")) {  // resident tail waves per CU (experiments)
+                    const long long v = atoll(e);
+                    if (v >= 1 && v * cus < capq) capq = v * cus;
+                }
                 long long lq = ((long long)left + capq - 1) / capq;
                 if (lq < 1) lq = 1;
                 if (lq > COOP_GROUPS_PER_WAVE) lq = COOP_GROUPS_PER_WAVE;
@@ -1801,6 +1807,7 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
                 HIP_TRY(hipMemsetAsync(t_count + 2, 0, sizeof(unsigned long long), stream));
                 HIP_TRY(quad_tail_launch(ch->n, tip, (int)gq, stream, tq));
                 ch->eng_tail_restarts = (int)left;
+                ch->eng_tail_solver = 3;
                 for (int p2 = 0; p2 < n_pools; ++p2) pools[p2].done = true;
                 all_done = true;
                 continue;
@@ -1835,6 +1842,7 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
 #undef M_TAIL_F
             HIP_TRY(hipGetLastError());
             ch->eng_tail_restarts = (int)left;
+            ch->eng_tail_solver = tail_coop ? 2 : 1;
             for (int p2 = 0; p2 < n_pools; ++p2) pools[p2].done = true;
             all_done = true;
         }
@@ -1971,6 +1979,11 @@ int optik_hip_engine_reserve(optik_hip_chain *ch, uint64_t slots, void *stream_v
 }
 
 int optik_hip_engine_last_trips(const optik_hip_chain *ch) { return ch ? ch->eng_trips : 0; }
+
+int optik_hip_engine_last_tail(const optik_hip_chain *ch, int32_t *restarts) {
+    if (restarts) *restarts = ch ? ch->eng_tail_restarts : 0;
+    return ch ? ch->eng_tail_solver : 0;
+}
 
 int optik_hip_engine_last_pools(const optik_hip_chain *ch, int32_t *launches) {
     if (!ch) return 0;

@@ -167,6 +167,13 @@ class HipChain:
         self._pending = []
         return int(nat.lib().optik_hip_engine_last_trips(self._h))
 
+    def engine_last_tail(self):
+        """(solver, restarts) of the last engine_run's tail: solver 0 none, 1 per-lane kernel, 2 cooperative
+        kernel, 3 quad solver; restarts = how many (upper bound) were taken over from the slot pool."""
+        n = C.c_int32(0)
+        solver = int(nat.lib().optik_hip_engine_last_tail(self._h, C.byref(n)))
+        return solver, int(n.value)
+
     def engine_stats(self):
         """Per-kernel mean ms {eval, update, nnls, finish} over the sampled trips of sub-pool 0 of
         the last engine_run (needs set_timing(True)), sampled trips, NNLS problems solved, the

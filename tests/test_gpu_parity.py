@@ -299,12 +299,18 @@ def test_engine_scheduling_does_not_change_results(dev, oracle, chains, hip_chai
     try:
         out = _run(hip_chains["panda"], "engine", cfg, torch.tensor(tg, device="cuda"),
                    torch.tensor(x0, device="cuda"), 0, R)
+        tail_solver, tail_restarts = hip_chains["panda"].engine_last_tail()
     finally:
         for k, v in old.items():
             if v is None:
                 del os.environ[k]
             else:
                 os.environ[k] = v
+    # the hand-over really happened where the setting asks for it, and on the solver it names
+    if knobs.get("OPTIK_ENG_NO_TAIL"):
+        assert tail_solver == 0 and tail_restarts == 0
+    elif knobs.get("OPTIK_ENG_TAIL_MAX") == "100000" or "OPTIK_ENG_TAIL" in knobs:
+        assert tail_restarts > 0 and tail_solver == (2 if knobs.get("OPTIK_ENG_TAIL") == "coop" else 3), (tail_solver, tail_restarts)
     ref = _oracle_all(oracle, ch, kw, tg[0], x0[0], 0, R)
     assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
     assert np.array_equal(out["evals"].cpu().numpy(), ref["evals"])
