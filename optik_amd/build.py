@@ -19,9 +19,13 @@ SOURCES = ["ik_kernels.hip", "ik_quad_kernel.hip", "robot_host.cpp"]
 # LDS addresses out of the solver loop only for the register allocator to spill them to scratch
 # (csrc/ik_quad_kernel.hip), its latency forms and the launch function with the default pipeline.
 UNITS = [("ik_kernels.hip", "ik_kernels.o", []),
-         ("ik_quad_kernel.hip", "ik_quad_latency.o", ["-DOPTIK_QUAD_PART=1"]),
+         # (the quad solver is issue-bound: the max-ILP scheduling strategy is worth +3 % restarts/s on the
+         # throughput form and -3 % on a single ik()'s latency; on the engine's kernels it costs 6 %)
+         ("ik_quad_kernel.hip", "ik_quad_latency.o",
+          ["-DOPTIK_QUAD_PART=1", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
          ("ik_quad_kernel.hip", "ik_quad_throughput.o",
-          ["-DOPTIK_QUAD_PART=2", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-use-amdgpu-trackers=1"]),
+          ["-DOPTIK_QUAD_PART=2", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-use-amdgpu-trackers=1",
+           "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
          ("robot_host.cpp", "robot_host.o", [])]
 HEADERS = ["ik_math.hpp", "ik_eval.hpp", "ik_slsqp.hpp", "ik_solve.hpp", "ik_nnls_coop.hpp", "ik_engine.hpp",
            "ik_tail.hpp", "ik_coop.hpp", "device_scope.hpp", "ik_host_params.hpp", "ik_launch.hpp",
