@@ -164,6 +164,11 @@ struct EngArgs {
     int pad4;
     unsigned long long *trace;          // OPTIK_NNLS_TRACE builds: per-wave {start, end, hw id, passes} of one trip
     unsigned long long tail_deadline_ticks;  // tail kernel: wall-clock ticks after its start at which max_time expires (0 = none)
+    // max_time on the device's own clock: *deadline_word = wall_clock64() value at which the run's budget
+    // expires (written once at the start of the run; 0 or a null pointer = none).  Every evaluation and every
+    // refill compares it with the clock (lib.rs:308 checks at every callback), so the run reacts within a
+    // trip instead of at the host's next look (`abort`, chunks of four trips queued two deep).
+    const unsigned long long *deadline_word;
     // objective + gradient evaluations actually executed (NLopt's per-restart count, out_evals, also
     // counts the re-evaluation of an accepted trial point that the kernels skip): 64 counters, one
     // per workgroup index mod 64, so that the per-wave additions do not queue on one L2 word
@@ -197,6 +202,14 @@ constexpr int ENG_EXEC_SHARDS = 64;
 #define ENG_D_AT(base, nd, C, p, s) (base)[(size_t)(p) * (C) + (s)]
 #endif
 #define ENG_I(plane) a.i32[(size_t)(plane) * a.C + slot]
+
+// lib.rs:260-264, 308: has the run's time budget expired (host's flag, or the device clock past the deadline)?
+OPTIK_DEV bool eng_timed_out(const EngArgs &a) {
+    if (a.abort) return true;
+    if (!a.deadline_word) return false;
+    const unsigned long long dl = *a.deadline_word;
+    return dl != 0ull && (unsigned long long)wall_clock64() > dl;
+}
 
 // Outcome of the direction search for one slot.
 enum : int { DIR_OK = 0, DIR_DEFER = 1, DIR_DEAD = 2 };
@@ -502,7 +515,7 @@ OPTIK_DEV bool eng_eval_body(const EngArgs &a, const ChainDev &ch, const EngJob 
                                                             __HIP_MEMORY_SCOPE_AGENT);
             if (J.find_any ? (fs != ~0ull) : (fs < index)) ret = RES_FORCED_STOP;
         }
-        if (a.abort) ret = RES_FORCED_STOP;  // lib.rs:308: timed out
+        if (eng_timed_out(a)) ret = RES_FORCED_STOP;  // lib.rs:308: timed out
     }
     const bool evaluated = ret == 0;
     if (ret == 0) {
@@ -649,7 +662,8 @@ OPTIK_DEV bool refill_slot(const EngArgs &a, const ChainDev &ch, size_t slot, un
         else { tslot = qi / J.n_restarts; r = qi - tslot * J.n_restarts; }
         const unsigned long long item = tslot * J.n_restarts + r;  // output column
         const unsigned long long index = J.restart_begin + r;
-        bool skip = a.abort != 0;  // timed out before the restart was issued (lib.rs:393)
+        const bool late = eng_timed_out(a);  // timed out before the restart was issued (lib.rs:393)
+        bool skip = late;
         if (!skip && J.first_success) {
             const unsigned long long fs = __hip_atomic_load(J.first_success + tslot, __ATOMIC_RELAXED,
                                                             __HIP_MEMORY_SCOPE_AGENT);
@@ -658,7 +672,7 @@ OPTIK_DEV bool refill_slot(const EngArgs &a, const ChainDev &ch, size_t slot, un
         if (skip) {
             if (J.out_status) J.out_status[item] = RES_FORCED_STOP;
             if (J.out_evals) J.out_evals[item] = 0;
-            if (a.abort && J.out_key) J.out_key[item] = __builtin_huge_val();
+            if (late && J.out_key) J.out_key[item] = __builtin_huge_val();
             return false;
         }
         double x[N];

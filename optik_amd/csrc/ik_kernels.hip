@@ -336,6 +336,11 @@ __global__ void fill_f64_kernel(double *p, unsigned long long n, double v) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
+// the run's deadline on the device clock (EngArgs::deadline_word)
+__global__ void eng_deadline_kernel(unsigned long long *word, unsigned long long ticks) {
+    *word = ticks ? (unsigned long long)wall_clock64() + ticks : 0ull;
+}
+
 __global__ void eng_init_kernel(int32_t *state, unsigned int *cls2, unsigned long long C) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < C) { state[i] = ST_REFILL; cls2[i] = NN_NONE; cls2[C + i] = NN_NONE; }  // every slot wants a work item
@@ -593,6 +598,7 @@ struct optik_hip_chain {
     int eng_pools = 1;
     int eng_fused = 0;                         // the last run used fused trips (eng_kernel_ms = {slot, bucket, nnls, -})
     int eng_launches = 0;                      // NNLS launches of the last run, all sub-pools
+    unsigned long long *eng_deadline = nullptr;  // device word: wall_clock64() value at which the run's max_time expires
     int eng_tail_restarts = 0;                 // restarts (upper bound) the tail kernel took over in the last run
     int eng_tail_solver = 0;                   // ... and on which solver: 0 none, 1 per-lane, 2 cooperative, 3 quad
     int eng_compactions = 0;
@@ -818,6 +824,7 @@ void optik_hip_chain_destroy(optik_hip_chain *ch) {
     if (ch->eng_djobs) hipFree(ch->eng_djobs);
     if (ch->eng_counters) hipFree(ch->eng_counters);
     if (ch->eng_trip_log) hipFree(ch->eng_trip_log);
+    if (ch->eng_deadline) hipFree(ch->eng_deadline);
     if (ch->hw_dev) hipFree(ch->hw_dev);
     if (ch->hw_pin) hipHostFree(ch->hw_pin);
     if (ch->eng_pinned) hipHostFree(ch->eng_pinned);
@@ -1464,6 +1471,16 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
         a.exec_evals = ch->eng_nn_total + 1;
         a.tail_deadline_ticks = 0;
         a.abort = 0;
+        a.deadline_word = nullptr;
+        if (deadline_s > 0.0) {
+            // max_time on the device clock: the kernels stop what is in flight within a trip of its expiry
+            if (!ch->eng_deadline) HIP_TRY(hipMalloc(&ch->eng_deadline, sizeof(unsigned long long)));
+            const double left_s = deadline_s - since_call();
+            const double khz = ch->wall_clock_khz > 0 ? (double)ch->wall_clock_khz : 100000.0;
+            const unsigned long long ticks = left_s > 0.0 ? (unsigned long long)(left_s * khz * 1e3) + 1ull : 1ull;
+            hipLaunchKernelGGL(eng_deadline_kernel, dim3(1), dim3(1), 0, stream, ch->eng_deadline, ticks);
+            a.deadline_word = ch->eng_deadline;
+        }
         a.parity = 0;
         a.prof = nullptr;
         a.prof2 = nullptr;

@@ -459,7 +459,7 @@ def test_engine_deadline_abandons_and_keeps_what_was_found(dev, oracle, chains, 
     evals = out["evals"].cpu().numpy()
     forced = status == nat.RES_FORCED_STOP
     assert forced.any() and (~forced).any(), "the deadline should fall inside the run"
-    assert took < 0.035, took                      # a full run of 2^20 restarts takes ~45 ms
+    assert took < 0.020, took                      # a full run of 2^20 restarts takes ~45 ms; the deadline is checked on the device clock at every evaluation / refill
     assert (evals[forced & (evals == 0)] == 0).all() and (forced & (evals == 0)).sum() > R // 4  # never started
     done = np.flatnonzero(~forced)[:200]
     xs = out["x"].cpu().numpy()
