@@ -75,7 +75,8 @@ __global__ __launch_bounds__(64, OPTIK_QUAD_WAVES) void eng_tail_quad_kernel(con
                                static_cast<const EngTail *>(&L.tail));
 }
 
-// (n = 8: nine-row columns make the blocks 22 KB per wave -- one wave per SIMD)
+// (n = 8: nine-row columns make the blocks 22 KB per wave: six waves per CU of the throughput form --
+// 236 B of scratch, 12.1 against 9.3 M restarts/s with four waves of the latency form)
 #if OPTIK_QUAD_PART != 1
 hipError_t quad_tail_launch(int n, bool tip, int grid, hipStream_t stream, const TailLaunch &a) {
 #define CALL_TAIL(NN)                                                                                   \
@@ -107,6 +108,7 @@ hipError_t quad_solve_launch_w2(int n, bool tip, int grid, hipStream_t stream, c
         CALL_QUAD2(OPTIK_QUAD_ONLY_N)
 #else
         CALL_QUAD2(1) CALL_QUAD2(2) CALL_QUAD2(3) CALL_QUAD2(4) CALL_QUAD2(5) CALL_QUAD2(6) CALL_QUAD2(7)
+        CALL_QUAD2(8)  // (nine-row columns: 26 KB of LDS per wave, six waves per CU)
 #endif
     default: return hipErrorInvalidValue;
     }
@@ -118,7 +120,7 @@ hipError_t quad_solve_launch_w2(int n, bool tip, int grid, hipStream_t stream, c
 #endif
 
 #if OPTIK_QUAD_PART != 2
-int quad_solve_waves_per_cu(int n) { return n <= 7 ? 4 * OPTIK_QUAD_WAVES : 4; }
+int quad_solve_waves_per_cu(int n) { return n <= 7 ? 4 * OPTIK_QUAD_WAVES : (OPTIK_QUAD_WAVES > 1 ? 6 : 4); }
 
 hipError_t quad_solve_launch(int n, bool tip, int grid, hipStream_t stream, const SolveLaunch &a, int *lds_bytes,
                              bool latency_form) {
@@ -139,10 +141,7 @@ hipError_t quad_solve_launch(int n, bool tip, int grid, hipStream_t stream, cons
         CALL_QUAD(OPTIK_QUAD_ONLY_N)
 #else
         CALL_QUAD(1) CALL_QUAD(2) CALL_QUAD(3) CALL_QUAD(4) CALL_QUAD(5) CALL_QUAD(6) CALL_QUAD(7)
-    case 8:
-        if (tip) hipLaunchKernelGGL((ik_quad_kernel<8, true, 1>), dim3(grid), dim3(64), 0, stream, a);
-        else hipLaunchKernelGGL((ik_quad_kernel<8, false, 1>), dim3(grid), dim3(64), 0, stream, a);
-        break;
+        CALL_QUAD(8)
 #endif
     default: return hipErrorInvalidValue;
     }
