@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OPTIK_HIP_MAX_DOF 8
+#define OPTIK_HIP_MAX_DOF 16 /* joint positions of a chain (9 .. 16: the general kernels, see below) */
 
 enum {
     OPTIK_HIP_OK = 0,
@@ -77,11 +77,14 @@ const char *optik_hip_last_error(void);
 
 /* origins: n_joints x 7 poses (Joint::origin), axes: n_joints x 3 (unit axis of
  * each chain joint, ignored for fixed), types: OPTIK_JOINT_*, lb/ub: n limits
- * (Robot::joint_limits, lib.rs:78-84).  Supported: 1 <= n <= 8 positional joints plus
- * an optional trailing fixed joint (what from_urdf's folding produces); the streaming engine
- * and the cooperative kernels cover n <= 7, an 8-DoF chain runs on the per-lane solve kernel;
- * prismatic joints: forward kinematics only (the reference's Jacobian is todo!(),
- * kinematics.rs:185). */
+ * (Robot::joint_limits, lib.rs:78-84).  Supported: 1 <= n <= 16 positional joints plus
+ * an optional trailing fixed joint (what from_urdf's folding produces).  n <= 8 runs on the
+ * tuned solvers (the streaming engine covers n <= 7, an 8-DoF chain's engine jobs run on the
+ * quad solver); 9 <= n <= 16 runs on one general kernel per entry point (joint count at run
+ * time, restart state in an HBM workspace: the same results as the CPU oracle bit for bit, a
+ * fraction of the tuned solvers' rate) -- the reference itself has no limit
+ * (kinematics.rs:107-110).  Prismatic joints (n <= 8): forward kinematics only (the reference's
+ * Jacobian is todo!(), kinematics.rs:185). */
 int optik_hip_chain_create(const double *origins, const double *axes, const int32_t *types,
                            int32_t n_joints, const double *lb, const double *ub, int32_t n,
                            optik_hip_chain **out);

@@ -13,7 +13,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "liboptik_amd.so")
-SOURCES = ["ik_kernels.hip", "ik_quad_kernel.hip", "robot_host.cpp"]
+SOURCES = ["ik_kernels.hip", "ik_quad_kernel.hip", "ik_wide_kernel.hip", "robot_host.cpp"]
 # translation units: (source, object, extra flags).  ik_quad_kernel.hip is compiled twice -- its
 # throughput form (two waves per SIMD) without the machine-LICM pass, which otherwise hoists constants and
 # LDS addresses out of the solver loop only for the register allocator to spill them to scratch
@@ -26,10 +26,12 @@ UNITS = [("ik_kernels.hip", "ik_kernels.o", []),
          ("ik_quad_kernel.hip", "ik_quad_throughput.o",
           ["-DOPTIK_QUAD_PART=2", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-use-amdgpu-trackers=1",
            "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
+         # chains with 9 .. 16 joint positions: one run-time-n body per kernel (ik_wide.hpp)
+         ("ik_wide_kernel.hip", "ik_wide_kernel.o", []),
          ("robot_host.cpp", "robot_host.o", [])]
 HEADERS = ["ik_math.hpp", "ik_eval.hpp", "ik_slsqp.hpp", "ik_solve.hpp", "ik_nnls_coop.hpp", "ik_engine.hpp",
            "ik_tail.hpp", "ik_coop.hpp", "device_scope.hpp", "ik_host_params.hpp", "ik_launch.hpp",
-           "urdf_chain.hpp",
+           "urdf_chain.hpp", "ik_wide_launch.hpp",
            os.path.join("..", "..", "include", "optik_hip.h"),
            os.path.join("..", "..", "include", "optik.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
@@ -38,7 +40,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
 # its object file; the objects are build artefacts, git-ignored like the library)
 QUAD_HEADERS = ["ik_math.hpp", "ik_eval.hpp", "ik_slsqp.hpp", "ik_solve.hpp", "ik_nnls_coop.hpp", "ik_nnls_quad.hpp", "ik_lane.hpp",
                 "ik_quad.hpp", "ik_launch.hpp"]
+WIDE_HEADERS = ["ik_math.hpp", "ik_eval.hpp", "ik_slsqp.hpp", "ik_solve.hpp", "ik_wide_launch.hpp", "ik_wide.hpp"]
 DEPS = {"ik_kernels.hip": HEADERS,
+        "ik_wide_kernel.hip": WIDE_HEADERS,
         "ik_quad_kernel.hip": QUAD_HEADERS,
         "robot_host.cpp": ["urdf_chain.hpp", "device_scope.hpp", os.path.join("..", "..", "include", "optik_hip.h"),
                            os.path.join("..", "..", "include", "optik.h")]}
@@ -55,7 +59,7 @@ def is_stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS + QUAD_HEADERS] + [os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS + QUAD_HEADERS + WIDE_HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 

@@ -25,6 +25,7 @@
 #include "device_scope.hpp"
 #include "ik_host_params.hpp"
 #include "ik_launch.hpp"
+#include "ik_wide_launch.hpp"
 #include "ik_engine.hpp"
 #include "ik_tail.hpp"
 #include "ik_coop.hpp"
@@ -541,8 +542,14 @@ struct optik_hip_chain {
     int n = 0;
     bool tip = false;
     uint32_t key[8];
-    double scale[MAX_DOF];
+    double scale[WIDE_MAX_DOF];
     int range_rule = 0;  // OPTIK_HIP_RANGE_*: how `scale` was formed
+    // a chain with 9 .. 16 joint positions (ik_wide.hpp): its own table, the general kernels, no engine
+    bool wide = false;
+    WideChainDev whost;
+    WideChainDev *wdev = nullptr;
+    double *wide_ws = nullptr;  // restart workspace of the resident waves
+    size_t wide_ws_waves = 0;
     int device_id = 0;   // the HIP device the chain lives on (the current device at creation)
     // a chain with prismatic joints: FK only (as in the reference); the joint table for fk_general_kernel
     bool prismatic = false;
@@ -685,10 +692,11 @@ int default_range_rule() {
 void set_chain_scales(optik_hip_chain *ch, int rule) {
     ch->range_rule = rule;
     for (int k = 0; k < ch->n; ++k) {
-        const double lb = ch->host.lb[k], ub = ch->host.ub[k];
+        const double lb = ch->wide ? ch->whost.lb[k] : ch->host.lb[k], ub = ch->wide ? ch->whost.ub[k] : ch->host.ub[k];
         // infinite limits (continuous joints) make random_range panic in the
         // reference (quirk Q5); restarts > 0 are refused at launch time instead.
         ch->scale[k] = (std::isfinite(lb) && std::isfinite(ub)) ? uniform_scale(lb, ub, rule) : NAN;
+        if (ch->wide) ch->whost.scale[k] = ch->scale[k];
     }
 }
 
@@ -713,7 +721,7 @@ int ensure_device() {
 // Kernels are instantiated for 1 <= n <= 8 revolute joints, each with and without a trailing
 // fixed joint; the streaming engine for n <= 7 (n + 1 <= 8 rows fit its register-resident
 // NNLS) -- an 8-DoF chain's engine jobs run on the single-kernel path, same results.
-#define OPTIK_N_RANGE_MSG "kernels are built for 1 <= n <= 8 revolute joints"
+#define OPTIK_N_RANGE_MSG "this kernel is built for 1 <= n <= 8 revolute joints"
 #define OPTIK_DISPATCH_ONE(NN, CALL)                                                   \
     if (!done_ && n_ == NN) {                                                          \
         if (tip_) { CALL(NN, true); } else { CALL(NN, false); }                        \
@@ -755,7 +763,7 @@ int optik_hip_chain_create(const double *origins, const double *axes, const int3
                            int32_t n_joints, const double *lb, const double *ub, int32_t n,
                            optik_hip_chain **out) {
     if (!origins || !axes || !types || !lb || !ub || !out) return fail(OPTIK_HIP_EINVAL, "null argument");
-    if (n < 1 || n > MAX_DOF) return fail(OPTIK_HIP_EUNSUPPORTED, "num_positions must be in 1..8");
+    if (n < 1 || n > WIDE_MAX_DOF) return fail(OPTIK_HIP_EUNSUPPORTED, "num_positions must be in 1..16");
     if (n_joints != n && n_joints != n + 1)
         return fail(OPTIK_HIP_EUNSUPPORTED, "chain must be n revolute joints plus an optional trailing fixed joint");
     bool prismatic = false;
@@ -766,11 +774,44 @@ int optik_hip_chain_create(const double *origins, const double *axes, const int3
     }
     if (n_joints == n + 1 && types[n] != OPTIK_JOINT_FIXED)
         return fail(OPTIK_HIP_EUNSUPPORTED, "joint after the last revolute joint must be fixed");
+    if (prismatic && n > MAX_DOF)
+        return fail(OPTIK_HIP_EUNSUPPORTED, "prismatic joints are supported for chains of at most 8 joint positions");
     if (int rc = ensure_device()) return rc;
 
     auto *ch = new optik_hip_chain();
     std::memset(&ch->host, 0, sizeof ch->host);
+    std::memset(&ch->whost, 0, sizeof ch->whost);
     ch->n = n;
+    if (n > MAX_DOF) {
+        // 9 .. 16 joint positions: the general kernels of ik_wide.hpp (one table, joint count at run time)
+        ch->wide = true;
+        ch->n_joints = n_joints;
+        ch->tip = (n_joints == n + 1);
+        WideChainDev &w = ch->whost;
+        w.n_pos = n;
+        w.has_tip = ch->tip;
+        for (int j = 0; j < n_joints; ++j)
+            for (int k = 0; k < 7; ++k) w.origin[j][k] = origins[j * 7 + k];
+        for (int j = 0; j < n; ++j)
+            for (int k = 0; k < 3; ++k) w.axis[j][k] = axes[j * 3 + k];
+        for (int k = 0; k < n; ++k) { w.lb[k] = lb[k]; w.ub[k] = ub[k]; }
+        set_chain_scales(ch, default_range_rule());
+        seed_from_u64(42, ch->key);  // RNG_SEED, lib.rs:360
+        hipError_t e = hipMalloc(&ch->wdev, sizeof(WideChainDev));
+        if (e == hipSuccess) e = hipMemcpy(ch->wdev, &ch->whost, sizeof(WideChainDev), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            if (ch->wdev) (void)hipFree(ch->wdev);
+            delete ch;
+            return fail(OPTIK_HIP_ENODEVICE, std::string("chain upload: ") + hipGetErrorString(e));
+        }
+        int dev = 0;
+        hipGetDevice(&dev);
+        ch->device_id = dev;
+        hipDeviceGetAttribute(&ch->num_cus, hipDeviceAttributeMultiprocessorCount, dev);
+        hipDeviceGetAttribute(&ch->wall_clock_khz, hipDeviceAttributeWallClockRate, dev);
+        *out = ch;
+        return 0;
+    }
     ch->prismatic = prismatic;
     ch->n_joints = n_joints;
     for (int j = 0; j < n_joints; ++j) {
@@ -809,6 +850,8 @@ void optik_hip_chain_destroy(optik_hip_chain *ch) {
     if (!ch) return;
     optik::DeviceScope dev_scope(ch->device_id);  // frees and the pool's last sync run on the chain's device
     if (ch->dev) hipFree(ch->dev);
+    if (ch->wdev) hipFree(ch->wdev);
+    if (ch->wide_ws) hipFree(ch->wide_ws);
     if (ch->tile_recs) hipFree(ch->tile_recs);
     if (ch->first_success) hipFree(ch->first_success);
     if (ch->tmp_x) hipFree(ch->tmp_x);
@@ -849,6 +892,10 @@ int optik_hip_chain_set_range_rule(optik_hip_chain *ch, int32_t rule) {
         return fail(OPTIK_HIP_EINVAL, "bad argument");
     std::lock_guard<std::mutex> lock(ch->mu);
     set_chain_scales(ch, rule);
+    if (ch->wide) {  // (the scales of a wide chain are part of its device table)
+        BIND_DEVICE(ch);
+        HIP_TRY(hipMemcpy(ch->wdev, &ch->whost, sizeof(WideChainDev), hipMemcpyHostToDevice));
+    }
     return 0;
 }
 
@@ -863,6 +910,16 @@ int optik_hip_eval_batch(const optik_hip_chain *ch, const optik_solver_config *c
         return fail(OPTIK_HIP_EUNSUPPORTED,
                     "prismatic joints: only forward kinematics is available (the reference's Jacobian panics, kinematics.rs:185)");
     BIND_DEVICE(ch);
+    if (ch->wide) {
+        WideBatchLaunch w;
+        std::memset(&w, 0, sizeof w);
+        w.chain = ch->wdev;
+        make_eval_params(cfg->linear_weight, cfg->angular_weight, ee_offset7, w.ep);
+        std::memcpy(w.target, target7, sizeof w.target);
+        w.q = d_q; w.B = B; w.f = d_f; w.g = d_g;
+        HIP_TRY(wide_batch_launch(0, grid_for(ch, B, 256, 8), (hipStream_t)stream, w));
+        return 0;
+    }
     EvalLaunch a;
     a.chain = ch->dev;
     make_eval_params(cfg->linear_weight, cfg->angular_weight, ee_offset7, a.ep);
@@ -899,6 +956,16 @@ int optik_hip_fk_batch(const optik_hip_chain *ch, const double *ee_offset7, cons
         HIP_TRY(hipGetLastError());
         return 0;
     }
+    if (ch->wide) {
+        WideBatchLaunch w;
+        std::memset(&w, 0, sizeof w);
+        w.chain = ch->wdev;
+        const double one_w[3] = {1, 1, 1};
+        make_eval_params(one_w, one_w, ee_offset7, w.ep);
+        w.q = d_q; w.B = B; w.pose = d_pose; w.jac = d_jac;
+        HIP_TRY(wide_batch_launch(1, grid_for(ch, B, 256, 8), (hipStream_t)stream, w));
+        return 0;
+    }
     FkLaunch a;
     a.chain = ch->dev;
     const double one[3] = {1, 1, 1};
@@ -919,6 +986,15 @@ int optik_hip_seed_batch(const optik_hip_chain *ch, uint64_t first, int64_t coun
         if (std::isnan(ch->scale[k]))
             return fail(OPTIK_HIP_EINVAL, "random restarts need finite joint limits (reference: random_range panics)");
     BIND_DEVICE(ch);
+    if (ch->wide) {
+        WideBatchLaunch w;
+        std::memset(&w, 0, sizeof w);
+        w.chain = ch->wdev;
+        std::memcpy(w.key, ch->key, sizeof w.key);
+        w.first = first; w.B = count; w.q_out = d_q;
+        HIP_TRY(wide_batch_launch(2, grid_for(ch, count, 256, 8), (hipStream_t)stream, w));
+        return 0;
+    }
     SeedLaunch a;
     std::memcpy(a.key, ch->key, sizeof a.key);
     std::memcpy(a.lb, ch->host.lb, sizeof a.lb);
@@ -1025,11 +1101,11 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
 
     SolveLaunch a;
     std::memset(&a, 0, sizeof a);
-    a.chain = ch->dev;
+    a.chain = ch->dev;  // (null for a wide chain: its launch takes ch->wdev)
     make_eval_params(cfg->linear_weight, cfg->angular_weight, ee_offset7, a.ep);
     fill_solve_params(cfg, a.sp);
     std::memcpy(a.key, ch->key, sizeof a.key);
-    std::memcpy(a.scale, ch->scale, sizeof a.scale);
+    std::memcpy(a.scale, ch->scale, sizeof a.scale);  // (n <= 8; a wide chain's scales are in its table)
     a.wq.next_item = ch->queue;
     a.wq.total_items = (unsigned long long)cols;
     a.wq.n_restarts = R;
@@ -1064,12 +1140,12 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     // quad, NNLS matrix in LDS; the default, n <= 8), round 2's cooperative one (OPTIK_SOLVE_KERNEL=coop:
     // the state in the quad's leader, ik_coop.hpp; n <= 7) or round 1's one-restart-per-lane kernel with
     // its per-lane LDS NNLS (OPTIK_SOLVE_KERNEL=lane).  Same results, bit for bit.
-    bool coop = ch->n <= 7, quadk = true;
+    bool coop = ch->n <= 7, quadk = !ch->wide;
     if (const char *e = std::getenv("OPTIK_SOLVE_KERNEL")) {
         coop = coop && std::strcmp(e, "lane") != 0;
-        quadk = std::strcmp(e, "lane") != 0 && std::strcmp(e, "coop") != 0;
+        quadk = quadk && std::strcmp(e, "lane") != 0 && std::strcmp(e, "coop") != 0;
     }
-    coop = coop && !quadk;
+    coop = coop && !quadk && !ch->wide;
     // Persistent waves, each pulling work items until the queue is dry: as many as a CU holds
     // (lane kernel: 2 workgroups, LDS-bound; cooperative kernel: 4, one per SIMD), times the CU count.
     const int cus = ch->num_cus > 0 ? ch->num_cus : 256;
@@ -1077,7 +1153,7 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     // one-wave-per-SIMD build -- no scratch, the lowest latency per iteration; anything bigger on the
     // two-waves-per-SIMD build)
     const bool quad_latency = quadk && (long long)cols <= (long long)cus * 4;
-    long long cap = (long long)cus * (quadk ? (quad_latency ? 4 : quad_solve_waves_per_cu(ch->n)) : (coop ? 4 : ch->waves_per_cu));
+    long long cap = (long long)cus * (quadk ? (quad_latency ? 4 : quad_solve_waves_per_cu(ch->n)) : (coop ? 4 : (ch->wide ? 4 : ch->waves_per_cu)));
     // (experiments: fewer resident waves per CU than the kernel could have, e.g. to share the chip with another stream's kernels)
     if (const char *e = std::getenv("OPTIK_SOLVE_WAVES_PER_CU")) {
         const long long v = std::atoll(e);
@@ -1119,7 +1195,25 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         HIP_TRY(hipEventRecord(ch->ev0[ev_slot], stream));
     }
     int lds = 0;
-    if (quadk) {
+    if (ch->wide) {
+        // 9 .. 16 joint positions: one restart per lane on the general kernel, two waves per CU, every
+        // resident wave with its own block of the restart workspace (ik_wide.hpp)
+        if ((size_t)grid > ch->wide_ws_waves) {
+            if (ch->wide_ws) HIP_TRY(hipFree(ch->wide_ws));
+            ch->wide_ws = nullptr; ch->wide_ws_waves = 0;
+            HIP_TRY(hipMalloc(&ch->wide_ws, sizeof(double) * wide_ws_doubles_per_wave() * (size_t)grid));
+            ch->wide_ws_waves = (size_t)grid;
+        }
+        WideSolveLaunch w;
+        std::memset(&w, 0, sizeof w);
+        w.chain = ch->wdev;
+        w.ep = a.ep; w.sp = a.sp; w.wq = a.wq;
+        std::memcpy(w.key, ch->key, sizeof w.key);
+        w.deadline_ticks = a.deadline_ticks;
+        w.ws = ch->wide_ws;
+        lds = (int)sizeof(WideChainDev);
+        HIP_TRY(wide_solve_launch(grid, stream, w));
+    } else if (quadk) {
         HIP_TRY(quad_solve_launch(ch->n, ch->tip, grid, stream, a, &lds, quad_latency));
     } else if (coop) {
 #define CALL_COOP(NN, TT)                                                                            \

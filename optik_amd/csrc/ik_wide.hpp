@@ -1,0 +1,755 @@
+// ik_wide.hpp -- chains with 9 .. 16 joint positions: one restart per lane, joint count at run time.
+//
+// The reference accepts any chain length (KinematicChain::num_positions,
+// /root/reference/crates/optik/src/kinematics.rs:107-110); the tuned solvers of this library stop at
+// n = 8 (a quad lane owns two joints, the NNLS permutation is sixteen nibbles, one ChaCha block per
+// restart).  This header is the general form for the chains beyond that: the closure of
+// lib.rs:301-391 and the SLSQP it calls (NLopt's: Kraft's SLSQPB / LSQ / LSI / LDP, Lawson-Hanson
+// NNLS / H12, the Fletcher-Powell LDL' update, NLopt's stopping rules) written as plain loops over a
+// run-time n, every array of a restart in a lane-strided HBM workspace ([slot][64 lanes]: the 64
+// lanes of a wave touch one 512-byte line per slot).  No register tiling, no LDS matrices: it is the
+// path that makes such robots *work* (~1.9 K doubles of state per restart), not a tuned one.
+//
+// Results are bit-identical to the CPU oracle's ok_solve_restart() (tests/test_gpu_wide.py): the
+// loops below perform the arithmetic of the textbook routines in the textbook order, and the
+// objective is ik_eval.hpp's operation sequence with the joint loop rolled.
+#pragma once
+
+#include "ik_wide_launch.hpp"
+
+namespace optik {
+
+// Lane-strided view of the workspace: element k of an array lives 64 doubles after element k - 1.
+struct WP {
+    double *p;
+    __device__ __forceinline__ double &operator[](int k) const { return p[(size_t)k * 64]; }
+    __device__ __forceinline__ WP operator+(int k) const { return WP{p + (size_t)k * 64}; }
+};
+
+// workspace slots of one restart (doubles per lane)
+namespace wide_ws {
+constexpr int N = WIDE_MAX_DOF;
+constexpr int X = 0, X0 = X + N, G = X0 + N, S = G + N, U = S + N, V = U + N, XBEST = V + N, XPREV = XBEST + N;
+constexpr int L = XPREV + N;                        // packed LDL' (n (n + 1) / 2, + 1)
+constexpr int E = L + N * (N + 1) / 2 + 1 + 7;      // LSQ: E (n x n)
+constexpr int F = E + N * N;                        //      f (n)
+constexpr int GG = F + N;                           //      G (2n x n)
+constexpr int H = GG + 2 * N * N;                   //      h (2n)
+constexpr int W = H + 2 * N;                        // LDP / NNLS workspace: (n + 1)(2n + 2) + 4n
+constexpr int LW = W + (N + 1) * (2 * N + 2) + 4 * N + 8;  // LDL' update: w (n)
+constexpr int TF = LW + N;                          // joint frames of the evaluation (7 per joint)
+constexpr int GN = TF + 7 * N;                      // gradient of an evaluation that is not wanted
+constexpr int SLOTS = GN + N;
+}  // namespace wide_ws
+
+// ---- objective and gradient (ik_eval.hpp's sequence, joint loop rolled) -------------------------
+
+// Forward pass: joint frames into tf (7 doubles per joint), returns the end-effector pose
+// (kinematics.rs:123-164).
+template <class PQ, class PT>
+__device__ Pose wide_forward(const WideChainDev &ch, const EvalParams &ep, int n, PQ q, PT tf) {
+    Pose state;
+    state.t = V3{0.0, 0.0, 0.0};
+    state.q = Q4{0.0, 0.0, 0.0, 1.0};
+#pragma unroll 1
+    for (int j = 0; j < n; ++j) {
+        double s, c;
+        sincos_dev(q[j] / 2.0, s, c);  // UnitQuaternion::from_axis_angle
+        const Q4 local{ch.axis[j][0] * s, ch.axis[j][1] * s, ch.axis[j][2] * s, c};
+        Pose jt;  // joint.origin * local_transform(q): the translation part is exact
+        jt.t = V3{ch.origin[j][0], ch.origin[j][1], ch.origin[j][2]};
+        jt.q = qmul(Q4{ch.origin[j][3], ch.origin[j][4], ch.origin[j][5], ch.origin[j][6]}, local);
+        state = (j == 0) ? jt : pose_mul(state, jt);  // identity * jt is exact
+        tf[7 * j + 0] = state.t.x; tf[7 * j + 1] = state.t.y; tf[7 * j + 2] = state.t.z;
+        tf[7 * j + 3] = state.q.i; tf[7 * j + 4] = state.q.j; tf[7 * j + 5] = state.q.k; tf[7 * j + 6] = state.q.w;
+    }
+    if (ch.has_tip) state = pose_mul(state, load_pose(ch.origin[n]));
+    return ep.has_ee_offset ? pose_mul(state, load_pose(ep.ee_offset)) : state;
+}
+
+// f at q; the gradient goes to g (objective.rs:40-110, kinematics.rs:166-196).
+template <class PQ, class PT, class PG>
+__device__ double wide_eval_fg(const WideChainDev &ch, const EvalParams &ep, const Pose target, int n, PQ q, PT tf,
+                               PG g) {
+    const Pose ee = wide_forward(ch, ep, n, q, tf);
+    // X = T_target^-1 T_ee  (objective.rs:69-70)
+    const Pose X = pose_inv_mul(target, ee);
+    const V3 w = so3_log(X.q);
+    const RotTerms rt = rot_terms(w);
+    const M3 Jr = so3_right_jacobian(rt);      // math.rs:195
+    const M3 Qm = se3_q_matrix(rt, X.t, Jr);   // math.rs:196
+    const V3 elin = se3_log_linear(rt, X.t);   // math.rs:120-122
+    V3 fl = elin, fa = w;
+    if (!ep.skip_lin) fl = weight_block(target.q, elin, ep.w_lin);
+    if (!ep.skip_ang) fa = weight_block(target.q, w, ep.w_ang);
+    V3 gl = fl, ga = fa;
+    if (!ep.grad_same_as_value) {
+        gl = elin; ga = w;
+        if (!ep.skip_lin2) gl = weight_block(target.q, elin, ep.w_lin2);
+        if (!ep.skip_ang2) ga = weight_block(target.q, w, ep.w_ang2);
+    }
+    const double e2[6] = {2.0 * gl.x, 2.0 * gl.y, 2.0 * gl.z, 2.0 * ga.x, 2.0 * ga.y, 2.0 * ga.z};
+    const double ef[6] = {fl.x, fl.y, fl.z, fa.x, fa.y, fa.z};
+    double f = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) f += ef[i] * ef[i];
+
+    const Q4 eeqc = qconj(ee.q);
+#pragma unroll 1
+    for (int k = 0; k < n; ++k) {
+        const V3 tk{tf[7 * k + 0], tf[7 * k + 1], tf[7 * k + 2]};
+        const Q4 tq{tf[7 * k + 3], tf[7 * k + 4], tf[7 * k + 5], tf[7 * k + 6]};
+        const V3 ax{ch.axis[k][0], ch.axis[k][1], ch.axis[k][2]};
+        const V3 angular = qrot(tq, ax);
+        const V3 d{ee.t.x - tk.x, ee.t.y - tk.y, ee.t.z - tk.z};
+        const V3 linear = cross(angular, d);
+        const V3 al = qrot(eeqc, angular);
+        const V3 ll = qrot(eeqc, linear);
+        const double lin[3] = {ll.x, ll.y, ll.z};
+        const double ang[3] = {al.x, al.y, al.z};
+        double jt[6];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            double acc = 0.0;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) acc += Jr.m[r][m] * lin[m];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) acc += Qm.m[r][m] * ang[m];
+            jt[r] = acc;
+            double acc2 = 0.0;  // lower-left block of Jlog6 is zero
+#pragma unroll
+            for (int m = 0; m < 3; ++m) acc2 += Jr.m[r][m] * ang[m];
+            jt[r + 3] = acc2;
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) acc += e2[r] * jt[r];
+        g[k] = acc;
+    }
+    return f;
+}
+
+// ---- RNG: one next_u64 per joint, as many ChaCha8 blocks as the chain needs (lib.rs:86-91, 358-370)
+
+template <class PQ>
+__device__ void wide_restart_seed(const uint32_t (&key)[8], const double *lb, const double *scale, uint64_t index,
+                                  int n, PQ q) {
+    uint32_t blk[16];
+#pragma unroll 1
+    for (int k0 = 0; k0 < n; k0 += 8) {
+        chacha8_block(key, (uint64_t)(k0 / 8), index, blk);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const int k = k0 + kk;
+            if (k < n) {
+                const uint64_t bits = (uint64_t)blk[2 * kk] | ((uint64_t)blk[2 * kk + 1] << 32);
+                q[k] = uniform_inclusive(lb[k], scale[k], bits);
+            }
+        }
+    }
+}
+
+// ---- SLSQP pieces over strided arrays --------------------------------------------------------------
+
+__device__ inline double w_dot(int n, WP x, int incx, WP y, int incy) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += x[i * incx] * y[i * incy];
+    return s;
+}
+
+// NLopt's dnrm2: scaled by the largest magnitude.
+__device__ inline double w_nrm2(int n, WP x, int incx) {
+    double xmax = 0.0;
+    for (int i = 0; i < n; ++i) { const double a = __builtin_fabs(x[i * incx]); if (a > xmax) xmax = a; }
+    if (xmax == 0.0) return 0.0;
+    const double scale = 1.0 / xmax;
+    double sum = 0.0;
+    for (int i = 0; i < n; ++i) { const double xs = scale * x[i * incx]; sum += xs * xs; }
+    return xmax * __builtin_sqrt(sum);
+}
+
+// Lawson-Hanson H12: construct (mode 1) / apply (mode 2) a Householder transformation.  u: pivot
+// vector with stride iue; the ncv vectors of c have element stride ice, vector stride icv.
+// lpivot, l1, m are 1-based.
+__device__ inline void w_h12(int mode, int lpivot, int l1, int m, WP u, int iue, double &up, WP c, int ice, int icv,
+                             int ncv) {
+    if (0 >= lpivot || lpivot >= l1 || l1 > m) return;
+    double cl = __builtin_fabs(u[(lpivot - 1) * iue]);
+    if (mode != 2) {
+        for (int j = l1; j <= m; ++j) { const double sm = __builtin_fabs(u[(j - 1) * iue]); if (sm > cl) cl = sm; }
+        if (cl <= 0.0) return;
+        const double clinv = 1.0 / cl;
+        double d = u[(lpivot - 1) * iue] * clinv;
+        double sm = d * d;
+        for (int j = l1; j <= m; ++j) { d = u[(j - 1) * iue] * clinv; sm += d * d; }
+        cl *= __builtin_sqrt(sm);
+        if (u[(lpivot - 1) * iue] > 0.0) cl = -cl;
+        up = u[(lpivot - 1) * iue] - cl;
+        u[(lpivot - 1) * iue] = cl;
+    } else if (cl <= 0.0) {
+        return;
+    }
+    if (ncv <= 0) return;
+    double b = up * u[(lpivot - 1) * iue];
+    if (b >= 0.0) return;
+    b = 1.0 / b;
+    int i2 = 1 - icv + ice * (lpivot - 1);
+    const int incr = ice * (l1 - lpivot);
+    for (int j = 1; j <= ncv; ++j) {
+        i2 += icv;
+        int i3 = i2 + incr, i4 = i3;
+        double sm = c[i2 - 1] * up;
+        for (int i = l1; i <= m; ++i) { sm += c[i3 - 1] * u[(i - 1) * iue]; i3 += ice; }
+        if (sm == 0.0) continue;
+        sm *= b;
+        c[i2 - 1] += sm * up;
+        for (int i = l1; i <= m; ++i) { c[i4 - 1] += sm * u[(i - 1) * iue]; i4 += ice; }
+    }
+}
+
+// Lawson-Hanson NNLS: min ||A x - b|| s.t. x >= 0.  A is m x n column-major (leading dimension mda).
+// Returns mode: 1 ok, 2 bad dimensions, 3 iteration count exceeded.
+__device__ inline int w_nnls(WP a, int mda, int m, int n, WP b, WP x, double &rnorm, WP w, WP z, int *indx) {
+#define WA(i, j) a[((j) - 1) * mda + ((i) - 1)]
+    const double factor = 0.01;
+    if (m <= 0 || n <= 0) return 2;
+    int mode = 1, iter = 0;
+    const int itmax = 3 * n;
+    for (int i = 1; i <= n; ++i) indx[i - 1] = i;
+    int iz1 = 1, nsetp = 0, npp1 = 1;
+    const int iz2 = n;
+    int izmax = 0, j, jj = 0;
+    double up = 0.0;
+    bool finished = false;
+    for (int i = 0; i < n; ++i) x[i] = 0.0;
+
+    while (!finished) {  // step two
+        if (iz1 > iz2 || nsetp >= m) break;
+        for (int iz = iz1; iz <= iz2; ++iz) {
+            j = indx[iz - 1];
+            w[j - 1] = w_dot(m - nsetp, a + ((j - 1) * mda + (npp1 - 1)), 1, b + (npp1 - 1), 1);
+        }
+        bool found = false;
+        for (;;) {  // step three
+            double wmax = 0.0;
+            for (int iz = iz1; iz <= iz2; ++iz) {
+                j = indx[iz - 1];
+                if (w[j - 1] <= wmax) continue;
+                wmax = w[j - 1];
+                izmax = iz;
+            }
+            if (wmax <= 0.0) break;  // step four: KKT satisfied
+            const int iz = izmax;
+            j = indx[iz - 1];
+            // step five
+            const double asave = WA(npp1, j);
+            w_h12(1, npp1, npp1 + 1, m, a + (j - 1) * mda, 1, up, z, 1, 1, 0);
+            const double unorm = w_nrm2(nsetp, a + (j - 1) * mda, 1);
+            const double t = factor * __builtin_fabs(WA(npp1, j));
+            const double d1 = unorm + t;
+            if (d1 - unorm > 0.0) {
+                for (int i = 0; i < m; ++i) z[i] = b[i];
+                w_h12(2, npp1, npp1 + 1, m, a + (j - 1) * mda, 1, up, z, 1, 1, 1);
+                if (z[npp1 - 1] / WA(npp1, j) > 0.0) found = true;
+            }
+            if (found) {
+                for (int i = 0; i < m; ++i) b[i] = z[i];
+                indx[iz - 1] = indx[iz1 - 1];
+                indx[iz1 - 1] = j;
+                ++iz1;
+                nsetp = npp1;
+                ++npp1;
+                for (int jz = iz1; jz <= iz2; ++jz) {
+                    jj = indx[jz - 1];
+                    w_h12(2, nsetp, npp1, m, a + (j - 1) * mda, 1, up, a + (jj - 1) * mda, 1, mda, 1);
+                }
+                w[j - 1] = 0.0;
+                for (int i = npp1; i <= m; ++i) WA(i, j) = 0.0;
+                break;
+            }
+            WA(npp1, j) = asave;
+            w[j - 1] = 0.0;
+        }
+        if (!found) break;  // wmax <= 0: done
+
+        // step six: solve the triangular system; then steps seven .. eleven
+        for (;;) {
+            for (int ip = nsetp; ip >= 1; --ip) {
+                if (ip != nsetp) {
+                    for (int i = 0; i < ip; ++i) z[i] -= z[ip] * WA(i + 1, jj);
+                }
+                jj = indx[ip - 1];
+                z[ip - 1] /= WA(ip, jj);
+            }
+            ++iter;
+            if (iter > itmax) { mode = 3; finished = true; break; }
+            double alpha = 1.0;
+            jj = 0;
+            for (int ip = 1; ip <= nsetp; ++ip) {
+                if (z[ip - 1] > 0.0) continue;
+                const int l = indx[ip - 1];
+                const double t = -x[l - 1] / (z[ip - 1] - x[l - 1]);
+                if (alpha < t) continue;
+                alpha = t;
+                jj = ip;
+            }
+            for (int ip = 1; ip <= nsetp; ++ip) {
+                const int l = indx[ip - 1];
+                x[l - 1] = (1.0 - alpha) * x[l - 1] + alpha * z[ip - 1];
+            }
+            if (jj == 0) break;  // back to step two
+            // step eleven: move coefficient i from set P to set Z
+            int i = indx[jj - 1];
+            bool failed = false;
+            for (;;) {
+                x[i - 1] = 0.0;
+                ++jj;
+                for (j = jj; j <= nsetp; ++j) {
+                    const int ii = indx[j - 1];
+                    indx[j - 2] = ii;
+                    double c, s;
+                    rotg(WA(j - 1, ii), WA(j, ii), c, s);
+                    const double t = WA(j - 1, ii);
+                    for (int col = 1; col <= n; ++col) {  // rot over the two rows, every column
+                        const double xi = WA(j - 1, col), yi = WA(j, col);
+                        WA(j - 1, col) = c * xi + s * yi;
+                        WA(j, col) = c * yi - s * xi;
+                    }
+                    WA(j - 1, ii) = t;
+                    WA(j, ii) = 0.0;
+                    {
+                        const double xi = b[j - 2], yi = b[j - 1];
+                        b[j - 2] = c * xi + s * yi;
+                        b[j - 1] = c * yi - s * xi;
+                    }
+                }
+                npp1 = nsetp;
+                --nsetp;
+                --iz1;
+                indx[iz1 - 1] = i;
+                if (nsetp <= 0) { mode = 3; failed = true; break; }
+                bool again = false;
+                for (jj = 1; jj <= nsetp; ++jj) {
+                    i = indx[jj - 1];
+                    if (x[i - 1] <= 0.0) { again = true; break; }
+                }
+                if (!again) break;
+            }
+            if (failed) { finished = true; break; }
+            for (int k = 0; k < m; ++k) z[k] = b[k];
+        }
+    }
+    {
+        const int k = (npp1 < m) ? npp1 : m;
+        rnorm = w_nrm2(m - nsetp, b + (k - 1), 1);
+        if (npp1 > m) for (int i = 0; i < n; ++i) w[i] = 0.0;
+    }
+    return mode;
+#undef WA
+}
+
+// Lawson-Hanson LDP: min ||x|| s.t. G x >= h.  G is m x n column-major (leading dimension mg).
+__device__ inline int w_ldp(WP g, int mg, int m, int n, WP h, WP x, double &xnorm, WP w, int *indx) {
+    if (n <= 0) return 2;
+    for (int i = 0; i < n; ++i) x[i] = 0.0;
+    xnorm = 0.0;
+    if (m == 0) return 1;
+    int iw = 0;
+    for (int j = 0; j < m; ++j) {
+        for (int i = 0; i < n; ++i) w[iw++] = g[i * mg + j];
+        w[iw++] = h[j];
+    }
+    const int if_ = iw;
+    for (int i = 0; i < n; ++i) w[iw++] = 0.0;
+    w[iw] = 1.0;
+    const int n1 = n + 1;
+    const int iz = iw + 1, iy = iz + n1, iwdual = iy + m;
+    double rnorm;
+    const int mode = w_nnls(w, n1, n1, m, w + if_, w + iy, rnorm, w + iwdual, w + iz, indx);
+    if (mode != 1) return mode;
+    if (rnorm <= 0.0) return 4;
+    double fac = 1.0 - w_dot(m, h, 1, w + iy, 1);
+    const double d1 = 1.0 + fac;
+    if (d1 - 1.0 <= 0.0) return 4;
+    fac = 1.0 / fac;
+    for (int j = 0; j < n; ++j) x[j] = fac * w_dot(m, g + j * mg, 1, w + iy, 1);
+    xnorm = w_nrm2(n, x, 1);
+    for (int i = 0; i < m; ++i) w[i] = 0.0;
+    for (int i = 0; i < m; ++i) w[i] += fac * w[iy + i];
+    return 1;
+}
+
+// Kraft LSI: min ||E x - f|| s.t. G x >= h.  E is me x n (ld le), G mg x n (ld lg).
+__device__ inline int w_lsi(WP e, WP f, WP g, WP h, int le, int me, int lg, int mg, int n, WP x, double &xnorm, WP w,
+                            int *jw) {
+#define WE(i, j) e[((j) - 1) * le + ((i) - 1)]
+#define WG(i, j) g[((j) - 1) * lg + ((i) - 1)]
+    double t = 0.0;
+    // QR factors of E and application to f
+    for (int i = 1; i <= n; ++i) {
+        const int j = (i + 1 < n) ? i + 1 : n;
+        w_h12(1, i, i + 1, me, e + (i - 1) * le, 1, t, e + (j - 1) * le, 1, le, n - i);
+        w_h12(2, i, i + 1, me, e + (i - 1) * le, 1, t, f, 1, 1, 1);
+    }
+    // transform G and h to get the least distance problem
+    for (int i = 1; i <= mg; ++i) {
+        for (int j = 1; j <= n; ++j) {
+            if (!(__builtin_fabs(WE(j, j)) >= EPMACH)) return 5;
+            WG(i, j) = (WG(i, j) - w_dot(j - 1, g + (i - 1), lg, e + (j - 1) * le, 1)) / WE(j, j);
+        }
+        h[i - 1] -= w_dot(n, g + (i - 1), lg, f, 1);
+    }
+    const int mode = w_ldp(g, lg, mg, n, h, x, xnorm, w, jw);
+    if (mode != 1) return mode;
+    // solution of the original problem
+    for (int i = 0; i < n; ++i) x[i] += f[i];
+    for (int i = n; i >= 1; --i) {
+        const int j = (i + 1 < n) ? i + 1 : n;
+        x[i - 1] = (x[i - 1] - w_dot(n - i, e + ((j - 1) * le + (i - 1)), le, x + (j - 1), 1)) / WE(i, i);
+    }
+    const int j = (n + 1 < me) ? n + 1 : me;
+    t = w_nrm2(me - n, f + (j - 1), 1);
+    xnorm = __builtin_sqrt(xnorm * xnorm + t * t);
+    return 1;
+#undef WE
+#undef WG
+}
+
+// Kraft LSQ for m = meq = 0 with finite bounds: min ||E s - f||, E = D^1/2 L', f = -D^-1/2 L^-1 g,
+// xl <= s <= xu, via LSEI (mc = 0) -> LSI -> LDP -> NNLS.  l: packed LDL'.  Returns the LSQ mode.
+__device__ inline int w_lsq_box(int n, WP ws, WP l, WP g, WP xl, WP xu, WP s) {
+    WP E = ws + wide_ws::E, f = ws + wide_ws::F, G = ws + wide_ws::GG, h = ws + wide_ws::H, w = ws + wide_ws::W;
+    int jw[2 * WIDE_MAX_DOF];
+    const int m1 = 2 * n;
+    for (int i = 0; i < n * n; ++i) E[i] = 0.0;
+    // recover matrix E and vector f from L and g
+    int i2 = 0;
+    for (int i = 0; i < n; ++i) {
+        const int i1 = n - i;
+        const double diag = __builtin_sqrt(l[i2]);
+        for (int k = 0; k < i1; ++k) E[(i + k) * n + i] = l[i2 + k] * diag;  // row i of E
+        E[i * n + i] = diag;
+        f[i] = (g[i] - w_dot(i, E + i * n, 1, f, 1)) / diag;
+        i2 += i1;
+    }
+    for (int i = 0; i < n; ++i) f[i] = -f[i];
+    // G = [+I; -I], h = [xl; -xu]
+    for (int i = 0; i < m1 * n; ++i) G[i] = 0.0;
+    for (int i = 0; i < n; ++i) {
+        G[i * m1 + i] = 1.0;
+        G[i * m1 + n + i] = -1.0;
+        h[i] = xl[i];
+        h[n + i] = -xu[i];
+    }
+    double xnorm;
+    const int mode = w_lsi(E, f, G, h, n, n, m1, m1, n, s, xnorm, w, jw);
+    if (mode == 1) {
+        // NLopt (SGJ 2010): enforce the bounds against roundoff
+        for (int i = 0; i < n; ++i) {
+            if (s[i] < xl[i]) s[i] = xl[i];
+            else if (s[i] > xu[i]) s[i] = xu[i];
+        }
+    }
+    return mode;
+}
+
+// Fletcher-Powell composite-t rank-one update LDL' := LDL' + sigma z z' (z is destroyed).
+__device__ inline void w_ldl_update(int n, WP a, WP z, double sigma, WP w) {
+    if (sigma == 0.0) return;
+    int ij = 0;
+    double t = 1.0 / sigma;
+    if (sigma < 0.0) {
+        for (int i = 0; i < n; ++i) w[i] = z[i];
+        for (int i = 0; i < n; ++i) {
+            const double v = w[i];
+            t += v * v / a[ij];
+            for (int j = i + 1; j < n; ++j) { ++ij; w[j] -= v * a[ij]; }
+            ++ij;
+        }
+        if (t >= 0.0) t = EPMACH / sigma;
+        for (int i = 0; i < n; ++i) {
+            const int j = n - 1 - i;
+            ij -= i + 1;
+            const double u = w[j];
+            w[j] = t;
+            t -= u * u / a[ij];
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        const double v = z[i];
+        const double delta = v / a[ij];
+        const double tp = (sigma < 0.0) ? w[i] : t + delta * v;
+        const double alpha = tp / t;
+        a[ij] = alpha * a[ij];
+        if (i == n - 1) return;
+        const double beta = delta / tp;
+        if (alpha > 4.0) {
+            const double gamma = t / tp;
+            for (int j = i + 1; j < n; ++j) {
+                ++ij;
+                const double u = a[ij];
+                a[ij] = gamma * u + beta * z[j];
+                z[j] -= v * u;
+            }
+        } else {
+            for (int j = i + 1; j < n; ++j) {
+                ++ij;
+                z[j] -= v * a[ij];
+                a[ij] += beta * z[j];
+            }
+        }
+        ++ij;
+        t = tp;
+    }
+}
+
+// Scalars of Kraft's SLSQPB body (m = 0) that survive between its reverse-communication calls.
+struct WideSlsqp {
+    double f, f0, t0, h3, alpha;
+    int ireset, line;
+};
+enum : int { WQ_INIT = 0, WQ_FEVAL = 1, WQ_FGEVAL = -2, WQ_GRAD = -1 };
+
+// One call of SLSQPB.  In: mode 0 (first call; f, g at x set), 1 / -2 (function [and gradient]
+// evaluated at x), -1 (gradient evaluated).  Out: 1 / -2 (evaluate at x), -1 (line search done,
+// gradient wanted) or a terminal mode (3 .. 9).  acc = 0 (NLopt does the convergence tests).
+__device__ inline int w_slsqpb(int n, WideSlsqp &st, WP ws, const double *xl, const double *xu, int mode) {
+    const double alfmin = 0.1;
+    const int n1 = n + 1, n2 = n1 * n / 2;
+    WP x = ws + wide_ws::X, x0 = ws + wide_ws::X0, g = ws + wide_ws::G, s = ws + wide_ws::S, u = ws + wide_ws::U,
+       v = ws + wide_ws::V, l = ws + wide_ws::L, lw = ws + wide_ws::LW;
+    bool reset = false;
+    if (mode == WQ_GRAD) {
+        // label 260: BFGS update of the LDL' factors
+        for (int i = 0; i < n; ++i) u[i] = g[i] - v[i];
+        {  // v = L D L' s
+            int k = -1;
+            for (int i = 0; i < n; ++i) {
+                double h = 0.0;
+                ++k;
+                for (int j = i + 1; j < n; ++j) { ++k; h += l[k] * s[j]; }
+                v[i] = s[i] + h;
+            }
+            k = 0;
+            for (int i = 0; i < n; ++i) { v[i] = l[k] * v[i]; k += n1 - (i + 1); }
+            for (int i = n - 1; i >= 0; --i) {
+                double h = 0.0;
+                k = i;
+                for (int j = 0; j < i; ++j) { h += l[k] * v[j]; k += n - (j + 1); }
+                v[i] += h;
+            }
+        }
+        double h1 = w_dot(n, s, 1, u, 1);
+        const double h2 = w_dot(n, s, 1, v, 1);
+        const double h3 = h2 * 0.2;
+        if (h1 < h3) {
+            const double h4 = (h2 - h3) / (h2 - h1);
+            h1 = h3;
+            for (int i = 0; i < n; ++i) u[i] *= h4;
+            for (int i = 0; i < n; ++i) u[i] += (1.0 - h4) * v[i];
+        }
+        w_ldl_update(n, l, u, 1.0 / h1, lw);
+        w_ldl_update(n, l, v, -1.0 / h2, lw);
+    } else if (mode == WQ_INIT) {
+        // label 100
+        st.ireset = 0;
+        for (int i = 0; i < n; ++i) s[i] = 0.0;
+        reset = true;
+    } else {
+        // label 220: function evaluated, L1 merit (m = 0: t = f)
+        const double h1 = st.f - st.t0;
+        if (__builtin_isfinite(h1)) {
+            if (h1 <= st.h3 / 10.0 || st.line > 10) { st.h3 = 0.0; return WQ_GRAD; }  // label 240
+            const double a = st.h3 / ((st.h3 - h1) * 2.0);
+            st.alpha = (a > alfmin) ? a : alfmin;
+        } else {
+            const double a = st.alpha * 0.5;
+            st.alpha = (a > alfmin) ? a : alfmin;
+        }
+        goto trial;
+    }
+    for (;;) {
+        if (reset) {  // label 110: reset the BFGS matrix
+            ++st.ireset;
+            if (st.ireset > 5) return 8;  // label 255 with acc = 0
+            for (int i = 0; i < n2; ++i) l[i] = 0.0;
+            int j = 0;
+            for (int i = 0; i < n; ++i) { l[j] = 1.0; j += n1 - (i + 1); }
+        }
+        // label 130: search direction
+        for (int i = 0; i < n; ++i) { u[i] = xl[i] - x[i]; v[i] = xu[i] - x[i]; }
+        const int lmode = w_lsq_box(n, ws, l, g, u, v, s);
+        if (lmode != 1) return lmode;
+        for (int i = 0; i < n; ++i) v[i] = g[i];
+        st.f0 = st.f;
+        for (int i = 0; i < n; ++i) x0[i] = x[i];
+        const double gs = w_dot(n, g, 1, s, 1);
+        st.t0 = st.f;
+        st.h3 = gs;  // gs - h1 * h4 with h1 = 0 (acc = 0, no constraints)
+        if (st.h3 >= 0.0) { reset = true; continue; }
+        st.line = 0;
+        st.alpha = 1.0;
+        break;
+    }
+trial:
+    // label 190: next trial point
+    ++st.line;
+    st.h3 = st.alpha * st.h3;
+    for (int i = 0; i < n; ++i) s[i] *= st.alpha;
+    for (int i = 0; i < n; ++i) x[i] = x0[i];
+    for (int i = 0; i < n; ++i) x[i] += s[i];
+    for (int i = 0; i < n; ++i) {  // NLopt (SGJ 2010): roundoff must not push x past the bounds
+        if (x[i] < xl[i]) x[i] = xl[i];
+        else if (x[i] > xu[i]) x[i] = xu[i];
+    }
+    return (st.line == 1) ? WQ_FGEVAL : WQ_FEVAL;  // NLopt: the first trial comes with its gradient
+}
+
+// nlopt_stop_x with xtol_rel = 0 and xtol_abs[i] = tol_dx (see stop_x in ik_solve.hpp).
+__device__ inline bool w_stop_x(const SolveParams &sp, int n, WP x, WP oldx) {
+    if (sp.stop_x_zero) {
+        bool zero = true;
+        for (int i = 0; i < n; ++i) zero = zero && (x[i] == oldx[i]);
+        if (zero) return true;
+    }
+    for (int i = 0; i < n; ++i)
+        if (__builtin_fabs(x[i] - oldx[i]) >= sp.xtol_abs) return false;
+    return true;
+}
+__device__ inline bool w_relstop(double vold, double vnew, double abstol) {
+    if (__builtin_isinf(vold)) return false;
+    return __builtin_fabs(vnew - vold) < abstol;  // (reltol = 0: the other two terms cannot fire)
+}
+
+// One 64-lane wave solving restarts until the queue is empty: the driver of nlopt_slsqp() and the
+// closure of lib.rs:301-391, one trip = (one evaluation, its bookkeeping, one SLSQPB call) per lane.
+__device__ inline void wide_solve_wave(const WideChainDev &ch, const EvalParams &ep, const SolveParams &sp,
+                                       const uint32_t (&key)[8], const WorkQueue &wq, double *ws_wave) {
+    const int n = ch.n_pos;
+    const int lane = (int)(threadIdx.x & 63u);
+    const WP ws{ws_wave + lane};
+    const WP x = ws + wide_ws::X, g = ws + wide_ws::G, xbest = ws + wide_ws::XBEST, xprev = ws + wide_ws::XPREV,
+             x0 = ws + wide_ws::X0, tf = ws + wide_ws::TF, gn = ws + wide_ws::GN;
+    WideSlsqp st{};
+    double minf = __builtin_huge_val(), fprev = __builtin_huge_val();
+    int mode = 0, nevals = 0;
+    bool do_eval = true, want_grad = true;
+    Pose target;
+    target.t = V3{0, 0, 0};
+    target.q = Q4{0, 0, 0, 1};
+    unsigned long long item = 0, index = 0;
+    unsigned tslot = 0;
+    bool active = false, want = lane < wq.lanes;
+
+    for (;;) {
+        // ---- refill: lanes without a restart pull the next work item ----------------------------
+        if (wave_any(want)) {
+            const unsigned long long it = fetch_items(wq.next_item, want);
+            if (want) {
+                want = false;
+                if (it < wq.total_items) {
+                    unsigned long long r;
+                    if (wq.restart_major) { r = it / wq.n_targets; tslot = (unsigned)(it - r * wq.n_targets); }
+                    else { tslot = (unsigned)(it / wq.n_restarts); r = it - (unsigned long long)tslot * wq.n_restarts; }
+                    item = (unsigned long long)tslot * wq.n_restarts + r;  // output column
+                    index = wq.restart_begin + r;
+                    target = load_pose(wq.targets + (size_t)tslot * 7);
+                    // lib.rs:366-370: restart 0 starts from the caller's seed
+                    if (index == 0) {
+                        const double *x0p = wq.x0 + (size_t)tslot * n;
+                        for (int i = 0; i < n; ++i) x[i] = x0p[i];
+                    } else {
+                        wide_restart_seed(key, ch.lb, ch.scale, index, n, x);
+                    }
+                    for (int i = 0; i < n; ++i) { xbest[i] = x[i]; xprev[i] = x[i]; }
+                    st = WideSlsqp{};
+                    minf = __builtin_huge_val(); fprev = __builtin_huge_val();
+                    mode = 0; nevals = 0;
+                    do_eval = true; want_grad = true;  // NLopt: "eval once before calling slsqp the first time"
+                    active = true;
+                }
+            }
+        }
+        if (!wave_any(active)) break;
+
+        int32_t ret = 0;
+        if (active) {
+            // lib.rs:308: abandon when timed out or a lower-index restart succeeded
+            bool stop = false;
+            if (wq.first_success) {
+                const unsigned long long fs = __hip_atomic_load(wq.first_success + tslot, __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_AGENT);
+                stop = wq.find_any ? (fs != ~0ull) : (fs < index);
+            }
+            if (wq.deadline && (unsigned long long)wall_clock64() > wq.deadline) stop = true;
+            if (stop) ret = RES_FORCED_STOP;
+        }
+        if (active && ret == 0) {
+            if (do_eval) {
+                st.f = want_grad ? wide_eval_fg(ch, ep, target, n, x, tf, g) : wide_eval_fg(ch, ep, target, n, x, tf, gn);
+                ++nevals;
+            }
+            const int prev_mode = mode;
+            if (st.f < minf) {  // NLopt: best point so far
+                minf = st.f;
+                for (int i = 0; i < n; ++i) xbest[i] = x[i];
+            }
+            if (mode == WQ_GRAD) {  // a line search completed: only then are ftol / xtol tested
+                if (!__builtin_isinf(fprev)) {
+                    if (w_relstop(fprev, st.f, sp.ftol_abs)) ret = RES_FTOL_REACHED;
+                    else if (w_stop_x(sp, n, x, xprev)) ret = RES_XTOL_REACHED;
+                }
+                fprev = st.f;
+                for (int i = 0; i < n; ++i) xprev[i] = x[i];
+            }
+            if (minf < sp.stopval) ret = RES_STOPVAL_REACHED;
+            if (ret == 0 && nevals >= MAX_EVALS_CAP) ret = RES_ITER_CAP;
+            if (ret == 0) {
+                mode = w_slsqpb(n, st, ws, ch.lb, ch.ub, mode);
+                switch (mode) {
+                case WQ_GRAD:
+                    do_eval = (prev_mode != WQ_FGEVAL);  // NLopt: that point was just evaluated with its gradient
+                    want_grad = true;
+                    break;
+                case WQ_FGEVAL: do_eval = true; want_grad = true; break;
+                case WQ_FEVAL: do_eval = true; want_grad = false; break;
+                case 8:  // positive directional derivative: the relaxed test against (f0, x0)
+                    ret = RES_ROUNDOFF_LIMITED;
+                    if (w_relstop(st.f0, st.f, sp.ftol_abs)) ret = RES_FTOL_REACHED;
+                    else if (w_stop_x(sp, n, x, x0)) ret = RES_XTOL_REACHED;
+                    break;
+                case 5: case 6: case 7: ret = RES_ROUNDOFF_LIMITED; break;
+                default: ret = RES_FAILURE; break;  // 3, 4, 9
+                }
+            }
+        }
+        // ---- a restart ended: classify (lib.rs:376-379), publish, free the lane -------------------
+        if (ret != 0) {
+            const bool success = (sp.ok_stopval && ret == RES_STOPVAL_REACHED) || (sp.ok_ftol && ret == RES_FTOL_REACHED)
+                                 || (sp.ok_xtol && ret == RES_XTOL_REACHED);
+            if (wq.out_x)
+                for (int i = 0; i < n; ++i) wq.out_x[(size_t)i * wq.total_items + item] = xbest[i];
+            if (wq.out_f) wq.out_f[item] = minf;
+            if (wq.out_status) wq.out_status[item] = ret;
+            if (wq.out_evals) wq.out_evals[item] = nevals;
+            // selection key (lib.rs:402-407): Quality = ||x - x0||_2, Speed = index
+            double k = __builtin_huge_val();
+            if (success) {
+                if (wq.quality) {
+                    const double *x0p = wq.x0 + (size_t)tslot * n;
+                    double acc = 0.0;
+                    for (int i = 0; i < n; ++i) { const double d = xbest[i] - x0p[i]; acc += d * d; }
+                    k = __builtin_sqrt(acc);
+                } else {
+                    k = (double)index;
+                    if (wq.first_success) atomicMin(wq.first_success + tslot, index);
+                }
+            }
+            if (wq.out_key) wq.out_key[item] = k;
+            active = false;
+            want = true;
+        }
+    }
+}
+
+}  // namespace optik

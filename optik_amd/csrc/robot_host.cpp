@@ -118,7 +118,7 @@ optik_robot *make_robot(const std::string &urdf, const char *base, const char *e
         const int n = r->n;
         delete r;
         throw std::runtime_error("chain has " + std::to_string(n) + " joint positions; the gfx950 kernels are built for "
-                                 "at most 8 (a limit of this implementation, not of the reference)");
+                                 "at most " + std::to_string(OPTIK_HIP_MAX_DOF) + " (a limit of this implementation, not of the reference)");
     }
     for (const auto &j : r->chain.joints) {
         for (int k = 0; k < 3; ++k) r->origins.push_back(j.origin.t[k]);
@@ -809,6 +809,9 @@ int optik_robot_diff_ik_ex(const optik_robot *r, const double *x0, const double 
                            const double *ee16, double *alpha_out, double *v_out) {
     if (!r || !x0 || !V_WE || !v_max) return set_err(-1, "null argument");
     const int n = r->n, nz = n + 1;
+    if (n > 8)
+        return set_err(-1, "diff_ik: chains of more than 8 joint positions are not supported (the reference's own "
+                           "diff_ik only runs for n = 6: lib.rs:196-197 builds a 6-row block for n columns)");
     double p7[7];
     std::vector<double> jac(6 * (size_t)n);
     if (fk_on_device(r, x0, ee16, p7, jac.data())) return -1;

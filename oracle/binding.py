@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboptik_oracle.so")
 
-MAX_JOINTS = 16
+MAX_JOINTS = 17
 MAX_DOF = 16
 
 RES_STOPVAL, RES_FTOL, RES_XTOL = 2, 3, 4

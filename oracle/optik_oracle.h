@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define OK_MAX_JOINTS 16 /* chain joints incl. trailing fixed */
+#define OK_MAX_JOINTS 17 /* chain joints incl. trailing fixed */
 #define OK_MAX_DOF 16
 
 /* Pose = translation + unit quaternion stored [i, j, k, w]  (SURVEY app. A). */

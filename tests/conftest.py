@@ -43,6 +43,12 @@ ROBOT_SPECS = {
     # the ends of the supported range: 1 joint, and 8 joints + trailing fixed joint
     "panda1": (os.path.join(ROBOTS, "panda.urdf"), "panda_link0", "panda_link1"),
     "arm8": (os.path.join(TEST_ROBOTS, "arm8.urdf"), "l0", "l9"),
+    # beyond the tuned solvers' range: 9 .. 16 joints on the general kernels (ik_wide.hpp); the reference
+    # has no limit (kinematics.rs:107-110).  Written by tools/gen_wide_robots.py
+    "arm9": (os.path.join(TEST_ROBOTS, "arm9.urdf"), "l0", "l9"),
+    "arm10": (os.path.join(TEST_ROBOTS, "arm10.urdf"), "l0", "l11"),
+    "arm12": (os.path.join(TEST_ROBOTS, "arm12.urdf"), "l0", "l12"),
+    "arm16": (os.path.join(TEST_ROBOTS, "arm16.urdf"), "l0", "l17"),
     # prismatic joints: forward kinematics only (kinematics.rs:185, 243-255)
     "gantry": (os.path.join(TEST_ROBOTS, "gantry.urdf"), "g0", "g5"),
 }

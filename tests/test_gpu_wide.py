@@ -1,0 +1,223 @@
+"""-m gpu: chains with 9 .. 16 joint positions (optik_amd/csrc/ik_wide.hpp -- the general kernels, joint
+count at run time) against the CPU oracle, bit for bit, through the C ABI.  The reference accepts any
+chain length (/root/reference/crates/optik/src/kinematics.rs:107-110); the tuned solvers stop at 8."""
+import os
+
+import numpy as np
+import pytest
+
+from gpu_util import assert_bit_equal, make_targets
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+WIDE = ["arm9", "arm10", "arm12", "arm16"]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from optik_amd import device
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return device
+
+
+@pytest.fixture(scope="module")
+def hip_chains(dev, chains):
+    return {name: dev.HipChain(**chains[name][0]) for name in WIDE}
+
+
+def _oracle_all(oracle, ch, cfg_kw, tgt, x0, begin, end):
+    return oracle.ik(ch, oracle.make_config(**cfg_kw), tgt, x0, begin, end, n_threads=4, early_exit=False,
+                     per_restart=True)
+
+
+@pytest.mark.parametrize("robot", WIDE)
+def test_restart_seeds_bit_exact(dev, oracle, chains, hip_chains, robot):
+    """More than eight joints draw from the second ChaCha8 block of the restart's stream
+    (lib.rs:86-91, 358-370: one next_u64 per joint)."""
+    _, ch = chains[robot]
+    for first, count in ((1, 2000), (4194304 - 5, 8), (2**32 - 3, 8), (2**40 + 7, 8)):
+        got = hip_chains[robot].seed_batch(first, count).cpu().numpy()
+        want = np.array([oracle.restart_seed(ch, i) for i in range(first, first + count)]).T
+        assert_bit_equal(got, want, f"restart seeds from {first}")
+
+
+@pytest.mark.parametrize("robot", WIDE)
+@pytest.mark.parametrize("weights", ["default", "reference_test", "identity_quirk"])
+def test_objective_and_gradient_bit_exact(dev, oracle, chains, hip_chains, robot, weights):
+    from optik_amd import _native as nat
+    d, ch = chains[robot]
+    n = len(d["lb"])
+    wl, wa = {"default": ((1, 1, 1), (1, 1, 1)),
+              "reference_test": ((0.0, 5.0, 0.25), (0.005, 1.0, 0.99)),  # tests/test_gradient.rs:37-38
+              "identity_quirk": ((1, 0, 0), (1, 1, 1))}[weights]
+    rng = np.random.default_rng(7)
+    B = 1500
+    q = rng.uniform(d["lb"], d["ub"], size=(B, n))
+    quat = rng.normal(size=4)
+    quat /= np.linalg.norm(quat)
+    tgt = np.concatenate([rng.uniform(-0.5, 0.5, 3), quat])
+    ee_off = None
+    if weights == "reference_test":
+        eq = rng.normal(size=4)
+        eq /= np.linalg.norm(eq)
+        ee_off = np.concatenate([rng.uniform(-0.1, 0.1, 3), eq])
+    cfg = nat.make_config(linear_weight=wl, angular_weight=wa)
+    f, g = hip_chains[robot].eval_batch(torch.tensor(q.T.copy(), device="cuda"), tgt, cfg, ee_off)
+    f, g = f.cpu().numpy(), g.cpu().numpy()
+    ee_pose = oracle.Pose.make(ee_off[:3], ee_off[3:]) if ee_off is not None else None
+    fr, gr = np.empty(B), np.empty((n, B))
+    for i in range(B):
+        fr[i], gr[:, i] = oracle.eval_fg(ch, tgt, q[i], wl, wa, ee_offset=ee_pose)
+    assert_bit_equal(f, fr, "objective")
+    assert_bit_equal(g, gr, "gradient")
+
+
+@pytest.mark.parametrize("robot", ["arm10", "arm16"])
+def test_fk_and_jacobian_bit_exact(dev, oracle, chains, hip_chains, robot):
+    d, ch = chains[robot]
+    n = len(d["lb"])
+    rng = np.random.default_rng(3)
+    B = 500
+    q = rng.uniform(d["lb"], d["ub"], size=(B, n))
+    pose, jac = hip_chains[robot].fk_batch(torch.tensor(q.T.copy(), device="cuda"), jacobian=True)
+    pose, jac = pose.cpu().numpy(), jac.cpu().numpy()
+    pr, jr = np.empty((7, B)), np.empty((6 * n, B))
+    for i in range(B):
+        _, ee = oracle.fk(ch, q[i])
+        pr[:, i] = ee
+        jr[:, i] = oracle.joint_jacobian(ch, q[i]).T.ravel()  # column-major 6 x n
+    assert_bit_equal(pose, pr, "fk pose")
+    assert_bit_equal(jac, jr, "jacobian")
+
+
+@pytest.mark.parametrize("robot,tol_f", [("arm9", 1e-6), ("arm10", 1e-8), ("arm12", 1e-10), ("arm16", 1e-8)])
+@pytest.mark.parametrize("mode", ["speed", "quality"])
+def test_every_restart_bit_exact(dev, oracle, chains, hip_chains, robot, tol_f, mode):
+    """Two targets, restarts 0..R-1 each: status, evaluation count, returned x and f of EVERY restart
+    equal the oracle's, and so does the selected winner (Speed: lowest index; Quality: nearest the seed)."""
+    from optik_amd import _native as nat
+    d, ch = chains[robot]
+    rng = np.random.default_rng(11)
+    T, R = 2, 700
+    tg, x0 = make_targets(oracle, d, ch, rng, T)
+    kw = dict(solution_mode=mode, tol_f=tol_f)
+    out = hip_chains[robot].ik_batch(nat.make_config(**kw), torch.tensor(tg, device="cuda"),
+                                     torch.tensor(x0, device="cuda"), 0, R)
+    torch.cuda.synchronize()
+    st = out["status"].cpu().numpy().reshape(T, R)
+    ev = out["evals"].cpu().numpy().reshape(T, R)
+    fs = out["f"].cpu().numpy().reshape(T, R)
+    xs = out["x"].cpu().numpy()
+    seen = set()
+    for t in range(T):
+        ref = _oracle_all(oracle, ch, kw, tg[t], x0[t], 0, R)
+        assert np.array_equal(st[t], ref["status"]), np.argwhere(st[t] != ref["status"])[:10]
+        assert np.array_equal(ev[t], ref["evals"])
+        assert_bit_equal(fs[t], ref["fs"], f"per-restart f, target {t}")
+        assert_bit_equal(xs[:, t * R:(t + 1) * R], ref["xs"].T, f"per-restart x, target {t}")
+        assert int(out["win_idx"].cpu()[t]) == (ref["winner"] if ref["found"] else -1)
+        if ref["found"]:
+            assert_bit_equal(out["win_x"].cpu().numpy()[t], ref["x"], "winner x")
+        seen.update(np.unique(ref["status"]).tolist())
+    assert len(seen) >= 2  # more than one way of ending is exercised
+
+
+@pytest.mark.parametrize("tols", [dict(tol_df=1e-18, tol_dx=1e-9), dict(tol_df=-1.0, tol_dx=-1.0)])
+def test_tight_tolerances_and_other_endings(dev, oracle, chains, hip_chains, tols):
+    """tol_f = 0: no restart can end on stopval; they end on the ftol / xtol branches of NLopt's driver
+    (lib.rs:376-379) or, with both disabled, on NLopt's zero-step rule -- the far side of the SLSQP
+    driver from the usual exit, including line searches that run to their last trial."""
+    from optik_amd import _native as nat
+    d, ch = chains["arm10"]
+    rng = np.random.default_rng(5)
+    tg, x0 = make_targets(oracle, d, ch, rng, 1)
+    kw = dict(solution_mode="quality", tol_f=0.0, **tols)
+    R = 400
+    out = hip_chains["arm10"].ik_batch(nat.make_config(**kw), torch.tensor(tg, device="cuda"),
+                                       torch.tensor(x0, device="cuda"), 0, R)
+    torch.cuda.synchronize()
+    ref = _oracle_all(oracle, ch, kw, tg[0], x0[0], 0, R)
+    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    assert np.array_equal(out["evals"].cpu().numpy(), ref["evals"])
+    assert_bit_equal(out["f"].cpu().numpy(), ref["fs"], "per-restart f")
+    assert_bit_equal(out["x"].cpu().numpy(), ref["xs"].T, "per-restart x")
+    assert 2 not in ref["status"]
+
+
+def test_restart_ranges_compose_and_engine_entry_point(dev, oracle, chains, hip_chains):
+    """The multi-GPU partition (contiguous index ranges) on a wide chain, a ragged range, and the engine's
+    entry points (a wide chain's engine jobs run on the general kernel, like an 8-DoF chain's on the quad
+    solver): the same bits."""
+    from optik_amd import _native as nat
+    d, ch = chains["arm12"]
+    hc = hip_chains["arm12"]
+    rng = np.random.default_rng(9)
+    tg, x0 = make_targets(oracle, d, ch, rng, 1)
+    cfg = nat.make_config(solution_mode="quality", tol_f=1e-8)
+    tgd, x0d = torch.tensor(tg, device="cuda"), torch.tensor(x0, device="cuda")
+    full = hc.ik_batch(cfg, tgd, x0d, 0, 500)
+    a = hc.ik_batch(cfg, tgd, x0d, 0, 133)
+    b = hc.ik_batch(cfg, tgd, x0d, 133, 500)
+    eng = hc.engine_submit(cfg, tgd, x0d, 0, 500)
+    hc.engine_run()
+    torch.cuda.synchronize()
+    for k in ("f", "status", "evals"):
+        assert torch.equal(torch.cat([a[k], b[k]]), full[k])
+        assert torch.equal(eng[k], full[k])
+    assert torch.equal(torch.cat([a["x"], b["x"]], dim=1), full["x"])
+    assert torch.equal(eng["x"], full["x"])
+    assert int(eng["win_idx"][0]) == int(full["win_idx"][0])
+
+
+def test_early_exit_speed_winner(dev, oracle, chains, hip_chains):
+    """Speed with the reference's should_exit (lib.rs:269, 308, 382-384) in its deterministic reading: the
+    winner is the lowest successful index whatever was abandoned on the way."""
+    from optik_amd import _native as nat
+    d, ch = chains["arm10"]
+    rng = np.random.default_rng(13)
+    T, R = 6, 256
+    tg, x0 = make_targets(oracle, d, ch, rng, T)
+    kw = dict(solution_mode="speed", tol_f=1e-8)
+    out = hip_chains["arm10"].ik_batch(nat.make_config(**kw), torch.tensor(tg, device="cuda"),
+                                       torch.tensor(x0, device="cuda"), 0, R, flags=nat.IK_EARLY_EXIT)
+    torch.cuda.synchronize()
+    win = out["win_idx"].cpu().numpy()
+    wx = out["win_x"].cpu().numpy()
+    for t in range(T):
+        ref = _oracle_all(oracle, ch, kw, tg[t], x0[t], 0, R)
+        assert win[t] == (ref["winner"] if ref["found"] else -1)
+        if ref["found"]:
+            assert_bit_equal(wx[t], ref["x"], f"winner x target {t}")
+
+
+def test_robot_api_ten_joints(dev, oracle, chains):
+    """The reference's own ik property (tests/test_ik.rs:91-130: FK(ik(T)) == T within 1e-6) through the
+    host API on a 10-joint URDF; the winning restart is the oracle's and the joint angles agree to 1e-6
+    (the target enters through the host layer's 4x4 -> pose conversion, hence not bit for bit)."""
+    from conftest import ROBOT_SPECS
+    from optik_amd import Robot, SolverConfig
+    from test_gpu_robot_api import _mat_to_pose7
+    path, base, ee = ROBOT_SPECS["arm10"]
+    robot = Robot.from_urdf_file(path, base, ee)
+    robot.set_parallelism(1)
+    assert robot.num_positions() == 10
+    d, ch = chains["arm10"]
+    rng = np.random.default_rng(21)
+    cfg = SolverConfig(solution_mode="speed", max_time=0.0, max_restarts=64, tol_f=1e-14)
+    for _ in range(4):
+        q = rng.uniform(d["lb"], d["ub"])
+        tgt = np.array(robot.fk(list(q)))
+        x0 = rng.uniform(d["lb"], d["ub"])
+        sol = robot.ik(cfg, tgt, list(x0), return_index=True)
+        assert sol is not None
+        x, f, idx = sol
+        got = np.array(robot.fk(list(x)))
+        assert np.abs(got - tgt).max() < 1e-6
+        ref = oracle.ik(ch, oracle.make_config(solution_mode="speed", tol_f=1e-14), _mat_to_pose7(tgt), x0, 0, 64)
+        assert ref["found"] and ref["winner"] == idx
+        np.testing.assert_allclose(x, ref["x"], atol=1e-6, rtol=0)
+    # the Jacobian of a wide chain through the host API; diff_ik is refused (the reference's only runs for n = 6)
+    J = np.array(robot.joint_jacobian(list(q)))
+    assert_bit_equal(J, oracle.joint_jacobian(ch, q), "jacobian")
