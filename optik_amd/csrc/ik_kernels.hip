@@ -1153,7 +1153,7 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     // one-wave-per-SIMD build -- no scratch, the lowest latency per iteration; anything bigger on the
     // two-waves-per-SIMD build)
     const bool quad_latency = quadk && (long long)cols <= (long long)cus * 4;
-    long long cap = (long long)cus * (quadk ? (quad_latency ? 4 : quad_solve_waves_per_cu(ch->n)) : (coop ? 4 : (ch->wide ? 4 : ch->waves_per_cu)));
+    long long cap = (long long)cus * (quadk ? (quad_latency ? 4 : quad_solve_waves_per_cu(ch->n)) : (coop ? 4 : (ch->wide ? 8 : ch->waves_per_cu)));
     // (experiments: fewer resident waves per CU than the kernel could have, e.g. to share the chip with another stream's kernels)
     if (const char *e = std::getenv("OPTIK_SOLVE_WAVES_PER_CU")) {
         const long long v = std::atoll(e);
@@ -1196,7 +1196,7 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     }
     int lds = 0;
     if (ch->wide) {
-        // 9 .. 16 joint positions: one restart per lane on the general kernel, two waves per CU, every
+        // 9 .. 16 joint positions: one restart per lane on the general kernel, eight waves per CU, every
         // resident wave with its own block of the restart workspace (ik_wide.hpp)
         if ((size_t)grid > ch->wide_ws_waves) {
             if (ch->wide_ws) HIP_TRY(hipFree(ch->wide_ws));

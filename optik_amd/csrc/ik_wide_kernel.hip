@@ -18,7 +18,7 @@ __device__ __forceinline__ void stage_wide_chain(WideChainDev &dst, const WideCh
     __syncthreads();
 }
 
-__global__ __launch_bounds__(64) void wide_solve_kernel(const WideSolveLaunch a) {
+__global__ __launch_bounds__(64, 2) void wide_solve_kernel(const WideSolveLaunch a) {
     __shared__ WideChainDev sch;
     stage_wide_chain(sch, a.chain);
     WorkQueue wq = a.wq;

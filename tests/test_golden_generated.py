@@ -15,7 +15,7 @@ import pytest
 from conftest import GOLDEN, ROBOT_SPECS
 
 GEN = os.path.join(GOLDEN, "generated")
-ROBOTS = ["ur3e", "panda", "ur10"]
+ROBOTS = ["ur3e", "panda", "ur10", "arm10"]
 RULES = {"single_inclusive": 0, "new_inclusive": 1}
 
 

@@ -25,10 +25,10 @@ def _load(name):
 def hip_chains(chains):
     from optik_amd import device
     assert torch.cuda.is_available(), "gpu tests need a GPU"
-    return {name: device.HipChain(**chains[name][0]) for name in ("ur3e", "panda", "ur10")}
+    return {name: device.HipChain(**chains[name][0]) for name in ("ur3e", "panda", "ur10", "arm10")}
 
 
-@pytest.mark.parametrize("robot", ["ur3e", "panda", "ur10"])
+@pytest.mark.parametrize("robot", ["ur3e", "panda", "ur10", "arm10"])
 @pytest.mark.parametrize("rule", ["single_inclusive", "new_inclusive"])
 def test_seeds_match_fixture(hip_chains, robot, rule):
     from optik_amd import _native as nat
@@ -42,7 +42,7 @@ def test_seeds_match_fixture(hip_chains, robot, rule):
         hc.set_range_rule(nat.RANGE_SINGLE_INCLUSIVE)
 
 
-@pytest.mark.parametrize("robot", ["ur3e", "panda", "ur10"])
+@pytest.mark.parametrize("robot", ["ur3e", "panda", "ur10", "arm10"])
 @pytest.mark.parametrize("rule", ["single_inclusive", "new_inclusive"])
 @pytest.mark.parametrize("path", ["kernel", "engine"])
 def test_restarts_and_winners_match_fixture(hip_chains, robot, rule, path):

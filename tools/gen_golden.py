@@ -43,6 +43,8 @@ ROBOTS = {
     "ur3e": ("tests/golden/reference/ur3e.urdf", "ur_base_link", "ur_ee_link", 20),
     "panda": ("optik_amd/robots/panda.urdf", "panda_link0", "panda_link8", 18),
     "ur10": ("optik_amd/robots/ur10.urdf", "base_link", "ee_link", 29),
+    # ten joints: two ChaCha blocks per restart seed, the general kernels of ik_wide.hpp on the GPU
+    "arm10": ("tests/golden/robots/arm10.urdf", "l0", "l11", 31),
 }
 RULES = {"single_inclusive": ob.RANGE_SINGLE_INCLUSIVE, "new_inclusive": ob.RANGE_NEW_INCLUSIVE}
 N_RESTARTS = 64
