@@ -151,9 +151,17 @@ __device__ void wide_restart_seed(const uint32_t (&key)[8], const double *lb, co
 
 // ---- SLSQP pieces over strided arrays --------------------------------------------------------------
 
+// (the loads of four terms are issued together -- a dependent HBM round trip per term is what this
+// path is bound by --, the sum is formed in the textbook order)
 __device__ inline double w_dot(int n, WP x, int incx, WP y, int incy) {
     double s = 0.0;
-    for (int i = 0; i < n; ++i) s += x[i * incx] * y[i * incy];
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {
+        const double x0 = x[i * incx], x1 = x[(i + 1) * incx], x2 = x[(i + 2) * incx], x3 = x[(i + 3) * incx];
+        const double y0 = y[i * incy], y1 = y[(i + 1) * incy], y2 = y[(i + 2) * incy], y3 = y[(i + 3) * incy];
+        s += x0 * y0; s += x1 * y1; s += x2 * y2; s += x3 * y3;
+    }
+    for (; i < n; ++i) s += x[i * incx] * y[i * incy];
     return s;
 }
 
@@ -176,12 +184,32 @@ __device__ inline void w_h12(int mode, int lpivot, int l1, int m, WP u, int iue,
     if (0 >= lpivot || lpivot >= l1 || l1 > m) return;
     double cl = __builtin_fabs(u[(lpivot - 1) * iue]);
     if (mode != 2) {
-        for (int j = l1; j <= m; ++j) { const double sm = __builtin_fabs(u[(j - 1) * iue]); if (sm > cl) cl = sm; }
+        {
+            int j = l1;
+            for (; j + 3 <= m; j += 4) {
+                const double u0 = u[(j - 1) * iue], u1 = u[j * iue], u2 = u[(j + 1) * iue], u3 = u[(j + 2) * iue];
+                double sm = __builtin_fabs(u0); if (sm > cl) cl = sm;
+                sm = __builtin_fabs(u1); if (sm > cl) cl = sm;
+                sm = __builtin_fabs(u2); if (sm > cl) cl = sm;
+                sm = __builtin_fabs(u3); if (sm > cl) cl = sm;
+            }
+            for (; j <= m; ++j) { const double sm = __builtin_fabs(u[(j - 1) * iue]); if (sm > cl) cl = sm; }
+        }
         if (cl <= 0.0) return;
         const double clinv = 1.0 / cl;
         double d = u[(lpivot - 1) * iue] * clinv;
         double sm = d * d;
-        for (int j = l1; j <= m; ++j) { d = u[(j - 1) * iue] * clinv; sm += d * d; }
+        {
+            int j = l1;
+            for (; j + 3 <= m; j += 4) {
+                const double u0 = u[(j - 1) * iue], u1 = u[j * iue], u2 = u[(j + 1) * iue], u3 = u[(j + 2) * iue];
+                d = u0 * clinv; sm += d * d;
+                d = u1 * clinv; sm += d * d;
+                d = u2 * clinv; sm += d * d;
+                d = u3 * clinv; sm += d * d;
+            }
+            for (; j <= m; ++j) { d = u[(j - 1) * iue] * clinv; sm += d * d; }
+        }
         cl *= __builtin_sqrt(sm);
         if (u[(lpivot - 1) * iue] > 0.0) cl = -cl;
         up = u[(lpivot - 1) * iue] - cl;
@@ -199,11 +227,31 @@ __device__ inline void w_h12(int mode, int lpivot, int l1, int m, WP u, int iue,
         i2 += icv;
         int i3 = i2 + incr, i4 = i3;
         double sm = c[i2 - 1] * up;
-        for (int i = l1; i <= m; ++i) { sm += c[i3 - 1] * u[(i - 1) * iue]; i3 += ice; }
+        {
+            int i = l1;
+            for (; i + 3 <= m; i += 4) {  // four terms' loads together, summed in order
+                const double c0 = c[i3 - 1], c1 = c[i3 - 1 + ice], c2 = c[i3 - 1 + 2 * ice], c3 = c[i3 - 1 + 3 * ice];
+                const double u0 = u[(i - 1) * iue], u1 = u[i * iue], u2 = u[(i + 1) * iue], u3 = u[(i + 2) * iue];
+                sm += c0 * u0; sm += c1 * u1; sm += c2 * u2; sm += c3 * u3;
+                i3 += 4 * ice;
+            }
+            for (; i <= m; ++i) { sm += c[i3 - 1] * u[(i - 1) * iue]; i3 += ice; }
+        }
         if (sm == 0.0) continue;
         sm *= b;
         c[i2 - 1] += sm * up;
-        for (int i = l1; i <= m; ++i) { c[i4 - 1] += sm * u[(i - 1) * iue]; i4 += ice; }
+        {
+            // (c is a column other than the pivot vector u: the elements are independent)
+            int i = l1;
+            for (; i + 3 <= m; i += 4) {
+                const double c0 = c[i4 - 1], c1 = c[i4 - 1 + ice], c2 = c[i4 - 1 + 2 * ice], c3 = c[i4 - 1 + 3 * ice];
+                const double u0 = u[(i - 1) * iue], u1 = u[i * iue], u2 = u[(i + 1) * iue], u3 = u[(i + 2) * iue];
+                c[i4 - 1] = c0 + sm * u0; c[i4 - 1 + ice] = c1 + sm * u1;
+                c[i4 - 1 + 2 * ice] = c2 + sm * u2; c[i4 - 1 + 3 * ice] = c3 + sm * u3;
+                i4 += 4 * ice;
+            }
+            for (; i <= m; ++i) { c[i4 - 1] += sm * u[(i - 1) * iue]; i4 += ice; }
+        }
     }
 }
 
@@ -276,7 +324,16 @@ __device__ inline int w_nnls(WP a, int mda, int m, int n, WP b, WP x, double &rn
         for (;;) {
             for (int ip = nsetp; ip >= 1; --ip) {
                 if (ip != nsetp) {
-                    for (int i = 0; i < ip; ++i) z[i] -= z[ip] * WA(i + 1, jj);
+                    const double zp = z[ip];
+                    int i = 0;
+                    for (; i + 4 <= ip; i += 4) {
+                        double zi[4], ai[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { zi[q] = z[i + q]; ai[q] = WA(i + q + 1, jj); }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) z[i + q] = zi[q] - zp * ai[q];
+                    }
+                    for (; i < ip; ++i) z[i] -= zp * WA(i + 1, jj);
                 }
                 jj = indx[ip - 1];
                 z[ip - 1] /= WA(ip, jj);
@@ -310,10 +367,23 @@ __device__ inline int w_nnls(WP a, int mda, int m, int n, WP b, WP x, double &rn
                     double c, s;
                     rotg(WA(j - 1, ii), WA(j, ii), c, s);
                     const double t = WA(j - 1, ii);
-                    for (int col = 1; col <= n; ++col) {  // rot over the two rows, every column
-                        const double xi = WA(j - 1, col), yi = WA(j, col);
-                        WA(j - 1, col) = c * xi + s * yi;
-                        WA(j, col) = c * yi - s * xi;
+                    {  // rot over the two rows, every column (four columns' loads together)
+                        int col = 1;
+                        for (; col + 3 <= n; col += 4) {
+                            double xi[4], yi[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { xi[q] = WA(j - 1, col + q); yi[q] = WA(j, col + q); }
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                WA(j - 1, col + q) = c * xi[q] + s * yi[q];
+                                WA(j, col + q) = c * yi[q] - s * xi[q];
+                            }
+                        }
+                        for (; col <= n; ++col) {
+                            const double xi = WA(j - 1, col), yi = WA(j, col);
+                            WA(j - 1, col) = c * xi + s * yi;
+                            WA(j, col) = c * yi - s * xi;
+                        }
                     }
                     WA(j - 1, ii) = t;
                     WA(j, ii) = 0.0;
@@ -356,7 +426,13 @@ __device__ inline int w_ldp(WP g, int mg, int m, int n, WP h, WP x, double &xnor
     if (m == 0) return 1;
     int iw = 0;
     for (int j = 0; j < m; ++j) {
-        for (int i = 0; i < n; ++i) w[iw++] = g[i * mg + j];
+        int i = 0;
+        for (; i + 4 <= n; i += 4) {
+            const double g0 = g[i * mg + j], g1 = g[(i + 1) * mg + j], g2 = g[(i + 2) * mg + j], g3 = g[(i + 3) * mg + j];
+            w[iw] = g0; w[iw + 1] = g1; w[iw + 2] = g2; w[iw + 3] = g3;
+            iw += 4;
+        }
+        for (; i < n; ++i) w[iw++] = g[i * mg + j];
         w[iw++] = h[j];
     }
     const int if_ = iw;
@@ -463,7 +539,18 @@ __device__ inline void w_ldl_update(int n, WP a, WP z, double sigma, WP w) {
         for (int i = 0; i < n; ++i) {
             const double v = w[i];
             t += v * v / a[ij];
-            for (int j = i + 1; j < n; ++j) { ++ij; w[j] -= v * a[ij]; }
+            {
+                int j = i + 1;
+                for (; j + 4 <= n; j += 4) {
+                    double au[4], wj[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { au[q] = a[ij + 1 + q]; wj[q] = w[j + q]; }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) w[j + q] = wj[q] - v * au[q];
+                    ij += 4;
+                }
+                for (; j < n; ++j) { ++ij; w[j] -= v * a[ij]; }
+            }
             ++ij;
         }
         if (t >= 0.0) t = EPMACH / sigma;
@@ -485,14 +572,32 @@ __device__ inline void w_ldl_update(int n, WP a, WP z, double sigma, WP w) {
         const double beta = delta / tp;
         if (alpha > 4.0) {
             const double gamma = t / tp;
-            for (int j = i + 1; j < n; ++j) {
+            int j = i + 1;
+            for (; j + 4 <= n; j += 4) {
+                double au[4], zj[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { au[q] = a[ij + 1 + q]; zj[q] = z[j + q]; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { a[ij + 1 + q] = gamma * au[q] + beta * zj[q]; z[j + q] = zj[q] - v * au[q]; }
+                ij += 4;
+            }
+            for (; j < n; ++j) {
                 ++ij;
                 const double u = a[ij];
                 a[ij] = gamma * u + beta * z[j];
                 z[j] -= v * u;
             }
         } else {
-            for (int j = i + 1; j < n; ++j) {
+            int j = i + 1;
+            for (; j + 4 <= n; j += 4) {
+                double au[4], zj[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { au[q] = a[ij + 1 + q]; zj[q] = z[j + q]; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { zj[q] -= v * au[q]; z[j + q] = zj[q]; a[ij + 1 + q] = au[q] + beta * zj[q]; }
+                ij += 4;
+            }
+            for (; j < n; ++j) {
                 ++ij;
                 z[j] -= v * a[ij];
                 a[ij] += beta * z[j];
@@ -525,9 +630,9 @@ __device__ inline int w_slsqpb(int n, WideSlsqp &st, WP ws, const double *xl, co
         {  // v = L D L' s
             int k = -1;
             for (int i = 0; i < n; ++i) {
-                double h = 0.0;
                 ++k;
-                for (int j = i + 1; j < n; ++j) { ++k; h += l[k] * s[j]; }
+                const double h = w_dot(n - i - 1, l + (k + 1), 1, s + (i + 1), 1);
+                k += n - i - 1;
                 v[i] = s[i] + h;
             }
             k = 0;
