@@ -41,8 +41,9 @@ const double *optik_robot_ik(const optik_robot *robot, const CSolverConfig *conf
                              const double *target, const double *x0);         /* lib.rs:128-162 */
 /* Differential IK (optik-cpp lib.rs:165-183; Robot::diff_ik, lib.rs:123-239): the joint
  * velocities v_n[n] realising alpha * V_WE for the largest feasible 0 <= alpha <= 1 under
- * |v_i| <= v_max_i.  The LP (<= 8 unknowns) is solved exactly on the host; FK and the Jacobian
- * come from the HIP kernels.  NULL = no solution. */
+ * |v_i| <= v_max_i.  The LP (<= 9 unknowns) is solved exactly on the host; FK and the Jacobian
+ * come from the HIP kernels.  NULL = no solution.  Chains of more than 8 joint positions are
+ * refused (the reference's own diff_ik only runs for n = 6: lib.rs:196-197). */
 const double *optik_robot_diff_ik(const optik_robot *robot, const double *x0, const double *V_WE,
                                   const double *v_max);
 
@@ -103,7 +104,8 @@ int optik_robot_joint_jacobian_ex(const optik_robot *robot, const double *x,
  * optik_robot_chain_tables: *n_joints is written only; non-NULL buffers must hold OPTIK_MAX_JOINTS
  * joints (x 7 / x 3 / x 1 elements).  optik_robot_chain_tables_n: the same with the caller's buffer
  * capacity (in joints) passed explicitly -- fewer than the chain has: error, nothing is written;
- * NULL buffers just report *n_joints. */
+ * NULL buffers just report *n_joints.  (A chain of more than 8 joint positions has more than
+ * OPTIK_MAX_JOINTS joints: the first form fails for it, use the second.) */
 #define OPTIK_MAX_JOINTS 9
 int optik_robot_chain_tables(const optik_robot *robot, int32_t *n_joints, double *origins7,
                              double *axes3, int32_t *types);
