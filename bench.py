@@ -96,7 +96,10 @@ def load_chain(robot):
     spec = {"panda": ("panda.urdf", "panda_link0", "panda_link8"),
             "ur10": ("ur10.urdf", "base_link", "ee_link"),
             # a synthetic 8-DoF chain (tests/golden/robots/): the largest n the kernels are built for
-            "arm8": (os.path.join("..", "..", "tests", "golden", "robots", "arm8.urdf"), "l0", "l9")}[robot]
+            "arm8": (os.path.join("..", "..", "tests", "golden", "robots", "arm8.urdf"), "l0", "l9"),
+            # synthetic 10- and 16-joint chains: the general kernels of ik_wide.hpp (use --path kernel)
+            "arm10": (os.path.join("..", "..", "tests", "golden", "robots", "arm10.urdf"), "l0", "l11"),
+            "arm16": (os.path.join("..", "..", "tests", "golden", "robots", "arm16.urdf"), "l0", "l17")}[robot]
     path = os.path.join(ROOT, "optik_amd", "robots", spec[0])
     return Robot.from_urdf_file(path, spec[1], spec[2])
 
@@ -245,7 +248,7 @@ def main():
     ap.add_argument("--restarts", type=int, default=None,
                     help="restarts per step: per GPU (weak) or in total (strong); per target with --targets; "
                          "default 65536 (256 with --targets)")
-    ap.add_argument("--robot", default="panda", choices=["panda", "ur10", "arm8"])
+    ap.add_argument("--robot", default="panda", choices=["panda", "ur10", "arm8", "arm10", "arm16"])
     ap.add_argument("--mode", default="speed", choices=["speed", "quality"], help="SolutionMode (config.rs:3-8)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--targets", type=int, default=0,
@@ -531,6 +534,8 @@ def main():
             achieved = out_bytes * per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
             kname = {"coop": "ik_coop_kernel", "lane": "ik_solve_kernel"}.get(os.environ.get("OPTIK_SOLVE_KERNEL", ""),
                                                                                 "ik_quad_kernel")
+            if n > 8:
+                kname = "wide_solve_kernel"  # (its restart state lives in an HBM workspace: DESIGN.md section 5.6)
             kp = (pmc or {}).get("kernel_path")
             traffic, traffic_note, secondary = None, f"no PMC pass of this command under profiles/ (key: {key})", None
             if kp:

@@ -221,3 +221,38 @@ def test_robot_api_ten_joints(dev, oracle, chains):
     # the Jacobian of a wide chain through the host API; diff_ik is refused (the reference's only runs for n = 6)
     J = np.array(robot.joint_jacobian(list(q)))
     assert_bit_equal(J, oracle.joint_jacobian(ch, q), "jacobian")
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_wide_chains_bit_exact(dev, oracle, seed):
+    """Random 9 .. 16-joint arms (tools/gen_wide_robots.py's generator, other seeds; with and without a
+    trailing fixed joint), weighted objective, an ee_offset: every restart against the oracle."""
+    import sys
+    from conftest import ROOT
+    from optik_amd import _native as nat
+    from oracle import urdf_chain
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_wide_robots
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(9, 17))
+    tip = bool(rng.integers(0, 2))
+    d = urdf_chain.chain_from_urdf(gen_wide_robots.arm(n, tip, 5000 + seed), "l0", f"l{n + (1 if tip else 0)}")
+    ch = oracle.make_chain(**d)
+    hc = dev.HipChain(**d)
+    tg, x0 = make_targets(oracle, d, ch, rng, 1)
+    eq = rng.normal(size=4)
+    eq /= np.linalg.norm(eq)
+    ee_off = np.concatenate([rng.uniform(-0.1, 0.1, 3), eq])
+    kw = dict(solution_mode=["speed", "quality"][seed % 2], tol_f=10.0 ** -int(rng.integers(5, 11)),
+              linear_weight=(1.0, 2.0, 0.5), angular_weight=(0.3, 1.0, 1.0))
+    R = 192
+    out = hc.ik_batch(nat.make_config(**kw), torch.tensor(tg, device="cuda"), torch.tensor(x0, device="cuda"), 0, R,
+                      ee_offset7=ee_off)
+    torch.cuda.synchronize()
+    ref = oracle.ik(ch, oracle.make_config(**kw), tg[0], x0[0], 0, R, n_threads=4, early_exit=False, per_restart=True,
+                    ee_offset=oracle.Pose.make(ee_off[:3], ee_off[3:]))
+    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+    assert np.array_equal(out["evals"].cpu().numpy(), ref["evals"])
+    assert_bit_equal(out["f"].cpu().numpy(), ref["fs"], "per-restart f")
+    assert_bit_equal(out["x"].cpu().numpy(), ref["xs"].T, "per-restart x")
+    assert int(out["win_idx"].cpu()[0]) == (ref["winner"] if ref["found"] else -1)
