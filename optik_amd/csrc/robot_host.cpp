@@ -406,7 +406,11 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
     // budget) is throughput-bound: rounds of 1 M restarts per GPU on the streaming engine (46 ms
     // against 118 on the solve kernel).
     const uint64_t cus = (uint64_t)(c0->num_cus > 0 ? c0->num_cus : 256);
-    const uint64_t first_batch = cus * 2, later_batch = cus * 2 * 64 * 2;
+    static const uint64_t first_per_cu = [] {
+        const char *e = std::getenv("OPTIK_IK_FIRST_ROUND_PER_CU");  // restarts per CU in the first, latency-sized launch
+        return e && std::atoll(e) > 0 ? (uint64_t)std::atoll(e) : (uint64_t)2;
+    }();
+    const uint64_t first_batch = cus * first_per_cu, later_batch = cus * 2 * 64 * 2;
     static const uint64_t engine_batch = [] {
         const char *e = std::getenv("OPTIK_IK_ENGINE_ROUND");  // restarts per GPU per engine round; 0 = never
         return e ? (uint64_t)std::atoll(e) : (uint64_t)1 << 20;
