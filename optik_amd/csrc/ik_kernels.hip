@@ -1198,7 +1198,9 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     if (ch->wide) {
         // 9 .. 16 joint positions: one restart per lane on the general kernel, eight waves per CU, every
         // resident wave with its own block of the restart workspace (ik_wide.hpp)
-        if ((size_t)grid > ch->wide_ws_waves) {
+        // (one restart per wave -- a single ik() call's rounds --: the restart's arrays in the wave's LDS)
+        const bool lds_form = lanes == 1;
+        if (!lds_form && (size_t)grid > ch->wide_ws_waves) {
             if (ch->wide_ws) HIP_TRY(hipFree(ch->wide_ws));
             ch->wide_ws = nullptr; ch->wide_ws_waves = 0;
             HIP_TRY(hipMalloc(&ch->wide_ws, sizeof(double) * wide_ws_doubles_per_wave() * (size_t)grid));
@@ -1211,8 +1213,8 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         std::memcpy(w.key, ch->key, sizeof w.key);
         w.deadline_ticks = a.deadline_ticks;
         w.ws = ch->wide_ws;
-        lds = (int)sizeof(WideChainDev);
-        HIP_TRY(wide_solve_launch(grid, stream, w));
+        lds = lds_form ? wide_lds_bytes() : (int)sizeof(WideChainDev);
+        HIP_TRY(wide_solve_launch(grid, stream, w, lds_form));
     } else if (quadk) {
         HIP_TRY(quad_solve_launch(ch->n, ch->tip, grid, stream, a, &lds, quad_latency));
     } else if (coop) {

@@ -19,11 +19,21 @@
 
 namespace optik {
 
-// Lane-strided view of the workspace: element k of an array lives 64 doubles after element k - 1.
-struct WP {
+// Where a restart's arrays live.  WPG: the lane-strided HBM workspace of a wave -- element k of an
+// array lives 64 doubles after element k - 1, so the 64 lanes of a wave touch one 512-byte line per
+// slot.  WPL: LDS, contiguous -- the form of launches with one restart per wave (a single ik() call's
+// rounds: the restart's 15 KB fit the wave's LDS, and a dependent access costs an LDS round trip
+// instead of an L2 / HBM one).
+struct WPG {
     double *p;
     __device__ __forceinline__ double &operator[](int k) const { return p[(size_t)k * 64]; }
-    __device__ __forceinline__ WP operator+(int k) const { return WP{p + (size_t)k * 64}; }
+    __device__ __forceinline__ WPG operator+(int k) const { return WPG{p + (size_t)k * 64}; }
+};
+typedef __attribute__((address_space(3))) double lds_double;
+struct WPL {
+    lds_double *p;
+    __device__ __forceinline__ lds_double &operator[](int k) const { return p[k]; }
+    __device__ __forceinline__ WPL operator+(int k) const { return WPL{p + k}; }
 };
 
 // workspace slots of one restart (doubles per lane)
@@ -153,6 +163,7 @@ __device__ void wide_restart_seed(const uint32_t (&key)[8], const double *lb, co
 
 // (the loads of four terms are issued together -- a dependent HBM round trip per term is what this
 // path is bound by --, the sum is formed in the textbook order)
+template <class WP>
 __device__ inline double w_dot(int n, WP x, int incx, WP y, int incy) {
     double s = 0.0;
     int i = 0;
@@ -166,6 +177,7 @@ __device__ inline double w_dot(int n, WP x, int incx, WP y, int incy) {
 }
 
 // NLopt's dnrm2: scaled by the largest magnitude.
+template <class WP>
 __device__ inline double w_nrm2(int n, WP x, int incx) {
     double xmax = 0.0;
     for (int i = 0; i < n; ++i) { const double a = __builtin_fabs(x[i * incx]); if (a > xmax) xmax = a; }
@@ -179,6 +191,7 @@ __device__ inline double w_nrm2(int n, WP x, int incx) {
 // Lawson-Hanson H12: construct (mode 1) / apply (mode 2) a Householder transformation.  u: pivot
 // vector with stride iue; the ncv vectors of c have element stride ice, vector stride icv.
 // lpivot, l1, m are 1-based.
+template <class WP>
 __device__ inline void w_h12(int mode, int lpivot, int l1, int m, WP u, int iue, double &up, WP c, int ice, int icv,
                              int ncv) {
     if (0 >= lpivot || lpivot >= l1 || l1 > m) return;
@@ -257,6 +270,7 @@ __device__ inline void w_h12(int mode, int lpivot, int l1, int m, WP u, int iue,
 
 // Lawson-Hanson NNLS: min ||A x - b|| s.t. x >= 0.  A is m x n column-major (leading dimension mda).
 // Returns mode: 1 ok, 2 bad dimensions, 3 iteration count exceeded.
+template <class WP>
 __device__ inline int w_nnls(WP a, int mda, int m, int n, WP b, WP x, double &rnorm, WP w, WP z, int *indx) {
 #define WA(i, j) a[((j) - 1) * mda + ((i) - 1)]
     const double factor = 0.01;
@@ -365,8 +379,11 @@ __device__ inline int w_nnls(WP a, int mda, int m, int n, WP b, WP x, double &rn
                     const int ii = indx[j - 1];
                     indx[j - 2] = ii;
                     double c, s;
-                    rotg(WA(j - 1, ii), WA(j, ii), c, s);
-                    const double t = WA(j - 1, ii);
+                    double ra = WA(j - 1, ii), rb = WA(j, ii);
+                    rotg(ra, rb, c, s);
+                    WA(j - 1, ii) = ra;
+                    WA(j, ii) = rb;
+                    const double t = ra;
                     {  // rot over the two rows, every column (four columns' loads together)
                         int col = 1;
                         for (; col + 3 <= n; col += 4) {
@@ -419,6 +436,7 @@ __device__ inline int w_nnls(WP a, int mda, int m, int n, WP b, WP x, double &rn
 }
 
 // Lawson-Hanson LDP: min ||x|| s.t. G x >= h.  G is m x n column-major (leading dimension mg).
+template <class WP>
 __device__ inline int w_ldp(WP g, int mg, int m, int n, WP h, WP x, double &xnorm, WP w, int *indx) {
     if (n <= 0) return 2;
     for (int i = 0; i < n; ++i) x[i] = 0.0;
@@ -456,6 +474,7 @@ __device__ inline int w_ldp(WP g, int mg, int m, int n, WP h, WP x, double &xnor
 }
 
 // Kraft LSI: min ||E x - f|| s.t. G x >= h.  E is me x n (ld le), G mg x n (ld lg).
+template <class WP>
 __device__ inline int w_lsi(WP e, WP f, WP g, WP h, int le, int me, int lg, int mg, int n, WP x, double &xnorm, WP w,
                             int *jw) {
 #define WE(i, j) e[((j) - 1) * le + ((i) - 1)]
@@ -493,6 +512,7 @@ __device__ inline int w_lsi(WP e, WP f, WP g, WP h, int le, int me, int lg, int 
 
 // Kraft LSQ for m = meq = 0 with finite bounds: min ||E s - f||, E = D^1/2 L', f = -D^-1/2 L^-1 g,
 // xl <= s <= xu, via LSEI (mc = 0) -> LSI -> LDP -> NNLS.  l: packed LDL'.  Returns the LSQ mode.
+template <class WP>
 __device__ inline int w_lsq_box(int n, WP ws, WP l, WP g, WP xl, WP xu, WP s) {
     WP E = ws + wide_ws::E, f = ws + wide_ws::F, G = ws + wide_ws::GG, h = ws + wide_ws::H, w = ws + wide_ws::W;
     int jw[2 * WIDE_MAX_DOF];
@@ -530,6 +550,7 @@ __device__ inline int w_lsq_box(int n, WP ws, WP l, WP g, WP xl, WP xu, WP s) {
 }
 
 // Fletcher-Powell composite-t rank-one update LDL' := LDL' + sigma z z' (z is destroyed).
+template <class WP>
 __device__ inline void w_ldl_update(int n, WP a, WP z, double sigma, WP w) {
     if (sigma == 0.0) return;
     int ij = 0;
@@ -618,6 +639,7 @@ enum : int { WQ_INIT = 0, WQ_FEVAL = 1, WQ_FGEVAL = -2, WQ_GRAD = -1 };
 // One call of SLSQPB.  In: mode 0 (first call; f, g at x set), 1 / -2 (function [and gradient]
 // evaluated at x), -1 (gradient evaluated).  Out: 1 / -2 (evaluate at x), -1 (line search done,
 // gradient wanted) or a terminal mode (3 .. 9).  acc = 0 (NLopt does the convergence tests).
+template <class WP>
 __device__ inline int w_slsqpb(int n, WideSlsqp &st, WP ws, const double *xl, const double *xu, int mode) {
     const double alfmin = 0.1;
     const int n1 = n + 1, n2 = n1 * n / 2;
@@ -711,6 +733,7 @@ trial:
 }
 
 // nlopt_stop_x with xtol_rel = 0 and xtol_abs[i] = tol_dx (see stop_x in ik_solve.hpp).
+template <class WP>
 __device__ inline bool w_stop_x(const SolveParams &sp, int n, WP x, WP oldx) {
     if (sp.stop_x_zero) {
         bool zero = true;
@@ -728,11 +751,11 @@ __device__ inline bool w_relstop(double vold, double vnew, double abstol) {
 
 // One 64-lane wave solving restarts until the queue is empty: the driver of nlopt_slsqp() and the
 // closure of lib.rs:301-391, one trip = (one evaluation, its bookkeeping, one SLSQPB call) per lane.
+template <class WP>
 __device__ inline void wide_solve_wave(const WideChainDev &ch, const EvalParams &ep, const SolveParams &sp,
-                                       const uint32_t (&key)[8], const WorkQueue &wq, double *ws_wave) {
+                                       const uint32_t (&key)[8], const WorkQueue &wq, const WP ws) {
     const int n = ch.n_pos;
     const int lane = (int)(threadIdx.x & 63u);
-    const WP ws{ws_wave + lane};
     const WP x = ws + wide_ws::X, g = ws + wide_ws::G, xbest = ws + wide_ws::XBEST, xprev = ws + wide_ws::XPREV,
              x0 = ws + wide_ws::X0, tf = ws + wide_ws::TF, gn = ws + wide_ws::GN;
     WideSlsqp st{};

@@ -23,7 +23,19 @@ __global__ __launch_bounds__(64, 2) void wide_solve_kernel(const WideSolveLaunch
     stage_wide_chain(sch, a.chain);
     WorkQueue wq = a.wq;
     wq.deadline = a.deadline_ticks ? (unsigned long long)wall_clock64() + a.deadline_ticks : 0ull;
-    wide_solve_wave(sch, a.ep, a.sp, a.key, wq, a.ws + (size_t)blockIdx.x * (size_t)wide_ws::SLOTS * 64);
+    wide_solve_wave(sch, a.ep, a.sp, a.key, wq,
+                    WPG{a.ws + (size_t)blockIdx.x * (size_t)wide_ws::SLOTS * 64 + (threadIdx.x & 63u)});
+}
+
+// One restart per wave (wq.lanes == 1: a single ik() call's rounds): the restart's arrays in the wave's LDS.
+__global__ __launch_bounds__(64) void wide_solve_lds_kernel(const WideSolveLaunch a) {
+    __shared__ WideChainDev sch;
+    __shared__ double ws_lds[wide_ws::SLOTS];
+    stage_wide_chain(sch, a.chain);
+    WorkQueue wq = a.wq;
+    wq.deadline = a.deadline_ticks ? (unsigned long long)wall_clock64() + a.deadline_ticks : 0ull;
+    wq.lanes = 1;
+    wide_solve_wave(sch, a.ep, a.sp, a.key, wq, WPL{(lds_double *)ws_lds});
 }
 
 __global__ __launch_bounds__(256) void wide_eval_batch_kernel(const WideBatchLaunch a) {
@@ -89,10 +101,12 @@ __global__ __launch_bounds__(256) void wide_seed_batch_kernel(const WideBatchLau
 
 size_t wide_ws_doubles_per_wave() { return (size_t)wide_ws::SLOTS * 64; }
 
-hipError_t wide_solve_launch(int grid, hipStream_t stream, const WideSolveLaunch &a) {
-    hipLaunchKernelGGL(wide_solve_kernel, dim3(grid), dim3(64), 0, stream, a);
+hipError_t wide_solve_launch(int grid, hipStream_t stream, const WideSolveLaunch &a, bool lds_form) {
+    if (lds_form) hipLaunchKernelGGL(wide_solve_lds_kernel, dim3(grid), dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL(wide_solve_kernel, dim3(grid), dim3(64), 0, stream, a);
     return hipGetLastError();
 }
+int wide_lds_bytes() { return (int)(sizeof(WideChainDev) + sizeof(double) * wide_ws::SLOTS); }
 
 hipError_t wide_batch_launch(int op, int grid, hipStream_t stream, const WideBatchLaunch &a) {
     switch (op) {

@@ -94,18 +94,22 @@ def test_fk_and_jacobian_bit_exact(dev, oracle, chains, hip_chains, robot):
 
 @pytest.mark.parametrize("robot,tol_f", [("arm9", 1e-6), ("arm10", 1e-8), ("arm12", 1e-10), ("arm16", 1e-8)])
 @pytest.mark.parametrize("mode", ["speed", "quality"])
-def test_every_restart_bit_exact(dev, oracle, chains, hip_chains, robot, tol_f, mode):
+@pytest.mark.parametrize("form", ["lds", "hbm"])
+def test_every_restart_bit_exact(dev, oracle, chains, hip_chains, robot, tol_f, mode, form):
     """Two targets, restarts 0..R-1 each: status, evaluation count, returned x and f of EVERY restart
-    equal the oracle's, and so does the selected winner (Speed: lowest index; Quality: nearest the seed)."""
+    equal the oracle's, and so does the selected winner (Speed: lowest index; Quality: nearest the seed).
+    Both forms of the general solver: one restart per wave with its arrays in LDS (launches that leave
+    waves to spare: a single ik() call's rounds) and several per wave with the HBM workspace."""
     from optik_amd import _native as nat
     d, ch = chains[robot]
     rng = np.random.default_rng(11)
-    T, R = 2, 700
+    T, R = 2, {"lds": 500, "hbm": 2600}[form]
     tg, x0 = make_targets(oracle, d, ch, rng, T)
     kw = dict(solution_mode=mode, tol_f=tol_f)
     out = hip_chains[robot].ik_batch(nat.make_config(**kw), torch.tensor(tg, device="cuda"),
                                      torch.tensor(x0, device="cuda"), 0, R)
     torch.cuda.synchronize()
+    assert (hip_chains[robot].last_launch()["lds_bytes"] > 8192) == (form == "lds")
     st = out["status"].cpu().numpy().reshape(T, R)
     ev = out["evals"].cpu().numpy().reshape(T, R)
     fs = out["f"].cpu().numpy().reshape(T, R)
@@ -221,6 +225,16 @@ def test_robot_api_ten_joints(dev, oracle, chains):
     # the Jacobian of a wide chain through the host API; diff_ik is refused (the reference's only runs for n = 6)
     J = np.array(robot.joint_jacobian(list(q)))
     assert_bit_equal(J, oracle.joint_jacobian(ch, q), "jacobian")
+    with pytest.raises(Exception):
+        robot.diff_ik(list(q), [0.1, 0, 0, 0, 0, 0], [1.0] * 10)
+    # many targets at once (the host scheduler's rounds on the general kernel) == one call per target
+    T = 24
+    targets = [np.array(robot.fk(list(rng.uniform(d["lb"], d["ub"])))) for _ in range(T)]
+    x0s = rng.uniform(d["lb"], d["ub"], size=(T, 10))
+    batch = robot.ik_batch(cfg, targets, x0s)
+    for t in range(T):
+        assert batch[t] == robot.ik(cfg, targets[t], x0s[t].tolist())
+    assert sum(b is not None for b in batch) >= T // 2
 
 
 @pytest.mark.parametrize("seed", range(6))
