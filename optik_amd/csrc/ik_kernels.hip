@@ -1184,6 +1184,14 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     long long lanes = (resident + cap - 1) / cap;
     if (lanes < 1) lanes = 1;
     if (lanes > per_wave_max) lanes = per_wave_max;
+    // (experiments: OPTIK_WIDE_FORM=lds keeps a wide chain's launches at one restart per wave -- the LDS form
+    // of the general solver -- whatever their size; =hbm never uses it)
+    if (ch->wide) {
+        if (const char *e = std::getenv("OPTIK_WIDE_FORM")) {
+            if (std::strcmp(e, "lds") == 0) lanes = 1;
+            else if (std::strcmp(e, "hbm") == 0 && lanes == 1) lanes = 2;
+        }
+    }
     a.wq.lanes = (int)lanes;
     long long grid_ll = (resident + lanes - 1) / lanes;
     if (grid_ll > cap) grid_ll = cap;
