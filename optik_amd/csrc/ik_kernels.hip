@@ -1152,8 +1152,12 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     // (quad solver: a launch with no more work items than the chip has SIMDs runs one restart per wave on the
     // one-wave-per-SIMD build -- no scratch, the lowest latency per iteration; anything bigger on the
     // two-waves-per-SIMD build)
+    static const long long wide_waves_per_cu = [] {  // resident waves per CU of the general solver (two per SIMD)
+        const char *e = std::getenv("OPTIK_WIDE_WAVES_PER_CU");
+        return e && std::atoll(e) > 0 ? std::atoll(e) : 8ll;
+    }();
     const bool quad_latency = quadk && (long long)cols <= (long long)cus * 4;
-    long long cap = (long long)cus * (quadk ? (quad_latency ? 4 : quad_solve_waves_per_cu(ch->n)) : (coop ? 4 : (ch->wide ? 8 : ch->waves_per_cu)));
+    long long cap = (long long)cus * (quadk ? (quad_latency ? 4 : quad_solve_waves_per_cu(ch->n)) : (coop ? 4 : (ch->wide ? wide_waves_per_cu : ch->waves_per_cu)));
     // (experiments: fewer resident waves per CU than the kernel could have, e.g. to share the chip with another stream's kernels)
     if (const char *e = std::getenv("OPTIK_SOLVE_WAVES_PER_CU")) {
         const long long v = std::atoll(e);

@@ -512,12 +512,26 @@ __device__ inline int w_lsi(WP e, WP f, WP g, WP h, int le, int me, int lg, int 
 
 // Kraft LSQ for m = meq = 0 with finite bounds: min ||E s - f||, E = D^1/2 L', f = -D^-1/2 L^-1 g,
 // xl <= s <= xu, via LSEI (mc = 0) -> LSI -> LDP -> NNLS.  l: packed LDL'.  Returns the LSQ mode.
+//
+// LSI and LDP are written for what this problem hands them (w_lsi / w_ldp above are the general
+// routines, kept for -DOPTIK_WIDE_GENERAL_LSI builds: same bits): E is upper triangular, so the sums
+// of a reflection over the zeros below its diagonal are skipped (a sum that only gains +-0 keeps its
+// value); G = [I; -I], so row n + i of the transformed G is row i negated -- only the top half is
+// formed and stored, its leading zeros without their dot products -- and the solution's norm and the
+// multipliers, which SLSQP does not read for m = 0, are not formed.  (A product by an exact zero is
+// +-0 and x + (+-0) == x: every non-zero keeps its bits; an exact zero of the top half keeps its sign
+// in the bottom half, as it does when the bottom row is computed.)  A third of the path's HBM
+// traffic was those zeros.
+__device__ __forceinline__ double w_mirror(double v) { return v == 0.0 ? v : -v; }
+
 template <class WP>
 __device__ inline int w_lsq_box(int n, WP ws, WP l, WP g, WP xl, WP xu, WP s) {
     WP E = ws + wide_ws::E, f = ws + wide_ws::F, G = ws + wide_ws::GG, h = ws + wide_ws::H, w = ws + wide_ws::W;
     int jw[2 * WIDE_MAX_DOF];
     const int m1 = 2 * n;
+#ifdef OPTIK_WIDE_GENERAL_LSI
     for (int i = 0; i < n * n; ++i) E[i] = 0.0;
+#endif
     // recover matrix E and vector f from L and g
     int i2 = 0;
     for (int i = 0; i < n; ++i) {
@@ -529,6 +543,7 @@ __device__ inline int w_lsq_box(int n, WP ws, WP l, WP g, WP xl, WP xu, WP s) {
         i2 += i1;
     }
     for (int i = 0; i < n; ++i) f[i] = -f[i];
+#ifdef OPTIK_WIDE_GENERAL_LSI
     // G = [+I; -I], h = [xl; -xu]
     for (int i = 0; i < m1 * n; ++i) G[i] = 0.0;
     for (int i = 0; i < n; ++i) {
@@ -539,6 +554,139 @@ __device__ inline int w_lsq_box(int n, WP ws, WP l, WP g, WP xl, WP xu, WP s) {
     }
     double xnorm;
     const int mode = w_lsi(E, f, G, h, n, n, m1, m1, n, s, xnorm, w, jw);
+#else
+#define WE(i, j) E[((j) - 1) * n + ((i) - 1)]
+#define WGT(i, j) G[((j) - 1) * n + ((i) - 1)]  // top half of the transformed G, n x n
+    for (int i = 0; i < n; ++i) { h[i] = xl[i]; h[n + i] = -xu[i]; }
+    // LSI: QR factors of E and application to f (H12 with lpivot = i, l1 = i + 1, m = n; i = n: l1 > m, no-op)
+    for (int i = 1; i < n; ++i) {
+        const double eii = WE(i, i);
+        double cl = __builtin_fabs(eii);
+        if (cl <= 0.0) continue;  // (mode 1 leaves the column alone; mode 2 finds the same zero pivot)
+        const double clinv = 1.0 / cl;
+        const double d = eii * clinv;
+        const double sm0 = d * d;
+        cl *= __builtin_sqrt(sm0);
+        if (eii > 0.0) cl = -cl;
+        const double up = eii - cl;
+        WE(i, i) = cl;
+        double b = up * cl;
+        if (b >= 0.0) continue;  // (both applications return)
+        b = 1.0 / b;
+        int col = i + 1;
+        for (; col + 3 <= n; col += 4) {  // row i of four columns at a time
+            double ci[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ci[q] = WE(i, col + q);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double sm = ci[q] * up;
+                if (sm == 0.0) continue;
+                sm *= b;
+                WE(i, col + q) = ci[q] + sm * up;
+            }
+        }
+        for (; col <= n; ++col) {
+            const double ci = WE(i, col);
+            double sm = ci * up;
+            if (sm == 0.0) continue;
+            sm *= b;
+            WE(i, col) = ci + sm * up;
+        }
+        {
+            const double fi = f[i - 1];
+            double sm = fi * up;
+            if (sm != 0.0) {
+                sm *= b;
+                f[i - 1] = fi + sm * up;
+            }
+        }
+    }
+    // transform G and h to get the least distance problem: rows 1 .. n (row n + i is row i negated)
+    for (int j = 1; j <= n; ++j)
+        if (!(__builtin_fabs(WE(j, j)) >= EPMACH)) return 5;
+    for (int i = 1; i <= n; ++i) {
+        for (int j = 1; j < i; ++j) WGT(i, j) = 0.0 / WE(j, j);  // (0 - 0) / E(j, j)
+        WGT(i, i) = 1.0 / WE(i, i);
+        for (int j = i + 1; j <= n; ++j)
+            WGT(i, j) = (0.0 - w_dot(j - i, G + ((i - 1) * n + (i - 1)), n, E + ((j - 1) * n + (i - 1)), 1)) / WE(j, j);
+        const double dt = w_dot(n - i + 1, G + ((i - 1) * n + (i - 1)), n, f + (i - 1), 1);
+        h[i - 1] -= dt;
+        h[n + i - 1] -= w_mirror(dt);
+    }
+    // LDP: the (n + 1) x 2n dual problem [G'; h'], NNLS, the primal solution
+    int mode;
+    {
+        for (int i = 0; i < n; ++i) s[i] = 0.0;
+        int iw = 0;
+        for (int j = 0; j < m1; ++j) {
+            const bool bottom = j >= n;
+            const int r = bottom ? j - n : j;  // row of the top half
+            int i = 0;
+            for (; i + 4 <= n; i += 4) {
+                double gv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gv[q] = G[(i + q) * n + r];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w[iw + q] = bottom ? w_mirror(gv[q]) : gv[q];
+                iw += 4;
+            }
+            for (; i < n; ++i) { const double gv = G[i * n + r]; w[iw++] = bottom ? w_mirror(gv) : gv; }
+            w[iw++] = h[j];
+        }
+        const int if_ = iw;
+        for (int i = 0; i < n; ++i) w[iw++] = 0.0;
+        w[iw] = 1.0;
+        const int n1 = n + 1;
+        const int iz = iw + 1, iy = iz + n1, iwdual = iy + m1;
+        double rnorm;
+        mode = w_nnls(w, n1, n1, m1, w + if_, w + iy, rnorm, w + iwdual, w + iz, jw);
+        if (mode == 1) {
+            if (rnorm <= 0.0) mode = 4;
+            else {
+                double fac = 1.0 - w_dot(m1, h, 1, w + iy, 1);
+                const double d1 = 1.0 + fac;
+                if (d1 - 1.0 <= 0.0) mode = 4;
+                else {
+                    fac = 1.0 / fac;
+                    for (int j = 0; j < n; ++j) {
+                        // dot(2n, column j of G, y): the top half, then the bottom half, one running sum
+                        double acc = 0.0;
+                        int r = 0;
+                        for (; r + 4 <= n; r += 4) {
+                            double gv[4], yv[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { gv[q] = G[j * n + r + q]; yv[q] = w[iy + r + q]; }
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc += gv[q] * yv[q];
+                        }
+                        for (; r < n; ++r) acc += G[j * n + r] * w[iy + r];
+                        r = 0;
+                        for (; r + 4 <= n; r += 4) {
+                            double gv[4], yv[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { gv[q] = G[j * n + r + q]; yv[q] = w[iy + n + r + q]; }
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc += w_mirror(gv[q]) * yv[q];
+                        }
+                        for (; r < n; ++r) acc += w_mirror(G[j * n + r]) * w[iy + n + r];
+                        s[j] = fac * acc;
+                    }
+                }
+            }
+        }
+    }
+    if (mode == 1) {
+        // solution of the original problem
+        for (int i = 0; i < n; ++i) s[i] += f[i];
+        for (int i = n; i >= 1; --i) {
+            const int j = (i + 1 < n) ? i + 1 : n;
+            s[i - 1] = (s[i - 1] - w_dot(n - i, E + ((j - 1) * n + (i - 1)), n, s + (j - 1), 1)) / WE(i, i);
+        }
+    }
+#undef WE
+#undef WGT
+#endif
     if (mode == 1) {
         // NLopt (SGJ 2010): enforce the bounds against roundoff
         for (int i = 0; i < n; ++i) {
