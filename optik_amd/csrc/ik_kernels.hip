@@ -1682,6 +1682,10 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
         }
 
         const int CHECK = 4;  // trips between termination checks
+        int check_drain = CHECK;  // ... of a sub-pool whose queue has run dry
+        if (const char *e = getenv("OPTIK_ENG_CHECK_DRAIN")) check_drain = atoi(e);
+        if (check_drain < 1) check_drain = 1;
+        if (check_drain > CHECK) check_drain = CHECK;
         int queue_depth = 2;  // chunks queued ahead of the one whose in-use count the host waits for
         if (const char *e = getenv("OPTIK_ENG_DEPTH")) queue_depth = atoi(e);
         if (queue_depth < 1) queue_depth = 1;
@@ -1704,12 +1708,14 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
             // abandons what is in flight and drains the queue without starting anything
             if (deadline_s > 0.0 && !aborted && since_call() > deadline_s) aborted = true;
             a.abort = aborted ? 1 : 0;
-            for (int k = 0; k < CHECK; ++k, ++trip) {
+            // (a draining sub-pool reports more often: the hand-over to the tail is decided on those counts)
+            const int check = P.drained ? check_drain : CHECK;
+            for (int k = 0; k < check; ++k, ++trip) {
                 // this trip consumes list[trip & 1]; the other list (consumed last trip) is
                 // reset for the finish kernel's re-deferrals and the next trip's update kernel
                 a.parity = trip & 1;
                 a.trip = trip < TRIP_LOG_MAX ? trip : TRIP_LOG_MAX - 1;
-                a.host_in_use = (k == CHECK - 1) ? &P.pinned[P.ring] : nullptr;
+                a.host_in_use = (k == check - 1) ? &P.pinned[P.ring] : nullptr;
                 // start / stop events on the kernels of sub-pool 0 (on its launch stream)
                 const bool timed = first_pool && ch->timing && trip > 0 && ch->eng_tcount < optik_hip_chain::ENG_EV;
                 const int ts = ch->eng_tcount;
