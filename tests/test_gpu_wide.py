@@ -270,3 +270,33 @@ def test_random_wide_chains_bit_exact(dev, oracle, seed):
     assert_bit_equal(out["f"].cpu().numpy(), ref["fs"], "per-restart f")
     assert_bit_equal(out["x"].cpu().numpy(), ref["xs"].T, "per-restart x")
     assert int(out["win_idx"].cpu()[0]) == (ref["winner"] if ref["found"] else -1)
+
+
+def test_multi_device_sharding_on_a_wide_chain():
+    """optik_robot_set_devices with a 10-joint chain: restart ranges (ik) and targets (ik_batch) spread over
+    two device contexts (the one GPU listed twice: the same sharding, threads and host-side min as two GPUs)
+    return exactly what one context returns."""
+    from conftest import ROBOT_SPECS
+    from optik_amd import Robot, SolverConfig
+    path, base, ee = ROBOT_SPECS["arm10"]
+    one = Robot.from_urdf_file(path, base, ee)
+    two = Robot.from_urdf_file(path, base, ee)
+    two.set_devices([0, 0])
+    one.set_parallelism(1)
+    two.set_parallelism(1)
+    assert one.num_devices() == 1 and two.num_devices() == 2
+    rng = np.random.default_rng(23)
+    lb, ub = (np.array(v) for v in one.joint_limits())
+    targets = [np.array(one.fk(rng.uniform(lb, ub))) for _ in range(7)]
+    x0s = rng.uniform(lb, ub, size=(7, 10))
+    cfg = SolverConfig(solution_mode="quality", max_time=0.0, max_restarts=20_000)
+    a = one.ik(cfg, targets[0], x0s[0].tolist(), return_index=True)
+    b = two.ik(cfg, targets[0], x0s[0].tolist(), return_index=True)
+    assert a is not None and a == b
+    cfg = SolverConfig(solution_mode="speed", max_time=0.0, max_restarts=3000)
+    for t in range(3):
+        assert one.ik(cfg, targets[t], x0s[t].tolist(), return_index=True) == \
+            two.ik(cfg, targets[t], x0s[t].tolist(), return_index=True)
+    for mode in ("speed", "quality"):
+        cfg = SolverConfig(solution_mode=mode, max_time=0.0, max_restarts=200)
+        assert one.ik_batch(cfg, targets, x0s) == two.ik_batch(cfg, targets, x0s)

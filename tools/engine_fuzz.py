@@ -27,6 +27,7 @@ KNOBS = {"OPTIK_ENGINE_SLOTS": [None, "1024", "1000", "2560", "4096", "20000"],
          "OPTIK_ENG_FUSED": [None, None, "1"],
          "OPTIK_ENG_NNLS_CONT": [None, None, "1"],
          "OPTIK_ENG_DEPTH": [None, "1", "3"],
+         "OPTIK_ENG_CHECK_DRAIN": [None, "1", "2", "3"],
          "OPTIK_SOLVE_KERNEL": [None, None, "lane"],
          # round 3: the quad solver's tail (default) or round 2's cooperative one
          "OPTIK_ENG_TAIL": [None, None, "coop"]}
