@@ -300,3 +300,29 @@ def test_multi_device_sharding_on_a_wide_chain():
     for mode in ("speed", "quality"):
         cfg = SolverConfig(solution_mode=mode, max_time=0.0, max_restarts=200)
         assert one.ik_batch(cfg, targets, x0s) == two.ik_batch(cfg, targets, x0s)
+
+
+def test_max_time_and_invalid_seed_on_a_wide_chain():
+    """tests/test_ik.rs:24-43 on a 16-joint chain: an impossible goal with max_time = 0.05 s returns None
+    within 0.05 +- 0.1 s (the general kernel's waves watch the device clock at every evaluation, lib.rs:308);
+    a seed outside the joint limits is refused as the reference's assert does (lib.rs:248-256)."""
+    import time
+    from conftest import ROBOT_SPECS
+    from optik_amd import Robot, SolverConfig
+    path, base, ee = ROBOT_SPECS["arm16"]
+    robot = Robot.from_urdf_file(path, base, ee)
+    lb, ub = (np.array(v) for v in robot.joint_limits())
+    mid = (0.5 * (lb + ub)).tolist()
+    far = np.eye(4)
+    far[:3, 3] = 100.0
+    robot.fk(mid)  # warm the device up before timing
+    robot.ik(SolverConfig(max_time=0.0, max_restarts=8), far, mid)
+    t0 = time.perf_counter()
+    sol = robot.ik(SolverConfig(max_time=0.05), far, mid)
+    dt = time.perf_counter() - t0
+    assert sol is None
+    assert abs(dt - 0.05) < 0.1, dt
+    bad = list(mid)
+    bad[3] = ub[3] + 1.0
+    with pytest.raises(Exception):
+        robot.ik(SolverConfig(max_time=0.0, max_restarts=8), np.array(robot.fk(mid)), bad)
