@@ -545,6 +545,15 @@ def main():
                                 f"{kp['hbm_bytes_per_restart']:.0f} B per restart at the fabric counters against "
                                 f"{out_bytes} B of outputs -- the difference is the kernel's few register spills (scratch: "
                                 "per-wave private memory) and the targets / launch parameters it re-reads, not restart state")
+                if n > 8:
+                    # the general solver streams a restart's whole SLSQP state through its HBM workspace: the fabric
+                    # bytes ARE the path's traffic, and they -- not the 8n + 24 output bytes -- are what it is bound by
+                    gbps = kp["hbm_bytes_per_restart"] * total / elapsed / 1e9
+                    traffic_note = (f"{os.path.relpath(PMC_FILE, ROOT)}: separate FETCH_SIZE / WRITE_SIZE passes of this command "
+                                    f"(2 x FETCH + WRITE), the {kp['launches']} launches of the timed repetitions: "
+                                    f"{kp['hbm_bytes_per_restart'] / 1e6:.2f} MB per restart at the fabric counters -- the restart "
+                                    f"state of the general solver lives in an HBM workspace (DESIGN.md section 5.6): "
+                                    f"{gbps:.0f} GB/s = {gbps / HBM_PEAK_GBS:.2f} of the HBM peak at this line's rate")
                 tf = total / elapsed * kp["f64_flops_per_restart"] / 1e12
                 secondary = {"bound": "valu_f64", "achieved": tf, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": tf / F64_VALU_PEAK_TFLOPS, "peak_no_fma": F64_VALU_NOFMA_TFLOPS,
