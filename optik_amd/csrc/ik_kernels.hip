@@ -1140,12 +1140,32 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     // quad, NNLS matrix in LDS; the default, n <= 8), round 2's cooperative one (OPTIK_SOLVE_KERNEL=coop:
     // the state in the quad's leader, ik_coop.hpp; n <= 7) or round 1's one-restart-per-lane kernel with
     // its per-lane LDS NNLS (OPTIK_SOLVE_KERNEL=lane).  Same results, bit for bit.
-    bool coop = ch->n <= 7, quadk = !ch->wide;
+    // (OPTIK_SOLVE_KERNEL=general: the run-time-n solver of ik_wide.hpp on a chain of at most 8 joints too -- a third,
+    // independently written device solver for the parity tests; chains of 9 .. 16 joints always run on it)
+    bool widek = ch->wide;
+    if (const char *e = std::getenv("OPTIK_SOLVE_KERNEL"))
+        if (std::strcmp(e, "general") == 0) widek = true;
+    if (widek && !ch->wide) {
+        // the chain's table in the general kernels' layout (uploaded per call: a test path)
+        WideChainDev &w = ch->whost;
+        std::memset(&w, 0, sizeof w);
+        w.n_pos = ch->n;
+        w.has_tip = ch->tip;
+        for (int j = 0; j < ch->n + (ch->tip ? 1 : 0); ++j)
+            for (int k = 0; k < 7; ++k) w.origin[j][k] = ch->host.origin[j][k];
+        for (int j = 0; j < ch->n; ++j) {
+            for (int k = 0; k < 3; ++k) w.axis[j][k] = ch->host.axis[j][k];
+            w.lb[j] = ch->host.lb[j]; w.ub[j] = ch->host.ub[j]; w.scale[j] = ch->scale[j];
+        }
+        if (!ch->wdev) HIP_TRY(hipMalloc(&ch->wdev, sizeof(WideChainDev)));
+        HIP_TRY(hipMemcpy(ch->wdev, &w, sizeof(WideChainDev), hipMemcpyHostToDevice));
+    }
+    bool coop = ch->n <= 7, quadk = !widek;
     if (const char *e = std::getenv("OPTIK_SOLVE_KERNEL")) {
         coop = coop && std::strcmp(e, "lane") != 0;
         quadk = quadk && std::strcmp(e, "lane") != 0 && std::strcmp(e, "coop") != 0;
     }
-    coop = coop && !quadk && !ch->wide;
+    coop = coop && !quadk && !widek;
     // Persistent waves, each pulling work items until the queue is dry: as many as a CU holds
     // (lane kernel: 2 workgroups, LDS-bound; cooperative kernel: 4, one per SIMD), times the CU count.
     const int cus = ch->num_cus > 0 ? ch->num_cus : 256;
@@ -1157,7 +1177,7 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         return e && std::atoll(e) > 0 ? std::atoll(e) : 8ll;
     }();
     const bool quad_latency = quadk && (long long)cols <= (long long)cus * 4;
-    long long cap = (long long)cus * (quadk ? (quad_latency ? 4 : quad_solve_waves_per_cu(ch->n)) : (coop ? 4 : (ch->wide ? wide_waves_per_cu : ch->waves_per_cu)));
+    long long cap = (long long)cus * (quadk ? (quad_latency ? 4 : quad_solve_waves_per_cu(ch->n)) : (coop ? 4 : (widek ? wide_waves_per_cu : ch->waves_per_cu)));
     // (experiments: fewer resident waves per CU than the kernel could have, e.g. to share the chip with another stream's kernels)
     if (const char *e = std::getenv("OPTIK_SOLVE_WAVES_PER_CU")) {
         const long long v = std::atoll(e);
@@ -1190,7 +1210,7 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     if (lanes > per_wave_max) lanes = per_wave_max;
     // (experiments: OPTIK_WIDE_FORM=lds keeps a wide chain's launches at one restart per wave -- the LDS form
     // of the general solver -- whatever their size; =hbm never uses it)
-    if (ch->wide) {
+    if (widek) {
         if (const char *e = std::getenv("OPTIK_WIDE_FORM")) {
             if (std::strcmp(e, "lds") == 0) lanes = 1;
             else if (std::strcmp(e, "hbm") == 0 && lanes == 1) lanes = 2;
@@ -1207,7 +1227,7 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         HIP_TRY(hipEventRecord(ch->ev0[ev_slot], stream));
     }
     int lds = 0;
-    if (ch->wide) {
+    if (widek) {
         // 9 .. 16 joint positions: one restart per lane on the general kernel, eight waves per CU, every
         // resident wave with its own block of the restart workspace (ik_wide.hpp)
         // (one restart per wave -- a single ik() call's rounds --: the restart's arrays in the wave's LDS)

@@ -326,3 +326,33 @@ def test_max_time_and_invalid_seed_on_a_wide_chain():
     bad[3] = ub[3] + 1.0
     with pytest.raises(Exception):
         robot.ik(SolverConfig(max_time=0.0, max_restarts=8), np.array(robot.fk(mid)), bad)
+
+
+@pytest.mark.parametrize("robot", ["panda", "ur10", "panda_hand", "panda3", "arm8"])
+@pytest.mark.parametrize("R", [400, 3000])
+def test_general_solver_equals_the_tuned_solvers(dev, oracle, chains, robot, R, monkeypatch):
+    """OPTIK_SOLVE_KERNEL=general runs a chain of at most 8 joints on the run-time-n solver too: a third,
+    independently written device solver (textbook loop nests over a workspace; both of its forms) gives the
+    bits of the quad solver -- and the oracle's -- for every restart."""
+    from optik_amd import _native as nat
+    d, ch = chains[robot]
+    hc = dev.HipChain(**d)
+    rng = np.random.default_rng(19)
+    tg, x0 = make_targets(oracle, d, ch, rng, 1)
+    kw = dict(solution_mode="quality", tol_f=1e-8)
+    cfg = nat.make_config(**kw)
+    tgd, x0d = torch.tensor(tg, device="cuda"), torch.tensor(x0, device="cuda")
+    tuned = hc.ik_batch(cfg, tgd, x0d, 0, R)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("OPTIK_SOLVE_KERNEL", "general")
+    general = hc.ik_batch(cfg, tgd, x0d, 0, R)
+    torch.cuda.synchronize()
+    assert (hc.last_launch()["lds_bytes"] > 8192) == (R <= 2048)  # the LDS form / the HBM workspace
+    monkeypatch.delenv("OPTIK_SOLVE_KERNEL")
+    for k in ("status", "evals", "win_idx"):
+        assert torch.equal(tuned[k], general[k]), k
+    for k in ("x", "f", "win_x", "win_f", "win_key"):
+        assert torch.equal(tuned[k].view(torch.int64), general[k].view(torch.int64)), k
+    ref = _oracle_all(oracle, ch, kw, tg[0], x0[0], 0, R)
+    assert np.array_equal(general["status"].cpu().numpy(), ref["status"])
+    assert_bit_equal(general["x"].cpu().numpy(), ref["xs"].T, "general solver vs oracle")
