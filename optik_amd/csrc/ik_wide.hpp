@@ -6,13 +6,17 @@
 // restart).  This header is the general form for the chains beyond that: the closure of
 // lib.rs:301-391 and the SLSQP it calls (NLopt's: Kraft's SLSQPB / LSQ / LSI / LDP, Lawson-Hanson
 // NNLS / H12, the Fletcher-Powell LDL' update, NLopt's stopping rules) written as plain loops over a
-// run-time n, every array of a restart in a lane-strided HBM workspace ([slot][64 lanes]: the 64
-// lanes of a wave touch one 512-byte line per slot).  No register tiling, no LDS matrices: it is the
-// path that makes such robots *work* (~1.9 K doubles of state per restart), not a tuned one.
+// run-time n.  No register tiling: ~1.9 K doubles of state per restart live either in a lane-strided
+// HBM workspace ([slot][64 lanes]: the 64 lanes of a wave touch one 512-byte line per slot; the
+// throughput form, HBM-bound) or, one restart per wave, in the wave's LDS (the latency form: a single
+// ik() call's rounds) -- the solver is a template over that choice (WPG / WPL).
 //
-// Results are bit-identical to the CPU oracle's ok_solve_restart() (tests/test_gpu_wide.py): the
-// loops below perform the arithmetic of the textbook routines in the textbook order, and the
-// objective is ik_eval.hpp's operation sequence with the joint loop rolled.
+// Results are bit-identical to the CPU oracle's ok_solve_restart() (tests/test_gpu_wide.py) and, on
+// chains of at most 8 joints (OPTIK_SOLVE_KERNEL=general), to the tuned solvers': the loops below
+// perform the arithmetic of the textbook routines in the textbook order -- loads are grouped four
+// terms at a time, sums are not reassociated, and LSI / LDP skip only what the box problem's
+// structure makes an exact zero (w_lsq_box) -- and the objective is ik_eval.hpp's operation sequence
+// with the joint loop rolled.
 #pragma once
 
 #include "ik_wide_launch.hpp"
