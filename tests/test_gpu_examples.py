@@ -65,3 +65,17 @@ def test_reference_style_script_runs_unchanged(tmp_path):
     res = subprocess.run([sys.executable, str(script), *PANDA], env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-500:] + res.stderr[-2000:]
     assert int(res.stdout.split()[-1]) >= 19
+
+
+@pytest.mark.parametrize("spec", [PANDA, [os.path.join(ROOT, "tests", "golden", "robots", "arm10.urdf"), "l0", "l11"]])
+def test_c_api_example(tmp_path, spec):
+    """examples/c_api.c: the reference's C ABI (include/optik.h) from plain C11 -- URDF in, ik() on the GPU, the
+    answer checked with fk(), every returned buffer freed with free() -- on Panda and on a 10-joint chain."""
+    libdir = os.path.join(ROOT, "optik_amd", "csrc")
+    exe = tmp_path / "c_api"
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "c_api.c"), "-L", libdir, "-loptik_amd",
+                           "-Wl,-rpath," + libdir, "-lm", "-o", str(exe)])
+    res = subprocess.run([str(exe), *spec], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-500:] + res.stderr[-2000:]
+    assert res.stdout.startswith("solved "), res.stdout
