@@ -1433,7 +1433,23 @@ static int engine_reserve(optik_hip_chain *ch, size_t AC, int /*nd*/, int ni, in
     for (auto &pe : ch->eng_pool_ev) for (auto &e : pe) if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (!ch->eng_fork_ev) HIP_TRY(hipEventCreateWithFlags(&ch->eng_fork_ev, hipEventDisableTiming));
     for (int p2 = 1; p2 < ENG_MAX_POOLS; ++p2) {
-        if (!ch->eng_streams[p2]) HIP_TRY(hipStreamCreateWithFlags(&ch->eng_streams[p2], hipStreamNonBlocking));
+        if (!ch->eng_streams[p2]) {
+            // (experiments, tools/hybrid_probe.py: OPTIK_ENG_CU_MASK = hex words, low CUs first, comma-separated --
+            // the sub-pools' own streams confined to those CUs, as the caller confines the stream it passes in)
+            const char *cm = getenv("OPTIK_ENG_CU_MASK");
+            if (cm && *cm) {
+                std::vector<uint32_t> words;
+                for (const char *q = cm; *q;) {
+                    char *endp = nullptr;
+                    words.push_back((uint32_t)std::strtoul(q, &endp, 16));
+                    q = (*endp == ',') ? endp + 1 : endp;
+                    if (endp == q && *q) break;
+                }
+                HIP_TRY(hipExtStreamCreateWithCUMask(&ch->eng_streams[p2], (uint32_t)words.size(), words.data()));
+            } else {
+                HIP_TRY(hipStreamCreateWithFlags(&ch->eng_streams[p2], hipStreamNonBlocking));
+            }
+        }
         if (!ch->eng_join_ev[p2]) HIP_TRY(hipEventCreateWithFlags(&ch->eng_join_ev[p2], hipEventDisableTiming));
     }
     return 0;
