@@ -39,6 +39,24 @@ struct WPL {
     __device__ __forceinline__ lds_double &operator[](int k) const { return p[k]; }
     __device__ __forceinline__ WPL operator+(int k) const { return WPL{p + k}; }
 };
+// WPC: the LDS form with the wave's 64 lanes working on its ONE restart together.  Every lane runs the
+// solver on the shared arrays -- the scalar recurrences redundantly (same loads, same values, same
+// stores) -- and the loops whose iterations are independent (the columns a reflection or a rotation is
+// applied to, the rows of the transformed G, the columns of the dual problem, the Jacobian's columns)
+// are dealt out lane by lane, each iteration still the sequential sum of the textbook loop: the same
+// bits, a several times shorter dependent chain.
+struct WPC {
+    lds_double *p;
+    __device__ __forceinline__ lds_double &operator[](int k) const { return p[k]; }
+    __device__ __forceinline__ WPC operator+(int k) const { return WPC{p + k}; }
+};
+template <class WP> struct wp_coop { static constexpr bool value = false; };
+template <> struct wp_coop<WPC> { static constexpr bool value = true; };
+// first index offset and stride of a dealt-out loop (0 and 1 in the one-lane forms), and the wave-wide
+// barrier that separates it from what reads its results
+template <class WP> __device__ __forceinline__ int w_first() { return wp_coop<WP>::value ? (int)(threadIdx.x & 63u) : 0; }
+template <class WP> __device__ __forceinline__ constexpr int w_step() { return wp_coop<WP>::value ? 64 : 1; }
+template <class WP> __device__ __forceinline__ void w_sync() { if constexpr (wp_coop<WP>::value) __syncthreads(); }
 
 // workspace slots of one restart (doubles per lane)
 namespace wide_ws {
@@ -109,8 +127,9 @@ __device__ double wide_eval_fg(const WideChainDev &ch, const EvalParams &ep, con
     for (int i = 0; i < 6; ++i) f += ef[i] * ef[i];
 
     const Q4 eeqc = qconj(ee.q);
+    w_sync<PT>();
 #pragma unroll 1
-    for (int k = 0; k < n; ++k) {
+    for (int k = w_first<PT>(); k < n; k += w_step<PT>()) {  // (coop: a Jacobian column per lane)
         const V3 tk{tf[7 * k + 0], tf[7 * k + 1], tf[7 * k + 2]};
         const Q4 tq{tf[7 * k + 3], tf[7 * k + 4], tf[7 * k + 5], tf[7 * k + 6]};
         const V3 ax{ch.axis[k][0], ch.axis[k][1], ch.axis[k][2]};
@@ -140,6 +159,7 @@ __device__ double wide_eval_fg(const WideChainDev &ch, const EvalParams &ep, con
         for (int r = 0; r < 6; ++r) acc += e2[r] * jt[r];
         g[k] = acc;
     }
+    w_sync<PT>();
     return f;
 }
 
@@ -291,10 +311,12 @@ __device__ inline int w_nnls(WP a, int mda, int m, int n, WP b, WP x, double &rn
 
     while (!finished) {  // step two
         if (iz1 > iz2 || nsetp >= m) break;
-        for (int iz = iz1; iz <= iz2; ++iz) {
-            j = indx[iz - 1];
-            w[j - 1] = w_dot(m - nsetp, a + ((j - 1) * mda + (npp1 - 1)), 1, b + (npp1 - 1), 1);
+        w_sync<WP>();
+        for (int iz = iz1 + w_first<WP>(); iz <= iz2; iz += w_step<WP>()) {
+            const int jc = indx[iz - 1];
+            w[jc - 1] = w_dot(m - nsetp, a + ((jc - 1) * mda + (npp1 - 1)), 1, b + (npp1 - 1), 1);
         }
+        w_sync<WP>();
         bool found = false;
         for (;;) {  // step three
             double wmax = 0.0;
@@ -325,10 +347,12 @@ __device__ inline int w_nnls(WP a, int mda, int m, int n, WP b, WP x, double &rn
                 ++iz1;
                 nsetp = npp1;
                 ++npp1;
-                for (int jz = iz1; jz <= iz2; ++jz) {
-                    jj = indx[jz - 1];
-                    w_h12(2, nsetp, npp1, m, a + (j - 1) * mda, 1, up, a + (jj - 1) * mda, 1, mda, 1);
+                w_sync<WP>();
+                for (int jz = iz1 + w_first<WP>(); jz <= iz2; jz += w_step<WP>()) {
+                    const int jc = indx[jz - 1];
+                    w_h12(2, nsetp, npp1, m, a + (j - 1) * mda, 1, up, a + (jc - 1) * mda, 1, mda, 1);
                 }
+                w_sync<WP>();
                 w[j - 1] = 0.0;
                 for (int i = npp1; i <= m; ++i) WA(i, j) = 0.0;
                 break;
@@ -388,7 +412,14 @@ __device__ inline int w_nnls(WP a, int mda, int m, int n, WP b, WP x, double &rn
                     WA(j - 1, ii) = ra;
                     WA(j, ii) = rb;
                     const double t = ra;
-                    {  // rot over the two rows, every column (four columns' loads together)
+                    w_sync<WP>();
+                    if constexpr (wp_coop<WP>::value) {
+                        for (int col = 1 + w_first<WP>(); col <= n; col += w_step<WP>()) {
+                            const double xi = WA(j - 1, col), yi = WA(j, col);
+                            WA(j - 1, col) = c * xi + s * yi;
+                            WA(j, col) = c * yi - s * xi;
+                        }
+                    } else {  // rot over the two rows, every column (four columns' loads together)
                         int col = 1;
                         for (; col + 3 <= n; col += 4) {
                             double xi[4], yi[4];
@@ -406,6 +437,7 @@ __device__ inline int w_nnls(WP a, int mda, int m, int n, WP b, WP x, double &rn
                             WA(j, col) = c * yi - s * xi;
                         }
                     }
+                    w_sync<WP>();
                     WA(j - 1, ii) = t;
                     WA(j, ii) = 0.0;
                     {
@@ -577,7 +609,17 @@ __device__ inline int w_lsq_box(int n, WP ws, WP l, WP g, WP xl, WP xu, WP s) {
         double b = up * cl;
         if (b >= 0.0) continue;  // (both applications return)
         b = 1.0 / b;
-        int col = i + 1;
+        w_sync<WP>();
+        int col = i + 1 + w_first<WP>();
+        if constexpr (wp_coop<WP>::value) {
+            for (; col <= n; col += w_step<WP>()) {  // row i of the later columns, a column per lane
+                const double ci = WE(i, col);
+                double sm = ci * up;
+                if (sm == 0.0) continue;
+                sm *= b;
+                WE(i, col) = ci + sm * up;
+            }
+        }
         for (; col + 3 <= n; col += 4) {  // row i of four columns at a time
             double ci[4];
 #pragma unroll
@@ -605,11 +647,13 @@ __device__ inline int w_lsq_box(int n, WP ws, WP l, WP g, WP xl, WP xu, WP s) {
                 f[i - 1] = fi + sm * up;
             }
         }
+        w_sync<WP>();
     }
     // transform G and h to get the least distance problem: rows 1 .. n (row n + i is row i negated)
     for (int j = 1; j <= n; ++j)
         if (!(__builtin_fabs(WE(j, j)) >= EPMACH)) return 5;
-    for (int i = 1; i <= n; ++i) {
+    w_sync<WP>();
+    for (int i = 1 + w_first<WP>(); i <= n; i += w_step<WP>()) {  // (coop: a row per lane)
         for (int j = 1; j < i; ++j) WGT(i, j) = 0.0 / WE(j, j);  // (0 - 0) / E(j, j)
         WGT(i, i) = 1.0 / WE(i, i);
         for (int j = i + 1; j <= n; ++j)
@@ -618,12 +662,14 @@ __device__ inline int w_lsq_box(int n, WP ws, WP l, WP g, WP xl, WP xu, WP s) {
         h[i - 1] -= dt;
         h[n + i - 1] -= w_mirror(dt);
     }
+    w_sync<WP>();
     // LDP: the (n + 1) x 2n dual problem [G'; h'], NNLS, the primal solution
     int mode;
     {
         for (int i = 0; i < n; ++i) s[i] = 0.0;
         int iw = 0;
-        for (int j = 0; j < m1; ++j) {
+        for (int j = w_first<WP>(); j < m1; j += w_step<WP>()) {  // (coop: a column of the dual problem per lane)
+            iw = j * (n + 1);
             const bool bottom = j >= n;
             const int r = bottom ? j - n : j;  // row of the top half
             int i = 0;
@@ -638,6 +684,8 @@ __device__ inline int w_lsq_box(int n, WP ws, WP l, WP g, WP xl, WP xu, WP s) {
             for (; i < n; ++i) { const double gv = G[i * n + r]; w[iw++] = bottom ? w_mirror(gv) : gv; }
             w[iw++] = h[j];
         }
+        iw = m1 * (n + 1);
+        w_sync<WP>();
         const int if_ = iw;
         for (int i = 0; i < n; ++i) w[iw++] = 0.0;
         w[iw] = 1.0;
@@ -653,7 +701,7 @@ __device__ inline int w_lsq_box(int n, WP ws, WP l, WP g, WP xl, WP xu, WP s) {
                 if (d1 - 1.0 <= 0.0) mode = 4;
                 else {
                     fac = 1.0 / fac;
-                    for (int j = 0; j < n; ++j) {
+                    for (int j = w_first<WP>(); j < n; j += w_step<WP>()) {
                         // dot(2n, column j of G, y): the top half, then the bottom half, one running sum
                         double acc = 0.0;
                         int r = 0;
@@ -679,6 +727,7 @@ __device__ inline int w_lsq_box(int n, WP ws, WP l, WP g, WP xl, WP xu, WP s) {
                 }
             }
         }
+        w_sync<WP>();
     }
     if (mode == 1) {
         // solution of the original problem
@@ -919,12 +968,20 @@ __device__ inline void wide_solve_wave(const WideChainDev &ch, const EvalParams 
     target.q = Q4{0, 0, 0, 1};
     unsigned long long item = 0, index = 0;
     unsigned tslot = 0;
-    bool active = false, want = lane < wq.lanes;
+    constexpr bool coop = wp_coop<WP>::value;  // the wave's 64 lanes share ONE restart (identical state in all of them)
+    bool active = false, want = coop || lane < wq.lanes;
 
     for (;;) {
         // ---- refill: lanes without a restart pull the next work item ----------------------------
         if (wave_any(want)) {
-            const unsigned long long it = fetch_items(wq.next_item, want);
+            unsigned long long it;
+            if constexpr (coop) {
+                it = 0;
+                if (lane == 0) it = atomicAdd(wq.next_item, 1ull);
+                it = __shfl(it, 0, 64);
+            } else {
+                it = fetch_items(wq.next_item, want);
+            }
             if (want) {
                 want = false;
                 if (it < wq.total_items) {
@@ -1007,11 +1064,12 @@ __device__ inline void wide_solve_wave(const WideChainDev &ch, const EvalParams 
         if (ret != 0) {
             const bool success = (sp.ok_stopval && ret == RES_STOPVAL_REACHED) || (sp.ok_ftol && ret == RES_FTOL_REACHED)
                                  || (sp.ok_xtol && ret == RES_XTOL_REACHED);
-            if (wq.out_x)
+            const bool writer = !coop || lane == 0;
+            if (wq.out_x && writer)
                 for (int i = 0; i < n; ++i) wq.out_x[(size_t)i * wq.total_items + item] = xbest[i];
-            if (wq.out_f) wq.out_f[item] = minf;
-            if (wq.out_status) wq.out_status[item] = ret;
-            if (wq.out_evals) wq.out_evals[item] = nevals;
+            if (wq.out_f && writer) wq.out_f[item] = minf;
+            if (wq.out_status && writer) wq.out_status[item] = ret;
+            if (wq.out_evals && writer) wq.out_evals[item] = nevals;
             // selection key (lib.rs:402-407): Quality = ||x - x0||_2, Speed = index
             double k = __builtin_huge_val();
             if (success) {
@@ -1022,10 +1080,10 @@ __device__ inline void wide_solve_wave(const WideChainDev &ch, const EvalParams 
                     k = __builtin_sqrt(acc);
                 } else {
                     k = (double)index;
-                    if (wq.first_success) atomicMin(wq.first_success + tslot, index);
+                    if (wq.first_success && writer) atomicMin(wq.first_success + tslot, index);
                 }
             }
-            if (wq.out_key) wq.out_key[item] = k;
+            if (wq.out_key && writer) wq.out_key[item] = k;
             active = false;
             want = true;
         }

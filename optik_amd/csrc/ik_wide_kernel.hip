@@ -3,6 +3,8 @@
 // translation unit: one run-time-n body each instead of a template instantiation per joint count.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "ik_wide.hpp"
 
 namespace optik {
@@ -36,6 +38,17 @@ __global__ __launch_bounds__(64) void wide_solve_lds_kernel(const WideSolveLaunc
     wq.deadline = a.deadline_ticks ? (unsigned long long)wall_clock64() + a.deadline_ticks : 0ull;
     wq.lanes = 1;
     wide_solve_wave(sch, a.ep, a.sp, a.key, wq, WPL{(lds_double *)ws_lds});
+}
+
+// The same with the wave's 64 lanes working on the restart together (WPC): the default latency form.
+__global__ __launch_bounds__(64) void wide_solve_coop_kernel(const WideSolveLaunch a) {
+    __shared__ WideChainDev sch;
+    __shared__ double ws_lds[wide_ws::SLOTS];
+    stage_wide_chain(sch, a.chain);
+    WorkQueue wq = a.wq;
+    wq.deadline = a.deadline_ticks ? (unsigned long long)wall_clock64() + a.deadline_ticks : 0ull;
+    wq.lanes = 1;
+    wide_solve_wave(sch, a.ep, a.sp, a.key, wq, WPC{(lds_double *)ws_lds});
 }
 
 __global__ __launch_bounds__(256) void wide_eval_batch_kernel(const WideBatchLaunch a) {
@@ -102,7 +115,13 @@ __global__ __launch_bounds__(256) void wide_seed_batch_kernel(const WideBatchLau
 size_t wide_ws_doubles_per_wave() { return (size_t)wide_ws::SLOTS * 64; }
 
 hipError_t wide_solve_launch(int grid, hipStream_t stream, const WideSolveLaunch &a, bool lds_form) {
-    if (lds_form) hipLaunchKernelGGL(wide_solve_lds_kernel, dim3(grid), dim3(64), 0, stream, a);
+    // (OPTIK_WIDE_LDS_COOP=0: the one-lane LDS form instead of the cooperative one)
+    static const bool lds_coop = [] {
+        const char *e = getenv("OPTIK_WIDE_LDS_COOP");
+        return !(e && atoi(e) == 0);
+    }();
+    if (lds_form && lds_coop) hipLaunchKernelGGL(wide_solve_coop_kernel, dim3(grid), dim3(64), 0, stream, a);
+    else if (lds_form) hipLaunchKernelGGL(wide_solve_lds_kernel, dim3(grid), dim3(64), 0, stream, a);
     else hipLaunchKernelGGL(wide_solve_kernel, dim3(grid), dim3(64), 0, stream, a);
     return hipGetLastError();
 }
