@@ -761,7 +761,12 @@ __device__ inline void w_ldl_update(int n, WP a, WP z, double sigma, WP w) {
         for (int i = 0; i < n; ++i) {
             const double v = w[i];
             t += v * v / a[ij];
-            {
+            if constexpr (wp_coop<WP>::value) {  // the row's elements, one per lane
+                w_sync<WP>();
+                for (int j = i + 1 + w_first<WP>(); j < n; j += w_step<WP>()) w[j] -= v * a[ij + (j - i)];
+                w_sync<WP>();
+                ij += n - 1 - i;
+            } else {
                 int j = i + 1;
                 for (; j + 4 <= n; j += 4) {
                     double au[4], wj[4];
@@ -795,6 +800,17 @@ __device__ inline void w_ldl_update(int n, WP a, WP z, double sigma, WP w) {
         if (alpha > 4.0) {
             const double gamma = t / tp;
             int j = i + 1;
+            if constexpr (wp_coop<WP>::value) {
+                w_sync<WP>();
+                for (int jj = i + 1 + w_first<WP>(); jj < n; jj += w_step<WP>()) {
+                    const double u = a[ij + (jj - i)];
+                    a[ij + (jj - i)] = gamma * u + beta * z[jj];
+                    z[jj] -= v * u;
+                }
+                w_sync<WP>();
+                ij += n - 1 - i;
+                j = n;
+            }
             for (; j + 4 <= n; j += 4) {
                 double au[4], zj[4];
 #pragma unroll
@@ -811,6 +827,17 @@ __device__ inline void w_ldl_update(int n, WP a, WP z, double sigma, WP w) {
             }
         } else {
             int j = i + 1;
+            if constexpr (wp_coop<WP>::value) {
+                w_sync<WP>();
+                for (int jj = i + 1 + w_first<WP>(); jj < n; jj += w_step<WP>()) {
+                    const double zn = z[jj] - v * a[ij + (jj - i)];
+                    z[jj] = zn;
+                    a[ij + (jj - i)] += beta * zn;
+                }
+                w_sync<WP>();
+                ij += n - 1 - i;
+                j = n;
+            }
             for (; j + 4 <= n; j += 4) {
                 double au[4], zj[4];
 #pragma unroll
@@ -852,6 +879,14 @@ __device__ inline int w_slsqpb(int n, WideSlsqp &st, WP ws, const double *xl, co
         for (int i = 0; i < n; ++i) u[i] = g[i] - v[i];
         {  // v = L D L' s
             int k = -1;
+            if constexpr (wp_coop<WP>::value) {  // (the rows are independent: one per lane)
+                w_sync<WP>();
+                for (int i = w_first<WP>(); i < n; i += w_step<WP>()) {
+                    const int kd = i * n - (i * (i - 1)) / 2;  // index of l(i, i) in the packed factor
+                    v[i] = s[i] + w_dot(n - i - 1, l + (kd + 1), 1, s + (i + 1), 1);
+                }
+                w_sync<WP>();
+            } else
             for (int i = 0; i < n; ++i) {
                 ++k;
                 const double h = w_dot(n - i - 1, l + (k + 1), 1, s + (i + 1), 1);
