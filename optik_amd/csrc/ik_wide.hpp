@@ -57,6 +57,8 @@ template <> struct wp_coop<WPC> { static constexpr bool value = true; };
 template <class WP> __device__ __forceinline__ int w_first() { return wp_coop<WP>::value ? (int)(threadIdx.x & 63u) : 0; }
 template <class WP> __device__ __forceinline__ constexpr int w_step() { return wp_coop<WP>::value ? 64 : 1; }
 template <class WP> __device__ __forceinline__ void w_sync() { if constexpr (wp_coop<WP>::value) __syncthreads(); }
+// an element-wise loop: every element by the one lane in the one-lane forms, an element per lane in WPC
+#define W_EACH(i, count) for (int i = w_first<WP>(); i < (count); i += w_step<WP>())
 
 // workspace slots of one restart (doubles per lane)
 namespace wide_ws {
@@ -307,7 +309,8 @@ __device__ inline int w_nnls(WP a, int mda, int m, int n, WP b, WP x, double &rn
     int izmax = 0, j, jj = 0;
     double up = 0.0;
     bool finished = false;
-    for (int i = 0; i < n; ++i) x[i] = 0.0;
+    W_EACH(i, n) x[i] = 0.0;
+    w_sync<WP>();
 
     while (!finished) {  // step two
         if (iz1 > iz2 || nsetp >= m) break;
@@ -336,12 +339,13 @@ __device__ inline int w_nnls(WP a, int mda, int m, int n, WP b, WP x, double &rn
             const double t = factor * __builtin_fabs(WA(npp1, j));
             const double d1 = unorm + t;
             if (d1 - unorm > 0.0) {
-                for (int i = 0; i < m; ++i) z[i] = b[i];
+                W_EACH(i, m) z[i] = b[i];
+                w_sync<WP>();
                 w_h12(2, npp1, npp1 + 1, m, a + (j - 1) * mda, 1, up, z, 1, 1, 1);
                 if (z[npp1 - 1] / WA(npp1, j) > 0.0) found = true;
             }
             if (found) {
-                for (int i = 0; i < m; ++i) b[i] = z[i];
+                W_EACH(i, m) b[i] = z[i];
                 indx[iz - 1] = indx[iz1 - 1];
                 indx[iz1 - 1] = j;
                 ++iz1;
@@ -392,10 +396,11 @@ __device__ inline int w_nnls(WP a, int mda, int m, int n, WP b, WP x, double &rn
                 alpha = t;
                 jj = ip;
             }
-            for (int ip = 1; ip <= nsetp; ++ip) {
-                const int l = indx[ip - 1];
-                x[l - 1] = (1.0 - alpha) * x[l - 1] + alpha * z[ip - 1];
+            W_EACH(ipz, nsetp) {
+                const int l = indx[ipz];
+                x[l - 1] = (1.0 - alpha) * x[l - 1] + alpha * z[ipz];
             }
+            w_sync<WP>();
             if (jj == 0) break;  // back to step two
             // step eleven: move coefficient i from set P to set Z
             int i = indx[jj - 1];
@@ -459,7 +464,8 @@ __device__ inline int w_nnls(WP a, int mda, int m, int n, WP b, WP x, double &rn
                 if (!again) break;
             }
             if (failed) { finished = true; break; }
-            for (int k = 0; k < m; ++k) z[k] = b[k];
+            W_EACH(k, m) z[k] = b[k];
+            w_sync<WP>();
         }
     }
     {
@@ -573,12 +579,14 @@ __device__ inline int w_lsq_box(int n, WP ws, WP l, WP g, WP xl, WP xu, WP s) {
     for (int i = 0; i < n; ++i) {
         const int i1 = n - i;
         const double diag = __builtin_sqrt(l[i2]);
-        for (int k = 0; k < i1; ++k) E[(i + k) * n + i] = l[i2 + k] * diag;  // row i of E
+        W_EACH(k, i1) E[(i + k) * n + i] = l[i2 + k] * diag;  // row i of E
+        w_sync<WP>();
         E[i * n + i] = diag;
         f[i] = (g[i] - w_dot(i, E + i * n, 1, f, 1)) / diag;
         i2 += i1;
     }
-    for (int i = 0; i < n; ++i) f[i] = -f[i];
+    W_EACH(i, n) f[i] = -f[i];
+    w_sync<WP>();
 #ifdef OPTIK_WIDE_GENERAL_LSI
     // G = [+I; -I], h = [xl; -xu]
     for (int i = 0; i < m1 * n; ++i) G[i] = 0.0;
@@ -593,7 +601,8 @@ __device__ inline int w_lsq_box(int n, WP ws, WP l, WP g, WP xl, WP xu, WP s) {
 #else
 #define WE(i, j) E[((j) - 1) * n + ((i) - 1)]
 #define WGT(i, j) G[((j) - 1) * n + ((i) - 1)]  // top half of the transformed G, n x n
-    for (int i = 0; i < n; ++i) { h[i] = xl[i]; h[n + i] = -xu[i]; }
+    W_EACH(i, n) { h[i] = xl[i]; h[n + i] = -xu[i]; }
+    w_sync<WP>();
     // LSI: QR factors of E and application to f (H12 with lpivot = i, l1 = i + 1, m = n; i = n: l1 > m, no-op)
     for (int i = 1; i < n; ++i) {
         const double eii = WE(i, i);
@@ -731,7 +740,8 @@ __device__ inline int w_lsq_box(int n, WP ws, WP l, WP g, WP xl, WP xu, WP s) {
     }
     if (mode == 1) {
         // solution of the original problem
-        for (int i = 0; i < n; ++i) s[i] += f[i];
+        W_EACH(i, n) s[i] += f[i];
+        w_sync<WP>();
         for (int i = n; i >= 1; --i) {
             const int j = (i + 1 < n) ? i + 1 : n;
             s[i - 1] = (s[i - 1] - w_dot(n - i, E + ((j - 1) * n + (i - 1)), n, s + (j - 1), 1)) / WE(i, i);
@@ -742,10 +752,11 @@ __device__ inline int w_lsq_box(int n, WP ws, WP l, WP g, WP xl, WP xu, WP s) {
 #endif
     if (mode == 1) {
         // NLopt (SGJ 2010): enforce the bounds against roundoff
-        for (int i = 0; i < n; ++i) {
+        W_EACH(i, n) {
             if (s[i] < xl[i]) s[i] = xl[i];
             else if (s[i] > xu[i]) s[i] = xu[i];
         }
+        w_sync<WP>();
     }
     return mode;
 }
@@ -876,7 +887,7 @@ __device__ inline int w_slsqpb(int n, WideSlsqp &st, WP ws, const double *xl, co
     bool reset = false;
     if (mode == WQ_GRAD) {
         // label 260: BFGS update of the LDL' factors
-        for (int i = 0; i < n; ++i) u[i] = g[i] - v[i];
+        W_EACH(i, n) u[i] = g[i] - v[i];
         {  // v = L D L' s
             int k = -1;
             if constexpr (wp_coop<WP>::value) {  // (the rows are independent: one per lane)
@@ -893,13 +904,32 @@ __device__ inline int w_slsqpb(int n, WideSlsqp &st, WP ws, const double *xl, co
                 k += n - i - 1;
                 v[i] = s[i] + h;
             }
-            k = 0;
-            for (int i = 0; i < n; ++i) { v[i] = l[k] * v[i]; k += n1 - (i + 1); }
-            for (int i = n - 1; i >= 0; --i) {
-                double h = 0.0;
-                k = i;
-                for (int j = 0; j < i; ++j) { h += l[k] * v[j]; k += n - (j + 1); }
-                v[i] += h;
+            if constexpr (wp_coop<WP>::value) {
+                W_EACH(i, n) v[i] = l[i * n - (i * (i - 1)) / 2] * v[i];
+                w_sync<WP>();
+                // (row i adds the products of the rows above it, which are still unchanged when it is formed going
+                // down from the last row: every lane forms its sum from the old values, then all add)
+                double hrow[(WIDE_MAX_DOF + 63) / 64];
+                int r = 0;
+                W_EACH(i, n) {
+                    double h = 0.0;
+                    int kk = i;
+                    for (int j = 0; j < i; ++j) { h += l[kk] * v[j]; kk += n - (j + 1); }
+                    hrow[r++] = h;
+                }
+                w_sync<WP>();
+                r = 0;
+                W_EACH(i, n) v[i] += hrow[r++];
+                w_sync<WP>();
+            } else {
+                k = 0;
+                for (int i = 0; i < n; ++i) { v[i] = l[k] * v[i]; k += n1 - (i + 1); }
+                for (int i = n - 1; i >= 0; --i) {
+                    double h = 0.0;
+                    k = i;
+                    for (int j = 0; j < i; ++j) { h += l[k] * v[j]; k += n - (j + 1); }
+                    v[i] += h;
+                }
             }
         }
         double h1 = w_dot(n, s, 1, u, 1);
@@ -908,15 +938,21 @@ __device__ inline int w_slsqpb(int n, WideSlsqp &st, WP ws, const double *xl, co
         if (h1 < h3) {
             const double h4 = (h2 - h3) / (h2 - h1);
             h1 = h3;
-            for (int i = 0; i < n; ++i) u[i] *= h4;
-            for (int i = 0; i < n; ++i) u[i] += (1.0 - h4) * v[i];
+            W_EACH(i, n) {
+                double ui = u[i];
+                ui *= h4;
+                ui += (1.0 - h4) * v[i];
+                u[i] = ui;
+            }
+            w_sync<WP>();
         }
         w_ldl_update(n, l, u, 1.0 / h1, lw);
         w_ldl_update(n, l, v, -1.0 / h2, lw);
     } else if (mode == WQ_INIT) {
         // label 100
         st.ireset = 0;
-        for (int i = 0; i < n; ++i) s[i] = 0.0;
+        W_EACH(i, n) s[i] = 0.0;
+        w_sync<WP>();
         reset = true;
     } else {
         // label 220: function evaluated, L1 merit (m = 0: t = f)
@@ -935,17 +971,19 @@ __device__ inline int w_slsqpb(int n, WideSlsqp &st, WP ws, const double *xl, co
         if (reset) {  // label 110: reset the BFGS matrix
             ++st.ireset;
             if (st.ireset > 5) return 8;  // label 255 with acc = 0
-            for (int i = 0; i < n2; ++i) l[i] = 0.0;
-            int j = 0;
-            for (int i = 0; i < n; ++i) { l[j] = 1.0; j += n1 - (i + 1); }
+            W_EACH(i, n2) l[i] = 0.0;
+            w_sync<WP>();
+            W_EACH(i, n) l[i * n - (i * (i - 1)) / 2] = 1.0;
+            w_sync<WP>();
         }
         // label 130: search direction
-        for (int i = 0; i < n; ++i) { u[i] = xl[i] - x[i]; v[i] = xu[i] - x[i]; }
+        W_EACH(i, n) { u[i] = xl[i] - x[i]; v[i] = xu[i] - x[i]; }
+        w_sync<WP>();
         const int lmode = w_lsq_box(n, ws, l, g, u, v, s);
         if (lmode != 1) return lmode;
-        for (int i = 0; i < n; ++i) v[i] = g[i];
+        W_EACH(i, n) { v[i] = g[i]; x0[i] = x[i]; }
+        w_sync<WP>();
         st.f0 = st.f;
-        for (int i = 0; i < n; ++i) x0[i] = x[i];
         const double gs = w_dot(n, g, 1, s, 1);
         st.t0 = st.f;
         st.h3 = gs;  // gs - h1 * h4 with h1 = 0 (acc = 0, no constraints)
@@ -958,19 +996,31 @@ trial:
     // label 190: next trial point
     ++st.line;
     st.h3 = st.alpha * st.h3;
-    for (int i = 0; i < n; ++i) s[i] *= st.alpha;
-    for (int i = 0; i < n; ++i) x[i] = x0[i];
-    for (int i = 0; i < n; ++i) x[i] += s[i];
-    for (int i = 0; i < n; ++i) {  // NLopt (SGJ 2010): roundoff must not push x past the bounds
-        if (x[i] < xl[i]) x[i] = xl[i];
-        else if (x[i] > xu[i]) x[i] = xu[i];
+    W_EACH(i, n) {
+        const double si = s[i] * st.alpha;
+        s[i] = si;
+        double xi = x0[i];
+        xi += si;
+        if (xi < xl[i]) xi = xl[i];  // NLopt (SGJ 2010): roundoff must not push x past the bounds
+        else if (xi > xu[i]) xi = xu[i];
+        x[i] = xi;
     }
+    w_sync<WP>();
     return (st.line == 1) ? WQ_FGEVAL : WQ_FEVAL;  // NLopt: the first trial comes with its gradient
 }
 
 // nlopt_stop_x with xtol_rel = 0 and xtol_abs[i] = tol_dx (see stop_x in ik_solve.hpp).
 template <class WP>
 __device__ inline bool w_stop_x(const SolveParams &sp, int n, WP x, WP oldx) {
+    if constexpr (wp_coop<WP>::value) {  // (an element per lane, the verdicts by ballot)
+        bool differs = false, large = false;
+        W_EACH(i, n) {
+            differs = differs || !(x[i] == oldx[i]);
+            large = large || (__builtin_fabs(x[i] - oldx[i]) >= sp.xtol_abs);
+        }
+        if (sp.stop_x_zero && !wave_any(differs)) return true;
+        return !wave_any(large);
+    }
     if (sp.stop_x_zero) {
         bool zero = true;
         for (int i = 0; i < n; ++i) zero = zero && (x[i] == oldx[i]);
@@ -1064,7 +1114,8 @@ __device__ inline void wide_solve_wave(const WideChainDev &ch, const EvalParams 
             const int prev_mode = mode;
             if (st.f < minf) {  // NLopt: best point so far
                 minf = st.f;
-                for (int i = 0; i < n; ++i) xbest[i] = x[i];
+                W_EACH(i, n) xbest[i] = x[i];
+                w_sync<WP>();
             }
             if (mode == WQ_GRAD) {  // a line search completed: only then are ftol / xtol tested
                 if (!__builtin_isinf(fprev)) {
@@ -1072,7 +1123,8 @@ __device__ inline void wide_solve_wave(const WideChainDev &ch, const EvalParams 
                     else if (w_stop_x(sp, n, x, xprev)) ret = RES_XTOL_REACHED;
                 }
                 fprev = st.f;
-                for (int i = 0; i < n; ++i) xprev[i] = x[i];
+                W_EACH(i, n) xprev[i] = x[i];
+                w_sync<WP>();
             }
             if (minf < sp.stopval) ret = RES_STOPVAL_REACHED;
             if (ret == 0 && nevals >= MAX_EVALS_CAP) ret = RES_ITER_CAP;
