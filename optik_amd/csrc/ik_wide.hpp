@@ -85,6 +85,27 @@ __device__ Pose wide_forward(const WideChainDev &ch, const EvalParams &ep, int n
     Pose state;
     state.t = V3{0.0, 0.0, 0.0};
     state.q = Q4{0.0, 0.0, 0.0, 1.0};
+    if constexpr (wp_coop<PT>::value) {
+        // joint.origin * local_transform(q_j) of every joint at once (a joint per lane: kinematics.rs:142-158 forms
+        // that product before it multiplies it onto the chain), then the chain product
+        for (int j = w_first<PT>(); j < n; j += w_step<PT>()) {
+            double s, c;
+            sincos_dev(q[j] / 2.0, s, c);
+            const Q4 local{ch.axis[j][0] * s, ch.axis[j][1] * s, ch.axis[j][2] * s, c};
+            const Q4 jq = qmul(Q4{ch.origin[j][3], ch.origin[j][4], ch.origin[j][5], ch.origin[j][6]}, local);
+            tf[7 * j + 3] = jq.i; tf[7 * j + 4] = jq.j; tf[7 * j + 5] = jq.k; tf[7 * j + 6] = jq.w;
+        }
+        w_sync<PT>();
+#pragma unroll 1
+        for (int j = 0; j < n; ++j) {
+            Pose jt;
+            jt.t = V3{ch.origin[j][0], ch.origin[j][1], ch.origin[j][2]};
+            jt.q = Q4{tf[7 * j + 3], tf[7 * j + 4], tf[7 * j + 5], tf[7 * j + 6]};
+            state = (j == 0) ? jt : pose_mul(state, jt);
+            tf[7 * j + 0] = state.t.x; tf[7 * j + 1] = state.t.y; tf[7 * j + 2] = state.t.z;
+            tf[7 * j + 3] = state.q.i; tf[7 * j + 4] = state.q.j; tf[7 * j + 5] = state.q.k; tf[7 * j + 6] = state.q.w;
+        }
+    } else
 #pragma unroll 1
     for (int j = 0; j < n; ++j) {
         double s, c;
@@ -200,6 +221,23 @@ __device__ inline double w_dot(int n, WP x, int incx, WP y, int incy) {
     }
     for (; i < n; ++i) s += x[i * incx] * y[i * incy];
     return s;
+}
+
+// The same dot product where the whole wave wants it (WPC, outside the dealt-out loops): lane i forms term i
+// -- one LDS round trip for all of them --, the sum is then formed in the textbook order from lane reads.
+// (n <= 64; the one-lane forms fall through to w_dot)
+template <class WP>
+__device__ inline double w_dot_all(int n, WP x, int incx, WP y, int incy) {
+    if constexpr (wp_coop<WP>::value) {
+        const int lane = (int)(threadIdx.x & 63u);
+        double term = 0.0;
+        if (lane < n) term = x[lane * incx] * y[lane * incy];
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += __shfl(term, i, 64);
+        return s;
+    } else {
+        return w_dot(n, x, incx, y, incy);
+    }
 }
 
 // NLopt's dnrm2: scaled by the largest magnitude.
@@ -323,6 +361,18 @@ __device__ inline int w_nnls(WP a, int mda, int m, int n, WP b, WP x, double &rn
         bool found = false;
         for (;;) {  // step three
             double wmax = 0.0;
+            if constexpr (wp_coop<WP>::value) {  // (a candidate per lane, the comparisons in index order from lane reads)
+                const int cnt = iz2 - iz1 + 1;
+                const int lane = (int)(threadIdx.x & 63u);
+                double cand = 0.0;
+                if (lane < cnt) cand = w[indx[iz1 - 1 + lane] - 1];
+                for (int t = 0; t < cnt; ++t) {
+                    const double wv = __shfl(cand, t, 64);
+                    if (wv <= wmax) continue;
+                    wmax = wv;
+                    izmax = iz1 + t;
+                }
+            } else
             for (int iz = iz1; iz <= iz2; ++iz) {
                 j = indx[iz - 1];
                 if (w[j - 1] <= wmax) continue;
@@ -582,7 +632,7 @@ __device__ inline int w_lsq_box(int n, WP ws, WP l, WP g, WP xl, WP xu, WP s) {
         W_EACH(k, i1) E[(i + k) * n + i] = l[i2 + k] * diag;  // row i of E
         w_sync<WP>();
         E[i * n + i] = diag;
-        f[i] = (g[i] - w_dot(i, E + i * n, 1, f, 1)) / diag;
+        f[i] = (g[i] - w_dot_all(i, E + i * n, 1, f, 1)) / diag;
         i2 += i1;
     }
     W_EACH(i, n) f[i] = -f[i];
@@ -705,7 +755,7 @@ __device__ inline int w_lsq_box(int n, WP ws, WP l, WP g, WP xl, WP xu, WP s) {
         if (mode == 1) {
             if (rnorm <= 0.0) mode = 4;
             else {
-                double fac = 1.0 - w_dot(m1, h, 1, w + iy, 1);
+                double fac = 1.0 - w_dot_all(m1, h, 1, w + iy, 1);
                 const double d1 = 1.0 + fac;
                 if (d1 - 1.0 <= 0.0) mode = 4;
                 else {
@@ -744,7 +794,7 @@ __device__ inline int w_lsq_box(int n, WP ws, WP l, WP g, WP xl, WP xu, WP s) {
         w_sync<WP>();
         for (int i = n; i >= 1; --i) {
             const int j = (i + 1 < n) ? i + 1 : n;
-            s[i - 1] = (s[i - 1] - w_dot(n - i, E + ((j - 1) * n + (i - 1)), n, s + (j - 1), 1)) / WE(i, i);
+            s[i - 1] = (s[i - 1] - w_dot_all(n - i, E + ((j - 1) * n + (i - 1)), n, s + (j - 1), 1)) / WE(i, i);
         }
     }
 #undef WE
@@ -932,8 +982,8 @@ __device__ inline int w_slsqpb(int n, WideSlsqp &st, WP ws, const double *xl, co
                 }
             }
         }
-        double h1 = w_dot(n, s, 1, u, 1);
-        const double h2 = w_dot(n, s, 1, v, 1);
+        double h1 = w_dot_all(n, s, 1, u, 1);
+        const double h2 = w_dot_all(n, s, 1, v, 1);
         const double h3 = h2 * 0.2;
         if (h1 < h3) {
             const double h4 = (h2 - h3) / (h2 - h1);
@@ -984,7 +1034,7 @@ __device__ inline int w_slsqpb(int n, WideSlsqp &st, WP ws, const double *xl, co
         W_EACH(i, n) { v[i] = g[i]; x0[i] = x[i]; }
         w_sync<WP>();
         st.f0 = st.f;
-        const double gs = w_dot(n, g, 1, s, 1);
+        const double gs = w_dot_all(n, g, 1, s, 1);
         st.t0 = st.f;
         st.h3 = gs;  // gs - h1 * h4 with h1 = 0 (acc = 0, no constraints)
         if (st.h3 >= 0.0) { reset = true; continue; }
