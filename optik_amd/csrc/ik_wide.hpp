@@ -57,6 +57,14 @@ template <> struct wp_coop<WPC> { static constexpr bool value = true; };
 template <class WP> __device__ __forceinline__ int w_first() { return wp_coop<WP>::value ? (int)(threadIdx.x & 63u) : 0; }
 template <class WP> __device__ __forceinline__ constexpr int w_step() { return wp_coop<WP>::value ? 64 : 1; }
 template <class WP> __device__ __forceinline__ void w_sync() { if constexpr (wp_coop<WP>::value) __syncthreads(); }
+// lane `src`'s value of v in every lane, `src` wave-uniform (two v_readlane_b32: a few cycles, where a
+// shuffle by a vector index is an LDS-crossbar round trip)
+__device__ __forceinline__ double w_lane_read(double v, int src) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 // an element-wise loop: every element by the one lane in the one-lane forms, an element per lane in WPC
 #define W_EACH(i, count) for (int i = w_first<WP>(); i < (count); i += w_step<WP>())
 
@@ -233,7 +241,7 @@ __device__ inline double w_dot_all(int n, WP x, int incx, WP y, int incy) {
         double term = 0.0;
         if (lane < n) term = x[lane * incx] * y[lane * incy];
         double s = 0.0;
-        for (int i = 0; i < n; ++i) s += __shfl(term, i, 64);
+        for (int i = 0; i < n; ++i) s += w_lane_read(term, i);
         return s;
     } else {
         return w_dot(n, x, incx, y, incy);
@@ -250,6 +258,73 @@ __device__ inline double w_nrm2(int n, WP x, int incx) {
     double sum = 0.0;
     for (int i = 0; i < n; ++i) { const double xs = scale * x[i * incx]; sum += xs * xs; }
     return xmax * __builtin_sqrt(sum);
+}
+
+// w_nrm2 where the whole wave wants it (WPC): an element per lane, maximum and sum in index order from lane reads.
+template <class WP>
+__device__ inline double w_nrm2_all(int n, WP x, int incx) {
+    if constexpr (wp_coop<WP>::value) {
+        const int lane = (int)(threadIdx.x & 63u);
+        double xi = 0.0;
+        if (lane < n) xi = x[lane * incx];
+        double xmax = 0.0;
+        for (int i = 0; i < n; ++i) { const double a = __builtin_fabs(w_lane_read(xi, i)); if (a > xmax) xmax = a; }
+        if (xmax == 0.0) return 0.0;
+        const double scale = 1.0 / xmax;
+        const double xs = scale * xi;
+        const double sq = xs * xs;
+        double sum = 0.0;
+        for (int i = 0; i < n; ++i) sum += w_lane_read(sq, i);
+        return xmax * __builtin_sqrt(sum);
+    } else {
+        return w_nrm2(n, x, incx);
+    }
+}
+
+// H12 where the whole wave wants it (WPC; NNLS's step five: the construction on the chosen column and its
+// application to ONE vector): the elements l1 .. m of u (and of c) one per lane, maxima and sums in index order
+// from lane reads, the update of c an element per lane.  ncv <= 1.
+template <class WP>
+__device__ inline void w_h12_all(int mode, int lpivot, int l1, int m, WP u, double &up, WP c, int ncv) {
+    if (0 >= lpivot || lpivot >= l1 || l1 > m) return;
+    const int lane = (int)(threadIdx.x & 63u);
+    const int cnt = m - l1 + 1;
+    const double up0 = u[lpivot - 1];
+    double uj = 0.0;
+    if (lane < cnt) uj = u[l1 - 1 + lane];
+    double cl = __builtin_fabs(up0);
+    if (mode != 2) {
+        for (int t = 0; t < cnt; ++t) { const double sm = __builtin_fabs(w_lane_read(uj, t)); if (sm > cl) cl = sm; }
+        if (cl <= 0.0) return;
+        const double clinv = 1.0 / cl;
+        double d = up0 * clinv;
+        double sm = d * d;
+        const double dj = uj * clinv;
+        const double dj2 = dj * dj;
+        for (int t = 0; t < cnt; ++t) sm += w_lane_read(dj2, t);
+        cl *= __builtin_sqrt(sm);
+        if (up0 > 0.0) cl = -cl;
+        up = up0 - cl;
+        u[lpivot - 1] = cl;
+    } else if (cl <= 0.0) {
+        return;
+    }
+    if (ncv <= 0) return;
+    const double pivot = (mode != 2) ? cl : up0;  // u(lpivot) as it stands now
+    double b = up * pivot;
+    if (b >= 0.0) return;
+    b = 1.0 / b;
+    const double c0 = c[lpivot - 1];
+    double cj = 0.0;
+    if (lane < cnt) cj = c[l1 - 1 + lane];
+    const double term = cj * uj;
+    double sm = c0 * up;
+    for (int t = 0; t < cnt; ++t) sm += w_lane_read(term, t);
+    if (sm == 0.0) return;
+    sm *= b;
+    c[lpivot - 1] = c0 + sm * up;
+    if (lane < cnt) c[l1 - 1 + lane] = cj + sm * uj;
+    w_sync<WP>();
 }
 
 // Lawson-Hanson H12: construct (mode 1) / apply (mode 2) a Householder transformation.  u: pivot
@@ -367,7 +442,7 @@ __device__ inline int w_nnls(WP a, int mda, int m, int n, WP b, WP x, double &rn
                 double cand = 0.0;
                 if (lane < cnt) cand = w[indx[iz1 - 1 + lane] - 1];
                 for (int t = 0; t < cnt; ++t) {
-                    const double wv = __shfl(cand, t, 64);
+                    const double wv = w_lane_read(cand, t);
                     if (wv <= wmax) continue;
                     wmax = wv;
                     izmax = iz1 + t;
@@ -384,14 +459,16 @@ __device__ inline int w_nnls(WP a, int mda, int m, int n, WP b, WP x, double &rn
             j = indx[iz - 1];
             // step five
             const double asave = WA(npp1, j);
-            w_h12(1, npp1, npp1 + 1, m, a + (j - 1) * mda, 1, up, z, 1, 1, 0);
-            const double unorm = w_nrm2(nsetp, a + (j - 1) * mda, 1);
+            if constexpr (wp_coop<WP>::value) w_h12_all(1, npp1, npp1 + 1, m, a + (j - 1) * mda, up, z, 0);
+            else w_h12(1, npp1, npp1 + 1, m, a + (j - 1) * mda, 1, up, z, 1, 1, 0);
+            const double unorm = w_nrm2_all(nsetp, a + (j - 1) * mda, 1);
             const double t = factor * __builtin_fabs(WA(npp1, j));
             const double d1 = unorm + t;
             if (d1 - unorm > 0.0) {
                 W_EACH(i, m) z[i] = b[i];
                 w_sync<WP>();
-                w_h12(2, npp1, npp1 + 1, m, a + (j - 1) * mda, 1, up, z, 1, 1, 1);
+                if constexpr (wp_coop<WP>::value) w_h12_all(2, npp1, npp1 + 1, m, a + (j - 1) * mda, up, z, 1);
+                else w_h12(2, npp1, npp1 + 1, m, a + (j - 1) * mda, 1, up, z, 1, 1, 1);
                 if (z[npp1 - 1] / WA(npp1, j) > 0.0) found = true;
             }
             if (found) {
@@ -438,6 +515,22 @@ __device__ inline int w_nnls(WP a, int mda, int m, int n, WP b, WP x, double &rn
             if (iter > itmax) { mode = 3; finished = true; break; }
             double alpha = 1.0;
             jj = 0;
+            if constexpr (wp_coop<WP>::value) {  // (the quotients a position per lane, the comparisons in order from lane reads)
+                const int lane = (int)(threadIdx.x & 63u);
+                double zq = 1.0, tq = 0.0;
+                if (lane < nsetp) {
+                    zq = z[lane];
+                    const double xl = x[indx[lane] - 1];
+                    tq = -xl / (zq - xl);
+                }
+                for (int ip = 1; ip <= nsetp; ++ip) {
+                    if (w_lane_read(zq, ip - 1) > 0.0) continue;
+                    const double t = w_lane_read(tq, ip - 1);
+                    if (alpha < t) continue;
+                    alpha = t;
+                    jj = ip;
+                }
+            } else
             for (int ip = 1; ip <= nsetp; ++ip) {
                 if (z[ip - 1] > 0.0) continue;
                 const int l = indx[ip - 1];
@@ -520,7 +613,7 @@ __device__ inline int w_nnls(WP a, int mda, int m, int n, WP b, WP x, double &rn
     }
     {
         const int k = (npp1 < m) ? npp1 : m;
-        rnorm = w_nrm2(m - nsetp, b + (k - 1), 1);
+        rnorm = w_nrm2_all(m - nsetp, b + (k - 1), 1);
         if (npp1 > m) for (int i = 0; i < n; ++i) w[i] = 0.0;
     }
     return mode;
