@@ -1208,13 +1208,21 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     long long lanes = (resident + cap - 1) / cap;
     if (lanes < 1) lanes = 1;
     if (lanes > per_wave_max) lanes = per_wave_max;
-    // (experiments: OPTIK_WIDE_FORM=lds keeps a wide chain's launches at one restart per wave -- the LDS form
-    // of the general solver -- whatever their size; =hbm never uses it)
+    // The general solver's two forms (ik_wide.hpp): one restart per wave with its arrays in LDS and the wave's 64
+    // lanes working on it together, or a restart per lane with the HBM workspace.  The first has the shorter
+    // dependent chain and no HBM traffic, the second 64 times the restarts in flight: measured (tools/
+    // wide_chain_bench.py, 262 144 restarts) the cooperative form is also the faster THROUGHPUT path from 12
+    // joints up (0.45 against 0.42 M restarts/s at 12, 0.70 against 0.40 M at 16; 0.71 / 0.48 against 1.05 / 0.67 M
+    // at 9 / 10), and a launch on the HBM form takes ~100 ms whatever its size -- so below 12 joints it is used up to
+    // ~49 000 restarts.  OPTIK_WIDE_FORM=lds / hbm forces one.
+    bool wide_lds = false;
     if (widek) {
+        wide_lds = ch->n >= 12 || resident <= 49152;
         if (const char *e = std::getenv("OPTIK_WIDE_FORM")) {
-            if (std::strcmp(e, "lds") == 0) lanes = 1;
-            else if (std::strcmp(e, "hbm") == 0 && lanes == 1) lanes = 2;
+            if (std::strcmp(e, "lds") == 0) wide_lds = true;
+            else if (std::strcmp(e, "hbm") == 0) wide_lds = false;
         }
+        if (wide_lds) lanes = 1;
     }
     a.wq.lanes = (int)lanes;
     long long grid_ll = (resident + lanes - 1) / lanes;
@@ -1231,7 +1239,7 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         // 9 .. 16 joint positions: one restart per lane on the general kernel, eight waves per CU, every
         // resident wave with its own block of the restart workspace (ik_wide.hpp)
         // (one restart per wave -- a single ik() call's rounds --: the restart's arrays in the wave's LDS)
-        const bool lds_form = lanes == 1;
+        const bool lds_form = wide_lds;
         if (!lds_form && (size_t)grid > ch->wide_ws_waves) {
             if (ch->wide_ws) HIP_TRY(hipFree(ch->wide_ws));
             ch->wide_ws = nullptr; ch->wide_ws_waves = 0;

@@ -95,7 +95,7 @@ def test_fk_and_jacobian_bit_exact(dev, oracle, chains, hip_chains, robot):
 @pytest.mark.parametrize("robot,tol_f", [("arm9", 1e-6), ("arm10", 1e-8), ("arm12", 1e-10), ("arm16", 1e-8)])
 @pytest.mark.parametrize("mode", ["speed", "quality"])
 @pytest.mark.parametrize("form", ["lds", "hbm"])
-def test_every_restart_bit_exact(dev, oracle, chains, hip_chains, robot, tol_f, mode, form):
+def test_every_restart_bit_exact(dev, oracle, chains, hip_chains, robot, tol_f, mode, form, monkeypatch):
     """Two targets, restarts 0..R-1 each: status, evaluation count, returned x and f of EVERY restart
     equal the oracle's, and so does the selected winner (Speed: lowest index; Quality: nearest the seed).
     Both forms of the general solver: one restart per wave with its arrays in LDS (launches that leave
@@ -104,6 +104,7 @@ def test_every_restart_bit_exact(dev, oracle, chains, hip_chains, robot, tol_f, 
     d, ch = chains[robot]
     rng = np.random.default_rng(11)
     T, R = 2, {"lds": 500, "hbm": 2600}[form]
+    monkeypatch.setenv("OPTIK_WIDE_FORM", form)  # (the scheduler would pick the cooperative LDS form for both sizes)
     tg, x0 = make_targets(oracle, d, ch, rng, T)
     kw = dict(solution_mode=mode, tol_f=tol_f)
     out = hip_chains[robot].ik_batch(nat.make_config(**kw), torch.tensor(tg, device="cuda"),
@@ -345,10 +346,12 @@ def test_general_solver_equals_the_tuned_solvers(dev, oracle, chains, robot, R, 
     tuned = hc.ik_batch(cfg, tgd, x0d, 0, R)
     torch.cuda.synchronize()
     monkeypatch.setenv("OPTIK_SOLVE_KERNEL", "general")
+    monkeypatch.setenv("OPTIK_WIDE_FORM", "lds" if R <= 2048 else "hbm")
     general = hc.ik_batch(cfg, tgd, x0d, 0, R)
     torch.cuda.synchronize()
     assert (hc.last_launch()["lds_bytes"] > 8192) == (R <= 2048)  # the LDS form / the HBM workspace
     monkeypatch.delenv("OPTIK_SOLVE_KERNEL")
+    monkeypatch.delenv("OPTIK_WIDE_FORM")
     for k in ("status", "evals", "win_idx"):
         assert torch.equal(tuned[k], general[k]), k
     for k in ("x", "f", "win_x", "win_f", "win_key"):

@@ -62,12 +62,16 @@ def main():
         early = kw["solution_mode"] == "speed" and rng.random() < 0.5
         if small:
             os.environ["OPTIK_SOLVE_KERNEL"] = "general"
+        forced = str(rng.choice(["", "", "lds", "hbm"]))  # (the scheduler's own choice, or one of the two forms)
+        if forced:
+            os.environ["OPTIK_WIDE_FORM"] = forced
         try:
             out = hc.ik_batch(nat.make_config(**kw), torch.tensor(tg, device="cuda"), torch.tensor(x0, device="cuda"),
                               begin, begin + R, flags=nat.IK_EARLY_EXIT if early else 0, ee_offset7=ee_off)
             torch.cuda.synchronize()
         finally:
             os.environ.pop("OPTIK_SOLVE_KERNEL", None)
+            os.environ.pop("OPTIK_WIDE_FORM", None)
         form = "lds" if hc.last_launch()["lds_bytes"] > 8192 else "hbm"
         ok = True
         st = out["status"].cpu().numpy().reshape(T, R)
