@@ -1213,11 +1213,12 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     // dependent chain and no HBM traffic, the second 64 times the restarts in flight: measured (tools/
     // wide_chain_bench.py, 262 144 restarts) the cooperative form is also the faster THROUGHPUT path from 12
     // joints up (0.45 against 0.42 M restarts/s at 12, 0.70 against 0.40 M at 16; 0.71 / 0.48 against 1.05 / 0.67 M
-    // at 9 / 10), and a launch on the HBM form takes ~100 ms whatever its size -- so below 12 joints it is used up to
-    // ~49 000 restarts.  OPTIK_WIDE_FORM=lds / hbm forces one.
+    // at 9 / 10), and a launch on the HBM form takes 50 - 100 ms however small it is (9 joints: 4 096 restarts 9.5 against
+    // 50 ms, 65 536: 95 against 124 ms, 131 072: 187 against 161 ms) -- so below 12 joints it is used up to 98 304
+    // restarts.  OPTIK_WIDE_FORM=lds / hbm forces one.
     bool wide_lds = false;
     if (widek) {
-        wide_lds = ch->n >= 12 || resident <= 49152;
+        wide_lds = ch->n >= 12 || resident <= 98304;
         if (const char *e = std::getenv("OPTIK_WIDE_FORM")) {
             if (std::strcmp(e, "lds") == 0) wide_lds = true;
             else if (std::strcmp(e, "hbm") == 0) wide_lds = false;
