@@ -534,8 +534,9 @@ def main():
             achieved = out_bytes * per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
             kname = {"coop": "ik_coop_kernel", "lane": "ik_solve_kernel"}.get(os.environ.get("OPTIK_SOLVE_KERNEL", ""),
                                                                                 "ik_quad_kernel")
-            if n > 8:
-                kname = "wide_solve_kernel"  # (its restart state lives in an HBM workspace: DESIGN.md section 5.6)
+            wide_hbm = n > 8 and os.environ.get("OPTIK_WIDE_FORM", "") == "hbm"
+            if n > 8:  # the general solver: a restart per wave in LDS, or per lane in an HBM workspace
+                kname = "wide_solve_kernel" if wide_hbm else "wide_solve_coop_kernel"
             kp = (pmc or {}).get("kernel_path")
             traffic, traffic_note, secondary = None, f"no PMC pass of this command under profiles/ (key: {key})", None
             if kp:
@@ -545,14 +546,14 @@ def main():
                                 f"{kp['hbm_bytes_per_restart']:.0f} B per restart at the fabric counters against "
                                 f"{out_bytes} B of outputs -- the difference is the kernel's few register spills (scratch: "
                                 "per-wave private memory) and the targets / launch parameters it re-reads, not restart state")
-                if n > 8:
-                    # the general solver streams a restart's whole SLSQP state through its HBM workspace: the fabric
+                if wide_hbm:
+                    # the general solver's HBM form streams a restart's whole SLSQP state through its workspace: the fabric
                     # bytes ARE the path's traffic, and they -- not the 8n + 24 output bytes -- are what it is bound by
                     gbps = kp["hbm_bytes_per_restart"] * total / elapsed / 1e9
                     traffic_note = (f"{os.path.relpath(PMC_FILE, ROOT)}: separate FETCH_SIZE / WRITE_SIZE passes of this command "
                                     f"(2 x FETCH + WRITE), the {kp['launches']} launches of the timed repetitions: "
                                     f"{kp['hbm_bytes_per_restart'] / 1e6:.2f} MB per restart at the fabric counters -- the restart "
-                                    f"state of the general solver lives in an HBM workspace (DESIGN.md section 5.6): "
+                                    f"state of the general solver's HBM form lives in an HBM workspace (DESIGN.md section 5.6): "
                                     f"{gbps:.0f} GB/s = {gbps / HBM_PEAK_GBS:.2f} of the HBM peak at this line's rate")
                 tf = total / elapsed * kp["f64_flops_per_restart"] / 1e12
                 secondary = {"bound": "valu_f64", "achieved": tf, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",

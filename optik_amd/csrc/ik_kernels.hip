@@ -1209,16 +1209,14 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     if (lanes < 1) lanes = 1;
     if (lanes > per_wave_max) lanes = per_wave_max;
     // The general solver's two forms (ik_wide.hpp): one restart per wave with its arrays in LDS and the wave's 64
-    // lanes working on it together, or a restart per lane with the HBM workspace.  The first has the shorter
-    // dependent chain and no HBM traffic, the second 64 times the restarts in flight: measured (tools/
-    // wide_chain_bench.py, 262 144 restarts) the cooperative form is also the faster THROUGHPUT path from 12
-    // joints up (0.45 against 0.42 M restarts/s at 12, 0.70 against 0.40 M at 16; 0.71 / 0.48 against 1.05 / 0.67 M
-    // at 9 / 10), and a launch on the HBM form takes 50 - 100 ms however small it is (9 joints: 4 096 restarts 9.5 against
-    // 50 ms, 65 536: 95 against 124 ms, 131 072: 187 against 161 ms) -- so below 12 joints it is used up to 98 304
-    // restarts.  OPTIK_WIDE_FORM=lds / hbm forces one.
+    // lanes working on it together, or a restart per lane with the HBM workspace.  The first has the short
+    // dependent chain and no HBM traffic, the second 64 times the restarts in flight -- and the first wins at
+    // every size and joint count measured (tools/wide_chain_bench.py, 262 144 restarts: 1.31 / 0.88 / 0.83 / 1.26 M
+    // restarts/s at 9 / 10 / 12 / 16 joints against 1.05 / 0.66 / 0.42 / 0.40 M; a launch on the HBM form takes
+    // 50 - 100 ms however small it is).  OPTIK_WIDE_FORM=hbm selects the HBM form (tests, comparisons).
     bool wide_lds = false;
     if (widek) {
-        wide_lds = ch->n >= 12 || resident <= 98304;
+        wide_lds = true;
         if (const char *e = std::getenv("OPTIK_WIDE_FORM")) {
             if (std::strcmp(e, "lds") == 0) wide_lds = true;
             else if (std::strcmp(e, "hbm") == 0) wide_lds = false;

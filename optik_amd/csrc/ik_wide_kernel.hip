@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64) void wide_solve_lds_kernel(const WideSolveLaunc
 }
 
 // The same with the wave's 64 lanes working on the restart together (WPC): the default latency form.
-__global__ __launch_bounds__(64) void wide_solve_coop_kernel(const WideSolveLaunch a) {
+__global__ __launch_bounds__(64, 2) void wide_solve_coop_kernel(const WideSolveLaunch a) {
     __shared__ WideChainDev sch;
     __shared__ double ws_lds[wide_ws::SLOTS];
     stage_wide_chain(sch, a.chain);
