@@ -116,10 +116,8 @@ size_t wide_ws_doubles_per_wave() { return (size_t)wide_ws::SLOTS * 64; }
 
 hipError_t wide_solve_launch(int grid, hipStream_t stream, const WideSolveLaunch &a, bool lds_form) {
     // (OPTIK_WIDE_LDS_COOP=0: the one-lane LDS form instead of the cooperative one)
-    static const bool lds_coop = [] {
-        const char *e = getenv("OPTIK_WIDE_LDS_COOP");
-        return !(e && atoi(e) == 0);
-    }();
+    const char *e_coop = getenv("OPTIK_WIDE_LDS_COOP");
+    const bool lds_coop = !(e_coop && atoi(e_coop) == 0);
     if (lds_form && lds_coop) hipLaunchKernelGGL(wide_solve_coop_kernel, dim3(grid), dim3(64), 0, stream, a);
     else if (lds_form) hipLaunchKernelGGL(wide_solve_lds_kernel, dim3(grid), dim3(64), 0, stream, a);
     else hipLaunchKernelGGL(wide_solve_kernel, dim3(grid), dim3(64), 0, stream, a);

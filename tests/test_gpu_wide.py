@@ -94,7 +94,7 @@ def test_fk_and_jacobian_bit_exact(dev, oracle, chains, hip_chains, robot):
 
 @pytest.mark.parametrize("robot,tol_f", [("arm9", 1e-6), ("arm10", 1e-8), ("arm12", 1e-10), ("arm16", 1e-8)])
 @pytest.mark.parametrize("mode", ["speed", "quality"])
-@pytest.mark.parametrize("form", ["lds", "hbm"])
+@pytest.mark.parametrize("form", ["lds", "lds_one_lane", "hbm"])
 def test_every_restart_bit_exact(dev, oracle, chains, hip_chains, robot, tol_f, mode, form, monkeypatch):
     """Two targets, restarts 0..R-1 each: status, evaluation count, returned x and f of EVERY restart
     equal the oracle's, and so does the selected winner (Speed: lowest index; Quality: nearest the seed).
@@ -103,14 +103,18 @@ def test_every_restart_bit_exact(dev, oracle, chains, hip_chains, robot, tol_f, 
     from optik_amd import _native as nat
     d, ch = chains[robot]
     rng = np.random.default_rng(11)
-    T, R = 2, {"lds": 500, "hbm": 2600}[form]
-    monkeypatch.setenv("OPTIK_WIDE_FORM", form)  # (the scheduler would pick the cooperative LDS form for both sizes)
+    T, R = 2, {"lds": 500, "lds_one_lane": 300, "hbm": 2600}[form]
+    # (the scheduler picks the cooperative LDS form: the wave's 64 lanes on its one restart; "lds_one_lane" is the
+    # same layout with one lane doing all the work, "hbm" a restart per lane with the HBM workspace)
+    monkeypatch.setenv("OPTIK_WIDE_FORM", "hbm" if form == "hbm" else "lds")
+    if form == "lds_one_lane":
+        monkeypatch.setenv("OPTIK_WIDE_LDS_COOP", "0")
     tg, x0 = make_targets(oracle, d, ch, rng, T)
     kw = dict(solution_mode=mode, tol_f=tol_f)
     out = hip_chains[robot].ik_batch(nat.make_config(**kw), torch.tensor(tg, device="cuda"),
                                      torch.tensor(x0, device="cuda"), 0, R)
     torch.cuda.synchronize()
-    assert (hip_chains[robot].last_launch()["lds_bytes"] > 8192) == (form == "lds")
+    assert (hip_chains[robot].last_launch()["lds_bytes"] > 8192) == (form != "hbm")
     st = out["status"].cpu().numpy().reshape(T, R)
     ev = out["evals"].cpu().numpy().reshape(T, R)
     fs = out["f"].cpu().numpy().reshape(T, R)
