@@ -718,15 +718,26 @@ __device__ inline int w_lsq_box(int n, WP ws, WP l, WP g, WP xl, WP xu, WP s) {
     for (int i = 0; i < n * n; ++i) E[i] = 0.0;
 #endif
     // recover matrix E and vector f from L and g
-    int i2 = 0;
-    for (int i = 0; i < n; ++i) {
-        const int i1 = n - i;
-        const double diag = __builtin_sqrt(l[i2]);
-        W_EACH(k, i1) E[(i + k) * n + i] = l[i2 + k] * diag;  // row i of E
+    if constexpr (wp_coop<WP>::value) {
+        // (the rows of E are independent: a row per lane; only f's forward substitution is a chain)
+        W_EACH(i, n) {
+            const int ii = i * n - (i * (i - 1)) / 2;  // index of l(i, i) in the packed factor
+            const double diag = __builtin_sqrt(l[ii]);
+            for (int k = 1; k < n - i; ++k) E[(i + k) * n + i] = l[ii + k] * diag;
+            E[i * n + i] = diag;
+        }
         w_sync<WP>();
-        E[i * n + i] = diag;
-        f[i] = (g[i] - w_dot_all(i, E + i * n, 1, f, 1)) / diag;
-        i2 += i1;
+        for (int i = 0; i < n; ++i) f[i] = (g[i] - w_dot_all(i, E + i * n, 1, f, 1)) / E[i * n + i];
+    } else {
+        int i2 = 0;
+        for (int i = 0; i < n; ++i) {
+            const int i1 = n - i;
+            const double diag = __builtin_sqrt(l[i2]);
+            for (int k = 0; k < i1; ++k) E[(i + k) * n + i] = l[i2 + k] * diag;  // row i of E
+            E[i * n + i] = diag;
+            f[i] = (g[i] - w_dot(i, E + i * n, 1, f, 1)) / diag;
+            i2 += i1;
+        }
     }
     W_EACH(i, n) f[i] = -f[i];
     w_sync<WP>();
@@ -746,8 +757,9 @@ __device__ inline int w_lsq_box(int n, WP ws, WP l, WP g, WP xl, WP xu, WP s) {
 #define WGT(i, j) G[((j) - 1) * n + ((i) - 1)]  // top half of the transformed G, n x n
     W_EACH(i, n) { h[i] = xl[i]; h[n + i] = -xu[i]; }
     w_sync<WP>();
-    // LSI: QR factors of E and application to f (H12 with lpivot = i, l1 = i + 1, m = n; i = n: l1 > m, no-op)
-    for (int i = 1; i < n; ++i) {
+    // LSI: QR factors of E and application to f (H12 with lpivot = i, l1 = i + 1, m = n; i = n: l1 > m, no-op).
+    // (E is upper triangular: reflection i touches row i of E and f(i) only -- in WPC a reflection per lane)
+    for (int i = 1 + w_first<WP>(); i < n; i += w_step<WP>()) {
         const double eii = WE(i, i);
         double cl = __builtin_fabs(eii);
         if (cl <= 0.0) continue;  // (mode 1 leaves the column alone; mode 2 finds the same zero pivot)
@@ -761,17 +773,7 @@ __device__ inline int w_lsq_box(int n, WP ws, WP l, WP g, WP xl, WP xu, WP s) {
         double b = up * cl;
         if (b >= 0.0) continue;  // (both applications return)
         b = 1.0 / b;
-        w_sync<WP>();
-        int col = i + 1 + w_first<WP>();
-        if constexpr (wp_coop<WP>::value) {
-            for (; col <= n; col += w_step<WP>()) {  // row i of the later columns, a column per lane
-                const double ci = WE(i, col);
-                double sm = ci * up;
-                if (sm == 0.0) continue;
-                sm *= b;
-                WE(i, col) = ci + sm * up;
-            }
-        }
+        int col = i + 1;
         for (; col + 3 <= n; col += 4) {  // row i of four columns at a time
             double ci[4];
 #pragma unroll
@@ -799,8 +801,8 @@ __device__ inline int w_lsq_box(int n, WP ws, WP l, WP g, WP xl, WP xu, WP s) {
                 f[i - 1] = fi + sm * up;
             }
         }
-        w_sync<WP>();
     }
+    w_sync<WP>();
     // transform G and h to get the least distance problem: rows 1 .. n (row n + i is row i negated)
     for (int j = 1; j <= n; ++j)
         if (!(__builtin_fabs(WE(j, j)) >= EPMACH)) return 5;
