@@ -910,6 +910,59 @@ __device__ inline int w_lsq_box(int n, WP ws, WP l, WP g, WP xl, WP xu, WP s) {
 template <class WP>
 __device__ inline void w_ldl_update(int n, WP a, WP z, double sigma, WP w) {
     if (sigma == 0.0) return;
+    if constexpr (wp_coop<WP>::value) {
+        // WPC: lane j keeps z(j) (and w(j)) in a register and owns row j's share of every pivot's update; the
+        // pivot's v = z(i) and the diagonal l(i, i) -- which only its own pivot changes -- come by lane read.  No
+        // LDS round trip and no barrier on the pivot-to-pivot chain; the same operations on the same operands.
+        const int lane = (int)(threadIdx.x & 63u);
+        const bool mine = lane < n;
+        double zr = mine ? (double)z[lane] : 0.0;
+        double dr = mine ? (double)a[lane * n - (lane * (lane - 1)) / 2] : 1.0;
+        double wr = 0.0;
+        double t = 1.0 / sigma;
+        if (sigma < 0.0) {
+            wr = zr;
+            for (int i = 0; i < n; ++i) {
+                const double v = w_lane_read(wr, i);
+                t += v * v / w_lane_read(dr, i);
+                if (mine && lane > i) wr -= v * a[i * n - (i * (i - 1)) / 2 + (lane - i)];
+            }
+            if (t >= 0.0) t = EPMACH / sigma;
+            for (int i = 0; i < n; ++i) {
+                const int j = n - 1 - i;
+                const double u = w_lane_read(wr, j);
+                if (lane == j) wr = t;
+                t -= u * u / w_lane_read(dr, j);
+            }
+        }
+        for (int i = 0; i < n; ++i) {
+            const int di = i * n - (i * (i - 1)) / 2;
+            const double v = w_lane_read(zr, i);
+            const double aii = w_lane_read(dr, i);
+            const double delta = v / aii;
+            const double tp = (sigma < 0.0) ? w_lane_read(wr, i) : t + delta * v;
+            const double alpha = tp / t;
+            if (lane == i) a[di] = alpha * aii;
+            if (i == n - 1) break;
+            const double beta = delta / tp;
+            if (alpha > 4.0) {
+                const double gamma = t / tp;
+                if (mine && lane > i) {
+                    const double u = a[di + (lane - i)];
+                    a[di + (lane - i)] = gamma * u + beta * zr;
+                    zr -= v * u;
+                }
+            } else {
+                if (mine && lane > i) {
+                    zr -= v * a[di + (lane - i)];
+                    a[di + (lane - i)] += beta * zr;
+                }
+            }
+            t = tp;
+        }
+        w_sync<WP>();
+        return;
+    }
     int ij = 0;
     double t = 1.0 / sigma;
     if (sigma < 0.0) {
