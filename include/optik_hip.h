@@ -81,8 +81,9 @@ const char *optik_hip_last_error(void);
  * an optional trailing fixed joint (what from_urdf's folding produces).  n <= 8 runs on the
  * tuned solvers (the streaming engine covers n <= 7, an 8-DoF chain's engine jobs run on the
  * quad solver); 9 <= n <= 16 runs on one general kernel per entry point (joint count at run
- * time, restart state in an HBM workspace: the same results as the CPU oracle bit for bit, a
- * fraction of the tuned solvers' rate) -- the reference itself has no limit
+ * time; the solver keeps one restart per wave in LDS with the wave's 64 lanes working on it
+ * together: the same results as the CPU oracle bit for bit, a fraction of the tuned solvers'
+ * rate) -- the reference itself has no limit
  * (kinematics.rs:107-110).  Prismatic joints (n <= 8): forward kinematics only (the reference's
  * Jacobian is todo!(), kinematics.rs:185). */
 int optik_hip_chain_create(const double *origins, const double *axes, const int32_t *types,
