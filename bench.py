@@ -258,6 +258,9 @@ def main():
                          "together share the slot pool); kernel: one persistent solve kernel per step; "
                          "auto (default) = engine, except Speed batches of --targets (kernel, as "
                          "Robot.ik_batch does); results are identical")
+    ap.add_argument("--force-distributed", action="store_true",
+                    help="run the process-group path (init_process_group, the min / sum / max all-reduces, "
+                         "all_gather_object) even with ONE rank: RCCL on a single GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -282,7 +285,15 @@ def main():
     if args.gpus is not None and args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to print a "
                          f"line whose n_gpus is not the number of ranks that ran")
-    distributed = world > 1
+    distributed = world > 1 or args.force_distributed
+    if distributed and env_world is None:
+        # one rank without a launcher: the rendezvous a launcher would have set up
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        os.environ.setdefault("MASTER_PORT", str(s_.getsockname()[1]))
+        s_.close()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: optik_amd has no CPU fallback")
     # OPTIK_BENCH_BACKEND=gloo + OPTIK_BENCH_ONE_DEVICE=1 exercise the multi-rank path on a
@@ -311,7 +322,7 @@ def main():
         backend_name = None
 
     from optik_amd import _native as nat
-    from optik_amd.parallel import shard_range, select_winner
+    from optik_amd.parallel import shard_range, select_winner, gather_winner_x
 
     robot = load_chain(args.robot)
     hc = robot.hip_chain(dev)
@@ -356,9 +367,22 @@ def main():
     # selected (and, with several ranks, reduced) in one piece without gathering them first
     win_idx_all = torch.zeros((n_buf, T_loc), dtype=torch.int64, device=dev)
     win_key_all = torch.zeros((n_buf, T_loc), dtype=torch.float64, device=dev)
+    win_x_all = torch.zeros((n_buf, T_loc, n), dtype=torch.float64, device=dev)
+    win_f_all = torch.zeros((n_buf, T_loc), dtype=torch.float64, device=dev)
     for k, b in enumerate(bufs):
         b["win_idx"] = win_idx_all[k]
         b["win_key"] = win_key_all[k]
+        b["win_x"] = win_x_all[k]
+        b["win_f"] = win_f_all[k]
+    win_xf = {}  # the global winners' x and f of the last run (every rank holds them, as Robot::ik returns them)
+
+    def exchange(rec, count):
+        """The cross-rank half of a step (lib.rs:397-413 over the ranks): two 8-byte min-all-reduces pick the
+        winner, a sum-all-reduce of <= 64 B per target hands its x and f to every rank."""
+        win = select_winner(rec, mode, distributed)
+        if distributed:
+            win_xf["x"], win_xf["f"] = gather_winner_x(rec, win, begin, end, True)
+        return win
     if args.path == "engine":
         hc.engine_reserve()  # the slot pool: allocated with the other buffers, not inside a run
     # plumbing first-use costs (torch's lazily loaded elementwise kernels, the communicator of the
@@ -381,20 +405,23 @@ def main():
                     hc.engine_submit(cfg, targets[i:i + T_loc], x0[i:i + T_loc], begin, end, flags=flags,
                                      bufs=bufs[k])
                 hc.engine_run()
-            stacked = {"win_idx": win_idx_all[:count].reshape(-1), "win_key": win_key_all[:count].reshape(-1)}
+            stacked = {"win_idx": win_idx_all[:count].reshape(-1), "win_key": win_key_all[:count].reshape(-1),
+                       "win_x": win_x_all[:count].reshape(-1, n), "win_f": win_f_all[:count].reshape(-1)}
             # config 5: every rank owns its targets outright -- no collective
-            return select_winner(stacked, mode, distributed and not T).reshape(count, T_loc)
+            if T:
+                return select_winner(stacked, mode, False).reshape(count, T_loc)
+            return exchange(stacked, count).reshape(count, T_loc)
         if pooled_kernel:
             i = first + t_lo
             kb = kbufs[count]
             hc.ik_batch(cfg, targets[i:i + count], x0[i:i + count], begin, end, flags=flags, bufs=kb, per_restart=True)
-            return select_winner(kb, mode, distributed).clone().reshape(count, 1)
+            return exchange(kb, count).clone().reshape(count, 1)
         winners = []
         for k in range(count):
             i = (first + k) * per_step + t_lo
             hc.ik_batch(cfg, targets[i:i + T_loc], x0[i:i + T_loc], begin, end, flags=flags, bufs=bufs[0],
                         per_restart=not T)
-            winners.append(select_winner(bufs[0], mode, distributed and not T).clone())
+            winners.append((select_winner(bufs[0], mode, False) if T else exchange(bufs[0], 1)).clone())
         return torch.stack(winners)
 
     if W:
@@ -598,6 +625,12 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "command_key": key,
                        "world": world, "backend": backend_name, "rank_devices": rank_devices,
+                       # what the process group executed in every timed repetition (None: no process group)
+                       "collectives": (["barrier", "all_reduce MIN int64 (key)", "all_reduce MIN int64 (index)",
+                                        "all_reduce SUM f64 (winner x)", "all_reduce SUM f64 (winner f)",
+                                        "all_reduce MAX f64 (elapsed)"] if distributed and not T else
+                                       (["barrier", "all_reduce MAX f64 (elapsed)"] if distributed else None)),
+                       "winner_f_last_step": (float(win_xf["f"].reshape(-1)[-1].item()) if win_xf else None),
                        "reps": len(rep_elapsed), "rep_reported": "median",
                        "value_reps": [total / e for e in rep_elapsed],
                        "value_min": total / max(rep_elapsed), "value_max": total / min(rep_elapsed),

@@ -9,6 +9,8 @@ from __future__ import annotations
 import os
 import shutil
 import subprocess
+import time
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -29,23 +31,13 @@ UNITS = [("ik_kernels.hip", "ik_kernels.o", []),
          # chains with 9 .. 16 joint positions: one run-time-n body per kernel (ik_wide.hpp)
          ("ik_wide_kernel.hip", "ik_wide_kernel.o", []),
          ("robot_host.cpp", "robot_host.o", [])]
-HEADERS = ["ik_math.hpp", "ik_eval.hpp", "ik_slsqp.hpp", "ik_solve.hpp", "ik_nnls_coop.hpp", "ik_engine.hpp",
-           "ik_tail.hpp", "ik_coop.hpp", "device_scope.hpp", "ik_host_params.hpp", "ik_launch.hpp",
-           "urdf_chain.hpp", "ik_wide_launch.hpp",
-           os.path.join("..", "..", "include", "optik_hip.h"),
-           os.path.join("..", "..", "include", "optik.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
          "-Wno-unused-value", "-pthread"]
-# headers each translation unit depends on (a source is recompiled when one of them is newer than
-# its object file; the objects are build artefacts, git-ignored like the library)
-QUAD_HEADERS = ["ik_math.hpp", "ik_eval.hpp", "ik_slsqp.hpp", "ik_solve.hpp", "ik_nnls_coop.hpp", "ik_nnls_quad.hpp", "ik_lane.hpp",
-                "ik_quad.hpp", "ik_launch.hpp"]
-WIDE_HEADERS = ["ik_math.hpp", "ik_eval.hpp", "ik_slsqp.hpp", "ik_solve.hpp", "ik_wide_launch.hpp", "ik_wide.hpp"]
-DEPS = {"ik_kernels.hip": HEADERS,
-        "ik_wide_kernel.hip": WIDE_HEADERS,
-        "ik_quad_kernel.hip": QUAD_HEADERS,
-        "robot_host.cpp": ["urdf_chain.hpp", "device_scope.hpp", os.path.join("..", "..", "include", "optik_hip.h"),
-                           os.path.join("..", "..", "include", "optik.h")]}
+# What a translation unit depends on is what the compiler says it read: every object is compiled with
+# -MD and its dependency file (<object>.d) is kept next to it; an object is stale when any file listed
+# there is newer than it, when the list is missing, or when it was compiled with other flags.  (Rounds
+# 1-3 kept the header lists by hand, and they drifted: ik_quad_kernel.hip's list missed ik_quad_tail.hpp
+# and ik_engine.hpp.)
 
 
 def _hipcc():
@@ -55,45 +47,86 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+def _unit_cmd(hipcc, src, objname, extra):
+    sp = os.path.join(CSRC, src)
+    obj = os.path.join(CSRC, objname)
+    return [hipcc, *FLAGS, *extra, "-MD", "-MF", obj + ".d", "-x", "hip", "-c", sp, "-o", obj]
+
+
+def _dep_files(obj):
+    """Prerequisites recorded by -MD for `obj` (None: no record)."""
+    try:
+        text = open(obj + ".d").read()
+    except OSError:
+        return None
+    text = text.replace("\\\n", " ")
+    if ":" not in text:
+        return None
+    return [t for t in text.split(":", 1)[1].split() if t]
+
+
+def _unit_stale(hipcc, src, objname, extra):
+    obj = os.path.join(CSRC, objname)
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    flags_file = obj + ".flags"
+    if not (os.path.exists(flags_file) and open(flags_file).read() == " ".join(_unit_cmd(hipcc, src, objname, extra)[1:])):
+        return True
+    deps = _dep_files(obj)
+    if deps is None:
+        return True
+    for d in deps:
+        d = d if os.path.isabs(d) else os.path.join(CSRC, d)
+        if not os.path.exists(d) or os.path.getmtime(d) > t:
+            return True
+    return False
+
+
 def is_stale() -> bool:
     if not os.path.exists(LIB):
         return True
+    hipcc = _hipcc()
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS + QUAD_HEADERS + WIDE_HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+    for src, objname, extra in UNITS:
+        if _unit_stale(hipcc, src, objname, extra) or os.path.getmtime(os.path.join(CSRC, objname)) > t:
+            return True
+    return os.path.getmtime(os.path.abspath(__file__)) > t
 
 
-def _newer(path, than):
-    return os.path.exists(path) and os.path.getmtime(path) > than
+def _compile(job):
+    cmd, verbose = job
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    t0 = time.perf_counter()
+    subprocess.check_call(cmd, cwd=CSRC)
+    with open(cmd[-1] + ".flags", "w") as fh:
+        fh.write(" ".join(cmd[1:]))
+    return cmd[-1], time.perf_counter() - t0
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -> str:
+    """Compiles the stale translation units (all of them with force) IN PARALLEL and links the library."""
     if not force and not is_stale():
         return LIB
     hipcc = _hipcc()
-    objs = []
-    for src, objname, extra in UNITS:
-        sp = os.path.join(CSRC, src)
-        if not os.path.exists(sp):
-            continue
-        obj = os.path.join(CSRC, objname)
-        t = os.path.getmtime(obj) if os.path.exists(obj) else -1.0
-        deps = [sp] + [os.path.join(CSRC, d) for d in DEPS.get(src, HEADERS)]
-        cmd = [hipcc, *FLAGS, *extra, "-x", "hip", "-c", sp, "-o", obj]
-        # (an object is also stale when it was compiled with other flags: they are kept next to it)
-        flags_file = obj + ".flags"
-        same_flags = os.path.exists(flags_file) and open(flags_file).read() == " ".join(cmd[1:])
-        if force or t < 0 or not same_flags or any(_newer(d, t) for d in deps):
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.check_call(cmd, cwd=CSRC)
-            with open(flags_file, "w") as fh:
-                fh.write(" ".join(cmd[1:]))
-        objs.append(obj)
+    todo = [(_unit_cmd(hipcc, src, objname, extra), verbose) for src, objname, extra in UNITS
+            if force or _unit_stale(hipcc, src, objname, extra)]
+    t0 = time.perf_counter()
+    if todo:
+        workers = max(1, min(len(todo), jobs or (os.cpu_count() or 1)))
+        with ThreadPoolExecutor(workers) as ex:
+            for obj, dt in ex.map(_compile, todo):
+                if verbose:
+                    print(f"  {os.path.basename(obj)}: {dt:.1f} s", flush=True)
+    objs = [os.path.join(CSRC, objname) for _, objname, _ in UNITS]
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", *objs, "-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
+    if verbose:
+        print(f"built {len(todo)} of {len(UNITS)} units + link in {time.perf_counter() - t0:.1f} s "
+              f"({'forced' if force else 'stale units only'})")
     return LIB
 
 

@@ -1302,6 +1302,10 @@ __device__ inline void wide_solve_wave(const WideChainDev &ch, const EvalParams 
                 stop = wq.find_any ? (fs != ~0ull) : (fs < index);
             }
             if (wq.deadline && (unsigned long long)wall_clock64() > wq.deadline) stop = true;
+            // (cooperative form: the 64 lanes share ONE restart in LDS, but each read first_success / the clock
+            // with its own vector load -- another wave's atomicMin can land between two lane groups of that
+            // load.  Lane 0 decides for the wave, as the quad solver's leader does (ik_quad.hpp: quad_get(ret, 0)))
+            if constexpr (wp_coop<WP>::value) stop = __builtin_amdgcn_readfirstlane((int)stop) != 0;
             if (stop) ret = RES_FORCED_STOP;
         }
         if (active && ret == 0) {

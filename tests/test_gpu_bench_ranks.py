@@ -126,3 +126,31 @@ def test_inprocess_two_devices_reports_two_gpus():
     a, b = _line(one.stdout), _line(two.stdout)
     assert b["n_gpus"] == 2 and b["config"]["inprocess"] and b["config"]["devices"] == [0, 0]
     assert a["config"]["winner_index_per_step"] == b["config"]["winner_index_per_step"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("launcher", ["plain", "torchrun"])
+def test_one_rank_goes_through_rccl(launcher):
+    """The process-group path on the real backend: ONE rank, backend nccl (= RCCL on ROCm) --
+    init_process_group(device_id=...), all_gather_object, the int64 MIN / f64 SUM / f64 MAX all-reduces on
+    device tensors and the barriers all execute on the GPU, and the winners are those of the plain run."""
+    common = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--reps", "2", "--restarts", "4096"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "OPTIK_BENCH_BACKEND")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    plain = subprocess.run([sys.executable, "bench.py", *common], cwd=ROOT, env=env, capture_output=True, text=True,
+                           timeout=600)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    if launcher == "plain":
+        cmd = [sys.executable, "bench.py", "--force-distributed", *common]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+               "127.0.0.1", "--master-port", str(_port()), "bench.py", "--gpus", "1", "--force-distributed", *common]
+    one = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    a, b = _line(plain.stdout), _line(one.stdout)
+    assert a["config"]["backend"] is None and a["config"]["collectives"] is None
+    assert b["n_gpus"] == 1 and b["config"]["world"] == 1 and b["config"]["backend"] == "nccl"
+    assert len(b["config"]["collectives"]) == 6
+    assert b["config"]["winner_index_per_step"] == a["config"]["winner_index_per_step"]
+    assert b["config"]["winner_f_last_step"] is not None and 0.0 <= b["config"]["winner_f_last_step"] < 1e-6
+    assert b["value"] > 0

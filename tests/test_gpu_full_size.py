@@ -1,6 +1,11 @@
-"""-m gpu: BASELINE.json's full-size configurations, checked through size-independent
-properties (the oracle would take minutes at these sizes; the bit-exact comparison against
-it is done at smaller sizes in test_gpu_parity.py):
+"""-m gpu: BASELINE.json's configurations at their full sizes.
+
+Every restart of config 2 (65 536 Panda restarts, both execution paths), of config 3 (2^20 UR10
+restarts at tol_f = 1e-12) and every target of one GPU's share of config 5 (512 targets x 256
+restarts) is compared with the CPU oracle bit for bit -- status, evaluation count, x, f, winner
+(the oracle runs 20-30 k restarts/s per host thread: a second or two for config 2, well under a
+minute for config 3 on the box's cores).  Config 4 (2^22 restarts, 8 shards) and the properties
+below hold at any size:
 
   * round trip: every restart reported as solved satisfies FK(x) == target to the pose
     tolerance implied by tol_f, and respects the joint limits;
@@ -16,6 +21,7 @@ import numpy as np
 import pytest
 
 from conftest import ROBOTS
+from gpu_util import assert_bit_equal
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -55,6 +61,111 @@ def _pose_error(hc, x, target7):
     dt = (pose[:3] - t[:3]).abs().amax(0)
     dq = torch.minimum((pose[3:] - t[3:]).abs().amax(0), (pose[3:] + t[3:]).abs().amax(0))
     return torch.maximum(dt, dq)
+
+
+def _threads():
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return max(1, os.cpu_count() or 1)
+
+
+def _assert_every_restart_equals_oracle(out, ref, what):
+    status = out["status"].cpu().numpy()
+    assert np.array_equal(status, ref["status"]), (what, np.argwhere(status != ref["status"])[:10])
+    assert np.array_equal(out["evals"].cpu().numpy(), ref["evals"]), what
+    assert_bit_equal(out["f"].cpu().numpy(), ref["fs"], what + ": per-restart f")
+    assert_bit_equal(out["x"].cpu().numpy(), ref["xs"].T, what + ": per-restart x")
+
+
+@pytest.mark.parametrize("path", ["kernel", "engine"])
+def test_config2_every_restart_equals_oracle(robots, oracle, chains, path):
+    """Config 2 at its own size: all 65 536 Panda restarts of the headline workload -- status,
+    evaluation count, x, f -- and the Speed winner against the oracle, on both execution paths
+    (lib.rs:297-413; the reference's own check of this shape is tests/test_ik.rs:91-130)."""
+    from optik_amd import _native as nat
+    robot = robots["panda"]
+    hc = robot.hip_chain("cuda:0")
+    tg, x0, lb, ub = _targets(robot, hc, 1, 0)
+    R = 65536
+    cfg = nat.make_config("speed", tol_f=1e-6)
+    if path == "kernel":
+        out = hc.ik_batch(cfg, tg, x0, 0, R)
+    else:
+        out = hc.engine_submit(cfg, tg, x0, 0, R)
+        hc.engine_run()
+    torch.cuda.synchronize()
+    _, ch = chains["panda"]
+    ref = oracle.ik(ch, oracle.make_config(solution_mode="speed", tol_f=1e-6), tg[0].cpu().numpy(), x0[0].cpu().numpy(),
+                    0, R, n_threads=_threads(), early_exit=False, per_restart=True)
+    _assert_every_restart_equals_oracle(out, ref, "config 2, " + path)
+    assert ref["found"] and int(out["win_idx"][0]) == ref["winner"]
+    assert_bit_equal(out["win_x"].cpu().numpy()[0], ref["x"], "winner x")
+    assert_bit_equal(out["win_f"].cpu().numpy(), [ref["f"]], "winner f")
+
+
+def test_config3_every_restart_equals_oracle(robots, oracle, chains):
+    """Config 3 at its own size: 2^20 UR10 restarts at tol_f = 1e-12, Quality -- every restart and the
+    winner (the solved restart closest to the seed) against the oracle."""
+    from optik_amd import _native as nat
+    robot = robots["ur10"]
+    hc = robot.hip_chain("cuda:0")
+    tg, x0, lb, ub = _targets(robot, hc, 1, 3)
+    R = 1 << 20
+    out = hc.engine_submit(nat.make_config("quality", tol_f=1e-12), tg, x0, 0, R)
+    hc.engine_run()
+    torch.cuda.synchronize()
+    _, ch = chains["ur10"]
+    ref = oracle.ik(ch, oracle.make_config(solution_mode="quality", tol_f=1e-12), tg[0].cpu().numpy(),
+                    x0[0].cpu().numpy(), 0, R, n_threads=_threads(), early_exit=False, per_restart=True)
+    _assert_every_restart_equals_oracle(out, ref, "config 3")
+    assert ref["found"] and int(out["win_idx"][0]) == ref["winner"]
+    assert_bit_equal(out["win_x"].cpu().numpy()[0], ref["x"], "winner x")
+    # ... and an eighth of it (one GPU's contiguous index range, section 8e) through the single-launch path
+    g = 5
+    part = hc.ik_batch(nat.make_config("quality", tol_f=1e-12), tg, x0, g * (R // 8), (g + 1) * (R // 8))
+    torch.cuda.synchronize()
+    sl = slice(g * (R // 8), (g + 1) * (R // 8))
+    sub = {k: ref[k][sl] for k in ("status", "evals", "fs", "xs")}
+    _assert_every_restart_equals_oracle(part, sub, "config 3, shard 5 on the kernel path")
+
+
+@pytest.mark.parametrize("path", ["kernel", "engine"])
+def test_config5_share_winners_equal_oracle(robots, oracle, chains, path):
+    """Config 5, one GPU's share (targets 512 .. 1023 of the 4096, 256 restarts each, Speed): the winner
+    index, x and f of EVERY target against the oracle's 1-thread run of that target (lowest solved
+    index: lib.rs:397-413 in the reference's deterministic reading)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from optik_amd import _native as nat
+    robot = robots["panda"]
+    hc = robot.hip_chain("cuda:0")
+    T, R = 4096, 256
+    tg, x0, lb, ub = _targets(robot, hc, T, 5)
+    tg, x0 = tg[512:1024].contiguous(), x0[512:1024].contiguous()
+    cfg = nat.make_config("speed", tol_f=1e-6)
+    if path == "kernel":
+        out = hc.ik_batch(cfg, tg, x0, 0, R, flags=nat.IK_EARLY_EXIT | nat.IK_RESTART_MAJOR, per_restart=False)
+    else:
+        out = hc.engine_submit(cfg, tg, x0, 0, R, flags=nat.IK_EARLY_EXIT, per_restart=False)
+        hc.engine_run()
+    torch.cuda.synchronize()
+    _, ch = chains["panda"]
+    ocfg = oracle.make_config(solution_mode="speed", tol_f=1e-6)
+    tgn, x0n = tg.cpu().numpy(), x0.cpu().numpy()
+
+    def one(t):
+        return oracle.ik(ch, ocfg, tgn[t], x0n[t], 0, R, n_threads=1, early_exit=True)
+
+    with ThreadPoolExecutor(_threads()) as ex:
+        refs = list(ex.map(one, range(len(tgn))))
+    win = out["win_idx"].cpu().numpy()
+    wx, wf = out["win_x"].cpu().numpy(), out["win_f"].cpu().numpy()
+    want = np.array([r["winner"] if r["found"] else -1 for r in refs])
+    assert np.array_equal(win, want), np.argwhere(win != want)[:10]
+    found = want >= 0
+    assert found.mean() > 0.99
+    assert_bit_equal(wx[found], np.array([r["x"] for r in refs])[found], "config 5 winners' x")
+    assert_bit_equal(wf[found], np.array([r["f"] for r in refs])[found], "config 5 winners' f")
 
 
 def test_config2_panda_65536_speed(robots):

@@ -201,6 +201,43 @@ def test_early_exit_speed_winner(dev, oracle, chains, hip_chains):
             assert_bit_equal(wx[t], ref["x"], f"winner x target {t}")
 
 
+def test_early_exit_many_concurrent_writers(dev, oracle, chains, hip_chains):
+    """Stress of the early-exit word under the cooperative form (a restart per wave, 64 lanes sharing its
+    state in LDS): hundreds of targets, each with thousands of restarts in flight whose successes land on
+    first_success concurrently.  The stop decision must be ONE per wave (lane 0's): every published record is
+    then a complete one -- the winner is a solved restart with in-limit joints whose FK meets the target -- and
+    the winners are the same from run to run and equal the no-early-exit run's lowest solved index."""
+    from optik_amd import _native as nat
+    d, ch = chains["arm10"]
+    hc = hip_chains["arm10"]
+    rng = np.random.default_rng(29)
+    T, R = 192, 512
+    tg, x0 = make_targets(oracle, d, ch, rng, T)
+    tgd, x0d = torch.tensor(tg, device="cuda"), torch.tensor(x0, device="cuda")
+    cfg = nat.make_config(solution_mode="speed", tol_f=1e-6)
+    full = hc.ik_batch(cfg, tgd, x0d, 0, R)
+    torch.cuda.synchronize()
+    ok = (full["status"] == nat.RES_STOPVAL).view(T, R)
+    want = torch.where(ok.any(1), ok.double().argmax(1), torch.full((T,), -1, device="cuda"))
+    lb, ub = torch.tensor(d["lb"], device="cuda"), torch.tensor(d["ub"], device="cuda")
+    for flags in (nat.IK_EARLY_EXIT, nat.IK_EARLY_EXIT | nat.IK_RESTART_MAJOR):
+        runs = []
+        for _ in range(3):
+            out = hc.ik_batch(cfg, tgd, x0d, 0, R, flags=flags, per_restart=False)
+            torch.cuda.synchronize()
+            runs.append(out)
+            assert torch.equal(out["win_idx"], want)
+            solved = out["win_idx"] >= 0
+            wx = out["win_x"][solved]
+            assert (wx >= lb).all() and (wx <= ub).all()
+            pose = hc.fk_batch(wx.T.contiguous())
+            t = tgd[solved].T
+            dq = torch.minimum((pose[3:] - t[3:]).abs().amax(0), (pose[3:] + t[3:]).abs().amax(0))
+            assert torch.maximum((pose[:3] - t[:3]).abs().amax(0), dq).max().item() < 2e-3
+            assert (out["win_f"][solved] < 1e-6).all()
+        assert torch.equal(runs[0]["win_x"], runs[1]["win_x"]) and torch.equal(runs[1]["win_x"], runs[2]["win_x"])
+
+
 def test_robot_api_ten_joints(dev, oracle, chains):
     """The reference's own ik property (tests/test_ik.rs:91-130: FK(ik(T)) == T within 1e-6) through the
     host API on a 10-joint URDF; the winning restart is the oracle's and the joint angles agree to 1e-6
