@@ -568,6 +568,10 @@ struct optik_hip_chain {
     double *tmp_x = nullptr, *tmp_f = nullptr, *tmp_key = nullptr;
     size_t tmp_cols = 0;
     unsigned long long *queue = nullptr;  // work-item counter of the in-flight launch
+    // quad solver: suspension slots of the resident waves' straggling sub-problems (ik_nnls_quad.hpp), one set for
+    // optik_hip_ik_batch's launch and one for an engine run's tail (they hold different locks)
+    double *defer = nullptr, *eng_defer = nullptr;
+    size_t defer_waves = 0, eng_defer_waves = 0;
     unsigned long long *prof = nullptr;   // phase timers (OPTIK_PROFILE builds)
     // streaming engine (ik_engine.hpp)
     struct EngineJobHost {
@@ -858,6 +862,8 @@ void optik_hip_chain_destroy(optik_hip_chain *ch) {
     if (ch->tmp_f) hipFree(ch->tmp_f);
     if (ch->tmp_key) hipFree(ch->tmp_key);
     if (ch->queue) hipFree(ch->queue);
+    if (ch->defer) hipFree(ch->defer);
+    if (ch->eng_defer) hipFree(ch->eng_defer);
     if (ch->eng_pool_attached) {  // the slot pool belongs to the device: released with its last user
         EnginePool &P = engine_pool_of(ch);
         std::lock_guard<std::mutex> run(P.run_mu);
@@ -1029,6 +1035,12 @@ int optik_hip_ik_batch(optik_hip_chain *ch, const optik_solver_config *cfg, cons
 }
 
 }  // extern "C"
+
+// OPTIK_QUAD_DEFER=0: every bounded sub-problem of the quad solver runs to its end within its trip (comparisons)
+static bool quad_defer_enabled() {
+    static const bool on = [] { const char *e = std::getenv("OPTIK_QUAD_DEFER"); return !(e && std::atoi(e) == 0); }();
+    return on;
+}
 
 static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, const double *d_targets,
                            const double *d_x0, int32_t T, const double *ee_offset7, uint64_t restart_begin,
@@ -1255,6 +1267,16 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         lds = lds_form ? wide_lds_bytes() : (int)sizeof(WideChainDev);
         HIP_TRY(wide_solve_launch(grid, stream, w, lds_form));
     } else if (quadk) {
+        // (the throughput form may suspend a wave's last few bounded sub-problems of a trip: their slots)
+        if (!quad_latency && lanes >= 4 && quad_defer_enabled()) {
+            if ((size_t)grid > ch->defer_waves) {
+                if (ch->defer) HIP_TRY(hipFree(ch->defer));
+                ch->defer = nullptr; ch->defer_waves = 0;
+                HIP_TRY(hipMalloc(&ch->defer, sizeof(double) * DEFER_WAVE_DOUBLES * (size_t)grid));
+                ch->defer_waves = (size_t)grid;
+            }
+            a.wq.defer = ch->defer;
+        }
         HIP_TRY(quad_solve_launch(ch->n, ch->tip, grid, stream, a, &lds, quad_latency));
     } else if (coop) {
 #define CALL_COOP(NN, TT)                                                                            \
@@ -1979,6 +2001,15 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
                 tq.tail.cursor = reinterpret_cast<unsigned long long *>(t_count + 2);  // (8-byte aligned word of the same scratch)
                 tq.tail.exec_evals = pa0.exec_evals;
                 HIP_TRY(hipMemsetAsync(t_count + 2, 0, sizeof(unsigned long long), stream));
+                if (lq >= 4 && quad_defer_enabled()) {
+                    if ((size_t)gq > ch->eng_defer_waves) {
+                        if (ch->eng_defer) HIP_TRY(hipFree(ch->eng_defer));
+                        ch->eng_defer = nullptr; ch->eng_defer_waves = 0;
+                        HIP_TRY(hipMalloc(&ch->eng_defer, sizeof(double) * DEFER_WAVE_DOUBLES * (size_t)gq));
+                        ch->eng_defer_waves = (size_t)gq;
+                    }
+                    tq.base.wq.defer = ch->eng_defer;
+                }
                 HIP_TRY(quad_tail_launch(ch->n, tip, (int)gq, stream, tq));
                 ch->eng_tail_restarts = (int)left;
                 ch->eng_tail_solver = 3;

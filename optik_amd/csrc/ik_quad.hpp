@@ -35,6 +35,14 @@
 #include "ik_solve.hpp"
 #include "ik_nnls_quad.hpp"
 
+// stragglers (ik_nnls_quad.hpp): a direction pass with P sub-problems may leave min(P / DIV, MAX) of them suspended
+#ifndef OPTIK_DEFER_DIV
+#define OPTIK_DEFER_DIV 4
+#endif
+#ifndef OPTIK_DEFER_MAX
+#define OPTIK_DEFER_MAX 3  // (<= DEFER_SLOTS)
+#endif
+
 namespace optik {
 
 template <int N>
@@ -139,7 +147,8 @@ OPTIK_DEV int opaque_int(int v) {
 template <int N, bool TIP>
 OPTIK_DEV double eval_quad(const ChainDev &ch, const EvalParams &ep, const double *target7,
                            const double (&x)[QuadDims<N>::NS], double (&gout)[QuadDims<N>::NS],
-                           double *park /* the lane's parking doubles in the quad's block: park[4 i], i < 12 */) {
+                           double *park /* the lane's parking doubles in the quad's block: park[4 i], i < 12 */,
+                           bool park_ok = true /* false: the block holds a suspended problem, leave it alone (the quad's result is not used) */) {
     constexpr int NS = QuadDims<N>::NS;
     const int q = quad_lane_now();
     Q4 jq[NS];
@@ -194,10 +203,12 @@ OPTIK_DEV double eval_quad(const ChainDev &ch, const EvalParams &ep, const doubl
     // X = T_target^-1 T_ee  (objective.rs:69-70)
     const Pose X = pose_inv_mul(load_pose(target7), ee);
     // (the columns' geometry waits in LDS while the error terms -- the register peak of the kernel -- are formed)
+    if (park_ok) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s)
+        for (int s = 0; s < NS; ++s)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { park[4 * (6 * s + c)] = lin[s][c]; park[4 * (6 * s + 3 + c)] = ang[s][c]; }
+            for (int c = 0; c < 3; ++c) { park[4 * (6 * s + c)] = lin[s][c]; park[4 * (6 * s + 3 + c)] = ang[s][c]; }
+    }
     OPTIK_SCHED_FENCE();
     const V3 w = so3_log(X.q);
     const RotTerms rt = rot_terms(w);
@@ -668,6 +679,15 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
     int ia = 0, ib = 0;
     bool first = true;
     bool active = false, want = member;
+    // stragglers (ik_nnls_quad.hpp): 0, or 1 + the suspension slot that holds the restart's bounded sub-problem
+    // -- the quad then sits out the evaluation and resumes inside the direction search
+    int sslot = 0;
+    // the wave's suspension slots (null: every sub-problem runs to its end within its trip)
+#ifdef OPTIK_LANE_EMU
+#define dslots_now() ((*reload_barrier(&wq_in)).defer)
+#else
+#define dslots_now() ((*reload_barrier(&wq_in)).defer ? (*reload_barrier(&wq_in)).defer + (size_t)blockIdx.x * DEFER_WAVE_DOUBLES : nullptr)
+#endif
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         x[s] = 0.0; x0[s] = 0.0; g[s] = 0.0; sv[s] = 0.0; xb[s * 64] = 0.0; xp[s * 64] = 0.0; dg[s] = 1.0;
@@ -691,6 +711,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                 if (want) {
                     want = false;
                     if (e < (unsigned long long)*tl.count) {
+                        sslot = 0;
                         active = tl.template import<N>(tl.list[e], qr, x, x0, g, sv, Lr, dg, pa, pb, ia, ib, first, pending, ret,
                                                        xb, xp);
                         want = !active;  // (an empty slot in the list: take the next entry)
@@ -743,6 +764,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                     ib = (qr == 0) ? (int)(unsigned)(rq & 0xffffffffull) : ((qr == 1) ? (int)(unsigned)(rq >> 32) : 0);
                     first = true;
                     active = true;
+                    sslot = 0;
                 }
             }
         }
@@ -787,7 +809,8 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
         // (the four lanes may have read first_success / the clock at different moments: the leader decides)
         ret = quad_get(ret, 0);
         const bool stepping = active && ret == 0;
-        const bool do_eval = stepping && !pending;
+        const bool resume = stepping && sslot != 0;  // a suspended sub-problem continues: no evaluation this trip
+        const bool do_eval = stepping && !pending && !resume;
         if constexpr (Tail::on) n_exec += (unsigned)__popcll(__ballot(do_eval)) / QUAD;
         double gn[NS];
         double fn = 0.0;
@@ -798,12 +821,23 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
             // the register peak of the loop (~200 VGPRs on its own)
             int pi = 0;
             double *const bp = blk + quad_lane_now();  // the lane's i-th parked double: bp[4 i]
+            // (a quad whose block holds a suspended sub-problem parks nothing: what it needs is in its slot)
+            if (sslot == 0) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    bp[4 * pi++] = x0[s]; bp[4 * pi++] = g[s]; bp[4 * pi++] = sv[s]; bp[4 * pi++] = dg[s];
+#pragma unroll
+                    for (int i = 0; i < NM; ++i)
+                        if (slot_has<N>(s, i)) bp[4 * pi++] = Lr[s][i];
+                }
+            }
+            pi = 0;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                bp[4 * pi++] = x0[s]; bp[4 * pi++] = g[s]; bp[4 * pi++] = sv[s]; bp[4 * pi++] = dg[s];
+                pi += 4;
 #pragma unroll
                 for (int i = 0; i < NM; ++i)
-                    if (slot_has<N>(s, i)) bp[4 * pi++] = Lr[s][i];
+                    if (slot_has<N>(s, i)) ++pi;
             }
             OPTIK_SCHED_FENCE();
             // (the target pose is re-read for every evaluation: seven L1 / L2 hits instead of 14 registers)
@@ -812,7 +846,20 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
             else target7 = (*reload_barrier(&wq_in)).targets + (size_t)tslot * 7;
             const EvalParams &ep = *reload_barrier(&ep_in);
 #ifndef OPTIK_QUAD_EXP_NO_EVAL
-            fn = eval_quad<N, TIP>(ch, ep, target7, x, gn, bp + 4 * pi);
+#ifdef OPTIK_QUAD_EXP_DUP_EVAL
+            // (cost-by-duplication experiments, tools/quad_dup_costs.sh: the phase runs twice on the same inputs,
+            // the results are those of the second run -- same bits, the time difference is the phase's cost)
+            {
+                double gn0[NS];
+                double xx[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) { xx[s] = x[s]; asm volatile("" : "+v"(xx[s])); }
+                double f0 = eval_quad<N, TIP>(ch, ep, target7, xx, gn0, bp + 4 * pi, sslot == 0);
+                asm volatile("" :: "v"(f0), "v"(gn0[0]), "v"(gn0[NS - 1]));
+                OPTIK_SCHED_FENCE();
+            }
+#endif
+            fn = eval_quad<N, TIP>(ch, ep, target7, x, gn, bp + 4 * pi, sslot == 0);
 #else
             fn = target7[0]; gn[0] = x[0]; if (NS > 1) gn[NS - 1] = x[NS - 1];
 #endif
@@ -828,13 +875,30 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                 for (int i = 0; i < NM; ++i)
                     if (slot_has<N>(s, i)) Lr[s][i] = pk[4 * pi++];
             }
+            if (wave_any(sslot != 0)) {
+                // a quad with a suspended sub-problem read its block's matrix just now: the gradient and the
+                // factor come back from its slot (x0 and s are dead until the direction search rewrites them)
+                const bool rs = sslot != 0;
+                const double *sp = dslots_now() + (rs ? sslot - 1 : 0) * (DEFER_VALS * 4) + DEFER_NNLS_VALS * 4 + quad_lane_now();
+                int qi = 0;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const double gq = sp[4 * qi++], dq = sp[4 * qi++];
+                    g[s] = rs ? gq : g[s];
+                    dg[s] = rs ? dq : dg[s];
+#pragma unroll
+                    for (int i = 0; i < NM; ++i)
+                        if (slot_has<N>(s, i)) { const double lq = sp[4 * qi++]; Lr[s][i] = rs ? lq : Lr[s][i]; }
+                }
+            }
         }
         OPTIK_PROF_END(1);
         OPTIK_SCHED_FENCE();
 
         // ---- NLopt bookkeeping and Kraft's line search (labels 100 / 220), replicated scalars ------
         OPTIK_PROF_BEGIN();
-        bool need_dir = stepping && pending, reset = false, do_bfgs = false;  // (a deferred direction resumes at its LSQ call)
+        bool need_dir = stepping && (pending || resume), reset = false, do_bfgs = false;  // (a deferred direction resumes at its LSQ call)
+        int dir_pass = 0;
         const SolveParams &sp = *reload_barrier(&sp_in);
         double u[NS];
 #pragma unroll
@@ -916,6 +980,26 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
         }
         OPTIK_SCHED_FENCE();
 #ifndef OPTIK_QUAD_EXP_NO_BFGS
+#ifdef OPTIK_QUAD_EXP_DUP_BFGS
+        if (wave_any(do_bfgs)) {
+            double Lr2[NS][NM], dg2[NS], u2[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                dg2[s] = dg[s]; u2[s] = u[s];
+                asm volatile("" : "+v"(dg2[s]), "+v"(u2[s]));
+#pragma unroll
+                for (int i = 0; i < NM; ++i) Lr2[s][i] = Lr[s][i];
+            }
+            bfgs_quad<N>(do_bfgs, Lr2, dg2, sv, u2);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                asm volatile("" :: "v"(dg2[s]), "v"(u2[s]));
+#pragma unroll
+                for (int i = 0; i < NM; ++i) asm volatile("" :: "v"(Lr2[s][i]));
+            }
+            OPTIK_SCHED_FENCE();
+        }
+#endif
         if (wave_any(do_bfgs)) bfgs_quad<N>(do_bfgs, Lr, dg, sv, u);
 #endif
         OPTIK_SCHED_FENCE();
@@ -965,6 +1049,30 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                 for (int i = 0; i < NM; ++i) Ec[s][i] = 0.0;
             }
             OPTIK_SCHED_FENCE();
+#ifdef OPTIK_QUAD_EXP_DUP_LSQ
+            {
+                double gg[NS], Ec0[NS][NM], Ed0[NS], fv0[NS], row0[NS][N], hl0[NS], hh0[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    gg[s] = g[s]; asm volatile("" : "+v"(gg[s]));
+                    fv0[s] = 0.0; Ed0[s] = 1.0;
+#pragma unroll
+                    for (int i = 0; i < NM; ++i) Ec0[s][i] = 0.0;
+#pragma unroll
+                    for (int j = 0; j < N; ++j) row0[s][j] = 0.0;
+                }
+                int m0 = lsq_factor_quad<N>(Lr, dg, gg, Ec0, Ed0, fv0);
+                bool n0 = bound_rows_quad<N>(Ec0, Ed0, fv0, lo, hi, row0, hl0, hh0);
+                asm volatile("" :: "v"(m0), "v"((int)n0));
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    asm volatile("" :: "v"(hl0[s]), "v"(hh0[s]));
+#pragma unroll
+                    for (int j = 0; j < N; ++j) asm volatile("" :: "v"(row0[s][j]));
+                }
+                OPTIK_SCHED_FENCE();
+            }
+#endif
             int lmode = lsq_factor_quad<N>(Lr, dg, g, Ec, Ed, fv);
             OPTIK_SCHED_FENCE();
             double row[NS][N], h_lo[NS], h_hi[NS];
@@ -989,6 +1097,11 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                 // bound, h_lo below it) and, negated, column N + r + 1 (upper bound, h_hi below it)
                 // (the lane number is made opaque here: the column ids and the dozen LDS addresses
                 // derived from them are loop invariants the compiler would otherwise hoist and spill)
+#ifdef OPTIK_QUAD_EXP_DUP_NNLS
+              for (int dup_ = 0; dup_ < 2; ++dup_) {
+                asm volatile("" : "+s"(dup_));
+                lds_sync();
+#endif
                 const int qn = quad_lane_now();
                 double *const bk = blk;
                 int ids[CPL];
@@ -1000,7 +1113,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                     if (s < NS) {
                         const int r = qn + 4 * s;
                         ids[k] = (r < N) ? (neg ? N : 0) + r + 1 : 0x7fff;
-                        if (need_nnls && r < N) {
+                        if (need_nnls && r < N && sslot == 0) {  // (a suspended sub-problem's matrix is there already, transformed)
                             double *c = bk + NnlsQuadGeom<N>::CS * (ids[k] - 1);
 #pragma unroll
                             for (int j = 0; j < N; ++j) {
@@ -1013,13 +1126,46 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                 }
                 int iters;
                 double xv[CPL];
+                // stragglers: the first direction pass of a trip may leave up to a quarter of its sub-problems
+                // (three at most) suspended once the others are done
+                double *const dsl = dslots_now();
+                int max_susp = 0, snew = 0;
+                if (dsl && dir_pass == 0) {
+                    const int n_part = (int)__popcll(__ballot(need_nnls)) / QUAD;
+                    max_susp = n_part / OPTIK_DEFER_DIV < OPTIK_DEFER_MAX ? n_part / OPTIK_DEFER_DIV : OPTIK_DEFER_MAX;
+                }
+#ifdef OPTIK_QUAD_EXP_DUP_NNLS
+                max_susp = 0;
+#endif
 #ifndef OPTIK_QUAD_EXP_NO_NNLS
-                nnls_quad<N>(need_nnls, ids, bk, nnls_lds + QUADS_PER_WAVE * NnlsQuadGeom<N>::STRIDE, xv, nmode, rnorm, iters);
+                nnls_quad<N>(need_nnls, ids, bk, nnls_lds + QUADS_PER_WAVE * NnlsQuadGeom<N>::STRIDE, xv, nmode, rnorm, iters,
+                             need_nnls ? sslot : 0, dsl, max_susp, snew);
+                if (need_nnls) sslot = snew;
+                if (wave_any(snew != 0)) {
+                    // what the sitting-out quad's evaluation slot would clobber goes to the suspension slot as well
+                    const bool sus = snew != 0;
+                    double *sp = dsl + (sus ? snew - 1 : 0) * (DEFER_VALS * 4) + DEFER_NNLS_VALS * 4 + qn;
+                    if (sus) {
+                        int qi = 0;
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) {
+                            sp[4 * qi++] = g[s]; sp[4 * qi++] = dg[s];
+#pragma unroll
+                            for (int i = 0; i < NM; ++i)
+                                if (slot_has<N>(s, i)) sp[4 * qi++] = Lr[s][i];
+                        }
+                        pass = false;      // the rest of this pass is not the quad's: it continues next trip
+                        need_dir = false;
+                    }
+                }
 #else
                 for (int k = 0; k < CPL; ++k) xv[k] = bk[k]; iters = 0;
 #endif
 #pragma unroll
                 for (int s = 0; s < NS; ++s) { ylo[s] = xv[s]; yhi[s] = xv[2 + s]; }
+#ifdef OPTIK_QUAD_EXP_DUP_NNLS
+              }
+#endif
 #ifdef OPTIK_PROFILE
                 OPTIK_PROF_COUNT(6, __builtin_readcyclecounter() - t_nn);
 #endif
@@ -1028,6 +1174,18 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
             double sn[NS];
 #pragma unroll
             for (int s = 0; s < NS; ++s) sn[s] = 0.0;
+#ifdef OPTIK_QUAD_EXP_DUP_FIN
+            {
+                double s0[NS], yl[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) { s0[s] = 0.0; yl[s] = ylo[s]; asm volatile("" : "+v"(yl[s])); }
+                int m0 = 0;
+                if (wave_any(need_nnls)) m0 = ldp_quad<N>(nmode, rnorm, row, h_lo, h_hi, yl, yhi, s0);
+                lsq_finish_quad<N>(Ec, Ed, fv, lo, hi, s0);
+                asm volatile("" :: "v"(m0), "v"(s0[0]), "v"(s0[NS - 1]));
+                OPTIK_SCHED_FENCE();
+            }
+#endif
             if (wave_any(need_nnls)) {
                 const int m2 = ldp_quad<N>(nmode, rnorm, row, h_lo, h_hi, ylo, yhi, sn);
                 if (need_nnls) lmode = m2;
@@ -1061,12 +1219,13 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                     }
                 }
             }
+            ++dir_pass;
         }
         OPTIK_PROF_END(5);
         OPTIK_PROF_BEGIN();
         const int qf = quad_lane_now();
         const double alpha_t = quad_get(pa, 3);
-        if (stepping && ret == 0) {
+        if (stepping && ret == 0 && sslot == 0) {
             // label 190: next trial point x = x0 + alpha * s, clipped (NLopt)
             ia = (qf == 1) ? ia + 1 : ia;           // ++line
             pa = (qf == 2) ? alpha_t * pa : pa;     // h3 = alpha * h3
@@ -1157,6 +1316,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                 }
                 active = false;
                 want = true;
+                sslot = 0;
             }
         }
         OPTIK_PROF_END(3);
@@ -1169,6 +1329,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
 #undef xb
 #undef xp
 #undef blk
+#undef dslots_now
 }
 
 }  // namespace optik

@@ -153,12 +153,19 @@ hipError_t quad_solve_launch(int n, bool tip, int grid, hipStream_t stream, cons
 
 }  // namespace optik
 
-#if defined(OPTIK_PROFILE) && OPTIK_QUAD_PART != 2
+#if defined(OPTIK_PROFILE) && OPTIK_QUAD_PART != 1  // (next to the throughput form: its copy of the counters)
 // diagnostic builds: cycles per part of the quad NNLS since the last call (ik_nnls_quad.hpp), then reset
 extern "C" int optik_hip_quad_nnls_profile(unsigned long long *out8) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(optik::g_quad_nnls_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
     unsigned long long z[8] = {0};
     return hipMemcpyToSymbol(HIP_SYMBOL(optik::g_quad_nnls_prof), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+// ... and the histograms of the same calls (ik_nnls_quad.hpp:g_quad_nnls_hist), then reset
+extern "C" int optik_hip_quad_nnls_hist(unsigned long long *out66) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out66, HIP_SYMBOL(optik::g_quad_nnls_hist), 66 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[66] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(optik::g_quad_nnls_hist), z, sizeof z) == hipSuccess ? 0 : -1;
 }
 #endif

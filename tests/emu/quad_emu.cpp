@@ -37,12 +37,15 @@ void run_wave(const ChainDev &ch, const EvalParams &ep, const SolveParams &sp, c
 
 extern "C" {
 
+// sub-problems suspended since the last call of this function
+long quad_emu_suspensions() { return optik_emu::g_suspensions.exchange(0); }
+
 // origins [J][7] (t, quat ijkw), axes [n][3], J = n or n + 1; restarts [begin, end) of ONE target.
 // out_x [n][R], out_f / out_key [R], out_status / out_evals [R].  quads: restarts in flight (1 .. 16).
 int quad_emu_solve(const double *origins, const double *axes, int n, int n_joints, const double *lb, const double *ub,
                    const optik_solver_config *cfg, const double *target7, const double *x0, const double *ee_offset7,
                    uint64_t restart_begin, uint64_t restart_end, int quads, int range_rule, double *out_x, double *out_f,
-                   double *out_key, int32_t *out_status, int32_t *out_evals) {
+                   double *out_key, int32_t *out_status, int32_t *out_evals, int defer /* 1: the wave may suspend straggling sub-problems */) {
     if (n < 1 || n > 8 || quads < 1 || quads > 16 || restart_end <= restart_begin) return -1;
     ChainDev ch;
     std::memset(&ch, 0, sizeof ch);
@@ -83,6 +86,8 @@ int quad_emu_solve(const double *origins, const double *axes, int n, int n_joint
     wq.out_key = out_key;
     wq.out_status = out_status;
     wq.out_evals = out_evals;
+    std::vector<double> dslots((size_t)DEFER_WAVE_DOUBLES, 0.0);
+    wq.defer = defer ? dslots.data() : nullptr;
 
 #define RUN(NN)                                                                              \
     case NN:                                                                                 \

@@ -49,6 +49,22 @@ def test_every_restart_bit_equal_to_the_oracle(emu, oracle, chains, robot, R, qu
     assert 0 < ref["success"].sum() < R or n < 3  # both outcomes are exercised on the real arms
 
 
+@pytest.mark.parametrize("robot,R,quads", [("panda", 40, 8), ("ur10", 32, 8), ("arm8", 24, 8)])
+def test_suspended_subproblems_bit_equal_to_the_oracle(emu, oracle, chains, robot, R, quads):
+    """Stragglers (ik_nnls_quad.hpp): with four or more restarts in a wave the direction search may suspend the last
+    quarter of a trip's bounded sub-problems and continue them in the next trip -- a pause between two loop trips of
+    Lawson-Hanson, not a change of its arithmetic: every restart still equals the oracle's bit for bit."""
+    from optik_amd import _native as nat
+    d, ch, tgt, x0 = _case(oracle, chains, robot, 7)
+    n = len(d["lb"])
+    emu.suspensions()
+    got = emu.solve(d, nat.make_config(solution_mode="speed"), tgt, x0, 0, R, quads=quads, defer=True)
+    assert emu.suspensions() > 0  # (the case does exercise the mechanism)
+    ref = oracle.ik(ch, oracle.make_config(solution_mode="speed"), tgt, x0, 0, R, n_threads=4, early_exit=False,
+                    per_restart=True)
+    _assert_same(got, ref, n)
+
+
 def test_quality_key_weights_and_tight_tolerance(emu, oracle, chains):
     """SolutionMode::Quality's key ||x - x0|| (an ordered sum over the quad), the reference test's
     non-trivial weights (tests/test_gradient.rs:37-38) and tol_f = 1e-12 (tests/test_ik.rs:99)."""

@@ -46,6 +46,8 @@ def main():
     for _ in range(2):
         if have_qn:
             nat.lib().optik_hip_quad_nnls_profile(qn)  # (reset)
+        if have_qn and hasattr(nat.lib(), "optik_hip_quad_nnls_hist"):
+            nat.lib().optik_hip_quad_nnls_hist((C.c_ulonglong * 66)())  # (reset)
         hc.ik_batch(cfg, tgt, x0, 0, R, bufs=bufs)
     torch.cuda.synchronize()
     out = (C.c_ulonglong * 8)()
@@ -68,6 +70,16 @@ def main():
               f"{q[6] / calls:.2f} Givens steps per call")
         for n_, c in zip(["steps 2-4 (duals, argmax)", "step 5 (Householder)", "steps 6-10 (solve, step)", "step 11 (remove)"], q[:4]):
             print(f"    {n_:26s} {c / calls:9.0f} cycles/call {c / loops:9.0f} cycles/loop trip")
+        if hasattr(nat.lib(), "optik_hip_quad_nnls_hist"):
+            h = (C.c_ulonglong * 66)()
+            nat.lib().optik_hip_quad_nnls_hist(h)
+            h = list(h)
+            tot = max(sum(h[:17]), 1)
+            print("    loop trips by quads still solving (0..16): " + " ".join(f"{100.0 * c / tot:.1f}" for c in h[:17]))
+            totc = max(sum(h[17:49]), 1)
+            print("    calls by loop trips (0..31+): " + " ".join(f"{100.0 * c / totc:.1f}" for c in h[17:49]))
+            totp = max(sum(h[49:66]), 1)
+            print("    calls by quads taking part (0..16): " + " ".join(f"{100.0 * c / totp:.1f}" for c in h[49:66]))
 
 
 def engine_profile():
