@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "liboptik_amd.so")
-SOURCES = ["ik_kernels.hip", "ik_quad_kernel.hip", "ik_wide_kernel.hip", "robot_host.cpp"]
+SOURCES = ["ik_kernels.hip", "ik_quad_kernel.hip", "ik_lane_kernel.hip", "ik_wide_kernel.hip", "robot_host.cpp"]
 # translation units: (source, object, extra flags).  ik_quad_kernel.hip is compiled twice -- its
 # throughput form (two waves per SIMD) without the machine-LICM pass, which otherwise hoists constants and
 # LDS addresses out of the solver loop only for the register allocator to spill them to scratch
@@ -28,6 +28,8 @@ UNITS = [("ik_kernels.hip", "ik_kernels.o", []),
          ("ik_quad_kernel.hip", "ik_quad_throughput.o",
           ["-DOPTIK_QUAD_PART=2", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-use-amdgpu-trackers=1",
            "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
+         # the throughput form for n <= 7: one restart per lane, one wave per SIMD (ik_lane64.hpp)
+         ("ik_lane_kernel.hip", "ik_lane_kernel.o", []),
          # chains with 9 .. 16 joint positions: one run-time-n body per kernel (ik_wide.hpp)
          ("ik_wide_kernel.hip", "ik_wide_kernel.o", []),
          ("robot_host.cpp", "robot_host.o", [])]

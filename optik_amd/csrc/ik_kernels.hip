@@ -568,10 +568,6 @@ struct optik_hip_chain {
     double *tmp_x = nullptr, *tmp_f = nullptr, *tmp_key = nullptr;
     size_t tmp_cols = 0;
     unsigned long long *queue = nullptr;  // work-item counter of the in-flight launch
-    // quad solver: suspension slots of the resident waves' straggling sub-problems (ik_nnls_quad.hpp), one set for
-    // optik_hip_ik_batch's launch and one for an engine run's tail (they hold different locks)
-    double *defer = nullptr, *eng_defer = nullptr;
-    size_t defer_waves = 0, eng_defer_waves = 0;
     unsigned long long *prof = nullptr;   // phase timers (OPTIK_PROFILE builds)
     // streaming engine (ik_engine.hpp)
     struct EngineJobHost {
@@ -862,8 +858,6 @@ void optik_hip_chain_destroy(optik_hip_chain *ch) {
     if (ch->tmp_f) hipFree(ch->tmp_f);
     if (ch->tmp_key) hipFree(ch->tmp_key);
     if (ch->queue) hipFree(ch->queue);
-    if (ch->defer) hipFree(ch->defer);
-    if (ch->eng_defer) hipFree(ch->eng_defer);
     if (ch->eng_pool_attached) {  // the slot pool belongs to the device: released with its last user
         EnginePool &P = engine_pool_of(ch);
         std::lock_guard<std::mutex> run(P.run_mu);
@@ -1036,12 +1030,6 @@ int optik_hip_ik_batch(optik_hip_chain *ch, const optik_solver_config *cfg, cons
 
 }  // extern "C"
 
-// OPTIK_QUAD_DEFER=0: every bounded sub-problem of the quad solver runs to its end within its trip (comparisons)
-static bool quad_defer_enabled() {
-    static const bool on = [] { const char *e = std::getenv("OPTIK_QUAD_DEFER"); return !(e && std::atoi(e) == 0); }();
-    return on;
-}
-
 static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, const double *d_targets,
                            const double *d_x0, int32_t T, const double *ee_offset7, uint64_t restart_begin,
                            uint64_t restart_end, uint32_t flags, double deadline_s, const optik_hip_ik_outputs *out,
@@ -1178,6 +1166,9 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         quadk = quadk && std::strcmp(e, "lane") != 0 && std::strcmp(e, "coop") != 0;
     }
     coop = coop && !quadk && !widek;
+    // the throughput form for n <= 7: one restart per lane, bounded sub-problems in class order (ik_lane64.hpp)
+    bool lanek = false;
+    if (const char *e = std::getenv("OPTIK_SOLVE_KERNEL")) lanek = quadk && ch->n <= 7 && std::strcmp(e, "lane64") == 0;
     // Persistent waves, each pulling work items until the queue is dry: as many as a CU holds
     // (lane kernel: 2 workgroups, LDS-bound; cooperative kernel: 4, one per SIMD), times the CU count.
     const int cus = ch->num_cus > 0 ? ch->num_cus : 256;
@@ -1189,13 +1180,14 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         return e && std::atoll(e) > 0 ? std::atoll(e) : 8ll;
     }();
     const bool quad_latency = quadk && (long long)cols <= (long long)cus * 4;
-    long long cap = (long long)cus * (quadk ? (quad_latency ? 4 : quad_solve_waves_per_cu(ch->n)) : (coop ? 4 : (widek ? wide_waves_per_cu : ch->waves_per_cu)));
+    lanek = lanek && !quad_latency;
+    long long cap = (long long)cus * (lanek ? lane_solve_waves_per_cu() : quadk ? (quad_latency ? 4 : quad_solve_waves_per_cu(ch->n)) : (coop ? 4 : (widek ? wide_waves_per_cu : ch->waves_per_cu)));
     // (experiments: fewer resident waves per CU than the kernel could have, e.g. to share the chip with another stream's kernels)
     if (const char *e = std::getenv("OPTIK_SOLVE_WAVES_PER_CU")) {
         const long long v = std::atoll(e);
         if (v >= 1 && v * cus < cap) cap = v * cus;
     }
-    const long long per_wave_max = (coop || quadk) ? COOP_GROUPS_PER_WAVE : WAVE;
+    const long long per_wave_max = lanek ? WAVE : ((coop || quadk) ? COOP_GROUPS_PER_WAVE : WAVE);
     // fewer work items than the chip holds: one restart per wave (or as few as fit).  A
     // restart-major Speed batch keeps about eight restarts per target in flight: the waves pull
     // the higher indices of the targets still unsolved as they go
@@ -1266,17 +1258,9 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         w.ws = ch->wide_ws;
         lds = lds_form ? wide_lds_bytes() : (int)sizeof(WideChainDev);
         HIP_TRY(wide_solve_launch(grid, stream, w, lds_form));
+    } else if (lanek) {
+        HIP_TRY(lane_solve_launch(ch->n, ch->tip, grid, stream, a, &lds));
     } else if (quadk) {
-        // (the throughput form may suspend a wave's last few bounded sub-problems of a trip: their slots)
-        if (!quad_latency && lanes >= 4 && quad_defer_enabled()) {
-            if ((size_t)grid > ch->defer_waves) {
-                if (ch->defer) HIP_TRY(hipFree(ch->defer));
-                ch->defer = nullptr; ch->defer_waves = 0;
-                HIP_TRY(hipMalloc(&ch->defer, sizeof(double) * DEFER_WAVE_DOUBLES * (size_t)grid));
-                ch->defer_waves = (size_t)grid;
-            }
-            a.wq.defer = ch->defer;
-        }
         HIP_TRY(quad_solve_launch(ch->n, ch->tip, grid, stream, a, &lds, quad_latency));
     } else if (coop) {
 #define CALL_COOP(NN, TT)                                                                            \
@@ -2001,15 +1985,6 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
                 tq.tail.cursor = reinterpret_cast<unsigned long long *>(t_count + 2);  // (8-byte aligned word of the same scratch)
                 tq.tail.exec_evals = pa0.exec_evals;
                 HIP_TRY(hipMemsetAsync(t_count + 2, 0, sizeof(unsigned long long), stream));
-                if (lq >= 4 && quad_defer_enabled()) {
-                    if ((size_t)gq > ch->eng_defer_waves) {
-                        if (ch->eng_defer) HIP_TRY(hipFree(ch->eng_defer));
-                        ch->eng_defer = nullptr; ch->eng_defer_waves = 0;
-                        HIP_TRY(hipMalloc(&ch->eng_defer, sizeof(double) * DEFER_WAVE_DOUBLES * (size_t)gq));
-                        ch->eng_defer_waves = (size_t)gq;
-                    }
-                    tq.base.wq.defer = ch->eng_defer;
-                }
                 HIP_TRY(quad_tail_launch(ch->n, tip, (int)gq, stream, tq));
                 ch->eng_tail_restarts = (int)left;
                 ch->eng_tail_solver = 3;

@@ -1,0 +1,461 @@
+// ik_lane64.hpp -- the restart solver with one restart per LANE and the wave's bounded sub-problems solved
+// sixteen at a time, in class order, by quads of lanes.
+//
+// Where the quad solver (ik_quad.hpp) spends a wave's instructions (MI355X, cost of every phase by
+// duplication, profiles/r4a_defer_experiment.txt): every scalar of Kraft's / NLopt's state machine, the
+// chain product, the error terms and the log maps are REPLICATED in the four lanes of a restart
+// (0.73 Mflop per restart at the wave level against 0.39 for a per-lane formulation), and a wave runs the
+// Lawson-Hanson loop of the dual problem until the slowest of its sixteen problems is done (4.7 - 5.4 loop
+// trips per call against 3.1 per problem) -- the sixteen are whatever the wave's restarts happen to need.
+//
+// Here a wave holds SIXTY-FOUR restarts, one per lane, and runs them phase by phase:
+//
+//   evaluation, NLopt bookkeeping, BFGS, LSQ factor,   per lane on the lane's own restart: no replication, no
+//   rows of E^-1, LDP tail, back-substitution          cross-lane traffic; the building blocks of ik_slsqp.hpp /
+//                                                      ik_eval.hpp that the engine's phase kernels use
+//   bounded dual problems (NNLS)                       the lanes that need one (~46 of 64 per trip) leave the
+//                                                      packed problem (rows of E^-1, h: 42 doubles) in LDS; the
+//                                                      wave ranks them by predicted pass count (what the restart's
+//                                                      previous problem took, or the number of violated bounds if
+//                                                      larger: 76 % repeat it, 92 % within one) and solves them in
+//                                                      rounds of sixteen -- quad q of round r takes the problem of
+//                                                      rank 16 r + q, expands it into its 1 KB block and runs
+//                                                      ik_nnls_quad.hpp on it; the owner lane reads the multipliers
+//                                                      back.  A round's sixteen problems take similar numbers of
+//                                                      passes, and the long ones share a round.
+//
+// The price: the per-lane state (~80 doubles) plus the working set of an evaluation need more than 256
+// registers, and 16 blocks + 64 packed problems fill 38 KB of LDS: ONE wave per SIMD (four per CU).
+//
+// Bit-exactness: the per-lane blocks execute the oracle's operation sequence as they do
+// in the engine; the NNLS is ik_nnls_quad.hpp's; the LDP tail is lsq_dual's.  A direction that is not a descent
+// direction (Kraft: reset B and search again, 5e-5 of the trips) repeats in the wave's NEXT trip instead of a
+// second pass of this one -- the lane sits out one evaluation, its arithmetic is the same.
+//
+// Restates, per lane: /root/reference/crates/optik/src/lib.rs:301-391 (the restart closure) with NLopt's SLSQP
+// (un-vendored; oracle/optik_oracle.c is the CPU statement of the same arithmetic).
+#pragma once
+
+#include "ik_lane.hpp"
+#include "ik_solve.hpp"
+#include "ik_nnls_quad.hpp"
+
+namespace optik {
+
+template <int N>
+struct Lane64Geom {
+    static constexpr int NG = N * (N + 1) / 2;  // entries of E^-1 (upper triangular, by row)
+    static constexpr int REC = NG + 2 * N;      // ... then h_lo[N], h_hi[N]
+    // the record of lane p, value v, at rec[v * 64 + p]: a wave-wide store of "my v-th value" is 512 contiguous bytes
+    OPTIK_DEV static constexpr int g(int i, int j) { return i * N - (i * (i - 1)) / 2 + (j - i); }  // E^-1(i, j), j >= i
+    OPTIK_DEV static constexpr int hlo(int i) { return NG + i; }
+    OPTIK_DEV static constexpr int hhi(int i) { return NG + N + i; }
+    // where a quad leaves {mode, rnorm, solve passes} of its problem: the spare doubles of its block
+    static constexpr int META = NnlsQuadGeom<N>::XS + 2 * N;
+    static_assert(NnlsQuadGeom<N>::XS + 2 * N + 3 <= NnlsQuadGeom<N>::STRIDE, "three spare doubles per block");
+};
+
+// doubles of LDS per wave: the NNLS blocks of its 16 quads (+ the column of zeros), the 64 packed problems
+template <int N>
+constexpr int lane64_block_lds() { return nnls_quad_wave_lds<N>(); }
+template <int N>
+constexpr int lane64_rec_lds() { return Lane64Geom<N>::REC * 64; }
+
+constexpr int LANE64_CLASSES = 8;  // predicted pass classes 1 .. 7 (0: no bounded problem this trip)
+
+// quads a wave has (the emulation of tests/emu runs partial waves)
+OPTIK_DEV int lane64_quads() {
+#ifdef OPTIK_LANE_EMU
+    return optik_emu::t_wave->lanes / QUAD;
+#else
+    return 64 / QUAD;
+#endif
+}
+
+template <int N, bool TIP>
+OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const SolveParams &sp, const uint32_t (&key)[8],
+                           const double (&scale)[MAX_DOF], const WorkQueue &wq,
+                           double *nnls_lds /* lane64_block_lds<N>() doubles, the last 16 zero */,
+                           double *rec_lds /* lane64_rec_lds<N>() doubles */, int *lor_lds /* 64 ints: lane of rank */) {
+    typedef Lane64Geom<N> G;
+    constexpr int NL = N * (N + 1) / 2;
+    constexpr int NS = (N > 4) ? 2 : 1;
+    constexpr int CS = NnlsQuadGeom<N>::CS;
+    static_assert(N <= 7, "the throughput form of chains with at most seven joints");
+    const double alfmin = 0.1;
+    const int lane = (int)(threadIdx.x & 63u);
+    // SLSQP state of the lane's restart (names as in solve_wave)
+    double x[N], x0[N], g[N], s[N], l[NL];
+    double xbest[N], xprev[N];
+    double f = 0.0, f0 = 0.0, t0 = 0.0, h3 = 0.0, alpha = 1.0;
+    double minf = __builtin_huge_val(), fprev = __builtin_huge_val();
+    int ireset = 0, line = 0, nevals = 0;
+    int pred = 1;          // solve passes of the restart's previous bounded problem
+    bool first = true;
+    bool again = false;    // the last direction was not a descent direction: reset B and search again, no evaluation
+    Pose target;
+    unsigned long long item = 0, index = 0;
+    unsigned tslot = 0;
+    bool active = false, want = lane < wq.lanes;
+#pragma unroll
+    for (int i = 0; i < N; ++i) { x[i] = 0.0; x0[i] = 0.0; g[i] = 0.0; s[i] = 0.0; xbest[i] = 0.0; xprev[i] = 0.0; }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) l[i] = 0.0;
+    target.t = V3{0, 0, 0};
+    target.q = Q4{0, 0, 0, 1};
+
+    for (;;) {
+        // ---- refill: lanes without a restart pull the next work item ----------------------------------
+        // (the seed generation runs for the whole wave: wait until several lanes are idle -- or none is busy)
+        const unsigned n_want = (unsigned)__popcll(__ballot(want));
+        if (n_want >= (unsigned)(wq.lanes < (int)REFILL_BATCH ? wq.lanes : (int)REFILL_BATCH) || (n_want > 0 && !wave_any(active))) {
+            const unsigned long long it = fetch_items(wq.next_item, want);
+            if (want) {
+                want = false;
+                if (it < wq.total_items) {
+                    unsigned long long r;
+                    if (wq.restart_major) { r = it / wq.n_targets; tslot = (unsigned)(it - r * wq.n_targets); }
+                    else { tslot = (unsigned)(it / wq.n_restarts); r = it - (unsigned long long)tslot * wq.n_restarts; }
+                    item = (unsigned long long)tslot * wq.n_restarts + r;  // output column
+                    index = wq.restart_begin + r;
+                    target = load_pose(wq.targets + (size_t)tslot * 7);
+                    // lib.rs:366-370: restart 0 starts from the caller's seed
+                    restart_seed<N>(key, ch.lb, scale, index, x);
+                    if (index == 0) {
+                        const double *x0p = wq.x0 + (size_t)tslot * N;
+#pragma unroll
+                        for (int i = 0; i < N; ++i) x[i] = x0p[i];
+                    }
+#pragma unroll
+                    for (int i = 0; i < N; ++i) { xbest[i] = x[i]; xprev[i] = x[i]; x0[i] = x[i]; s[i] = 0.0; g[i] = 0.0; }
+                    f = 0.0; f0 = 0.0; t0 = 0.0; h3 = 0.0; alpha = 1.0;
+                    minf = __builtin_huge_val(); fprev = __builtin_huge_val();
+                    ireset = 0; line = 0; nevals = 0; pred = 1;
+                    first = true;
+                    again = false;
+                    active = true;
+                }
+            }
+        }
+        if (!wave_any(active)) break;
+
+        int32_t ret = 0;
+        if (active) {
+            // lib.rs:308: abandon when timed out or a lower-index restart succeeded
+            bool stop = false;
+            if (wq.first_success) {
+                const unsigned long long fs = __hip_atomic_load(wq.first_success + tslot, __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_AGENT);
+                stop = wq.find_any ? (fs != ~0ull) : (fs < index);
+            }
+            if (wq.deadline && (unsigned long long)wall_clock64() > wq.deadline) stop = true;
+            if (stop) ret = RES_FORCED_STOP;
+        }
+        const bool stepping = active && ret == 0;
+        const bool do_eval = stepping && !again;
+        double gn[N];
+        double fn = 0.0;
+        OPTIK_SCHED_FENCE();
+        if (do_eval) fn = eval_fg<N, TIP>(ch, ep, target, x, gn);
+        OPTIK_SCHED_FENCE();
+
+        // ---- NLopt bookkeeping and Kraft's line search (labels 100 / 220), per lane ---------------------
+        bool need_dir = stepping && again, reset = stepping && again;
+        again = false;
+        if (do_eval) {
+            f = fn;
+            ++nevals;
+            // NLopt: update best point so far; stopval is tested after every evaluation
+            if (f < minf) {
+                minf = f;
+#pragma unroll
+                for (int i = 0; i < N; ++i) xbest[i] = x[i];
+            }
+            if (minf < sp.stopval) {
+                ret = RES_STOPVAL_REACHED;
+            } else if (nevals >= MAX_EVALS_CAP) {
+                ret = RES_ITER_CAP;
+            } else if (first) {
+                // SLSQPB label 100/110: initialise, reset the BFGS matrix
+                first = false;
+#pragma unroll
+                for (int i = 0; i < N; ++i) g[i] = gn[i];
+                need_dir = true;
+                reset = true;
+            } else {
+                // label 220: L1 merit (m = 0: the objective itself)
+                const double h1 = f - t0;
+                bool accept = false;
+                if (__builtin_isfinite(h1)) {
+                    if (h1 <= h3 / 10.0 || line > 10) accept = true;
+                    else {
+                        const double a = h3 / ((h3 - h1) * 2.0);
+                        alpha = (a > alfmin) ? a : alfmin;
+                    }
+                } else {
+                    const double a = alpha * 0.5;
+                    alpha = (a > alfmin) ? a : alfmin;
+                }
+                if (accept) {
+                    // line search complete (mode -1): NLopt re-evaluates f and the gradient there unless the
+                    // accepted trial was the first one
+                    if (line > 1) ++nevals;
+                    if (!__builtin_isinf(fprev)) {
+                        if (__builtin_fabs(f - fprev) < sp.ftol_abs) ret = RES_FTOL_REACHED;
+                        else if (xprev_live(sp) && stop_x<N>(sp, x, xprev)) ret = RES_XTOL_REACHED;
+                    }
+                    fprev = f;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) xprev[i] = x[i];
+                    if (ret == 0 && nevals >= MAX_EVALS_CAP) ret = RES_ITER_CAP;
+                    if (ret == 0) {
+                        // label 260: BFGS update with u = g_new - g_old
+                        double u[N];
+#pragma unroll
+                        for (int i = 0; i < N; ++i) { u[i] = gn[i] - g[i]; g[i] = gn[i]; }
+                        OPTIK_SCHED_FENCE();
+                        bfgs_update<N>(l, s, u);
+                        OPTIK_SCHED_FENCE();
+                        need_dir = true;
+                    }
+                }
+            }
+        }
+        OPTIK_SCHED_FENCE();
+
+        // ---- labels 110/130: (reset,) search direction, descent test -- one pass per trip -----------------
+        if (wave_any(need_dir)) {
+            if (need_dir && reset) {
+                ++ireset;
+                if (ireset > 5) {
+                    // label 255 with acc = 0 -> mode 8; NLopt's relaxed test vs (f0, x0)
+                    ret = RES_ROUNDOFF_LIMITED;
+                    if (__builtin_fabs(f - f0) < sp.ftol_abs && !__builtin_isinf(f0)) ret = RES_FTOL_REACHED;
+                    else if (stop_x<N>(sp, x, x0)) ret = RES_XTOL_REACHED;
+                    need_dir = false;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NL; ++i) l[i] = 0.0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) l[lidx<N>(i, i)] = 1.0;
+                }
+            }
+            double E[N][N], fv[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                fv[i] = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) E[i][j] = 0.0;
+            }
+            int lmode = lsq_factor<N>(l, g, E, fv);
+            OPTIK_SCHED_FENCE();
+            // rows of E^-1 and the bound rows they give: into the lane's packed problem in LDS
+            int nviol = 0;
+            bool need_nnls;
+            {
+                double lo[N], hi[N];
+#pragma unroll
+                for (int i = 0; i < N; ++i) { lo[i] = ch.lb[i] - x[i]; hi[i] = ch.ub[i] - x[i]; }
+                double *const rp = rec_lds + lane;
+                need_nnls = lsq_bound_rows<N>(E, fv, lo, hi, [&](int i, const double (&row)[N], double h_lo, double h_hi) {
+#pragma unroll
+                    for (int j = i; j < N; ++j) rp[64 * G::g(i, j)] = row[j];
+                    rp[64 * G::hlo(i)] = h_lo;
+                    rp[64 * G::hhi(i)] = h_hi;
+                    nviol += (h_lo > 0.0 ? 1 : 0) + (h_hi > 0.0 ? 1 : 0);
+                });
+            }
+            const bool has = need_dir && lmode == 1 && need_nnls;
+            OPTIK_SCHED_FENCE();
+
+            // ---- the wave's bounded problems by predicted class, the largest first -----------------------
+            int cls = 0;
+            if (has) {
+                cls = nviol > pred ? nviol : pred;
+                cls = cls < 1 ? 1 : (cls > LANE64_CLASSES - 1 ? LANE64_CLASSES - 1 : cls);
+            }
+            int rank = 0, n_prob = 0;
+            {
+                const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+                for (int c = LANE64_CLASSES - 1; c >= 1; --c) {
+                    const unsigned long long mc = __ballot(cls == c);
+                    if (cls == c) rank = n_prob + (int)__popcll(mc & below);
+                    n_prob += (int)__popcll(mc);
+                }
+            }
+            if (has) lor_lds[rank] = lane;
+            lds_sync();
+
+            double y[2 * N];
+#pragma unroll
+            for (int r = 0; r < 2 * N; ++r) y[r] = 0.0;
+            int nmode = 1;
+            double rnorm = 1.0;
+            const int nq = lane64_quads();
+            const int qi = lane >> 2, ql = lane & 3;
+            for (int r0 = 0; r0 < n_prob; r0 += nq) {
+                // quad qi takes the problem of rank r0 + qi: its columns from the owner's packed record
+                const int pr = r0 + qi;
+                const bool live = pr < n_prob;
+                const int p = lor_lds[live ? pr : 0];
+                double *const bk = nnls_lds + (unsigned)qi * NnlsQuadGeom<N>::STRIDE;
+                const double *const rq = rec_lds + p;
+                int ids[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int sl = k & 1;
+                    const bool neg = k >= 2;
+                    ids[k] = 0x7fff;
+                    if (sl < NS) {
+                        const int rr = ql + 4 * sl;
+                        ids[k] = (rr < N) ? (neg ? N : 0) + rr + 1 : 0x7fff;
+                        if (live && rr < N) {
+                            double *c = bk + CS * (ids[k] - 1);
+                            // (row rr of E^-1 is zero before column rr; entry (rr, j) of the packed triangle otherwise)
+                            const int tri = rr * N - (rr * (rr - 1)) / 2 - rr;  // G::g(rr, j) - j
+#pragma unroll
+                            for (int j = 0; j < N; ++j) {
+                                const double e = rq[64 * (j >= rr ? tri + j : 0)];
+                                const double v = (j >= rr) ? e : 0.0;
+                                c[j] = neg ? ((j >= rr) ? -v : 0.0) : v;
+                            }
+                            c[N] = neg ? rq[64 * (G::NG + N + rr)] : rq[64 * (G::NG + rr)];
+                        }
+                    }
+                }
+                int iters, qmode;
+                double xv[4], qrnorm;
+                nnls_quad<N>(live, ids, bk, nnls_lds + 16 * NnlsQuadGeom<N>::STRIDE, xv, qmode, qrnorm, iters);
+                // the multipliers are in the block (by column id); mode, rnorm and the pass count next to them
+                if (live && ql == 0) {
+                    bk[G::META] = (double)qmode;
+                    bk[G::META + 1] = qrnorm;
+                    bk[G::META + 2] = (double)iters;
+                }
+                lds_sync();
+                // the owners of this round's problems read their answers back
+                if (has && rank >= r0 && rank < r0 + nq) {
+                    const double *ob = nnls_lds + (unsigned)(rank - r0) * NnlsQuadGeom<N>::STRIDE;
+#pragma unroll
+                    for (int r = 0; r < 2 * N; ++r) y[r] = ob[NnlsQuadGeom<N>::XS + r];
+                    nmode = (int)ob[G::META];
+                    rnorm = ob[G::META + 1];
+                    pred = (int)ob[G::META + 2];
+                }
+                lds_sync();  // (before the next round rewrites the blocks)
+            }
+            OPTIK_SCHED_FENCE();
+
+            // ---- LDP tail (lsq_dual), back-substitution, descent test, per lane ------------------------------
+            double sn[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) sn[j] = 0.0;
+            if (has) {
+                const double *const rp = rec_lds + lane;
+                int mode = nmode;
+                if (mode == 1 && rnorm <= 0.0) mode = 4;
+                if (mode == 1) {
+                    double hy = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 2 * N; ++r) hy += rp[64 * (r < N ? G::hlo(r) : G::hhi(r - N))] * y[r];
+                    double fac = 1.0 - hy;
+                    const double d1 = 1.0 + fac;
+                    if (d1 - 1.0 <= 0.0) mode = 4;
+                    else {
+                        fac = 1.0 / fac;
+#pragma unroll
+                        for (int j = 0; j < N; ++j) {
+                            double acc = 0.0;
+#pragma unroll
+                            for (int r = 0; r <= j; ++r) acc += rp[64 * G::g(r, j)] * y[r];
+#pragma unroll
+                            for (int r = 0; r <= j; ++r) acc += (-rp[64 * G::g(r, j)]) * y[N + r];
+                            sn[j] = fac * acc;
+                            OPTIK_SCHED_FENCE();
+                        }
+                    }
+                }
+                lmode = mode;
+            }
+            {
+                double lo[N], hi[N];
+#pragma unroll
+                for (int i = 0; i < N; ++i) { lo[i] = ch.lb[i] - x[i]; hi[i] = ch.ub[i] - x[i]; }
+                lsq_finish<N>(E, fv, lo, hi, sn);
+            }
+            OPTIK_SCHED_FENCE();
+            if (need_dir) {
+                if (lmode != 1) {
+                    // NLopt: modes 5,6,7 -> ROUNDOFF_LIMITED; 3,4,9 -> FAILURE
+                    ret = (lmode == 5 || lmode == 6 || lmode == 7) ? RES_ROUNDOFF_LIMITED : RES_FAILURE;
+                } else {
+                    // (g is also Kraft's v: the gradient at the start of the line search)
+                    double gs = 0.0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) { s[i] = sn[i]; x0[i] = x[i]; }
+                    f0 = f;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) gs += g[i] * s[i];
+                    t0 = f;
+                    h3 = gs;  // h3 = gs - h1 * h4 with h1 = 0 (no constraints)
+                    if (h3 >= 0.0) {
+                        again = true;  // not a descent direction: reset B and search again (next trip)
+                    } else {
+                        line = 0;
+                        alpha = 1.0;
+                    }
+                }
+            }
+            lds_sync();  // (the records are read: the next trip may rewrite them)
+        }
+        OPTIK_SCHED_FENCE();
+        if (stepping && ret == 0 && !again) {
+            // label 190: next trial point x = x0 + alpha * s, clipped (NLopt)
+            ++line;
+            h3 = alpha * h3;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                s[i] *= alpha;
+                double xi = x0[i];
+                xi += s[i];
+                if (xi < ch.lb[i]) xi = ch.lb[i];
+                else if (xi > ch.ub[i]) xi = ch.ub[i];
+                x[i] = xi;
+            }
+        }
+        // ---- a restart ended: classify (lib.rs:376-379), publish, free the lane ---------------------------
+        if (active && ret != 0) {
+            const bool success = (sp.ok_stopval && ret == RES_STOPVAL_REACHED)
+                                 || (sp.ok_ftol && ret == RES_FTOL_REACHED)
+                                 || (sp.ok_xtol && ret == RES_XTOL_REACHED);
+            if (wq.out_x) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) wq.out_x[(size_t)i * wq.total_items + item] = xbest[i];
+            }
+            if (wq.out_f) wq.out_f[item] = minf;
+            if (wq.out_status) wq.out_status[item] = ret;
+            if (wq.out_evals) wq.out_evals[item] = nevals;
+            // selection key (lib.rs:402-407): Quality = ||x - x0||_2, Speed = index
+            double k = __builtin_huge_val();
+            if (success) {
+                if (wq.quality) {
+                    const double *x0p = wq.x0 + (size_t)tslot * N;
+                    double acc = 0.0;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) { const double d = xbest[i] - x0p[i]; acc += d * d; }
+                    k = __builtin_sqrt(acc);
+                } else {
+                    k = (double)index;
+                    if (wq.first_success) atomicMin(wq.first_success + tslot, index);
+                }
+            }
+            if (wq.out_key) wq.out_key[item] = k;
+            active = false;
+            want = true;
+            again = false;
+        }
+    }
+}
+
+}  // namespace optik

@@ -55,6 +55,10 @@ hipError_t quad_solve_launch(int n, bool tip, int grid, hipStream_t stream, cons
                              bool latency_form);
 // resident single-wave workgroups per CU the kernel is built for (registers and LDS)
 int quad_solve_waves_per_cu(int n);
+// ik_lane_kernel.hip: one restart per lane, bounded sub-problems in class order (ik_lane64.hpp), n <= 7; one wave
+// per SIMD
+hipError_t lane_solve_launch(int n, bool tip, int grid, hipStream_t stream, const SolveLaunch &a, int *lds_bytes);
+int lane_solve_waves_per_cu();
 // the engine's tail on the quad solver (n <= 7, the two-waves-per-SIMD build)
 hipError_t quad_tail_launch(int n, bool tip, int grid, hipStream_t stream, const TailLaunch &a);
 

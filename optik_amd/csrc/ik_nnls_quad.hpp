@@ -59,25 +59,6 @@ __device__ unsigned long long g_quad_nnls_hist[66];
 #define QNNLS_COUNT(slot, n)
 #endif
 
-// ---- stragglers ------------------------------------------------------------------------------------
-// A wave runs the loop below until the slowest of its problems is done (5.2 loop
-// trips per call against 3.1 per problem).  With deferral the loop stops as soon as at most `max_susp`
-// problems are still running: those are SUSPENDED -- matrix and multipliers stay where they are, in
-// the quad's block; b, up, the permutation, the set sizes and the column positions go to one of the
-// wave's suspension slots in global memory (the LDS is full) -- and continue in the wave's next call
-// (ik_quad.hpp: the quad sits out one evaluation).  The arithmetic of a problem is untouched: it is
-// paused between two loop trips, at a point where everything it needs next is in those records.
-// Slot layout: value v of lane ql at slot[4 v + ql]; values [0, DEFER_NNLS_VALS) belong to this file.
-// (DEFER_SLOTS, DEFER_NNLS_VALS, DEFER_VALS, DEFER_WAVE_DOUBLES: ik_solve.hpp, next to WorkQueue::defer)
-#ifndef OPTIK_DEFER_MIN_TRIPS
-#define OPTIK_DEFER_MIN_TRIPS 2       // loop trips of a call before anything is suspended
-#endif
-
-OPTIK_DEV double u64_as_double(unsigned long long v) { return __hiloint2double((int)(unsigned)(v >> 32), (int)(unsigned)(v & 0xffffffffull)); }
-OPTIK_DEV unsigned long long double_as_u64(double d) {
-    return ((unsigned long long)(unsigned)__double2hiint(d) << 32) | (unsigned long long)(unsigned)__double2loint(d);
-}
-
 template <int N>
 OPTIK_DEV typename NnlsQuadGeom<N>::rowvec lds_col_load(const double *p) {
     const double *a = (const double *)__builtin_assume_aligned(p, 16);
@@ -98,13 +79,10 @@ OPTIK_DEV void lds_col_store(double *p, const typename NnlsQuadGeom<N>::rowvec v
 // blk + 8 (c - 1), rows 0 .. N) and an lds_sync() has made them visible; ids[k] = 1-based id of the
 // lane's k-th column (> 2N: padding).  `live` = the quad has a problem.  On return xv[k] = the
 // multiplier of the lane's k-th column; quad-uniform: mode (1 ok, 3 iteration cap), rnorm, and the
-// number of solve passes.  Stragglers (above): resume_slot = 0 for a fresh problem, 1 + s to continue the
-// one suspended in slot s of `dslots` (its block untouched since); max_susp = problems the call may leave
-// suspended (0: run every problem to its end); susp_out = 0, or 1 + the slot the quad's problem was
-// suspended to -- the other outputs then mean nothing.
+// number of solve passes.
 template <int N>
 OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const double *zeros, double (&xv)[4], int &mode_out,
-                         double &rnorm_out, int &iters_out, int resume_slot, double *dslots, int max_susp, int &susp_out) {
+                         double &rnorm_out, int &iters_out) {
     constexpr int m = N + 1, n = 2 * N;
     constexpr int CPL = 4;
     static_assert(m <= 9 && n <= 16, "row vectors hold up to sixteen entries, the permutation sixteen nibbles");
@@ -134,38 +112,12 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
         wv[k] = 0.0;
         xv[k] = 0.0;
         colp[k] = blk + CS * ((isc[k] ? ids[k] : 1) - 1);
-        if (live && isc[k] && resume_slot == 0) xs[ids[k] - 1] = 0.0;
+        if (live && isc[k]) xs[ids[k] - 1] = 0.0;
     }
     int rem_jj = 0;  // step eleven: position being removed
     // phases: 0 = step two (recompute duals, then choose), 1 = step three (choose again),
     // 2 = step six (solve), 3 = step eleven (remove), 4 = done
     int phase = live ? 0 : 4;
-    if (wave_any(live && resume_slot != 0)) {
-        // a suspended problem continues: the quad-uniform state from its slot, the multipliers from the block
-        const bool rs = live && resume_slot != 0;
-        const double *sp = dslots + (rs ? resume_slot - 1 : 0) * (DEFER_VALS * 4) + ql;
-        dvecm bl = 0.0;
-#pragma unroll
-        for (int r = 0; r < m; ++r) bl[r] = sp[4 * r];
-        const double upl = sp[4 * 9];
-        const unsigned long long il = double_as_u64(sp[4 * 10]), pk = double_as_u64(sp[4 * 11]);
-        if (rs) {
-            b = bl;
-            up = upl;
-            indx.v = il;
-            nsetp = (int)(pk & 15ull);
-            npp1 = nsetp + 1;
-            iter = (int)((pk >> 4) & 0xffull);
-            phase = (int)((pk >> 12) & 3ull);
-            rem_jj = (int)((pk >> 14) & 15ull);
-#pragma unroll
-            for (int k = 0; k < CPL; ++k) {
-                pos[k] = isc[k] ? (int)((pk >> (32 + 8 * k)) & 0xffull) : pos[k];
-                inZ[k] = isc[k] && pos[k] > nsetp;  // (positions 1 .. nsetp are set P)
-                xv[k] = isc[k] ? xs[ids[k] - 1] : 0.0;
-            }
-        }
-    }
     lds_sync();
 #if defined(OPTIK_PROFILE) && !defined(OPTIK_LANE_EMU)
     unsigned long long np_[8] = {0, 0, 0, 0, 0, 1, 0, 0};
@@ -179,18 +131,7 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
         if ((threadIdx.x & 63u) == 0) atomicAdd(&g_quad_nnls_hist[49 + n_live_], 1ull);
     }
 #endif
-    int trips_done = 0;
-    for (;;) {
-        {
-            const unsigned long long rm = __ballot(phase < 4);
-            if (rm == 0ull) break;
-            // stragglers: at most max_susp problems left, each between two trips at a point its records describe
-            // (phase 1 -- "choose again" -- would need the duals as well; it lasts one trip)
-            if (max_susp > 0 && trips_done >= OPTIK_DEFER_MIN_TRIPS && __popcll(rm) <= 4 * max_susp
-                && !wave_any(phase == 1))
-                break;
-        }
-        ++trips_done;
+    while (wave_any(phase < 4)) {
         QNNLS_COUNT(4, 1);
 #if defined(OPTIK_PROFILE) && !defined(OPTIK_LANE_EMU)
         ++trips_;
@@ -540,29 +481,6 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
             }
             lds_sync();
             QNNLS_PROBE(3);
-        }
-    }
-    susp_out = 0;
-    if (wave_any(phase < 4)) {
-        // suspend what is still running: slot = the quad's rank among the suspended quads
-        const bool sus = phase < 4;
-        const unsigned long long sm = __ballot(sus);
-        const int rank = (int)__popcll(sm & ((1ull << quad_base()) - 1ull)) / 4;
-#ifdef OPTIK_LANE_EMU
-        if (sus && ql == 0) optik_emu::g_suspensions.fetch_add(1);  // (tests/emu: the test wants to see some)
-#endif
-        if (sus) {
-            double *sp = dslots + rank * (DEFER_VALS * 4) + ql;
-#pragma unroll
-            for (int r = 0; r < m; ++r) sp[4 * r] = b[r];
-            sp[4 * 9] = up;
-            sp[4 * 10] = u64_as_double(indx.v);
-            unsigned long long pk = (unsigned long long)(nsetp & 15) | ((unsigned long long)(iter & 0xff) << 4)
-                                    | ((unsigned long long)(phase & 3) << 12) | ((unsigned long long)(rem_jj & 15) << 14);
-#pragma unroll
-            for (int k = 0; k < CPL; ++k) pk |= (unsigned long long)(pos[k] & 0xff) << (32 + 8 * k);
-            sp[4 * 11] = u64_as_double(pk);
-            susp_out = 1 + rank;
         }
     }
 #if defined(OPTIK_PROFILE) && !defined(OPTIK_LANE_EMU)

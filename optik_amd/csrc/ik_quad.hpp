@@ -35,14 +35,6 @@
 #include "ik_solve.hpp"
 #include "ik_nnls_quad.hpp"
 
-// stragglers (ik_nnls_quad.hpp): a direction pass with P sub-problems may leave min(P / DIV, MAX) of them suspended
-#ifndef OPTIK_DEFER_DIV
-#define OPTIK_DEFER_DIV 4
-#endif
-#ifndef OPTIK_DEFER_MAX
-#define OPTIK_DEFER_MAX 3  // (<= DEFER_SLOTS)
-#endif
-
 namespace optik {
 
 template <int N>
@@ -133,6 +125,22 @@ OPTIK_DEV const T *reload_barrier(const T *p) {
     return p;
 }
 
+// The same for a pointer INTO LDS: only the offset is laundered, the address space is kept.  (A generic pointer
+// laundered whole comes back as FLAT accesses: the LDS is reached through the aperture check of the vector-memory
+// path, every access counts on both wait counters, and nothing the LDS returns can be waited for selectively.)
+template <class T>
+OPTIK_DEV const T *reload_barrier_lds(const T *p) {
+#ifdef OPTIK_LANE_EMU
+    asm volatile("" : "+r"(p));
+    return p;
+#else
+    typedef const T __attribute__((address_space(3))) *lds_cptr;
+    unsigned off = (unsigned)(__UINTPTR_TYPE__)(lds_cptr)p;
+    asm volatile("" : "+v"(off));
+    return (const T *)(lds_cptr)(__UINTPTR_TYPE__)off;
+#endif
+}
+
 // (the same for an integer: what is computed from the result is computed where it is used, not hoisted out
 // of the solver loop as an invariant -- and then spilled for the whole loop)
 OPTIK_DEV int opaque_int(int v) {
@@ -147,8 +155,7 @@ OPTIK_DEV int opaque_int(int v) {
 template <int N, bool TIP>
 OPTIK_DEV double eval_quad(const ChainDev &ch, const EvalParams &ep, const double *target7,
                            const double (&x)[QuadDims<N>::NS], double (&gout)[QuadDims<N>::NS],
-                           double *park /* the lane's parking doubles in the quad's block: park[4 i], i < 12 */,
-                           bool park_ok = true /* false: the block holds a suspended problem, leave it alone (the quad's result is not used) */) {
+                           double *park /* the lane's parking doubles in the quad's block: park[4 i], i < 12 */) {
     constexpr int NS = QuadDims<N>::NS;
     const int q = quad_lane_now();
     Q4 jq[NS];
@@ -203,12 +210,10 @@ OPTIK_DEV double eval_quad(const ChainDev &ch, const EvalParams &ep, const doubl
     // X = T_target^-1 T_ee  (objective.rs:69-70)
     const Pose X = pose_inv_mul(load_pose(target7), ee);
     // (the columns' geometry waits in LDS while the error terms -- the register peak of the kernel -- are formed)
-    if (park_ok) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
+    for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { park[4 * (6 * s + c)] = lin[s][c]; park[4 * (6 * s + 3 + c)] = ang[s][c]; }
-    }
+        for (int c = 0; c < 3; ++c) { park[4 * (6 * s + c)] = lin[s][c]; park[4 * (6 * s + 3 + c)] = ang[s][c]; }
     OPTIK_SCHED_FENCE();
     const V3 w = so3_log(X.q);
     const RotTerms rt = rot_terms(w);
@@ -238,7 +243,7 @@ OPTIK_DEV double eval_quad(const ChainDev &ch, const EvalParams &ep, const doubl
     OPTIK_SCHED_FENCE();
 
     // Jtask = Jlog6 * J (objective.rs:81) and g = (2 e') Jtask (objective.rs:106-109) for the lane's columns
-    const double *pk = reload_barrier((const double *)park);
+    const double *pk = reload_barrier_lds((const double *)park);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
 #pragma unroll
@@ -679,15 +684,6 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
     int ia = 0, ib = 0;
     bool first = true;
     bool active = false, want = member;
-    // stragglers (ik_nnls_quad.hpp): 0, or 1 + the suspension slot that holds the restart's bounded sub-problem
-    // -- the quad then sits out the evaluation and resumes inside the direction search
-    int sslot = 0;
-    // the wave's suspension slots (null: every sub-problem runs to its end within its trip)
-#ifdef OPTIK_LANE_EMU
-#define dslots_now() ((*reload_barrier(&wq_in)).defer)
-#else
-#define dslots_now() ((*reload_barrier(&wq_in)).defer ? (*reload_barrier(&wq_in)).defer + (size_t)blockIdx.x * DEFER_WAVE_DOUBLES : nullptr)
-#endif
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         x[s] = 0.0; x0[s] = 0.0; g[s] = 0.0; sv[s] = 0.0; xb[s * 64] = 0.0; xp[s * 64] = 0.0; dg[s] = 1.0;
@@ -704,14 +700,13 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
         // ---- refill: quads without a restart pull the next work item (the leader fetches) ----------
         if constexpr (Tail::on) {
             if (wave_any(want)) {
-                const Tail &tl = *reload_barrier(tail_in);
+                const Tail &tl = *reload_barrier_lds(tail_in);
                 const int qr = quad_lane_now();
                 unsigned long long e = fetch_items(tl.cursor, want && qr == 0);
                 e = quad_get_u64(e, 0);
                 if (want) {
                     want = false;
                     if (e < (unsigned long long)*tl.count) {
-                        sslot = 0;
                         active = tl.template import<N>(tl.list[e], qr, x, x0, g, sv, Lr, dg, pa, pb, ia, ib, first, pending, ret,
                                                        xb, xp);
                         want = !active;  // (an empty slot in the list: take the next entry)
@@ -721,7 +716,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
         } else if (wave_any(want)) {
             // (the launch parameters live in LDS: every region of a trip re-reads what it needs through a
             // laundered pointer, so that none of them is carried -- and spilled -- across the other regions)
-            const WorkQueue &wq = *reload_barrier(&wq_in);
+            const WorkQueue &wq = *reload_barrier_lds(&wq_in);
             unsigned long long it = fetch_items(wq.next_item, want && quad_lane_now() == 0);
             it = quad_get_u64(it, 0);
             // (the seed of the item's restart index, by every quad alike: the block's rounds move values
@@ -764,7 +759,6 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                     ib = (qr == 0) ? (int)(unsigned)(rq & 0xffffffffull) : ((qr == 1) ? (int)(unsigned)(rq >> 32) : 0);
                     first = true;
                     active = true;
-                    sslot = 0;
                 }
             }
         }
@@ -777,7 +771,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
         if constexpr (Tail::on) {
             const unsigned rlo = (unsigned)quad_get(ib, 0), rhi = (unsigned)quad_get(ib, 1);
             if (active && ret == 0) {
-                const Tail &tl = *reload_barrier(tail_in);
+                const Tail &tl = *reload_barrier_lds(tail_in);
                 const auto &J = tl.jobs[job];
                 const unsigned long long index = J.restart_begin + (((unsigned long long)rhi << 32) | rlo);
                 // lib.rs:308: abandon when timed out or another restart of the target succeeded
@@ -793,7 +787,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
         } else {
             const unsigned rlo = (unsigned)quad_get(ib, 0), rhi = (unsigned)quad_get(ib, 1);
             if (active) {
-                const WorkQueue &wq = *reload_barrier(&wq_in);
+                const WorkQueue &wq = *reload_barrier_lds(&wq_in);
                 const unsigned long long index = wq.restart_begin + (((unsigned long long)rhi << 32) | rlo);
                 // lib.rs:308: abandon when timed out or another restart of the target succeeded
                 bool stop = false;
@@ -809,8 +803,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
         // (the four lanes may have read first_success / the clock at different moments: the leader decides)
         ret = quad_get(ret, 0);
         const bool stepping = active && ret == 0;
-        const bool resume = stepping && sslot != 0;  // a suspended sub-problem continues: no evaluation this trip
-        const bool do_eval = stepping && !pending && !resume;
+        const bool do_eval = stepping && !pending;
         if constexpr (Tail::on) n_exec += (unsigned)__popcll(__ballot(do_eval)) / QUAD;
         double gn[NS];
         double fn = 0.0;
@@ -821,30 +814,19 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
             // the register peak of the loop (~200 VGPRs on its own)
             int pi = 0;
             double *const bp = blk + quad_lane_now();  // the lane's i-th parked double: bp[4 i]
-            // (a quad whose block holds a suspended sub-problem parks nothing: what it needs is in its slot)
-            if (sslot == 0) {
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    bp[4 * pi++] = x0[s]; bp[4 * pi++] = g[s]; bp[4 * pi++] = sv[s]; bp[4 * pi++] = dg[s];
-#pragma unroll
-                    for (int i = 0; i < NM; ++i)
-                        if (slot_has<N>(s, i)) bp[4 * pi++] = Lr[s][i];
-                }
-            }
-            pi = 0;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                pi += 4;
+                bp[4 * pi++] = x0[s]; bp[4 * pi++] = g[s]; bp[4 * pi++] = sv[s]; bp[4 * pi++] = dg[s];
 #pragma unroll
                 for (int i = 0; i < NM; ++i)
-                    if (slot_has<N>(s, i)) ++pi;
+                    if (slot_has<N>(s, i)) bp[4 * pi++] = Lr[s][i];
             }
             OPTIK_SCHED_FENCE();
             // (the target pose is re-read for every evaluation: seven L1 / L2 hits instead of 14 registers)
             const double *target7;
-            if constexpr (Tail::on) target7 = (*reload_barrier(tail_in)).jobs[job].targets + (size_t)tslot * 7;
-            else target7 = (*reload_barrier(&wq_in)).targets + (size_t)tslot * 7;
-            const EvalParams &ep = *reload_barrier(&ep_in);
+            if constexpr (Tail::on) target7 = (*reload_barrier_lds(tail_in)).jobs[job].targets + (size_t)tslot * 7;
+            else target7 = (*reload_barrier_lds(&wq_in)).targets + (size_t)tslot * 7;
+            const EvalParams &ep = *reload_barrier_lds(&ep_in);
 #ifndef OPTIK_QUAD_EXP_NO_EVAL
 #ifdef OPTIK_QUAD_EXP_DUP_EVAL
             // (cost-by-duplication experiments, tools/quad_dup_costs.sh: the phase runs twice on the same inputs,
@@ -854,19 +836,19 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                 double xx[NS];
 #pragma unroll
                 for (int s = 0; s < NS; ++s) { xx[s] = x[s]; asm volatile("" : "+v"(xx[s])); }
-                double f0 = eval_quad<N, TIP>(ch, ep, target7, xx, gn0, bp + 4 * pi, sslot == 0);
+                double f0 = eval_quad<N, TIP>(ch, ep, target7, xx, gn0, bp + 4 * pi);
                 asm volatile("" :: "v"(f0), "v"(gn0[0]), "v"(gn0[NS - 1]));
                 OPTIK_SCHED_FENCE();
             }
 #endif
-            fn = eval_quad<N, TIP>(ch, ep, target7, x, gn, bp + 4 * pi, sslot == 0);
+            fn = eval_quad<N, TIP>(ch, ep, target7, x, gn, bp + 4 * pi);
 #else
             fn = target7[0]; gn[0] = x[0]; if (NS > 1) gn[NS - 1] = x[NS - 1];
 #endif
             OPTIK_SCHED_FENCE();
             // (through a pointer the compiler knows nothing about: otherwise it forwards the stored values to
             // these loads, i.e. keeps them in registers across the evaluation after all)
-            const double *pk = reload_barrier((const double *)bp);
+            const double *pk = reload_barrier_lds((const double *)bp);
             pi = 0;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -875,31 +857,14 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                 for (int i = 0; i < NM; ++i)
                     if (slot_has<N>(s, i)) Lr[s][i] = pk[4 * pi++];
             }
-            if (wave_any(sslot != 0)) {
-                // a quad with a suspended sub-problem read its block's matrix just now: the gradient and the
-                // factor come back from its slot (x0 and s are dead until the direction search rewrites them)
-                const bool rs = sslot != 0;
-                const double *sp = dslots_now() + (rs ? sslot - 1 : 0) * (DEFER_VALS * 4) + DEFER_NNLS_VALS * 4 + quad_lane_now();
-                int qi = 0;
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const double gq = sp[4 * qi++], dq = sp[4 * qi++];
-                    g[s] = rs ? gq : g[s];
-                    dg[s] = rs ? dq : dg[s];
-#pragma unroll
-                    for (int i = 0; i < NM; ++i)
-                        if (slot_has<N>(s, i)) { const double lq = sp[4 * qi++]; Lr[s][i] = rs ? lq : Lr[s][i]; }
-                }
-            }
         }
         OPTIK_PROF_END(1);
         OPTIK_SCHED_FENCE();
 
         // ---- NLopt bookkeeping and Kraft's line search (labels 100 / 220), replicated scalars ------
         OPTIK_PROF_BEGIN();
-        bool need_dir = stepping && (pending || resume), reset = false, do_bfgs = false;  // (a deferred direction resumes at its LSQ call)
-        int dir_pass = 0;
-        const SolveParams &sp = *reload_barrier(&sp_in);
+        bool need_dir = stepping && pending, reset = false, do_bfgs = false;  // (a deferred direction resumes at its LSQ call)
+        const SolveParams &sp = *reload_barrier_lds(&sp_in);
         double u[NS];
 #pragma unroll
         for (int s = 0; s < NS; ++s) u[s] = 0.0;
@@ -1010,7 +975,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
         OPTIK_PROF_BEGIN();
         while (wave_any(need_dir)) {
             OPTIK_PROF_COUNT(2, 1);  // (direction passes: more than one per trip when some quad has to reset and search again)
-            const SolveParams &sp = *reload_barrier(&sp_in);
+            const SolveParams &sp = *reload_barrier_lds(&sp_in);
             bool pass = need_dir;
             const bool sx0 = stop_x_quad<N>(sp, x, x0);
             const int qd = quad_lane_now();
@@ -1113,7 +1078,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                     if (s < NS) {
                         const int r = qn + 4 * s;
                         ids[k] = (r < N) ? (neg ? N : 0) + r + 1 : 0x7fff;
-                        if (need_nnls && r < N && sslot == 0) {  // (a suspended sub-problem's matrix is there already, transformed)
+                        if (need_nnls && r < N) {
                             double *c = bk + NnlsQuadGeom<N>::CS * (ids[k] - 1);
 #pragma unroll
                             for (int j = 0; j < N; ++j) {
@@ -1126,38 +1091,8 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                 }
                 int iters;
                 double xv[CPL];
-                // stragglers: the first direction pass of a trip may leave up to a quarter of its sub-problems
-                // (three at most) suspended once the others are done
-                double *const dsl = dslots_now();
-                int max_susp = 0, snew = 0;
-                if (dsl && dir_pass == 0) {
-                    const int n_part = (int)__popcll(__ballot(need_nnls)) / QUAD;
-                    max_susp = n_part / OPTIK_DEFER_DIV < OPTIK_DEFER_MAX ? n_part / OPTIK_DEFER_DIV : OPTIK_DEFER_MAX;
-                }
-#ifdef OPTIK_QUAD_EXP_DUP_NNLS
-                max_susp = 0;
-#endif
 #ifndef OPTIK_QUAD_EXP_NO_NNLS
-                nnls_quad<N>(need_nnls, ids, bk, nnls_lds + QUADS_PER_WAVE * NnlsQuadGeom<N>::STRIDE, xv, nmode, rnorm, iters,
-                             need_nnls ? sslot : 0, dsl, max_susp, snew);
-                if (need_nnls) sslot = snew;
-                if (wave_any(snew != 0)) {
-                    // what the sitting-out quad's evaluation slot would clobber goes to the suspension slot as well
-                    const bool sus = snew != 0;
-                    double *sp = dsl + (sus ? snew - 1 : 0) * (DEFER_VALS * 4) + DEFER_NNLS_VALS * 4 + qn;
-                    if (sus) {
-                        int qi = 0;
-#pragma unroll
-                        for (int s = 0; s < NS; ++s) {
-                            sp[4 * qi++] = g[s]; sp[4 * qi++] = dg[s];
-#pragma unroll
-                            for (int i = 0; i < NM; ++i)
-                                if (slot_has<N>(s, i)) sp[4 * qi++] = Lr[s][i];
-                        }
-                        pass = false;      // the rest of this pass is not the quad's: it continues next trip
-                        need_dir = false;
-                    }
-                }
+                nnls_quad<N>(need_nnls, ids, bk, nnls_lds + QUADS_PER_WAVE * NnlsQuadGeom<N>::STRIDE, xv, nmode, rnorm, iters);
 #else
                 for (int k = 0; k < CPL; ++k) xv[k] = bk[k]; iters = 0;
 #endif
@@ -1219,13 +1154,12 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                     }
                 }
             }
-            ++dir_pass;
         }
         OPTIK_PROF_END(5);
         OPTIK_PROF_BEGIN();
         const int qf = quad_lane_now();
         const double alpha_t = quad_get(pa, 3);
-        if (stepping && ret == 0 && sslot == 0) {
+        if (stepping && ret == 0) {
             // label 190: next trial point x = x0 + alpha * s, clipped (NLopt)
             ia = (qf == 1) ? ia + 1 : ia;           // ++line
             pa = (qf == 2) ? alpha_t * pa : pa;     // h3 = alpha * h3
@@ -1244,7 +1178,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
         // ---- a restart ended: classify (lib.rs:376-379), publish, free the quad -------------------
         const bool ended = active && ret != 0;
         if (wave_any(ended)) {
-            const SolveParams &sp = *reload_barrier(&sp_in);
+            const SolveParams &sp = *reload_barrier_lds(&sp_in);
             const double minf = quad_get(pb, 0);
             const int nevals = quad_get(ia, 2);
             const unsigned long long rr = ((unsigned long long)(unsigned)quad_get(ib, 1) << 32) | (unsigned)quad_get(ib, 0);
@@ -1256,12 +1190,12 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
             unsigned long long o_restarts, o_begin, o_stride;
             bool o_quality;
             if constexpr (Tail::on) {
-                const auto &J = (*reload_barrier(tail_in)).jobs[job];
+                const auto &J = (*reload_barrier_lds(tail_in)).jobs[job];
                 o_x0 = J.x0; o_x = J.out_x; o_f = J.out_f; o_key = J.out_key; o_status = J.out_status; o_evals = J.out_evals;
                 o_fs = J.first_success; o_restarts = J.n_restarts; o_begin = J.restart_begin; o_stride = J.n_items;
                 o_quality = J.quality != 0;
             } else {
-                const WorkQueue &wq = *reload_barrier(&wq_in);
+                const WorkQueue &wq = *reload_barrier_lds(&wq_in);
                 o_x0 = wq.x0; o_x = wq.out_x; o_f = wq.out_f; o_key = wq.out_key; o_status = wq.out_status; o_evals = wq.out_evals;
                 o_fs = wq.first_success; o_restarts = wq.n_restarts; o_begin = wq.restart_begin; o_stride = wq.total_items;
                 o_quality = wq.quality != 0;
@@ -1312,24 +1246,22 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                         }
                     }
                     if (o_key) o_key[item] = k;
-                    if constexpr (Tail::on) (*reload_barrier(tail_in)).template release<N>(slot_u);
+                    if constexpr (Tail::on) (*reload_barrier_lds(tail_in)).template release<N>(slot_u);
                 }
                 active = false;
                 want = true;
-                sslot = 0;
             }
         }
         OPTIK_PROF_END(3);
     }
     OPTIK_PROF_FLUSH(wq_in.prof);
     if constexpr (Tail::on) {
-        const Tail &tl = *reload_barrier(tail_in);
+        const Tail &tl = *reload_barrier_lds(tail_in);
         if (tl.exec_evals && n_exec && (threadIdx.x & 63u) == 0) atomicAdd(tl.exec_evals + (blockIdx.x % 64u), (unsigned long long)n_exec);
     }
 #undef xb
 #undef xp
 #undef blk
-#undef dslots_now
 }
 
 }  // namespace optik

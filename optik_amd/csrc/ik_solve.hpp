@@ -176,16 +176,7 @@ struct WorkQueue {
     int32_t *out_status;                 // [T*R]
     int32_t *out_evals;                  // [T*R]
     unsigned long long *prof;            // [8] phase cycle totals (OPTIK_PROFILE builds), else null
-    double *defer;                       // quad solver: [grid][DEFER_WAVE_DOUBLES] suspension slots of the waves' straggling
-                                         // bounded sub-problems (ik_nnls_quad.hpp), or null: none is ever suspended
 };
-
-// Suspension slots of the quad solver's straggling bounded sub-problems (ik_nnls_quad.hpp, ik_quad.hpp): value v
-// of quad lane ql at slot[4 v + ql]; DEFER_WAVE_DOUBLES per resident wave behind WorkQueue::defer.
-constexpr int DEFER_SLOTS = 3;        // problems a wave may have suspended at a time
-constexpr int DEFER_NNLS_VALS = 12;   // b[<= 9], up, permutation, {nsetp, iter, phase, rem_jj | positions}
-constexpr int DEFER_VALS = DEFER_NNLS_VALS + 18;  // + the solver state an evaluation would clobber: g, l(j,j), rows of L
-constexpr int DEFER_WAVE_DOUBLES = DEFER_SLOTS * DEFER_VALS * 4;
 
 // Wave-aggregated fetch of one work item per requesting lane: one atomic per wave.
 OPTIK_DEV unsigned long long fetch_items(unsigned long long *counter, bool want) {

@@ -42,7 +42,6 @@ struct Dim3 {
 };
 
 inline thread_local Wave *t_wave = nullptr;
-inline std::atomic<long> g_suspensions{0};  // bounded sub-problems the emulated waves suspended (ik_nnls_quad.hpp)
 inline unsigned threadIdx_x();
 
 inline void barrier() {

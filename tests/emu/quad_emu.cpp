@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "ik_quad.hpp"
+#include "ik_lane64.hpp"
 #include "ik_host_params.hpp"
 
 using namespace optik;
@@ -33,20 +34,37 @@ void run_wave(const ChainDev &ch, const EvalParams &ep, const SolveParams &sp, c
     for (auto &t : th) t.join();
 }
 
+// the lane-per-restart form (ik_lane64.hpp): `lanes` emulated lanes (a multiple of 4), each with its own restart
+template <int N, bool TIP>
+void run_wave_lane64(const ChainDev &ch, const EvalParams &ep, const SolveParams &sp, const uint32_t (&key)[8],
+                     const double (&scale)[MAX_DOF], const WorkQueue &wq, int lanes) {
+    optik_emu::Wave wave;
+    wave.lanes = lanes;
+    std::vector<double> lds((size_t)lane64_block_lds<N>(), 0.0), rec((size_t)lane64_rec_lds<N>(), 0.0);
+    std::vector<int> lor(64, 0);
+    std::vector<std::thread> th;
+    for (int lane = 0; lane < wave.lanes; ++lane) {
+        th.emplace_back([&, lane]() {
+            optik_emu::t_wave = &wave;
+            threadIdx.x = (unsigned)lane;
+            lane64_wave<N, TIP>(ch, ep, sp, key, scale, wq, lds.data(), rec.data(), lor.data());
+        });
+    }
+    for (auto &t : th) t.join();
+}
+
 }  // namespace
 
 extern "C" {
-
-// sub-problems suspended since the last call of this function
-long quad_emu_suspensions() { return optik_emu::g_suspensions.exchange(0); }
 
 // origins [J][7] (t, quat ijkw), axes [n][3], J = n or n + 1; restarts [begin, end) of ONE target.
 // out_x [n][R], out_f / out_key [R], out_status / out_evals [R].  quads: restarts in flight (1 .. 16).
 int quad_emu_solve(const double *origins, const double *axes, int n, int n_joints, const double *lb, const double *ub,
                    const optik_solver_config *cfg, const double *target7, const double *x0, const double *ee_offset7,
                    uint64_t restart_begin, uint64_t restart_end, int quads, int range_rule, double *out_x, double *out_f,
-                   double *out_key, int32_t *out_status, int32_t *out_evals, int defer /* 1: the wave may suspend straggling sub-problems */) {
+                   double *out_key, int32_t *out_status, int32_t *out_evals, int lane64 /* 1: ik_lane64.hpp, 4 * quads lanes */) {
     if (n < 1 || n > 8 || quads < 1 || quads > 16 || restart_end <= restart_begin) return -1;
+    if (lane64 && n > 7) return -1;
     ChainDev ch;
     std::memset(&ch, 0, sizeof ch);
     ch.n_pos = n;
@@ -80,25 +98,36 @@ int quad_emu_solve(const double *origins, const double *axes, int n, int n_joint
     wq.first_success = nullptr;
     wq.n_targets = 1;
     wq.quality = cfg->solution_mode == 1;
-    wq.lanes = quads;
+    wq.lanes = lane64 ? 4 * quads : quads;
     wq.out_x = out_x;
     wq.out_f = out_f;
     wq.out_key = out_key;
     wq.out_status = out_status;
     wq.out_evals = out_evals;
-    std::vector<double> dslots((size_t)DEFER_WAVE_DOUBLES, 0.0);
-    wq.defer = defer ? dslots.data() : nullptr;
 
 #define RUN(NN)                                                                              \
     case NN:                                                                                 \
         if (ch.has_tip) run_wave<NN, true>(ch, ep, sp, key, scale, wq, quads);               \
         else run_wave<NN, false>(ch, ep, sp, key, scale, wq, quads);                         \
         break;
+#define RUN64(NN)                                                                            \
+    case NN:                                                                                 \
+        if (ch.has_tip) run_wave_lane64<NN, true>(ch, ep, sp, key, scale, wq, 4 * quads);    \
+        else run_wave_lane64<NN, false>(ch, ep, sp, key, scale, wq, 4 * quads);              \
+        break;
+    if (lane64) {
+        switch (n) {
+            RUN64(1) RUN64(2) RUN64(3) RUN64(4) RUN64(5) RUN64(6) RUN64(7)
+        default: return -1;
+        }
+        return 0;
+    }
     switch (n) {
         RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8)
     default: return -1;
     }
 #undef RUN
+#undef RUN64
     return 0;
 }
 

@@ -49,17 +49,15 @@ def test_every_restart_bit_equal_to_the_oracle(emu, oracle, chains, robot, R, qu
     assert 0 < ref["success"].sum() < R or n < 3  # both outcomes are exercised on the real arms
 
 
-@pytest.mark.parametrize("robot,R,quads", [("panda", 40, 8), ("ur10", 32, 8), ("arm8", 24, 8)])
-def test_suspended_subproblems_bit_equal_to_the_oracle(emu, oracle, chains, robot, R, quads):
-    """Stragglers (ik_nnls_quad.hpp): with four or more restarts in a wave the direction search may suspend the last
-    quarter of a trip's bounded sub-problems and continue them in the next trip -- a pause between two loop trips of
-    Lawson-Hanson, not a change of its arithmetic: every restart still equals the oracle's bit for bit."""
+@pytest.mark.parametrize("robot,R,quads", [("panda", 48, 4), ("ur10", 40, 4), ("panda_hand", 24, 2), ("ur3e", 24, 3),
+                                           ("panda3", 24, 2), ("panda1", 8, 1)])
+def test_lane_per_restart_form_bit_equal_to_the_oracle(emu, oracle, chains, robot, R, quads):
+    """ik_lane64.hpp (one restart per lane, the wave's bounded sub-problems ranked by predicted pass count and solved
+    in rounds by its quads) on a partial wave of 4 * quads lanes: more problems than quads, so several rounds per trip."""
     from optik_amd import _native as nat
     d, ch, tgt, x0 = _case(oracle, chains, robot, 7)
     n = len(d["lb"])
-    emu.suspensions()
-    got = emu.solve(d, nat.make_config(solution_mode="speed"), tgt, x0, 0, R, quads=quads, defer=True)
-    assert emu.suspensions() > 0  # (the case does exercise the mechanism)
+    got = emu.solve(d, nat.make_config(solution_mode="speed"), tgt, x0, 0, R, quads=quads, lane64=True)
     ref = oracle.ik(ch, oracle.make_config(solution_mode="speed"), tgt, x0, 0, R, n_threads=4, early_exit=False,
                     per_restart=True)
     _assert_same(got, ref, n)
