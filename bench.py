@@ -62,7 +62,8 @@ F64_VALU_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 16 f64 lanes/clk x 2 (FMA) x 
 # ... and what this path can reach at best: -ffp-contract=off (rustc never fuses a*b+c, and the
 # bit-exactness contract with the oracle forbids it) makes every f64 instruction ONE flop
 F64_VALU_NOFMA_TFLOPS = 39.3
-PMC_FILES = [os.path.join(ROOT, "profiles", "r3_pmc_by_command.json"),
+PMC_FILES = [os.path.join(ROOT, "profiles", "r4_pmc_by_command.json"),
+             os.path.join(ROOT, "profiles", "r3_pmc_by_command.json"),
              os.path.join(ROOT, "profiles", "r2_pmc_by_command.json")]
 PMC_FILE = PMC_FILES[0]
 
@@ -254,10 +255,9 @@ def main():
     ap.add_argument("--targets", type=int, default=0,
                     help="config 5: targets per step (cut into one part per rank), each an independent ik() call")
     ap.add_argument("--path", default="auto", choices=["auto", "engine", "kernel"],
-                    help="engine: streaming phase kernels with continuous batching (steps submitted "
-                         "together share the slot pool); kernel: one persistent solve kernel per step; "
-                         "auto (default) = engine, except Speed batches of --targets (kernel, as "
-                         "Robot.ik_batch does); results are identical")
+                    help="kernel (= auto, the default): ONE persistent solve kernel for the run's steps, restart state "
+                         "in registers and LDS; engine: streaming phase kernels over an HBM slot pool with "
+                         "continuous batching; results are identical")
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the process-group path (init_process_group, the min / sum / max all-reduces, "
                          "all_gather_object) even with ONE rank: RCCL on a single GPU")
@@ -265,9 +265,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
     if args.path == "auto":
-        # what the product picks (robot_host.cpp:ik_batch_on_device): a Speed batch of targets runs on
-        # the cooperative kernel with restart-major hand-out, everything else on the streaming engine
-        args.path = "kernel" if (args.targets and args.mode == "speed") else "engine"
+        # the single-launch solvers (state in registers and LDS, one launch per run): from one full load of the
+        # chip on the lane-per-restart form (ik_lane64.hpp), below it the quad solver; `--path engine` is the
+        # streaming engine of rounds 1-3 (state in an HBM slot pool, five phase kernels per trip)
+        args.path = "kernel"
     if args.restarts is None:
         args.restarts = 256 if args.targets else 65536
 
@@ -561,6 +562,8 @@ def main():
             achieved = out_bytes * per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
             kname = {"coop": "ik_coop_kernel", "lane": "ik_solve_kernel"}.get(os.environ.get("OPTIK_SOLVE_KERNEL", ""),
                                                                                 "ik_quad_kernel")
+            if kname == "ik_quad_kernel" and info["lds_bytes"] > 30000:
+                kname = "ik_lane_kernel"  # one restart per lane (ik_lane64.hpp): 39 KB of LDS per single-wave workgroup
             wide_hbm = n > 8 and os.environ.get("OPTIK_WIDE_FORM", "") == "hbm"
             if n > 8:  # the general solver: a restart per wave in LDS, or per lane in an HBM workspace
                 kname = "wide_solve_kernel" if wide_hbm else "wide_solve_coop_kernel"

@@ -1167,8 +1167,14 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     }
     coop = coop && !quadk && !widek;
     // the throughput form for n <= 7: one restart per lane, bounded sub-problems in class order (ik_lane64.hpp)
-    bool lanek = false;
-    if (const char *e = std::getenv("OPTIK_SOLVE_KERNEL")) lanek = quadk && ch->n <= 7 && std::strcmp(e, "lane64") == 0;
+    // (the default from one full load of the chip on -- 64 restarts for each of its four waves per CU: below that a
+    // launch is as long as its longest restart, and the quad solver's trip is the shorter one; tools/lane_vs_quad_probe.py)
+    bool lanek = quadk && ch->n <= 7;
+    bool lane_forced = false;
+    if (const char *e = std::getenv("OPTIK_SOLVE_KERNEL")) {
+        lane_forced = lanek && std::strcmp(e, "lane64") == 0;
+        lanek = lanek && std::strcmp(e, "quad") != 0;
+    }
     // Persistent waves, each pulling work items until the queue is dry: as many as a CU holds
     // (lane kernel: 2 workgroups, LDS-bound; cooperative kernel: 4, one per SIMD), times the CU count.
     const int cus = ch->num_cus > 0 ? ch->num_cus : 256;
@@ -1180,7 +1186,7 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         return e && std::atoll(e) > 0 ? std::atoll(e) : 8ll;
     }();
     const bool quad_latency = quadk && (long long)cols <= (long long)cus * 4;
-    lanek = lanek && !quad_latency;
+    lanek = lanek && !quad_latency && (lane_forced || (long long)cols >= (long long)cus * lane_solve_waves_per_cu() * 64);
     long long cap = (long long)cus * (lanek ? lane_solve_waves_per_cu() : quadk ? (quad_latency ? 4 : quad_solve_waves_per_cu(ch->n)) : (coop ? 4 : (widek ? wide_waves_per_cu : ch->waves_per_cu)));
     // (experiments: fewer resident waves per CU than the kernel could have, e.g. to share the chip with another stream's kernels)
     if (const char *e = std::getenv("OPTIK_SOLVE_WAVES_PER_CU")) {

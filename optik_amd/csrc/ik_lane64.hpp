@@ -62,6 +62,9 @@ template <int N>
 constexpr int lane64_rec_lds() { return Lane64Geom<N>::REC * 64; }
 
 constexpr int LANE64_CLASSES = 8;  // predicted pass classes 1 .. 7 (0: no bounded problem this trip)
+#ifndef OPTIK_LANE_REFILL
+#define OPTIK_LANE_REFILL 4       // idle lanes a wave accumulates before it refills (the seed generation runs for the whole wave)
+#endif
 
 // quads a wave has (the emulation of tests/emu runs partial waves)
 OPTIK_DEV int lane64_quads() {
@@ -108,7 +111,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
         // ---- refill: lanes without a restart pull the next work item ----------------------------------
         // (the seed generation runs for the whole wave: wait until several lanes are idle -- or none is busy)
         const unsigned n_want = (unsigned)__popcll(__ballot(want));
-        if (n_want >= (unsigned)(wq.lanes < (int)REFILL_BATCH ? wq.lanes : (int)REFILL_BATCH) || (n_want > 0 && !wave_any(active))) {
+        if (n_want >= (unsigned)(wq.lanes < OPTIK_LANE_REFILL ? wq.lanes : OPTIK_LANE_REFILL) || (n_want > 0 && !wave_any(active))) {
             const unsigned long long it = fetch_items(wq.next_item, want);
             if (want) {
                 want = false;
@@ -156,6 +159,16 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
         double gn[N];
         double fn = 0.0;
         OPTIK_SCHED_FENCE();
+#ifdef OPTIK_LANE_EXP_DUP_EVAL  // (cost-by-duplication experiments, tools/lane_dup_costs.sh: same results, the phase runs twice)
+        if (do_eval) {
+            double xx[N], g0[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) { xx[i] = x[i]; asm volatile("" : "+v"(xx[i])); }
+            const double f0_ = eval_fg<N, TIP>(ch, ep, target, xx, g0);
+            asm volatile("" :: "v"(f0_), "v"(g0[0]), "v"(g0[N - 1]));
+        }
+        OPTIK_SCHED_FENCE();
+#endif
         if (do_eval) fn = eval_fg<N, TIP>(ch, ep, target, x, gn);
         OPTIK_SCHED_FENCE();
 
@@ -294,6 +307,10 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
             double rnorm = 1.0;
             const int nq = lane64_quads();
             const int qi = lane >> 2, ql = lane & 3;
+#ifdef OPTIK_LANE_EXP_DUP_NNLS
+          for (int dup_ = 0; dup_ < 2; ++dup_) {
+            asm volatile("" : "+s"(dup_));
+#endif
             for (int r0 = 0; r0 < n_prob; r0 += nq) {
                 // quad qi takes the problem of rank r0 + qi: its columns from the owner's packed record
                 const int pr = r0 + qi;
@@ -345,6 +362,9 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
                 }
                 lds_sync();  // (before the next round rewrites the blocks)
             }
+#ifdef OPTIK_LANE_EXP_DUP_NNLS
+          }
+#endif
             OPTIK_SCHED_FENCE();
 
             // ---- LDP tail (lsq_dual), back-substitution, descent test, per lane ------------------------------
