@@ -258,6 +258,10 @@ def main():
                     help="kernel (= auto, the default): ONE persistent solve kernel for the run's steps, restart state "
                          "in registers and LDS; engine: streaming phase kernels over an HBM slot pool with "
                          "continuous batching; results are identical")
+    ap.add_argument("--find-any", action="store_true",
+                    help="--targets: the reference's default reading of should_exit (rayon find_any, lib.rs:409-412: ANY "
+                         "success ends a target's other restarts) as Robot.ik_batch runs it unless set_parallelism(1); the "
+                         "default here is the deterministic reading (lowest solved index), which every rank count reproduces")
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the process-group path (init_process_group, the min / sum / max all-reduces, "
                          "all_gather_object) even with ONE rank: RCCL on a single GPU")
@@ -323,7 +327,7 @@ def main():
         backend_name = None
 
     from optik_amd import _native as nat
-    from optik_amd.parallel import shard_range, select_winner, gather_winner_x
+    from optik_amd.parallel import I64_MAX, shard_range, select_winner, gather_winner_x
 
     robot = load_chain(args.robot)
     hc = robot.hip_chain(dev)
@@ -420,10 +424,31 @@ def main():
         winners = []
         for k in range(count):
             i = (first + k) * per_step + t_lo
+            if T and mode == "speed":
+                winners.append(batch_rounds(targets[i:i + T_loc], x0[i:i + T_loc]))
+                continue
             hc.ik_batch(cfg, targets[i:i + T_loc], x0[i:i + T_loc], begin, end, flags=flags, bufs=bufs[0],
                         per_restart=not T)
             winners.append((select_winner(bufs[0], mode, False) if T else exchange(bufs[0], 1)).clone())
         return torch.stack(winners)
+
+    def batch_rounds(tg, xs):
+        """One Speed batch of independent ik() calls as the product schedules it (robot_host.cpp:ik_batch_on_device):
+        a latency-sized first round of 128 restart indices per target with early exit and restart-major hand-out,
+        then rounds four times as long for the targets still unsolved (they drop out as they are solved)."""
+        win = torch.full((tg.shape[0],), I64_MAX, dtype=torch.int64, device=dev)
+        live = torch.arange(tg.shape[0], device=dev)
+        b, rnd = begin, 128
+        while b < end and live.numel():
+            e = min(end, b + rnd)
+            out = hc.ik_batch(cfg, tg[live].contiguous(), xs[live].contiguous(), b, e,
+                              flags=nat.IK_EARLY_EXIT | (nat.IK_RESTART_MAJOR if b < 256 else 0)
+                              | (nat.IK_FIND_ANY if args.find_any else 0), per_restart=False)
+            solved = out["win_idx"] >= 0
+            win[live[solved]] = out["win_idx"][solved]
+            live = live[~solved]
+            b, rnd = e, rnd * 4
+        return win
 
     if W:
         run_steps(0, W)
@@ -455,7 +480,7 @@ def main():
             _all_reduce(tmax, dist.ReduceOp.MAX)
             el = float(tmax.item())
         rep_elapsed.append(el)
-        if winners is not None and not torch.equal(winners, w_rep):
+        if winners is not None and not torch.equal(winners, w_rep) and not (T and args.find_any):
             raise SystemExit("winners differ between repetitions of the same steps")
         winners = w_rep
     elapsed = sorted(rep_elapsed)[len(rep_elapsed) // 2]  # the median repetition (upper median for even counts)
@@ -554,6 +579,15 @@ def main():
                                      "per restart and SQ_ACTIVE_INST_VALU per kernel of this command"}
             else:
                 roof["secondary"] = None
+            eng_bytes = None
+            if pmc and pmc.get("kernels") and not T:
+                eng_bytes = sum((2.0 * k_["FETCH_SIZE_kb_per_launch"] + k_["WRITE_SIZE_kb_per_launch"]) * 1024.0 * k_["launches"]
+                                for k_ in pmc["kernels"].values() if "FETCH_SIZE_kb_per_launch" in k_) / total
+            roof.update({"frac_path": None if T else total / elapsed * (16 * n + 16) / 1e9 / HBM_PEAK_GBS,
+                         "bytes_per_restart_pmc": eng_bytes,
+                         "traffic_ratio": (eng_bytes / (16 * n + 16)) if eng_bytes else None,
+                         "valu_frac_no_fma": roof["secondary"]["frac_no_fma"] if roof["secondary"] else None,
+                         "valu_active_lane_frac": (pmc or {}).get("valu_active_lane_frac")})
             info = {"grid": None, "block": 128, "lds_bytes": 0}
         else:
             kernel_ms, launches = hc.timing_mean()
@@ -595,6 +629,14 @@ def main():
                              "source": os.path.relpath(PMC_FILE, ROOT)}
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note, "kernel": kname,
+                    # the whole path by SURVEY 8d's own unit (16n + 16 bytes per restart, seeds counted as read), what
+                    # the fabric counters saw per restart and its ratio to that unit, and the f64 VALU view: fraction of
+                    # the no-FMA ceiling at wave level and the part of it that is lane work (EXEC masks applied)
+                    "frac_path": total / elapsed * (16 * n + 16) / 1e9 / HBM_PEAK_GBS,
+                    "bytes_per_restart_pmc": kp["hbm_bytes_per_restart"] if kp else None,
+                    "traffic_ratio": (kp["hbm_bytes_per_restart"] / (16 * n + 16)) if kp else None,
+                    "valu_frac_no_fma": secondary["frac_no_fma"] if secondary else None,
+                    "valu_active_lane_frac": kp.get("valu_active_lane_frac") if kp else None,
                     "kernel_ms": kernel_ms, "launches_timed": launches,
                     "algorithmic_bytes_per_launch": out_bytes * per_launch,
                     "algorithmic_bytes_per_unit": out_bytes, "unit_name": "restart (seeds are generated in-kernel: "

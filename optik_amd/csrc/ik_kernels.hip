@@ -1186,7 +1186,11 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         return e && std::atoll(e) > 0 ? std::atoll(e) : 8ll;
     }();
     const bool quad_latency = quadk && (long long)cols <= (long long)cus * 4;
-    lanek = lanek && !quad_latency && (lane_forced || (long long)cols >= (long long)cus * lane_solve_waves_per_cu() * 64);
+    // (not for a Speed batch's latency-sized rounds: restart-major hand-out with early exit keeps a few restarts per
+    // target in flight and abandons most of the rest -- the quad solver's shorter trip wins there)
+    lanek = lanek && !quad_latency
+            && (lane_forced || ((long long)cols >= (long long)cus * lane_solve_waves_per_cu() * 64
+                                && !(early && (flags & OPTIK_HIP_IK_RESTART_MAJOR))));
     long long cap = (long long)cus * (lanek ? lane_solve_waves_per_cu() : quadk ? (quad_latency ? 4 : quad_solve_waves_per_cu(ch->n)) : (coop ? 4 : (widek ? wide_waves_per_cu : ch->waves_per_cu)));
     // (experiments: fewer resident waves per CU than the kernel could have, e.g. to share the chip with another stream's kernels)
     if (const char *e = std::getenv("OPTIK_SOLVE_WAVES_PER_CU")) {

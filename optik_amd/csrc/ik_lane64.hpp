@@ -62,6 +62,10 @@ template <int N>
 constexpr int lane64_rec_lds() { return Lane64Geom<N>::REC * 64; }
 
 constexpr int LANE64_CLASSES = 8;  // predicted pass classes 1 .. 7 (0: no bounded problem this trip)
+#ifndef OPTIK_LANE_REGCOLS
+#define OPTIK_LANE_REGCOLS 0      // 1: the NNLS keeps a lane's four columns in registers as well (ik_nnls_quad.hpp): slower
+                                  // here -- 64 registers more across the rounds spill the lane's state (27.0 -> 24.4 M)
+#endif
 #ifndef OPTIK_LANE_REFILL
 #define OPTIK_LANE_REFILL 4       // idle lanes a wave accumulates before it refills (the seed generation runs for the whole wave)
 #endif
@@ -343,7 +347,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
                 }
                 int iters, qmode;
                 double xv[4], qrnorm;
-                nnls_quad<N>(live, ids, bk, nnls_lds + 16 * NnlsQuadGeom<N>::STRIDE, xv, qmode, qrnorm, iters);
+                nnls_quad<N, OPTIK_LANE_REGCOLS != 0>(live, ids, bk, nnls_lds + 16 * NnlsQuadGeom<N>::STRIDE, xv, qmode, qrnorm, iters);
                 // the multipliers are in the block (by column id); mode, rnorm and the pass count next to them
                 if (live && ql == 0) {
                     bk[G::META] = (double)qmode;

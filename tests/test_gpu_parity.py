@@ -122,8 +122,22 @@ def _oracle_all(oracle, ch, cfg_kw, tgt, x0, begin, end):
 
 
 def _run(hc, path, cfg, tgd, x0d, begin, end, flags=0):
-    """The two GPU paths: the single-kernel solver and the streaming engine."""
-    if path == "kernel":
+    """The GPU paths: the single-launch solvers -- `kernel`: what a launch of this size gets (the quad solver below
+    one full load of the chip), `lane64`: the lane-per-restart form (ik_lane64.hpp), the default from there on,
+    forced here at the test's size -- and the streaming engine."""
+    import os
+    if path == "lane64":
+        prev = os.environ.get("OPTIK_SOLVE_KERNEL")
+        os.environ["OPTIK_SOLVE_KERNEL"] = "lane64"   # (read per call by optik_hip_ik_batch)
+        try:
+            out = hc.ik_batch(cfg, tgd, x0d, begin, end, flags=flags)
+            torch.cuda.synchronize()
+        finally:
+            if prev is None:
+                del os.environ["OPTIK_SOLVE_KERNEL"]
+            else:
+                os.environ["OPTIK_SOLVE_KERNEL"] = prev
+    elif path == "kernel":
         out = hc.ik_batch(cfg, tgd, x0d, begin, end, flags=flags)
     else:
         out = hc.engine_submit(cfg, tgd, x0d, begin, end, flags=flags)
@@ -135,7 +149,7 @@ def _run(hc, path, cfg, tgd, x0d, begin, end, flags=0):
 @pytest.mark.parametrize("robot,tol_f,R", [("panda", 1e-6, 4096), ("ur10", 1e-12, 2048),
                                            ("ur3e", 1e-6, 2048), ("panda_hand", 1e-8, 2048)])
 @pytest.mark.parametrize("mode", ["speed", "quality"])
-@pytest.mark.parametrize("path", ["kernel", "engine"])
+@pytest.mark.parametrize("path", ["kernel", "engine", "lane64"])
 def test_every_restart_bit_exact(dev, oracle, chains, hip_chains, robot, tol_f, R, mode, path):
     """One target, restarts 0..R-1: status, evaluation count, returned x and f of EVERY
     restart equal the oracle's, and so does the selected winner."""
@@ -160,7 +174,7 @@ def test_every_restart_bit_exact(dev, oracle, chains, hip_chains, robot, tol_f, 
 
 
 @pytest.mark.parametrize("robot", ["panda1", "panda2", "panda3", "panda4", "panda5", "arm8"])
-@pytest.mark.parametrize("path", ["kernel", "engine"])
+@pytest.mark.parametrize("path", ["kernel", "engine", "lane64"])
 def test_other_joint_counts_bit_exact(dev, oracle, chains, hip_chains, robot, path):
     """Kernels are instantiated for 1 <= n <= 8: sub-chains of the Panda (no trailing fixed
     joint) and a synthetic 8-joint arm through both paths, every restart against the oracle
@@ -204,7 +218,7 @@ def test_restart_ranges_compose(dev, oracle, chains, hip_chains):
     assert int(idxs[best]) == int(full["win_idx"][0])
 
 
-@pytest.mark.parametrize("path", ["kernel", "engine"])
+@pytest.mark.parametrize("path", ["kernel", "engine", "lane64"])
 def test_many_targets_batch(dev, oracle, chains, hip_chains, path):
     """Config-5 shape: T targets x R restarts each; per-target winners match the oracle
     run target by target (Speed: lowest successful index)."""
@@ -370,6 +384,34 @@ def test_early_exit_keeps_the_winner(dev, oracle, chains, hip_chains):
         assert torch.equal(st_full[t, : w + 1], st_fast[t, : w + 1])  # nothing below the winner is abandoned
 
 
+@pytest.mark.parametrize("flags", ["early", "early+restart_major", "early+find_any"])
+def test_early_exit_on_the_lane_per_restart_form(dev, oracle, chains, hip_chains, flags):
+    """The same rule on ik_lane64.hpp (forced at this size): every lane checks first_success before its evaluation;
+    the deterministic readings return the full run's winners, find_any a solved restart of every solvable target."""
+    from optik_amd import _native as nat
+    d, ch = chains["panda"]
+    rng = np.random.default_rng(4)
+    T, R = 12, 1024
+    tg, x0 = make_targets(oracle, d, ch, rng, T)
+    cfg = nat.make_config(solution_mode="speed")
+    tgd, x0d = torch.tensor(tg, device="cuda"), torch.tensor(x0, device="cuda")
+    full = _run(hip_chains["panda"], "lane64", cfg, tgd, x0d, 0, R)
+    fl = nat.IK_EARLY_EXIT | (nat.IK_RESTART_MAJOR if "restart_major" in flags else 0) | (nat.IK_FIND_ANY if "find_any" in flags else 0)
+    fast = _run(hip_chains["panda"], "lane64", cfg, tgd, x0d, 0, R, flags=fl)
+    assert (fast["status"] == nat.RES_FORCED_STOP).any()
+    if "find_any" in flags:
+        ok = (full["status"] == nat.RES_STOPVAL).view(T, R)
+        w = fast["win_idx"]
+        assert torch.equal(w >= 0, ok.any(1))
+        for t in range(T):
+            if int(w[t]) >= 0:
+                assert bool(ok[t, int(w[t])])
+                assert torch.equal(fast["win_x"][t], full["x"][:, t * R + int(w[t])])
+    else:
+        assert torch.equal(full["win_idx"], fast["win_idx"])
+        assert torch.equal(full["win_x"], fast["win_x"])
+
+
 def test_ftol_and_xtol_count_as_success_when_enabled(dev, oracle, chains, hip_chains):
     """tol_df >= 0 / tol_dx >= 0 (lib.rs:376-379): FTOL / XTOL exits become successes and
     return NLopt's best-so-far point."""
@@ -389,7 +431,7 @@ def test_ftol_and_xtol_count_as_success_when_enabled(dev, oracle, chains, hip_ch
     assert int(out["win_idx"].cpu()[0]) == ref["winner"]
 
 
-@pytest.mark.parametrize("path", ["kernel", "engine"])
+@pytest.mark.parametrize("path", ["kernel", "engine", "lane64"])
 @pytest.mark.parametrize("tol_dx", [-1.0, 0.0])
 def test_zero_step_counts_as_xtol(dev, oracle, chains, hip_chains, path, tol_dx):
     """ftol_abs = 0 (tol_f = tol_df = 0): neither stopval nor ftol can fire, and restarts end

@@ -50,6 +50,20 @@ rec["f64_flops_per_restart"] = flops / (per_launch * max(n, 1))
 rec["valu_insts_per_restart"] = acc["SQ_INSTS_VALU"] * 64.0 * scale / (per_launch * max(n, 1))
 rec["valu_busy"] = acc["SQ_ACTIVE_INST_VALU"] / acc["SQ_WAVE_CYCLES"] if acc.get("SQ_WAVE_CYCLES") else None
 rec["sq_scale"] = scale
+try:
+    rs2, n2 = timed_rows("sq2")
+    a2 = collections.defaultdict(float)
+    for r in rs2:
+        a2[r["Counter_Name"]] += float(r["Counter_Value"])
+    if a2.get("SQ_ACTIVE_INST_VALU"):
+        # lanes active per VALU instruction cycle (EXEC masks applied): what part of the wave-level flops are lane flops
+        rec["valu_active_lane_frac"] = a2["SQ_THREAD_CYCLES_VALU"] / (64.0 * a2["SQ_ACTIVE_INST_VALU"])
+    if a2.get("SQ_WAVE_CYCLES"):
+        rec["wait_any_frac"] = a2["SQ_WAIT_ANY"] / a2["SQ_WAVE_CYCLES"]
+        rec["wait_inst_any_frac"] = a2["SQ_WAIT_INST_ANY"] / a2["SQ_WAVE_CYCLES"]
+        rec["lds_insts_per_restart"] = a2["SQ_INSTS_LDS"] * 64.0 / (per_launch * max(n2, 1)) / 64.0
+except (IndexError, OSError, KeyError):
+    pass
 rec["kernel_ms_under_profiler"] = sum(dur.values()) / max(len(dur), 1)
 rec["bench_value_unprofiled"] = line["value"]
 json.dump(rec, open(f"{out}/pmc_kernel_path.json", "w"), indent=1)
