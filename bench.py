@@ -594,11 +594,10 @@ def main():
             info = hc.last_launch()
             per_launch = cols * (K if pooled_kernel else 1)
             achieved = out_bytes * per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-            kname = {"coop": "ik_coop_kernel", "lane": "ik_solve_kernel"}.get(os.environ.get("OPTIK_SOLVE_KERNEL", ""),
-                                                                                "ik_quad_kernel")
+            kname = "ik_quad_kernel"
             if kname == "ik_quad_kernel" and info["lds_bytes"] > 30000:
                 kname = "ik_lane_kernel"  # one restart per lane (ik_lane64.hpp): 39 KB of LDS per single-wave workgroup
-            wide_hbm = n > 8 and os.environ.get("OPTIK_WIDE_FORM", "") == "hbm"
+            wide_hbm = n > 8 and nat.get_option("wide_form") == 1
             if n > 8:  # the general solver: a restart per wave in LDS, or per lane in an HBM workspace
                 kname = "wide_solve_kernel" if wide_hbm else "wide_solve_coop_kernel"
             kp = (pmc or {}).get("kernel_path")

@@ -101,11 +101,10 @@ int optik_robot_fk_ex(const optik_robot *robot, const double *x, const double *e
 int optik_robot_joint_jacobian_ex(const optik_robot *robot, const double *x,
                                   const double *ee_offset16, double *jac6n_out);
 /* Flat chain table (what KinematicChain::from_urdf produced): n_joints poses, axes, types.
- * optik_robot_chain_tables: *n_joints is written only; non-NULL buffers must hold OPTIK_MAX_JOINTS
- * joints (x 7 / x 3 / x 1 elements).  optik_robot_chain_tables_n: the same with the caller's buffer
- * capacity (in joints) passed explicitly -- fewer than the chain has: error, nothing is written;
- * NULL buffers just report *n_joints.  (A chain of more than 8 joint positions has more than
- * OPTIK_MAX_JOINTS joints: the first form fails for it, use the second.) */
+ * optik_robot_chain_tables: *n_joints is IN/OUT -- with non-NULL buffers it holds their capacity in joints on
+ * entry (x 7 / x 3 / x 1 elements each; OPTIK_MAX_JOINTS covers every chain of at most 8 joint positions) and the
+ * chain's joint count on return; fewer than the chain has: error, nothing is written.  With NULL buffers it just
+ * reports the count.  optik_robot_chain_tables_n: the same with the capacity as its own argument. */
 #define OPTIK_MAX_JOINTS 9
 int optik_robot_chain_tables(const optik_robot *robot, int32_t *n_joints, double *origins7,
                              double *axes3, int32_t *types);

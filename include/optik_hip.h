@@ -237,6 +237,27 @@ uint64_t optik_hip_engine_executed_evals(const optik_hip_chain *chain);
  * default five-kernel trips ({eval, update, NNLS, finish}). */
 int optik_hip_engine_last_fused(const optik_hip_chain *chain);
 
+/* Tuning options of the kernel layer (diagnostics: tests and tools; the defaults are what the product runs with).
+ * Each option's default comes from the environment variable named with it, read ONCE when the library first needs
+ * an option; afterwards only this call changes it.  Not synchronised with calls in flight.
+ *   solve_kernel        OPTIK_SOLVE_KERNEL = quad | lane64 | general   0 auto (by launch size), 1 quad solver
+ *                                                                       (ik_quad.hpp), 2 lane-per-restart form
+ *                                                                       (ik_lane64.hpp), 3 general solver (ik_wide.hpp)
+ *   engine_slots        OPTIK_ENGINE_SLOTS       capacity of the streaming engine's slot pool (0: default)
+ *   engine_pools        OPTIK_ENG_POOLS          sub-pools of an engine run (0: default)
+ *   engine_nnls_budget  OPTIK_ENG_NNLS_BUDGET    solve passes per bounded sub-problem per NNLS launch (default 6)
+ *   engine_nnls_slack   OPTIK_ENG_NNLS_SLACK     ... and per problem: its predicted count + this (default 1)
+ *   engine_tail_max     OPTIK_ENG_TAIL_MAX       restarts left at which the quad solver takes an engine run over
+ *                                                (-1: default, 0: never)
+ *   wide_form           OPTIK_WIDE_FORM = lds | hbm   form of the general solver (0 lds, 1 hbm)
+ *   range_rule          OPTIK_RANDOM_RANGE_RULE = new_inclusive   OPTIK_HIP_RANGE_* of chains created afterwards
+ *   engine_compact      (none)                   0: no drain compaction of an engine run's sub-pools
+ *   stop_x_legacy       (none)                   1: nlopt_stop_x of NLopt 2.5 (no zero-step rule)
+ * The host layer (optik.h) reads OPTIK_HOST_THREADS and OPTIK_DEVICES; nothing else in the library reads the
+ * environment.  Returns 0, or OPTIK_HIP_EINVAL for an unknown name; optik_hip_get_option returns -1 for one. */
+int optik_hip_set_option(const char *name, long long value);
+long long optik_hip_get_option(const char *name);
+
 /* Host-buffer convenience over optik_hip_ik_batch (what Robot::ik calls): copies
  * targets/x0 in, runs, synchronises, copies the per-target winners out.
  * win_x [T][n], win_f [T], win_idx [T] (UINT64_MAX = no solution), win_key [T]

@@ -76,6 +76,9 @@ def lib():
     L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)
     L.optik_hip_device_count.restype = C.c_int
+    L.optik_hip_set_option.argtypes = [C.c_char_p, C.c_longlong]
+    L.optik_hip_get_option.argtypes = [C.c_char_p]
+    L.optik_hip_get_option.restype = C.c_longlong
     L.optik_hip_last_error.restype = C.c_char_p
     L.optik_hip_chain_create.argtypes = [dp, dp, ip, C.c_int32, dp, dp, C.c_int32, C.POINTER(vp)]
     L.optik_hip_chain_destroy.argtypes = [vp]
@@ -128,3 +131,37 @@ def make_config(solution_mode="speed", max_time=0.0, max_restarts=0, tol_f=1e-6,
     cfg.linear_weight[:] = [float(v) for v in linear_weight]
     cfg.angular_weight[:] = [float(v) for v in angular_weight]
     return cfg
+
+
+SOLVE_KERNELS = {"auto": 0, "quad": 1, "lane64": 2, "general": 3, "coop": 4, "lane": 5}
+WIDE_FORMS = {"lds": 0, "hbm": 1}
+
+
+def set_option(name, value):
+    """Tuning option of the kernel layer (include/optik_hip.h: optik_hip_set_option) -- tests and tools.  `value`: an
+    integer, or for solve_kernel / wide_form one of their names."""
+    if isinstance(value, str):
+        value = {"solve_kernel": SOLVE_KERNELS, "wide_form": WIDE_FORMS}[name][value]
+    check(lib().optik_hip_set_option(name.encode(), int(value)))
+
+
+def get_option(name):
+    return int(lib().optik_hip_get_option(name.encode()))
+
+
+class options:
+    """``with options(solve_kernel="lane64", engine_slots=4096): ...`` -- set for the block, restored after it."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.prev = {k: get_option(k) for k in self.kw}
+        for k, v in self.kw.items():
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            set_option(k, v)
+        return False

@@ -1189,4 +1189,18 @@ OPTIK_DEV void eng_finish_body(const EngArgs &a, const ChainDev &ch, size_t slot
     }
 }
 
+// Lists the slots of [0, n_slots) that still hold a restart (one atomic per wave).
+OPTIK_DEV void tail_list_body(const int32_t *state, unsigned long long n_slots, unsigned int *count,
+                              unsigned int *list) {
+    const unsigned long long slot = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int st = slot < n_slots ? state[slot] : ST_EMPTY;
+    const bool live = st != ST_EMPTY && st != ST_REFILL;
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned long long m = __ballot(live);
+    unsigned base = 0;
+    if (lane == 0 && m) base = atomicAdd(count, (unsigned)__popcll(m));
+    base = (unsigned)__shfl((int)base, 0, 64);
+    if (live) list[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (unsigned)slot;
+}
+
 }  // namespace optik

@@ -80,7 +80,7 @@ inline void make_eval_params(const double wl[3], const double wa[3], const doubl
     std::memcpy(ep.ee_offset, ee_offset7 ? ee_offset7 : ident, sizeof ident);
 }
 
-inline void fill_solve_params(const optik_solver_config *cfg, SolveParams &sp) {
+inline void fill_solve_params(const optik_solver_config *cfg, SolveParams &sp, bool stop_x_legacy = false) {
     sp.stopval = cfg->tol_f;
     sp.ftol_abs = (cfg->tol_df > 0.0) ? cfg->tol_df : 1e-3 * cfg->tol_f;  // lib.rs:283-293
     sp.xtol_abs = cfg->tol_dx;
@@ -89,7 +89,7 @@ inline void fill_solve_params(const optik_solver_config *cfg, SolveParams &sp) {
     sp.ok_xtol = cfg->tol_dx >= 0.0;
     // nlopt_stop_x of the bundled NLopt (2.7.1): a zero step counts as x-converged; the 2.5
     // behaviour (per-coordinate test only) for anyone pinning against an older build
-    sp.stop_x_zero = std::getenv("OPTIK_NLOPT_STOP_X_LEGACY") ? 0 : 1;
+    sp.stop_x_zero = stop_x_legacy ? 0 : 1;
 }
 
 

@@ -27,8 +27,10 @@
 #include "ik_launch.hpp"
 #include "ik_wide_launch.hpp"
 #include "ik_engine.hpp"
-#include "ik_tail.hpp"
+#ifdef OPTIK_LEGACY_KERNELS  // rounds 1-2: the per-lane and leader-lane solvers, their engine tails, fused engine trips
+#include "ik_tail.hpp"       // (tools/build_lib_variant.py legacy -DOPTIK_LEGACY_KERNELS; not in the product library)
 #include "ik_coop.hpp"
+#endif
 
 using namespace optik;
 using namespace optik::hostparams;
@@ -57,7 +59,10 @@ __device__ __forceinline__ void wave_argmin(double &key, unsigned long long &idx
     }
 }
 
-// The hot path: every wave pulls (target, restart) work items until the queue is dry.
+constexpr int QUADS_PER_WAVE_HOST = 16;  // restarts a wave of the quad solver holds
+
+#ifdef OPTIK_LEGACY_KERNELS
+// Round 1: every wave pulls (target, restart) work items until the queue is dry, one restart per lane.
 template <int N, bool TIP>
 __global__ __launch_bounds__(WAVE) void ik_solve_kernel(const SolveLaunch a) {
     __shared__ ChainDev sch;
@@ -82,6 +87,7 @@ __global__ __launch_bounds__(WAVE) void ik_coop_kernel(const SolveLaunch a) {
     wq.deadline = a.deadline_ticks ? wall_clock64() + a.deadline_ticks : 0ull;
     coop_wave<N, TIP>(sch, a.ep, a.sp, a.key, a.scale, wq, nnls_lds, rec_lds);
 }
+#endif  // OPTIK_LEGACY_KERNELS
 
 struct SelectLaunch {
     const double *out_key;   // [T*R] selection key, +inf unless the restart succeeded
@@ -259,6 +265,7 @@ __global__ __launch_bounds__(OPTIK_ENG_UPD_BLOCK, OPTIK_ENG_UPD_WAVES) void eng_
     eng_finish_body<N>(a, sch, local < a.n_slots ? slot : (size_t)a.slot_base, local, local < a.n_slots);
 }
 
+#ifdef OPTIK_LEGACY_KERNELS
 // Fused trips: everything a slot's owner lane does in a trip, in one launch -- the finishing pass of
 // the direction the NNLS kernel just answered (and the refill of the listed slots), the
 // evaluation of the trial point, and on an accepted step the BFGS update with the next
@@ -325,6 +332,7 @@ __global__ __launch_bounds__(WAVE) void eng_tail_coop_kernel(const EngArgs a, co
     if (threadIdx.x < 8) nnls_lds[coop_wave_lds<4>() - 8 + threadIdx.x] = 0.0;  // the column of zeros
     tail_wave_coop<N, TIP>(a, sch, a.jobs, list, *count, groups, nnls_lds, rec_lds);
 }
+#endif  // OPTIK_LEGACY_KERNELS
 __global__ __launch_bounds__(256) void eng_tail_list_kernel(const int32_t *state, unsigned long long n_slots,
                                                             unsigned int *count, unsigned int *list) {
     tail_list_body(state, n_slots, count, list);
@@ -636,6 +644,51 @@ struct optik_hip_chain {
 
 namespace {
 
+// ---- options ---------------------------------------------------------------------------------------------
+// Every tuning option of the kernel layer, in one place.  The defaults come from the environment ONCE, at the
+// first use (the OPTIK_* names below); tests and tools change them through optik_hip_set_option (optik_hip.h).
+// Nothing else in this library reads the environment (robot_host.cpp: OPTIK_HOST_THREADS, OPTIK_DEVICES).
+enum : int { SK_AUTO = 0, SK_QUAD = 1, SK_LANE64 = 2, SK_GENERAL = 3, SK_COOP = 4, SK_LANE = 5 };
+struct Options {
+    int solve_kernel = SK_AUTO;      // OPTIK_SOLVE_KERNEL = quad | lane64 | general: which single-launch solver (auto: by size)
+    long long engine_slots = 0;      // OPTIK_ENGINE_SLOTS: capacity of the engine's slot pool (0: 393 216, fewer for early-exit jobs)
+    int engine_pools = 0;            // OPTIK_ENG_POOLS: sub-pools of an engine run (0: three, fewer for small pools)
+    int engine_nnls_budget = 6;      // OPTIK_ENG_NNLS_BUDGET: solve passes per problem per NNLS launch
+    int engine_nnls_slack = 1;       // OPTIK_ENG_NNLS_SLACK: ... and per problem: its predicted count + this
+    long long engine_tail_max = -1;  // OPTIK_ENG_TAIL_MAX: restarts left at which the quad solver takes a run over (-1: total / 8; 0: never)
+    int wide_form = 0;               // OPTIK_WIDE_FORM = lds | hbm: the general solver's form (9 .. 16 joints); 2: one-lane LDS form
+    int range_rule = OPTIK_HIP_RANGE_SINGLE_INCLUSIVE;  // OPTIK_RANDOM_RANGE_RULE = new_inclusive: rand 0.9.2 reading of new chains
+    int engine_compact = 1;          // (no environment name) drain compaction of an engine run's sub-pools
+    int stop_x_legacy = 0;           // (no environment name) nlopt_stop_x of NLopt 2.5: no zero-step rule
+};
+int solve_kernel_from(const char *e) {
+    if (!e) return SK_AUTO;
+    if (!std::strcmp(e, "quad")) return SK_QUAD;
+    if (!std::strcmp(e, "lane64")) return SK_LANE64;
+    if (!std::strcmp(e, "general")) return SK_GENERAL;
+#ifdef OPTIK_LEGACY_KERNELS
+    if (!std::strcmp(e, "coop")) return SK_COOP;
+    if (!std::strcmp(e, "lane")) return SK_LANE;
+#endif
+    return SK_AUTO;
+}
+Options &opt() {
+    static Options o = [] {
+        Options v;
+        v.solve_kernel = solve_kernel_from(std::getenv("OPTIK_SOLVE_KERNEL"));
+        if (const char *e = std::getenv("OPTIK_ENGINE_SLOTS")) v.engine_slots = std::atoll(e);
+        if (const char *e = std::getenv("OPTIK_ENG_POOLS")) v.engine_pools = std::atoi(e);
+        if (const char *e = std::getenv("OPTIK_ENG_NNLS_BUDGET")) v.engine_nnls_budget = std::atoi(e) > 0 ? std::atoi(e) : 1;
+        if (const char *e = std::getenv("OPTIK_ENG_NNLS_SLACK")) v.engine_nnls_slack = std::atoi(e) > 0 ? std::atoi(e) : 0;
+        if (const char *e = std::getenv("OPTIK_ENG_TAIL_MAX")) v.engine_tail_max = std::atoll(e);
+        if (const char *e = std::getenv("OPTIK_WIDE_FORM")) v.wide_form = std::strcmp(e, "hbm") == 0 ? 1 : 0;
+        if (const char *e = std::getenv("OPTIK_RANDOM_RANGE_RULE"))
+            if (std::strcmp(e, "new_inclusive") == 0 || std::strcmp(e, "1") == 0) v.range_rule = OPTIK_HIP_RANGE_NEW_INCLUSIVE;
+        return v;
+    }();
+    return o;
+}
+
 // The slot pool of the streaming engine: ONE per device, shared by every chain (robot) of that
 // device -- ~1 GB at the default capacity, sized for n = 7 (a superset of every smaller chain's
 // planes and records).  An engine run owns it from its set-up to its last kernel (run_mu): runs
@@ -683,11 +736,7 @@ int fail(int code, const std::string &msg) {
             return fail(OPTIK_HIP_ENODEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-int default_range_rule() {
-    if (const char *e = std::getenv("OPTIK_RANDOM_RANGE_RULE"))
-        if (std::strcmp(e, "new_inclusive") == 0 || std::strcmp(e, "1") == 0) return OPTIK_HIP_RANGE_NEW_INCLUSIVE;
-    return OPTIK_HIP_RANGE_SINGLE_INCLUSIVE;
-}
+int default_range_rule() { return opt().range_rule; }
 
 void set_chain_scales(optik_hip_chain *ch, int rule) {
     ch->range_rule = rule;
@@ -1103,7 +1152,7 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     std::memset(&a, 0, sizeof a);
     a.chain = ch->dev;  // (null for a wide chain: its launch takes ch->wdev)
     make_eval_params(cfg->linear_weight, cfg->angular_weight, ee_offset7, a.ep);
-    fill_solve_params(cfg, a.sp);
+    fill_solve_params(cfg, a.sp, opt().stop_x_legacy != 0);
     std::memcpy(a.key, ch->key, sizeof a.key);
     std::memcpy(a.scale, ch->scale, sizeof a.scale);  // (n <= 8; a wide chain's scales are in its table)
     a.wq.next_item = ch->queue;
@@ -1136,15 +1185,14 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         if (a.deadline_ticks == 0) a.deadline_ticks = 1;
     }
 
-    // Which solver: the quad solver of ik_quad.hpp (a restart per quad of lanes, its state spread over the
-    // quad, NNLS matrix in LDS; the default, n <= 8), round 2's cooperative one (OPTIK_SOLVE_KERNEL=coop:
-    // the state in the quad's leader, ik_coop.hpp; n <= 7) or round 1's one-restart-per-lane kernel with
-    // its per-lane LDS NNLS (OPTIK_SOLVE_KERNEL=lane).  Same results, bit for bit.
-    // (OPTIK_SOLVE_KERNEL=general: the run-time-n solver of ik_wide.hpp on a chain of at most 8 joints too -- a third,
-    // independently written device solver for the parity tests; chains of 9 .. 16 joints always run on it)
-    bool widek = ch->wide;
-    if (const char *e = std::getenv("OPTIK_SOLVE_KERNEL"))
-        if (std::strcmp(e, "general") == 0) widek = true;
+    // Which solver (option solve_kernel; same results, bit for bit): the quad solver of ik_quad.hpp (a restart per
+    // quad of lanes, its state spread over the quad, NNLS matrix in LDS; n <= 8), from one full load of the chip
+    // on the lane-per-restart form of ik_lane64.hpp (n <= 7), or -- `general` -- the run-time-n solver of
+    // ik_wide.hpp on a chain of at most 8 joints too: a third, independently written device solver for the parity
+    // tests; chains of 9 .. 16 joints always run on it.  (-DOPTIK_LEGACY_KERNELS builds: `coop`, round 2's
+    // leader-lane solver of ik_coop.hpp, and `lane`, round 1's per-lane kernel with its per-lane LDS NNLS.)
+    const int sk = opt().solve_kernel;
+    bool widek = ch->wide || sk == SK_GENERAL;
     if (widek && !ch->wide) {
         // the chain's table in the general kernels' layout (uploaded per call: a test path)
         WideChainDev &w = ch->whost;
@@ -1160,31 +1208,23 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         if (!ch->wdev) HIP_TRY(hipMalloc(&ch->wdev, sizeof(WideChainDev)));
         HIP_TRY(hipMemcpy(ch->wdev, &w, sizeof(WideChainDev), hipMemcpyHostToDevice));
     }
-    bool coop = ch->n <= 7, quadk = !widek;
-    if (const char *e = std::getenv("OPTIK_SOLVE_KERNEL")) {
-        coop = coop && std::strcmp(e, "lane") != 0;
-        quadk = quadk && std::strcmp(e, "lane") != 0 && std::strcmp(e, "coop") != 0;
-    }
-    coop = coop && !quadk && !widek;
+    bool coop = false, quadk = !widek;
+#ifdef OPTIK_LEGACY_KERNELS
+    quadk = quadk && sk != SK_LANE && !(sk == SK_COOP && ch->n <= 7);
+    coop = !quadk && !widek && sk == SK_COOP;
+#endif
     // the throughput form for n <= 7: one restart per lane, bounded sub-problems in class order (ik_lane64.hpp)
     // (the default from one full load of the chip on -- 64 restarts for each of its four waves per CU: below that a
     // launch is as long as its longest restart, and the quad solver's trip is the shorter one; tools/lane_vs_quad_probe.py)
-    bool lanek = quadk && ch->n <= 7;
-    bool lane_forced = false;
-    if (const char *e = std::getenv("OPTIK_SOLVE_KERNEL")) {
-        lane_forced = lanek && std::strcmp(e, "lane64") == 0;
-        lanek = lanek && std::strcmp(e, "quad") != 0;
-    }
+    bool lanek = quadk && ch->n <= 7 && sk != SK_QUAD;
+    const bool lane_forced = lanek && sk == SK_LANE64;
     // Persistent waves, each pulling work items until the queue is dry: as many as a CU holds
     // (lane kernel: 2 workgroups, LDS-bound; cooperative kernel: 4, one per SIMD), times the CU count.
     const int cus = ch->num_cus > 0 ? ch->num_cus : 256;
     // (quad solver: a launch with no more work items than the chip has SIMDs runs one restart per wave on the
     // one-wave-per-SIMD build -- no scratch, the lowest latency per iteration; anything bigger on the
     // two-waves-per-SIMD build)
-    static const long long wide_waves_per_cu = [] {  // resident waves per CU of the general solver (two per SIMD)
-        const char *e = std::getenv("OPTIK_WIDE_WAVES_PER_CU");
-        return e && std::atoll(e) > 0 ? std::atoll(e) : 8ll;
-    }();
+    const long long wide_waves_per_cu = 8;  // resident waves per CU of the general solver (two per SIMD)
     const bool quad_latency = quadk && (long long)cols <= (long long)cus * 4;
     // (not for a Speed batch's latency-sized rounds: restart-major hand-out with early exit keeps a few restarts per
     // target in flight and abandons most of the rest -- the quad solver's shorter trip wins there)
@@ -1192,31 +1232,19 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
             && (lane_forced || ((long long)cols >= (long long)cus * lane_solve_waves_per_cu() * 64
                                 && !(early && (flags & OPTIK_HIP_IK_RESTART_MAJOR))));
     long long cap = (long long)cus * (lanek ? lane_solve_waves_per_cu() : quadk ? (quad_latency ? 4 : quad_solve_waves_per_cu(ch->n)) : (coop ? 4 : (widek ? wide_waves_per_cu : ch->waves_per_cu)));
-    // (experiments: fewer resident waves per CU than the kernel could have, e.g. to share the chip with another stream's kernels)
-    if (const char *e = std::getenv("OPTIK_SOLVE_WAVES_PER_CU")) {
-        const long long v = std::atoll(e);
-        if (v >= 1 && v * cus < cap) cap = v * cus;
-    }
-    const long long per_wave_max = lanek ? WAVE : ((coop || quadk) ? COOP_GROUPS_PER_WAVE : WAVE);
+    const long long per_wave_max = lanek ? WAVE : ((coop || quadk) ? QUADS_PER_WAVE_HOST : WAVE);
     // fewer work items than the chip holds: one restart per wave (or as few as fit).  A
     // restart-major Speed batch keeps about eight restarts per target in flight: the waves pull
     // the higher indices of the targets still unsolved as they go
     long long resident = (long long)cols;
     // (but never fewer than one restart per resident wave: a small batch has the chip to itself, and
     // the more of a target's restarts run at once the sooner its first success comes)
-    static const long long inflight = [] {
-        const char *e = std::getenv("OPTIK_IK_BATCH_INFLIGHT");  // restarts per target in flight
-        return e && std::atoll(e) > 0 ? std::atoll(e) : 8ll;
-    }();
+    const long long inflight = 8;  // restarts per target in flight
     // (a few targets have the chip to themselves: two restarts per resident wave at least, 32 per
     // target up to 256 targets -- measured: 64 targets 1.01 -> 0.79 ms, 256: 1.66 -> 1.47 ms, and the
     // few hundred targets a big batch's short engine round leaves over 8 ms sooner)
-    static const long long min_resident = [] {
-        const char *e = std::getenv("OPTIK_IK_BATCH_MIN_RESIDENT");
-        return e && std::atoll(e) > 0 ? std::atoll(e) : 0ll;
-    }();
     if (early && (flags & OPTIK_HIP_IK_RESTART_MAJOR) && resident > (long long)T * inflight) {
-        const long long floor_res = min_resident > 0 ? min_resident : std::max(2 * cap, (long long)T * 32);
+        const long long floor_res = std::max(2 * cap, (long long)T * 32);
         resident = std::max((long long)T * inflight, std::min(resident, floor_res));
     }
     long long lanes = (resident + cap - 1) / cap;
@@ -1227,14 +1255,10 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     // dependent chain and no HBM traffic, the second 64 times the restarts in flight -- and the first wins at
     // every size and joint count measured (tools/wide_chain_bench.py, 262 144 restarts: 1.31 / 0.88 / 0.83 / 1.26 M
     // restarts/s at 9 / 10 / 12 / 16 joints against 1.05 / 0.66 / 0.42 / 0.40 M; a launch on the HBM form takes
-    // 50 - 100 ms however small it is).  OPTIK_WIDE_FORM=hbm selects the HBM form (tests, comparisons).
+    // 50 - 100 ms however small it is).  Option wide_form = hbm selects the HBM form (tests, comparisons).
     bool wide_lds = false;
     if (widek) {
-        wide_lds = true;
-        if (const char *e = std::getenv("OPTIK_WIDE_FORM")) {
-            if (std::strcmp(e, "lds") == 0) wide_lds = true;
-            else if (std::strcmp(e, "hbm") == 0) wide_lds = false;
-        }
+        wide_lds = opt().wide_form != 1;
         if (wide_lds) lanes = 1;
     }
     a.wq.lanes = (int)lanes;
@@ -1267,12 +1291,14 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         w.deadline_ticks = a.deadline_ticks;
         w.ws = ch->wide_ws;
         lds = lds_form ? wide_lds_bytes() : (int)sizeof(WideChainDev);
-        HIP_TRY(wide_solve_launch(grid, stream, w, lds_form));
+        HIP_TRY(wide_solve_launch(grid, stream, w, lds_form, opt().wide_form != 2));
     } else if (lanek) {
         HIP_TRY(lane_solve_launch(ch->n, ch->tip, grid, stream, a, &lds));
     } else if (quadk) {
         HIP_TRY(quad_solve_launch(ch->n, ch->tip, grid, stream, a, &lds, quad_latency));
-    } else if (coop) {
+    }
+#ifdef OPTIK_LEGACY_KERNELS
+    else if (coop) {
 #define CALL_COOP(NN, TT)                                                                            \
     lds = (int)(sizeof(ChainDev) + sizeof(double) * (coop_wave_lds<4>() + COOP_GROUPS_PER_WAVE * coop_rec_lds<NN>())); \
     hipLaunchKernelGGL((ik_coop_kernel<NN, TT>), dim3(grid), dim3(WAVE), 0, stream, a)
@@ -1291,6 +1317,9 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     OPTIK_DISPATCH(ch, CALL);
 #undef CALL
     }
+#else
+    else return fail(OPTIK_HIP_EUNSUPPORTED, "no solver for this chain in this build");
+#endif
     HIP_TRY(hipGetLastError());
     if (ch->timing) { HIP_TRY(hipEventRecord(ch->ev1[ev_slot], stream)); ch->ev_count += 1; }
     ch->last.grid = grid; ch->last.block = WAVE; ch->last.lds_bytes = lds; ch->last.tiles = n_tiles;
@@ -1457,21 +1486,7 @@ static int engine_reserve(optik_hip_chain *ch, size_t AC, int /*nd*/, int ni, in
     if (!ch->eng_fork_ev) HIP_TRY(hipEventCreateWithFlags(&ch->eng_fork_ev, hipEventDisableTiming));
     for (int p2 = 1; p2 < ENG_MAX_POOLS; ++p2) {
         if (!ch->eng_streams[p2]) {
-            // (experiments, tools/hybrid_probe.py: OPTIK_ENG_CU_MASK = hex words, low CUs first, comma-separated --
-            // the sub-pools' own streams confined to those CUs, as the caller confines the stream it passes in)
-            const char *cm = getenv("OPTIK_ENG_CU_MASK");
-            if (cm && *cm) {
-                std::vector<uint32_t> words;
-                for (const char *q = cm; *q;) {
-                    char *endp = nullptr;
-                    words.push_back((uint32_t)std::strtoul(q, &endp, 16));
-                    q = (*endp == ',') ? endp + 1 : endp;
-                    if (endp == q && *q) break;
-                }
-                HIP_TRY(hipExtStreamCreateWithCUMask(&ch->eng_streams[p2], (uint32_t)words.size(), words.data()));
-            } else {
-                HIP_TRY(hipStreamCreateWithFlags(&ch->eng_streams[p2], hipStreamNonBlocking));
-            }
+            HIP_TRY(hipStreamCreateWithFlags(&ch->eng_streams[p2], hipStreamNonBlocking));
         }
         if (!ch->eng_join_ev[p2]) HIP_TRY(hipEventCreateWithFlags(&ch->eng_join_ev[p2], hipEventDisableTiming));
     }
@@ -1526,7 +1541,7 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
 
     // pool size: enough slots for every CU to hold several waves of each phase kernel
     size_t cap = 393216;  // 3 sub-pools x 131072 slots = 2048 waves: one full round of the chip (2 waves per SIMD) per kernel; 417792 is 6 % slower
-    if (const char *e = std::getenv("OPTIK_ENGINE_SLOTS")) { const long v = std::atol(e); if (v >= 256) cap = (size_t)v; }
+    if (opt().engine_slots >= 256) cap = (size_t)opt().engine_slots;
     size_t C = (size_t)((total + 255ull) / 256ull * 256ull);
     if (C > cap) C = cap;
     {
@@ -1539,7 +1554,7 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
             all_early = all_early && j.own_fs != nullptr && !j.full_pool;
             targets += (unsigned long long)j.T;
         }
-        if (all_early && !std::getenv("OPTIK_ENGINE_SLOTS")) {
+        if (all_early && opt().engine_slots < 256) {
             // (many targets: every slot beyond one per target runs a restart that is abandoned if an
             // earlier one of its target succeeds -- measured best, 16 indices per target: 196 608
             // slots at 65 536 targets (17.4 against 21.0 ms with 393 216) and at 131 072 (26.4 against
@@ -1595,7 +1610,7 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
         std::memset(&a, 0, sizeof a);
         a.chain = ch->dev;
         make_eval_params(ch->eng_cfg.linear_weight, ch->eng_cfg.angular_weight, ch->eng_has_ee ? ch->eng_ee : nullptr, a.ep);
-        fill_solve_params(&ch->eng_cfg, a.sp);
+        fill_solve_params(&ch->eng_cfg, a.sp, opt().stop_x_legacy != 0);
         std::memcpy(a.key, ch->key, sizeof a.key);
         std::memcpy(a.scale, ch->scale, sizeof a.scale);
         a.d = ch->eng_d; a.i32 = ch->eng_i32; a.item = ch->eng_item; a.C = C;
@@ -1606,18 +1621,14 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
         a.nn_prob = ch->eng_prob;
         a.nn_y = ch->eng_y;
         a.nn_meta = ch->eng_meta;
-        a.nn_budget = 6;
-        if (const char *e = getenv("OPTIK_ENG_NNLS_BUDGET")) a.nn_budget = atoi(e) > 0 ? atoi(e) : 1;
+        a.nn_budget = opt().engine_nnls_budget > 0 ? opt().engine_nnls_budget : 1;
         a.nn_pred_viol = 1;
-        if (const char *e = getenv("OPTIK_ENG_NNLS_PRED_VIOL")) a.nn_pred_viol = atoi(e);
         // per-problem pass cap = predicted count + slack.  With the same-trip continuation launch
         // the cap sits at the prediction itself (slack 0): the problems that need more continue a
         // few microseconds later instead of holding their wave's other 15 (without it: no cap
         // 23.9, slack 1 -> 24.6, slack 0 -> 23.2 M restarts/s -- a suspended solve cost its slot a trip)
-        bool nn_cont = false;  // (measured r2: 23.5 M restarts/s with the continuation launch against 26.4 M without -- the extra launch on each trip's critical path costs more than the tighter cap saves; kept as a knob)
-        if (const char *e = getenv("OPTIK_ENG_NNLS_CONT")) nn_cont = atoi(e) != 0;
-        a.nn_slack = nn_cont ? 0 : 1;
-        if (const char *e = getenv("OPTIK_ENG_NNLS_SLACK")) a.nn_slack = atoi(e) > 0 ? atoi(e) : 0;
+        const bool nn_cont = false;  // (measured r2: 23.5 M restarts/s with the continuation launch against 26.4 M without -- the extra launch on each trip's critical path costs more than the tighter cap saves)
+        a.nn_slack = opt().engine_nnls_slack > 0 ? opt().engine_nnls_slack : 0;
         a.cont_pass = 0;
         a.cont_count = nullptr; a.cont_list = nullptr; a.cont_cap = 0;
         // five-kernel trips (default), or fused trips (OPTIK_ENG_FUSED=1: bucket -> NNLS -> slot kernel).
@@ -1628,12 +1639,14 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
         // trip for its first evaluation; HBM bytes per restart fall by 4 % only (111 -> 106 KB: the
         // stores, 45 % of the traffic, go to memory either way and most loads are of lines the
         // previous trip wrote).  Kept as a knob: identical results (tests/test_gpu_parity.py).
-        bool fused = false;
-        if (const char *e = getenv("OPTIK_ENG_FUSED")) fused = atoi(e) != 0;
+#ifdef OPTIK_LEGACY_KERNELS
+        const bool fused = std::getenv("OPTIK_ENG_FUSED") && std::atoi(std::getenv("OPTIK_ENG_FUSED")) != 0;  // (legacy builds only)
+#else
+        const bool fused = false;
+#endif
         a.fused = fused ? 1 : 0;
         ch->eng_fused = a.fused;
-        unsigned cont_waves_per_cu = 4;  // grid of the continuation launch (it grid-strides over the lists)
-        if (const char *e = getenv("OPTIK_ENG_NNLS_CONT_WAVES")) cont_waves_per_cu = (unsigned)atoi(e) > 0 ? (unsigned)atoi(e) : 1u;
+        const unsigned cont_waves_per_cu = 4;  // grid of the continuation launch (it grid-strides over the lists)
         a.nn_total = ch->eng_nn_total;
         a.exec_evals = ch->eng_nn_total + 1;
         a.tail_deadline_ticks = 0;
@@ -1646,6 +1659,7 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
             const double khz = ch->wall_clock_khz > 0 ? (double)ch->wall_clock_khz : 100000.0;
             const unsigned long long ticks = left_s > 0.0 ? (unsigned long long)(left_s * khz * 1e3) + 1ull : 1ull;
             hipLaunchKernelGGL(eng_deadline_kernel, dim3(1), dim3(1), 0, stream, ch->eng_deadline, ticks);
+            HIP_TRY(hipGetLastError());  // (a failed launch would leave the previous run's deadline in the word)
             a.deadline_word = ch->eng_deadline;
         }
         a.parity = 0;
@@ -1654,7 +1668,11 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
         a.trace = nullptr;
         a.trip_log = nullptr;
         a.trip = 0;
-        const char *trip_log_path = getenv("OPTIK_ENG_TRIP_LOG");
+#ifdef OPTIK_PROFILE
+        const char *trip_log_path = std::getenv("OPTIK_ENG_TRIP_LOG");  // (diagnostic builds: per-trip in-use counts of sub-pool 0)
+#else
+        const char *trip_log_path = nullptr;
+#endif
         constexpr int TRIP_LOG_MAX = 65536;
         if (trip_log_path) {
             if (!ch->eng_trip_log) HIP_TRY(hipMalloc(&ch->eng_trip_log, sizeof(unsigned int) * 2 * TRIP_LOG_MAX));
@@ -1669,11 +1687,9 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
 #endif
 
         ch->eng_compactions = 0;
-        const bool allow_compact = !getenv("OPTIK_ENG_NO_COMPACT");
+        const bool allow_compact = opt().engine_compact != 0;
         const int cus = ch->num_cus > 0 ? ch->num_cus : 256;
-        unsigned nn_waves_per_cu = 32;
-        if (const char *e = getenv("OPTIK_ENG_NNLS_WAVES_PER_CU")) nn_waves_per_cu = (unsigned)atoi(e);
-        if (nn_waves_per_cu < 1) nn_waves_per_cu = 1;
+        const unsigned nn_waves_per_cu = 32;
         const unsigned nn_blocks = (unsigned)cus * nn_waves_per_cu * 64u / OPTIK_ENG_NNLS_BLOCK;
         HIP_TRY(hipMemsetAsync(ch->eng_counters, 0, ENG_MAX_POOLS * PCB * sizeof(unsigned int), stream));
         HIP_TRY(hipMemsetAsync(ch->eng_cont + ch->eng_C, 0, ENG_MAX_POOLS * NN_CONT_SHARDS * sizeof(unsigned int), stream));
@@ -1683,7 +1699,7 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
         // sub-pools: equal slot ranges (multiples of 256), each with its own stream and lists
         int n_pools = 3;  // (measured on MI355X: 1 -> 12.6, 2 -> 14.0, 3 -> 14.6, 4 -> 13.9 M restarts/s)
         size_t min_pool = 16384;  // small pools: one trip loop
-        if (const char *e = getenv("OPTIK_ENG_POOLS")) { n_pools = atoi(e); min_pool = 1024; }
+        if (opt().engine_pools > 0) { n_pools = opt().engine_pools; min_pool = 1024; }
         if (n_pools < 1) n_pools = 1;
         if (n_pools > ENG_MAX_POOLS) n_pools = ENG_MAX_POOLS;
         while (n_pools > 1 && C / (size_t)n_pools < min_pool) --n_pools;
@@ -1740,20 +1756,19 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
             for (int p2 = 1; p2 < n_pools; ++p2) HIP_TRY(hipStreamWaitEvent(ch->eng_streams[p2], ch->eng_fork_ev, 0));
         }
 
+#ifdef OPTIK_ENG_DEBUG
+        constexpr bool ENG_DEBUG_PRINTS = true;   // (diagnostic builds: where an engine run's host time goes)
+#else
+        constexpr bool ENG_DEBUG_PRINTS = false;
+#endif
         const int CHECK = 4;  // trips between termination checks
-        int check_drain = CHECK;  // ... of a sub-pool whose queue has run dry
-        if (const char *e = getenv("OPTIK_ENG_CHECK_DRAIN")) check_drain = atoi(e);
-        if (check_drain < 1) check_drain = 1;
-        if (check_drain > CHECK) check_drain = CHECK;
-        int queue_depth = 2;  // chunks queued ahead of the one whose in-use count the host waits for
-        if (const char *e = getenv("OPTIK_ENG_DEPTH")) queue_depth = atoi(e);
-        if (queue_depth < 1) queue_depth = 1;
-        if (queue_depth > 6) queue_depth = 6;
+        const int check_drain = CHECK;  // ... of a sub-pool whose queue has run dry
+        const int queue_depth = 2;  // chunks queued ahead of the one whose in-use count the host waits for
         const bool tip = ch->tip;
         double dbg_wait_bulk = 0.0, dbg_wait_drain = 0.0;  // host time blocked on the GPU (OPTIK_ENG_DEBUG)
         double dbg_drain_t0 = -1.0;  // when the first sub-pool fell under half of its live prefix
         const auto dbg_t0 = std::chrono::steady_clock::now();
-        if (getenv("OPTIK_ENG_DEBUG"))
+        if (ENG_DEBUG_PRINTS)
             fprintf(stderr, "[optik engine] set-up %.2f ms (C = %zu)\n", std::chrono::duration<double>(dbg_t0 - dbg_entry).count() * 1e3, (size_t)C);
         // queues CHECK trips of one sub-pool, then looks at the in-use count of its previous chunk
         const size_t eval_lds = sizeof(EngJob) * n_jobs;  // the eval kernel's copy of the job table
@@ -1791,6 +1806,7 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
 #define ENG_LAUNCH_LDS(kernel, grid, block, lds) do { if (tev0) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, tev0, tev1, 0, a); \
                                                        else hipLaunchKernelGGL(kernel, grid, block, lds, stream, a); } while (0)
 #define ENG_LAUNCH(kernel, grid, block) ENG_LAUNCH_LDS(kernel, grid, block, 0)
+#ifdef OPTIK_LEGACY_KERNELS
                 if (fused) {
                     // trip t: bucket pass over what the previous slot kernel left, NNLS, slot kernel
                     unsigned int *cnt = ch->eng_counters + (size_t)(&P - pools) * PCB;
@@ -1814,6 +1830,7 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
                     ch->eng_launches += 1;
                     continue;
                 }
+#endif
                 TEV(0);
                 if (trip > 0) {
 #define M_EVAL_T(NN) ENG_LAUNCH_LDS((eng_eval_kernel<NN, true>), dim3(blocks), dim3(OPTIK_ENG_SLOT_BLOCK), eval_lds)
@@ -1918,19 +1935,18 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
         // the rest of the list as groups finish -- at half the time per iteration of the per-lane
         // one: measured best between 24 k and 48 k since the group evaluation, 24.3 against 23.9 M
         // restarts/s at 16 k and 22.4 at 4 096 for a 20-step run)
-        // Which tail: the quad solver (ik_quad_tail.hpp; default), round 2's cooperative kernel
-        // (OPTIK_ENG_TAIL=coop or OPTIK_SOLVE_KERNEL=coop) or round 1's per-lane one (OPTIK_SOLVE_KERNEL=lane).
-        // The quad solver runs a restart ~2.7 times as fast as the cooperative kernel, so it takes over earlier.
+        // The tail is the quad solver (ik_quad_tail.hpp): it runs a restart ~2.7 times as fast as round 2's cooperative
+        // kernel, so it takes over early.  (-DOPTIK_LEGACY_KERNELS builds: solve_kernel = coop / lane select the
+        // tails of rounds 2 / 1.)
         bool tail_quad = true;
-        if (const char *e = getenv("OPTIK_ENG_TAIL")) tail_quad = std::strcmp(e, "coop") != 0 && std::strcmp(e, "lane") != 0;
-        if (const char *e = getenv("OPTIK_SOLVE_KERNEL")) tail_quad = tail_quad && std::strcmp(e, "lane") != 0 && std::strcmp(e, "coop") != 0;
-        unsigned long long tail_max = total / 16;
-        unsigned long long tail_cap = (getenv("OPTIK_SOLVE_KERNEL") && std::strcmp(getenv("OPTIK_SOLVE_KERNEL"), "lane") == 0) ? 4096ull : 32768ull;
-        if (tail_quad) { tail_max = total / 8; tail_cap = 131072ull; }
+        unsigned long long tail_max = total / 8, tail_cap = 131072ull;
+#ifdef OPTIK_LEGACY_KERNELS
+        tail_quad = opt().solve_kernel != SK_COOP && opt().solve_kernel != SK_LANE;
+        if (!tail_quad) { tail_max = total / 16; tail_cap = opt().solve_kernel == SK_LANE ? 4096ull : 32768ull; }
+#endif
         if (tail_max > tail_cap) tail_max = tail_cap;
         if (tail_max < 64) tail_max = 64;
-        if (getenv("OPTIK_ENG_NO_TAIL")) tail_max = 0;
-        if (const char *e = getenv("OPTIK_ENG_TAIL_MAX")) tail_max = (unsigned long long)atoll(e);
+        if (opt().engine_tail_max >= 0) tail_max = (unsigned long long)opt().engine_tail_max;
         ch->eng_tail_restarts = 0;
         ch->eng_tail_solver = 0;
         for (bool all_done = false; !all_done;) {
@@ -1972,13 +1988,9 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
                 tq.base.ep = pa0.ep;
                 tq.base.sp = pa0.sp;
                 long long capq = (long long)cus * quad_solve_waves_per_cu(ch->n);
-                if (const char *e = getenv("OPTIK_ENG_TAIL_WAVES")) {  // resident tail waves per CU (experiments)
-                    const long long v = atoll(e);
-                    if (v >= 1 && v * cus < capq) capq = v * cus;
-                }
                 long long lq = ((long long)left + capq - 1) / capq;
                 if (lq < 1) lq = 1;
-                if (lq > COOP_GROUPS_PER_WAVE) lq = COOP_GROUPS_PER_WAVE;
+                if (lq > QUADS_PER_WAVE_HOST) lq = QUADS_PER_WAVE_HOST;
                 tq.base.wq.lanes = (int)lq;
                 long long gq = ((long long)left + lq - 1) / lq;
                 if (gq > capq) gq = capq;
@@ -2002,8 +2014,9 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
                 all_done = true;
                 continue;
             }
+#ifdef OPTIK_LEGACY_KERNELS
             bool tail_coop = true;  // (n <= 7 always here) the cooperative tail, unless the per-lane one is asked for
-            if (const char *e = getenv("OPTIK_SOLVE_KERNEL")) tail_coop = std::strcmp(e, "lane") != 0;
+            if (opt().solve_kernel == SK_LANE) tail_coop = false;
             const unsigned long long cap_waves = (unsigned long long)cus * (unsigned long long)(tail_coop ? 4 : ch->waves_per_cu);
             unsigned long long lanes = (left + cap_waves - 1) / cap_waves;
             if (lanes < 1) lanes = 1;
@@ -2035,8 +2048,11 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
             ch->eng_tail_solver = tail_coop ? 2 : 1;
             for (int p2 = 0; p2 < n_pools; ++p2) pools[p2].done = true;
             all_done = true;
+#else
+            return fail(OPTIK_HIP_EUNSUPPORTED, "engine tail: no solver in this build");
+#endif
         }
-        if (getenv("OPTIK_ENG_DEBUG"))
+        if (ENG_DEBUG_PRINTS)
             fprintf(stderr, "[optik engine] loop %.2f ms (drain from %.2f ms), host waited on the GPU %.2f ms (bulk) + %.2f ms (drain), %d launches\n",
                     std::chrono::duration<double>(std::chrono::steady_clock::now() - dbg_t0).count() * 1e3, dbg_drain_t0 * 1e3,
                     dbg_wait_bulk * 1e3, dbg_wait_drain * 1e3, ch->eng_launches);
@@ -2081,7 +2097,7 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipStreamSynchronize(stream));
-        if (getenv("OPTIK_ENG_DEBUG"))
+        if (ENG_DEBUG_PRINTS)
             fprintf(stderr, "[optik engine] run complete %.2f ms after the loop started (tail kernel took over <= %d restarts)\n",
                     std::chrono::duration<double>(std::chrono::steady_clock::now() - dbg_t0).count() * 1e3, ch->eng_tail_restarts);
         for (int k = 0; k < 4; ++k) {
@@ -2151,7 +2167,7 @@ int optik_hip_engine_reserve(optik_hip_chain *ch, uint64_t slots, void *stream_v
     std::lock_guard<std::mutex> lock(ch->mu);
     BIND_DEVICE(ch);
     size_t cap = 393216;
-    if (const char *e = std::getenv("OPTIK_ENGINE_SLOTS")) { const long v = std::atol(e); if (v >= 256) cap = (size_t)v; }
+    if (opt().engine_slots >= 256) cap = (size_t)opt().engine_slots;
     const size_t AC = slots ? (size_t)((slots + 255) / 256 * 256) : cap;
     int nd = 0, ni = 0, rec_len = 0;
     switch (ch->n) {
@@ -2201,6 +2217,38 @@ int optik_hip_nnls_step_profile(unsigned long long *out8) {
 }
 #endif
 int optik_hip_engine_last_fused(const optik_hip_chain *ch) { return ch ? ch->eng_fused : 0; }
+
+/* Tuning options (tests, tools): see `struct Options`.  Names: solve_kernel (0 auto, 1 quad, 2 lane64, 3 general),
+ * engine_slots, engine_pools, engine_nnls_budget, engine_nnls_slack, engine_tail_max, engine_compact, wide_form
+ * (0 lds, 1 hbm), range_rule (of chains created afterwards), stop_x_legacy.  Not synchronised with calls in flight. */
+static long long *option_slot(const char *name, int **islot) {
+    Options &o = opt();
+    *islot = nullptr;
+    if (!name) return nullptr;
+    if (!std::strcmp(name, "solve_kernel")) { *islot = &o.solve_kernel; return nullptr; }
+    if (!std::strcmp(name, "engine_slots")) return &o.engine_slots;
+    if (!std::strcmp(name, "engine_pools")) { *islot = &o.engine_pools; return nullptr; }
+    if (!std::strcmp(name, "engine_nnls_budget")) { *islot = &o.engine_nnls_budget; return nullptr; }
+    if (!std::strcmp(name, "engine_nnls_slack")) { *islot = &o.engine_nnls_slack; return nullptr; }
+    if (!std::strcmp(name, "engine_tail_max")) return &o.engine_tail_max;
+    if (!std::strcmp(name, "engine_compact")) { *islot = &o.engine_compact; return nullptr; }
+    if (!std::strcmp(name, "wide_form")) { *islot = &o.wide_form; return nullptr; }
+    if (!std::strcmp(name, "range_rule")) { *islot = &o.range_rule; return nullptr; }
+    if (!std::strcmp(name, "stop_x_legacy")) { *islot = &o.stop_x_legacy; return nullptr; }
+    return nullptr;
+}
+int optik_hip_set_option(const char *name, long long value) {
+    int *is = nullptr;
+    long long *ls = option_slot(name, &is);
+    if (ls) { *ls = value; return 0; }
+    if (is) { *is = (int)value; return 0; }
+    return fail(OPTIK_HIP_EINVAL, "unknown option");
+}
+long long optik_hip_get_option(const char *name) {
+    int *is = nullptr;
+    long long *ls = option_slot(name, &is);
+    return ls ? *ls : (is ? (long long)*is : -1);
+}
 
 int optik_hip_ik_host(optik_hip_chain *ch, const optik_solver_config *cfg, const double *targets,
                       const double *x0, int32_t T, const double *ee_offset7, uint64_t restart_begin,
@@ -2287,14 +2335,17 @@ int optik_hip_probe_math(int32_t op, const double *poses7, int64_t count, double
     if (int rc = ensure_device()) return rc;
     if (count == 0) return 0;
     const int stride = op == 0 ? 3 : (op == 1 ? 9 : (op == 2 ? 6 : 36));
-    double *d_p = nullptr, *d_o = nullptr;
-    HIP_TRY(hipMalloc(&d_p, sizeof(double) * 7 * (size_t)count));
-    HIP_TRY(hipMalloc(&d_o, sizeof(double) * (size_t)stride * (size_t)count));
-    HIP_TRY(hipMemcpy(d_p, poses7, sizeof(double) * 7 * (size_t)count, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(probe_math_kernel, dim3(64), dim3(64), 0, nullptr, op, d_p, (long long)count, d_o, stride);
+    // (both buffers are released on every path out)
+    struct DevBuf {
+        double *p = nullptr;
+        ~DevBuf() { if (p) (void)hipFree(p); }
+    } d_p, d_o;
+    HIP_TRY(hipMalloc(&d_p.p, sizeof(double) * 7 * (size_t)count));
+    HIP_TRY(hipMalloc(&d_o.p, sizeof(double) * (size_t)stride * (size_t)count));
+    HIP_TRY(hipMemcpy(d_p.p, poses7, sizeof(double) * 7 * (size_t)count, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(probe_math_kernel, dim3(64), dim3(64), 0, nullptr, op, d_p.p, (long long)count, d_o.p, stride);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, d_o, sizeof(double) * (size_t)stride * (size_t)count, hipMemcpyDeviceToHost));
-    hipFree(d_p); hipFree(d_o);
+    HIP_TRY(hipMemcpy(out, d_o.p, sizeof(double) * (size_t)stride * (size_t)count, hipMemcpyDeviceToHost));
     return 0;
 }
 

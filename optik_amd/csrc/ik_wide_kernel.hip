@@ -114,10 +114,8 @@ __global__ __launch_bounds__(256) void wide_seed_batch_kernel(const WideBatchLau
 
 size_t wide_ws_doubles_per_wave() { return (size_t)wide_ws::SLOTS * 64; }
 
-hipError_t wide_solve_launch(int grid, hipStream_t stream, const WideSolveLaunch &a, bool lds_form) {
-    // (OPTIK_WIDE_LDS_COOP=0: the one-lane LDS form instead of the cooperative one)
-    const char *e_coop = getenv("OPTIK_WIDE_LDS_COOP");
-    const bool lds_coop = !(e_coop && atoi(e_coop) == 0);
+hipError_t wide_solve_launch(int grid, hipStream_t stream, const WideSolveLaunch &a, bool lds_form, bool lds_coop) {
+    // (lds_coop false: the one-lane LDS form instead of the cooperative one -- option wide_form = 2, comparisons)
     if (lds_form && lds_coop) hipLaunchKernelGGL(wide_solve_coop_kernel, dim3(grid), dim3(64), 0, stream, a);
     else if (lds_form) hipLaunchKernelGGL(wide_solve_lds_kernel, dim3(grid), dim3(64), 0, stream, a);
     else hipLaunchKernelGGL(wide_solve_kernel, dim3(grid), dim3(64), 0, stream, a);

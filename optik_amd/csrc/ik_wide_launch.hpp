@@ -52,7 +52,7 @@ struct WideBatchLaunch {
 size_t wide_ws_doubles_per_wave();
 // `grid` single-wave workgroups pulling work items until the queue is dry.  lds_form: one restart per
 // wave with its arrays in LDS (a.wq.lanes must be 1; a.ws is not used) -- the latency form
-hipError_t wide_solve_launch(int grid, hipStream_t stream, const WideSolveLaunch &a, bool lds_form);
+hipError_t wide_solve_launch(int grid, hipStream_t stream, const WideSolveLaunch &a, bool lds_form, bool lds_coop = true);
 int wide_lds_bytes();  // static LDS of the latency form
 // op 0: objective + gradient, 1: forward kinematics (+ body Jacobian), 2: restart seeds
 hipError_t wide_batch_launch(int op, int grid, hipStream_t stream, const WideBatchLaunch &a);

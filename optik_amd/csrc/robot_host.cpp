@@ -406,23 +406,14 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
     // budget) is throughput-bound: rounds of 1 M restarts per GPU on the streaming engine (46 ms
     // against 118 on the solve kernel).
     const uint64_t cus = (uint64_t)(c0->num_cus > 0 ? c0->num_cus : 256);
-    static const uint64_t first_per_cu = [] {
-        const char *e = std::getenv("OPTIK_IK_FIRST_ROUND_PER_CU");  // restarts per CU in the first, latency-sized launch
-        return e && std::atoll(e) > 0 ? (uint64_t)std::atoll(e) : (uint64_t)2;
-    }();
+    const uint64_t first_per_cu = 2;  // restarts per CU in the first, latency-sized launch
     const uint64_t first_batch = cus * first_per_cu, later_batch = cus * 2 * 64 * 2;
-    static const uint64_t engine_batch = [] {
-        const char *e = std::getenv("OPTIK_IK_ENGINE_ROUND");  // restarts per GPU per engine round; 0 = never
-        return e ? (uint64_t)std::atoll(e) : (uint64_t)1 << 20;
-    }();
+    const uint64_t engine_batch = (uint64_t)1 << 20;  // restarts per GPU per engine round
     const bool engine_ok = engine_batch > 0 && r->n <= 7;
     // One job of this many restarts is where the engine's ~10 ms floor is amortised against the solve kernel
     // (tools/kernel_vs_engine_probe.py, quad kernel: 131 072 restarts 12.0 against 15.2 ms, 262 144: 20.2
     // against 20.8, 524 288: 37.7 against 34.3; with round 2's kernel the two met at ~100 000)
-    static const uint64_t engine_from = [] {
-        const char *e = std::getenv("OPTIK_IK_ENGINE_FROM");
-        return e && std::atoll(e) > 0 ? (uint64_t)std::atoll(e) : (uint64_t)262144;
-    }();
+    const uint64_t engine_from = 262144;
     const size_t G = device_count(r);
     const uint32_t speed_flags = OPTIK_HIP_IK_EARLY_EXIT | (r->parallelism != 1 ? OPTIK_HIP_IK_FIND_ANY : 0u);
     struct Part {
@@ -451,7 +442,9 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
         // (with a time budget too when the whole range is one solve-kernel launch: its waves watch the clock)
         const bool all_at_once = quality && config->max_restarts > 0
                                  && (config->max_time <= 0.0 || config->max_restarts < engine_from);
-        const size_t g_round = (begin == 0 && !(all_at_once && max_restarts >= 2 * engine_from)) ? 1 : G;  // (the latency-sized first launch stays on one GPU)
+        // (the latency-sized first launch stays on one GPU; a Quality range run at once is cut over the G devices as
+        // soon as every part is a few waves per CU -- decided on its own, not by the engine / kernel crossover)
+        const size_t g_round = (begin == 0 && !(all_at_once && max_restarts / G >= cus * 64)) ? 1 : G;
         // (what is left must be worth an engine run: below engine_from restarts the solve kernel is faster)
         const bool on_engine = engine_ok && max_restarts - begin >= engine_from
                                && (all_at_once || begin >= first_batch + later_batch);
@@ -530,21 +523,9 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
     // with 262 144 targets x 256 indices the finish kernel spent 0.55 instead of 0.07 ms per trip
     // on 66 M such fetches.  Rounds of ~4 M items keep that below a few percent; the handful of
     // targets a short round leaves unsolved go through the next round (on the cooperative kernel).
-    static const uint64_t round_items = [] {
-        const char *e = std::getenv("OPTIK_IK_BATCH_ROUND_ITEMS");
-        return e ? (uint64_t)std::atoll(e) : (uint64_t)4 << 20;
-    }();
-    static const uint64_t engine_first_round = [] {
-        // restart indices per target in the first round of a Speed batch on the engine: 16 measured best
-        // at 65 536 / 131 072 / 262 144 targets (8: 30.0 / 43.2 ms, 16: 26.5 / 34.6, 32: 27.0 / 40.1,
-        // 64: 31.0 / - ms); 0.03 % of reachable targets are left for the next round
-        const char *e = std::getenv("OPTIK_IK_BATCH_ENGINE_ROUND");
-        return e && std::atoll(e) > 0 ? (uint64_t)std::atoll(e) : (uint64_t)16;
-    }();
-    static const size_t engine_min = [] {
-        const char *e = std::getenv("OPTIK_IK_BATCH_ENGINE_MIN");  // Speed batches from this many targets: engine
-        return e ? (size_t)std::atoll(e) : (size_t)40960;  // 32 768 targets: 16.8 (kernel) against 18.5 ms, 49 152: 24.7 against 22.7
-    }();
+    const uint64_t round_items = (uint64_t)4 << 20;
+    const uint64_t engine_first_round = 16;
+    const size_t engine_min = 40960;  // Speed batches from this many targets: engine (32 768 targets: 16.8 (kernel) against 18.5 ms, 49 152: 24.7 against 22.7)
     std::lock_guard<std::mutex> lock(c->batch_mu);
     optik::DeviceScope dev_scope(c->device);
     if (!dev_scope.ok()) { err = "hipSetDevice failed"; return -1; }
@@ -587,10 +568,7 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
     // targets 15.9 ms at 64, 13.5 at 128, 16.8 at 256); what is
     // still unsolved after it is hard or unreachable and throughput-bound, so every later round covers
     // four times as many indices (ten unreachable targets x 100 000 restarts are 8 rounds instead of 390)
-    static const uint64_t first_round = [] {
-        const char *e = std::getenv("OPTIK_IK_BATCH_FIRST_ROUND");
-        return e && std::atoll(e) > 0 ? (uint64_t)std::atoll(e) : (uint64_t)128;
-    }();
+    const uint64_t first_round = 128;
     uint64_t speed_round = first_round;
     for (uint64_t begin = 0; begin < max_restarts && !live.empty();) {
         double deadline = 0.0;
@@ -639,16 +617,10 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
         // 1.05 M).  Everything else -- a Quality batch, the later rounds of a Speed batch (whatever
         // 256 restarts did not solve runs nearly all of its restarts) -- is throughput-bound: the
         // engine's domain, unless the round is a few launches' worth of restarts.
-        static const size_t small_batch = [] {
-            const char *e = std::getenv("OPTIK_IK_BATCH_KERNEL_MAX");  // targets; 0 = always the engine
-            return e ? (size_t)std::atoll(e) : (size_t)-1;
-        }();
+        const size_t small_batch = (size_t)-1;
         // (one job of ~260 000 restarts is where the engine overtakes the quad solve kernel: 131 072 take 12.0
         // against 15.2 ms, 524 288 take 37.7 against 34.3 ms; n = 8 has no engine)
-        static const uint64_t kernel_below = [] {
-            const char *e = std::getenv("OPTIK_IK_ENGINE_FROM");
-            return e && std::atoll(e) > 0 ? (uint64_t)std::atoll(e) : (uint64_t)262144;
-        }();
+        const uint64_t kernel_below = 262144;
         const bool kernel_path = r->n <= 7 && !big_speed && L <= small_batch
                                  && ((!quality && begin < 256) || (uint64_t)L * (end - begin) < kernel_below);
         const uint32_t mode_flags =
@@ -981,10 +953,13 @@ int optik_robot_chain_tables_n(const optik_robot *r, int32_t capacity, int32_t *
     return 0;
 }
 
-// (the original contract: *n_joints is an out-parameter only, the buffers hold OPTIK_MAX_JOINTS joints)
+// (the original, in/out contract: with buffers, *n_joints holds their capacity in joints on entry -- a buffer that is
+// too small is an error, never an overrun; without buffers it is written only)
 int optik_robot_chain_tables(const optik_robot *r, int32_t *n_joints, double *origins7, double *axes3,
                              int32_t *types) {
-    return optik_robot_chain_tables_n(r, OPTIK_MAX_JOINTS, n_joints, origins7, axes3, types);
+    if (!r || !n_joints) return set_err(-1, "null argument");
+    const int32_t capacity = (origins7 || axes3 || types) ? *n_joints : 0;
+    return optik_robot_chain_tables_n(r, capacity, n_joints, origins7, axes3, types);
 }
 
 optik_hip_chain *optik_robot_hip_chain(const optik_robot *r) {

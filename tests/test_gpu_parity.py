@@ -125,18 +125,11 @@ def _run(hc, path, cfg, tgd, x0d, begin, end, flags=0):
     """The GPU paths: the single-launch solvers -- `kernel`: what a launch of this size gets (the quad solver below
     one full load of the chip), `lane64`: the lane-per-restart form (ik_lane64.hpp), the default from there on,
     forced here at the test's size -- and the streaming engine."""
-    import os
+    from optik_amd import _native as nat
     if path == "lane64":
-        prev = os.environ.get("OPTIK_SOLVE_KERNEL")
-        os.environ["OPTIK_SOLVE_KERNEL"] = "lane64"   # (read per call by optik_hip_ik_batch)
-        try:
+        with nat.options(solve_kernel="lane64"):
             out = hc.ik_batch(cfg, tgd, x0d, begin, end, flags=flags)
             torch.cuda.synchronize()
-        finally:
-            if prev is None:
-                del os.environ["OPTIK_SOLVE_KERNEL"]
-            else:
-                os.environ["OPTIK_SOLVE_KERNEL"] = prev
     elif path == "kernel":
         out = hc.ik_batch(cfg, tgd, x0d, begin, end, flags=flags)
     else:
@@ -259,12 +252,9 @@ def test_engine_pools_jobs_and_matches_the_single_kernel_path(dev, oracle, chain
         jobs.append((torch.tensor(tg, device="cuda"), torch.tensor(x0, device="cuda"), begin, end))
     ref = [hc.ik_batch(cfg, t, x, b, e) for t, x, b, e in jobs]
     torch.cuda.synchronize()
-    os.environ["OPTIK_ENGINE_SLOTS"] = "1024"
-    try:
+    with nat.options(engine_slots=1024):
         outs = [hc.engine_submit(cfg, t, x, b, e) for t, x, b, e in jobs]
         trips = hc.engine_run()
-    finally:
-        del os.environ["OPTIK_ENGINE_SLOTS"]
     torch.cuda.synchronize()
     assert trips > 50
     for r, o in zip(ref, outs):
@@ -275,26 +265,19 @@ def test_engine_pools_jobs_and_matches_the_single_kernel_path(dev, oracle, chain
 
 
 @pytest.mark.parametrize("knobs", [
-    {"OPTIK_ENG_POOLS": "3", "OPTIK_ENGINE_SLOTS": "3072"},                       # three sub-pools, refilled many times
-    {"OPTIK_ENG_POOLS": "4", "OPTIK_ENGINE_SLOTS": "8192", "OPTIK_ENG_NNLS_BUDGET": "1"},  # every solve suspended each pass
-    {"OPTIK_ENG_POOLS": "2", "OPTIK_ENGINE_SLOTS": "4096", "OPTIK_ENG_NNLS_BUDGET": "2"},
-    {"OPTIK_ENG_POOLS": "1", "OPTIK_ENG_NO_COMPACT": "1"},                         # no drain compaction
-    {"OPTIK_ENG_POOLS": "1", "OPTIK_ENGINE_SLOTS": "2048", "OPTIK_ENG_NNLS_BUDGET": "3"},
-    {"OPTIK_ENGINE_SLOTS": "1000", "OPTIK_ENG_POOLS": "1"},                        # pool that is not a whole number of 64-slot tiles
-    {"OPTIK_ENGINE_SLOTS": "1900", "OPTIK_ENG_POOLS": "3"},
-    {"OPTIK_ENG_NNLS_SLACK": "0", "OPTIK_ENGINE_SLOTS": "4096"},                   # every solve capped at its predicted pass count
-    {"OPTIK_ENG_NNLS_SLACK": "100"},                                               # ... or only by the launch budget
-    {"OPTIK_ENG_NO_TAIL": "1"},                                                    # the engine finishes every restart itself
-    {"OPTIK_ENG_TAIL_MAX": "100000", "OPTIK_ENGINE_SLOTS": "4096"},                # tail kernel takes over as soon as the queue is empty
-    {"OPTIK_ENG_TAIL_MAX": "7", "OPTIK_ENG_POOLS": "2"},                           # ... or only for the last handful
-    {"OPTIK_ENG_TAIL": "coop", "OPTIK_ENG_TAIL_MAX": "100000", "OPTIK_ENGINE_SLOTS": "4096"},  # round 2's cooperative tail instead of the quad solver's
-    {"OPTIK_ENG_TAIL": "coop"},
-    {"OPTIK_ENG_TAIL_MAX": "100000", "OPTIK_ENGINE_SLOTS": "4096", "OPTIK_ENG_NNLS_BUDGET": "1"},  # quad tail taking over slots with suspended solves
-    {"OPTIK_ENG_FUSED": "1"},                                                      # fused trips: bucket -> NNLS -> slot kernel
-    {"OPTIK_ENG_FUSED": "1", "OPTIK_ENGINE_SLOTS": "3072", "OPTIK_ENG_POOLS": "3", "OPTIK_ENG_NNLS_BUDGET": "2"},
-    {"OPTIK_ENG_FUSED": "1", "OPTIK_ENG_NO_TAIL": "1", "OPTIK_ENGINE_SLOTS": "2048"},
-    {"OPTIK_ENG_NNLS_CONT": "1", "OPTIK_ENGINE_SLOTS": "4096"},                    # same-trip NNLS continuation launch
-    {"OPTIK_ENG_DEPTH": "1"}, {"OPTIK_ENG_DEPTH": "4", "OPTIK_ENGINE_SLOTS": "4096"},  # chunks the host keeps queued ahead
+    dict(engine_pools=3, engine_slots=3072),                           # three sub-pools, refilled many times
+    dict(engine_pools=4, engine_slots=8192, engine_nnls_budget=1),     # every solve suspended each pass
+    dict(engine_pools=2, engine_slots=4096, engine_nnls_budget=2),
+    dict(engine_pools=1, engine_compact=0),                            # no drain compaction
+    dict(engine_pools=1, engine_slots=2048, engine_nnls_budget=3),
+    dict(engine_slots=1000, engine_pools=1),                           # pool that is not a whole number of 64-slot tiles
+    dict(engine_slots=1900, engine_pools=3),
+    dict(engine_nnls_slack=0, engine_slots=4096),                      # every solve capped at its predicted pass count
+    dict(engine_nnls_slack=100),                                       # ... or only by the launch budget
+    dict(engine_tail_max=0),                                           # the engine finishes every restart itself
+    dict(engine_tail_max=100000, engine_slots=4096),                   # the quad solver takes over as soon as the queue is empty
+    dict(engine_tail_max=7, engine_pools=2),                           # ... or only for the last handful
+    dict(engine_tail_max=100000, engine_slots=4096, engine_nnls_budget=1),  # quad tail taking over slots with suspended solves
 ])
 def test_engine_scheduling_does_not_change_results(dev, oracle, chains, hip_chains, knobs):
     """Sub-pools, the per-launch NNLS pass budget (suspend / resume), pool size (refills) and
@@ -308,23 +291,15 @@ def test_engine_scheduling_does_not_change_results(dev, oracle, chains, hip_chai
     kw = dict(solution_mode="quality", tol_f=1e-6)
     cfg = nat.make_config(**kw)
     R = 6000
-    old = {k: os.environ.get(k) for k in knobs}
-    os.environ.update(knobs)
-    try:
+    with nat.options(**knobs):
         out = _run(hip_chains["panda"], "engine", cfg, torch.tensor(tg, device="cuda"),
                    torch.tensor(x0, device="cuda"), 0, R)
         tail_solver, tail_restarts = hip_chains["panda"].engine_last_tail()
-    finally:
-        for k, v in old.items():
-            if v is None:
-                del os.environ[k]
-            else:
-                os.environ[k] = v
-    # the hand-over really happened where the setting asks for it, and on the solver it names
-    if knobs.get("OPTIK_ENG_NO_TAIL"):
+    # the hand-over really happened where the setting asks for it (solver 3 = the quad solver)
+    if knobs.get("engine_tail_max") == 0:
         assert tail_solver == 0 and tail_restarts == 0
-    elif knobs.get("OPTIK_ENG_TAIL_MAX") == "100000" or "OPTIK_ENG_TAIL" in knobs:
-        assert tail_restarts > 0 and tail_solver == (2 if knobs.get("OPTIK_ENG_TAIL") == "coop" else 3), (tail_solver, tail_restarts)
+    elif knobs.get("engine_tail_max") == 100000:
+        assert tail_restarts > 0 and tail_solver == 3, (tail_solver, tail_restarts)
     ref = _oracle_all(oracle, ch, kw, tg[0], x0[0], 0, R)
     assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
     assert np.array_equal(out["evals"].cpu().numpy(), ref["evals"])

@@ -202,21 +202,29 @@ def test_c_abi_ik_returns_malloced_buffer(ur3e):
     assert not bool(L.optik_robot_ik(ur3e._h, C.byref(cfg), far, x0))   # NULL = no solution
 
 
-@pytest.mark.parametrize("kernel_max", [None, "0"])
-def test_ik_batch_equals_individual_calls(panda, oracle, chains, kernel_max, monkeypatch):
-    """Robot.ik_batch (restart-major queue, early exit; on the cooperative kernel, or on the
-    streaming engine with OPTIK_IK_BATCH_KERNEL_MAX=0 -- read once per process, so the engine leg
-    runs in a fresh interpreter) returns for every target exactly what ik() returns for it
-    alone -- and what the oracle's restart loop returns."""
-    if kernel_max is not None:
-        import subprocess
-        import sys
-        env = dict(os.environ, OPTIK_IK_BATCH_KERNEL_MAX=kernel_max)
-        res = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", __file__, "-k",
-                              "test_ik_batch_equals_individual_calls and None"], env=env, capture_output=True,
-                             text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-1000:]
-        return
+def test_ik_batch_on_the_engine_equals_individual_calls(panda):
+    """A Speed batch of 40 960 targets or more runs its first round on the streaming engine
+    (robot_host.cpp:ik_batch_on_device): the same answers as ik() target by target."""
+    from optik_amd import SolverConfig
+    rng = np.random.default_rng(18)
+    lb, ub = (np.array(v) for v in panda.joint_limits())
+    T = 41000
+    base = [np.array(panda.fk(rng.uniform(lb, ub))) for _ in range(40)]
+    targets = np.stack([base[t % 40] for t in range(T)])
+    x0s = rng.uniform(lb, ub, size=(T, 7))
+    cfg = SolverConfig(solution_mode="speed", max_time=0.0, max_restarts=64)
+    x, f, found = panda.ik_batch_arrays(cfg, targets, x0s)
+    assert found.mean() > 0.9
+    for t in (0, 13, 4097, 20011, 40999):
+        single = panda.ik(cfg, targets[t], x0s[t].tolist())
+        assert (single is not None) == bool(found[t])
+        if single is not None:
+            assert x[t].tolist() == single[0] and f[t] == single[1]
+
+
+def test_ik_batch_equals_individual_calls(panda, oracle, chains):
+    """Robot.ik_batch (restart-major queue, early exit, on the quad solver) returns for every target exactly
+    what ik() returns for it alone -- and what the oracle's restart loop returns."""
     from optik_amd import SolverConfig
     _, ch = chains["panda"]
     rng = np.random.default_rng(8)

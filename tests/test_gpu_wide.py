@@ -106,14 +106,12 @@ def test_every_restart_bit_exact(dev, oracle, chains, hip_chains, robot, tol_f, 
     T, R = 2, {"lds": 500, "lds_one_lane": 300, "hbm": 2600}[form]
     # (the scheduler picks the cooperative LDS form: the wave's 64 lanes on its one restart; "lds_one_lane" is the
     # same layout with one lane doing all the work, "hbm" a restart per lane with the HBM workspace)
-    monkeypatch.setenv("OPTIK_WIDE_FORM", "hbm" if form == "hbm" else "lds")
-    if form == "lds_one_lane":
-        monkeypatch.setenv("OPTIK_WIDE_LDS_COOP", "0")
     tg, x0 = make_targets(oracle, d, ch, rng, T)
     kw = dict(solution_mode=mode, tol_f=tol_f)
-    out = hip_chains[robot].ik_batch(nat.make_config(**kw), torch.tensor(tg, device="cuda"),
-                                     torch.tensor(x0, device="cuda"), 0, R)
-    torch.cuda.synchronize()
+    with nat.options(wide_form={"lds": 0, "hbm": 1, "lds_one_lane": 2}[form]):
+        out = hip_chains[robot].ik_batch(nat.make_config(**kw), torch.tensor(tg, device="cuda"),
+                                         torch.tensor(x0, device="cuda"), 0, R)
+        torch.cuda.synchronize()
     assert (hip_chains[robot].last_launch()["lds_bytes"] > 8192) == (form != "hbm")
     st = out["status"].cpu().numpy().reshape(T, R)
     ev = out["evals"].cpu().numpy().reshape(T, R)
@@ -373,7 +371,7 @@ def test_max_time_and_invalid_seed_on_a_wide_chain():
 @pytest.mark.parametrize("robot", ["panda", "ur10", "panda_hand", "panda3", "arm8"])
 @pytest.mark.parametrize("R", [400, 3000])
 def test_general_solver_equals_the_tuned_solvers(dev, oracle, chains, robot, R, monkeypatch):
-    """OPTIK_SOLVE_KERNEL=general runs a chain of at most 8 joints on the run-time-n solver too: a third,
+    """Option solve_kernel = general runs a chain of at most 8 joints on the run-time-n solver too: a third,
     independently written device solver (textbook loop nests over a workspace; both of its forms) gives the
     bits of the quad solver -- and the oracle's -- for every restart."""
     from optik_amd import _native as nat
@@ -386,13 +384,10 @@ def test_general_solver_equals_the_tuned_solvers(dev, oracle, chains, robot, R, 
     tgd, x0d = torch.tensor(tg, device="cuda"), torch.tensor(x0, device="cuda")
     tuned = hc.ik_batch(cfg, tgd, x0d, 0, R)
     torch.cuda.synchronize()
-    monkeypatch.setenv("OPTIK_SOLVE_KERNEL", "general")
-    monkeypatch.setenv("OPTIK_WIDE_FORM", "lds" if R <= 2048 else "hbm")
-    general = hc.ik_batch(cfg, tgd, x0d, 0, R)
-    torch.cuda.synchronize()
+    with nat.options(solve_kernel="general", wide_form="lds" if R <= 2048 else "hbm"):
+        general = hc.ik_batch(cfg, tgd, x0d, 0, R)
+        torch.cuda.synchronize()
     assert (hc.last_launch()["lds_bytes"] > 8192) == (R <= 2048)  # the LDS form / the HBM workspace
-    monkeypatch.delenv("OPTIK_SOLVE_KERNEL")
-    monkeypatch.delenv("OPTIK_WIDE_FORM")
     for k in ("status", "evals", "win_idx"):
         assert torch.equal(tuned[k], general[k]), k
     for k in ("x", "f", "win_x", "win_f", "win_key"):

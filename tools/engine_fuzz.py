@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Scheduler fuzz: random jobs (robot, targets, restart ranges, mode, tolerances, weights) under
-random engine knobs (pool size, sub-pools, NNLS budget / slack, tail hand-over, compaction) must
+random engine options (pool size, sub-pools, NNLS budget / slack, tail hand-over, compaction) must
 give, restart for restart, the bits of the single-kernel path (status, evaluations, x, f, winners).
 Usage: python tools/engine_fuzz.py [rounds] [seed]"""
 import os
@@ -17,21 +17,15 @@ from optik_amd import _native as nat  # noqa: E402
 ROBOTS = os.path.join(ROOT, "optik_amd", "robots")
 SPECS = {"panda": ("panda.urdf", "panda_link0", "panda_link8"), "ur10": ("ur10.urdf", "base_link", "ee_link"),
          "panda_hand": ("panda.urdf", "panda_link0", "panda_hand"), "panda5": ("panda.urdf", "panda_link0", "panda_link5")}
-KNOBS = {"OPTIK_ENGINE_SLOTS": [None, "1024", "1000", "2560", "4096", "20000"],
-         "OPTIK_ENG_POOLS": [None, "1", "2", "3", "4"],
-         "OPTIK_ENG_NNLS_BUDGET": [None, "1", "2", "3", "6", "12"],
-         "OPTIK_ENG_NNLS_SLACK": [None, "0", "1", "2", "100"],
-         "OPTIK_ENG_TAIL_MAX": [None, "0", "7", "300", "100000"],
-         "OPTIK_ENG_NO_COMPACT": [None, None, "1"],
-         # round 2: fused trips, same-trip NNLS continuation, host queue depth, per-lane tail / solve kernels
-         "OPTIK_ENG_FUSED": [None, None, "1"],
-         "OPTIK_ENG_NNLS_CONT": [None, None, "1"],
-         "OPTIK_ENG_DEPTH": [None, "1", "3"],
-         "OPTIK_ENG_CHECK_DRAIN": [None, "1", "2", "3"],
-         "OPTIK_SOLVE_KERNEL": [None, None, "lane"],
-         # round 3: the quad solver's tail (default) or round 2's cooperative one
-         "OPTIK_ENG_TAIL": [None, None, "coop"]}
-
+# options of the kernel layer (include/optik_hip.h: optik_hip_set_option); None = the default
+KNOBS = {"engine_slots": [None, 1024, 1000, 2560, 4096, 20000],
+         "engine_pools": [None, 1, 2, 3, 4],
+         "engine_nnls_budget": [None, 1, 2, 3, 6, 12],
+         "engine_nnls_slack": [None, 0, 1, 2, 100],
+         "engine_tail_max": [None, 0, 7, 300, 100000],
+         "engine_compact": [None, None, 0],
+         # the reference answers come from the single-launch path: the quad solver, or forced onto the lane-per-restart form
+         "solve_kernel": [None, None, "lane64", "quad"]}
 
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
@@ -57,28 +51,22 @@ def main():
             x0 = torch.tensor(rng.uniform(lb, ub, size=(T, len(lb))), device="cuda")
             begin = int(rng.integers(0, 3000))
             jobs.append((tg, x0, begin, begin + int(rng.integers(1, 1500))))
-        knobs = {k: rng.choice(v) for k, v in KNOBS.items()}
+        knobs = {k: v[int(rng.integers(len(v)))] for k, v in KNOBS.items()}
         knobs = {k: v for k, v in knobs.items() if v is not None}
-        ref = None if early else [hc.ik_batch(cfg, t, x, b, e) for t, x, b, e in jobs]
-        old = {k: os.environ.get(k) for k in KNOBS}
-        for k in KNOBS:
-            os.environ.pop(k, None)
-        os.environ.update(knobs)
-        try:
+        sk = knobs.pop("solve_kernel", None)
+        with nat.options(**({"solve_kernel": sk} if sk else {})):
+            ref = None if early else [hc.ik_batch(cfg, t, x, b, e) for t, x, b, e in jobs]
+            torch.cuda.synchronize()
+        with nat.options(**knobs):
             outs = [hc.engine_submit(cfg, t, x, b, e, flags=flags) for t, x, b, e in jobs]
             hc.engine_run()
             torch.cuda.synchronize()
-            if early:  # compare with the engine under default knobs: early exit is order dependent only in what it skips
-                for k in KNOBS:
-                    os.environ.pop(k, None)
-                ref = [hc.engine_submit(cfg, t, x, b, e, flags=flags) for t, x, b, e in jobs]
-                hc.engine_run()
-                torch.cuda.synchronize()
-        finally:
-            for k, v in old.items():
-                os.environ.pop(k, None)
-                if v is not None:
-                    os.environ[k] = v
+        if early:  # compare with the engine under default options: early exit is order dependent only in what it skips
+            ref = [hc.engine_submit(cfg, t, x, b, e, flags=flags) for t, x, b, e in jobs]
+            hc.engine_run()
+            torch.cuda.synchronize()
+        if sk:
+            knobs["solve_kernel(reference)"] = sk
         ok = True
         for r, o in zip(ref, outs):
             if early:

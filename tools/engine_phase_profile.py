@@ -20,7 +20,7 @@ def main():
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
                            "-shared", "-Wno-unused-value", "-pthread", "-DOPTIK_PROFILE", "-x", "hip",
                            os.path.join(CSRC, "ik_kernels.hip"), os.path.join(CSRC, "robot_host.cpp"), "-o", LIB])
-    os.environ["OPTIK_ENG_POOLS"] = "1"
+    os.environ["OPTIK_ENG_POOLS"] = "1"  # (read once, at the library's first use)
     from optik_amd import _native as nat
     nat.LIB_PATH = LIB
     import numpy as np

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Launch time of one optik_hip_ik_batch call of R restarts (one target) on the quad solver and on the lane-per-restart
-solver (OPTIK_SOLVE_KERNEL unset / =quad / =lane64 read per call): where the crossover between the two lies.
+solver (option solve_kernel = quad / lane64): where the crossover between the two lies.
 Usage: python tools/lane_vs_quad_probe.py [robot]"""
 import os
 import sys
@@ -28,7 +28,7 @@ cfg = nat.make_config("speed")
 for R in (1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072, 262144, 1048576):
     row = []
     for kern in ("quad", "lane64"):
-        os.environ["OPTIK_SOLVE_KERNEL"] = kern
+        nat.set_option("solve_kernel", kern)
         bufs = hc.alloc_ik_buffers(1, R)
         hc.ik_batch(cfg, tgt, x0, 0, R, bufs=bufs)
         torch.cuda.synchronize()

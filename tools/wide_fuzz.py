@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Fuzz of the general solver (optik_amd/csrc/ik_wide.hpp): random 9 .. 16-joint arms (and, through
-OPTIK_SOLVE_KERNEL=general, random sub-chains of at most 8 joints), random targets / seeds / tolerances /
+option solve_kernel = general, random sub-chains of at most 8 joints), random targets / seeds / tolerances /
 weights / ee offsets / restart ranges / launch sizes (both forms of the solver), Speed with and without early
 exit -- every restart's status, evaluation count, x and f against the CPU oracle, bit for bit, and the winners.
 Usage: python tools/wide_fuzz.py [rounds] [seed]"""
@@ -60,18 +60,16 @@ def main():
             q = rng.normal(size=4)
             ee_off = np.concatenate([rng.uniform(-0.1, 0.1, 3), q / np.linalg.norm(q)])
         early = kw["solution_mode"] == "speed" and rng.random() < 0.5
-        if small:
-            os.environ["OPTIK_SOLVE_KERNEL"] = "general"
         forced = str(rng.choice(["", "", "lds", "hbm"]))  # (the scheduler's own choice, or one of the two forms)
+        opts = {}
+        if small:
+            opts["solve_kernel"] = "general"
         if forced:
-            os.environ["OPTIK_WIDE_FORM"] = forced
-        try:
+            opts["wide_form"] = forced
+        with nat.options(**opts):
             out = hc.ik_batch(nat.make_config(**kw), torch.tensor(tg, device="cuda"), torch.tensor(x0, device="cuda"),
                               begin, begin + R, flags=nat.IK_EARLY_EXIT if early else 0, ee_offset7=ee_off)
             torch.cuda.synchronize()
-        finally:
-            os.environ.pop("OPTIK_SOLVE_KERNEL", None)
-            os.environ.pop("OPTIK_WIDE_FORM", None)
         form = "lds" if hc.last_launch()["lds_bytes"] > 8192 else "hbm"
         ok = True
         st = out["status"].cpu().numpy().reshape(T, R)
