@@ -20,21 +20,12 @@ OPTIK_DEV int quad_base() { return (int)(threadIdx.x & 63u) & ~3; }
 // numbers, masks, LDS addresses -- is then computed in that region, not hoisted out of the loop as
 // an invariant and spilled for its whole length.
 OPTIK_DEV int wave_lane_now() {
-#ifdef OPTIK_LANE_EMU
-    int v = (int)(threadIdx.x & 63u);
-    asm volatile("" : "+r"(v));
-#else
     int v = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    asm volatile("" : "+v"(v));
-#endif
+    asm volatile("" : OPTIK_REG_INOUT(v));
     return v;
 }
 OPTIK_DEV int quad_lane_now() { return wave_lane_now() & 3; }
 
-#ifdef OPTIK_LANE_EMU
-OPTIK_DEV double quad_get(double v, int k) { return __shfl(v, quad_base() + (k & 3), 64); }
-OPTIK_DEV int quad_get(int v, int k) { return __shfl(v, quad_base() + (k & 3), 64); }
-#else
 // (bound_ctrl = true: every lane of a full wave has a valid source, so no "old" value has to be
 // materialised in the destination first -- with false the compiler emits a v_mov 0 before every DPP move)
 template <int K>
@@ -62,14 +53,9 @@ OPTIK_DEV int quad_get(int v, int k) {
     default: return quad_get_c<3>(v);
     }
 }
-#endif
 
 // value held by lane (own ^ mask) of the caller's quad, mask = 1 or 2: the butterflies of a quad-wide
 // min / argmax.  DPP quad_perm [1,0,3,2] / [2,3,0,1] on the device (ds_bpermute costs an LDS round trip).
-#ifdef OPTIK_LANE_EMU
-OPTIK_DEV double quad_xor(double v, int mask) { return __shfl_xor(v, mask, 64); }
-OPTIK_DEV int quad_xor(int v, int mask) { return __shfl_xor(v, mask, 64); }
-#else
 OPTIK_DEV double quad_xor(double v, int mask) {
     return mask == 1 ? __builtin_amdgcn_update_dpp(0.0, v, 0xB1, 0xf, 0xf, true)
                      : __builtin_amdgcn_update_dpp(0.0, v, 0x4E, 0xf, 0xf, true);
@@ -78,21 +64,16 @@ OPTIK_DEV int quad_xor(int v, int mask) {
     return mask == 1 ? __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true)
                      : __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);
 }
-#endif
 
 // value held by lane (own + r) & 3 of the caller's quad, r = 1, 2, 3 (a rotation of the quad): the
 // diagonal rounds of a ChaCha block whose columns live in the four lanes.  quad_perm [1,2,3,0] /
 // [2,3,0,1] / [3,0,1,2].
-#ifdef OPTIK_LANE_EMU
-OPTIK_DEV uint32_t quad_rot(uint32_t v, int r) { return (uint32_t)__shfl((int)v, quad_base() + ((quad_lane() + r) & 3), 64); }
-#else
 OPTIK_DEV uint32_t quad_rot(uint32_t v, int r) {
     const int i = (int)v;
     return (uint32_t)(r == 1 ? __builtin_amdgcn_update_dpp(0, i, 0x39, 0xf, 0xf, true)
                              : (r == 2 ? __builtin_amdgcn_update_dpp(0, i, 0x4E, 0xf, 0xf, true)
                                        : __builtin_amdgcn_update_dpp(0, i, 0x93, 0xf, 0xf, true)));
 }
-#endif
 
 // does p hold in some / every lane of the caller's quad
 OPTIK_DEV bool quad_any(bool p) {

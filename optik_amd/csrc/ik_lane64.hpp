@@ -70,15 +70,6 @@ constexpr int LANE64_CLASSES = 8;  // predicted pass classes 1 .. 7 (0: no bound
 #define OPTIK_LANE_REFILL 4       // idle lanes a wave accumulates before it refills (the seed generation runs for the whole wave)
 #endif
 
-// quads a wave has (the emulation of tests/emu runs partial waves)
-OPTIK_DEV int lane64_quads() {
-#ifdef OPTIK_LANE_EMU
-    return optik_emu::t_wave->lanes / QUAD;
-#else
-    return 64 / QUAD;
-#endif
-}
-
 template <int N, bool TIP>
 OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const SolveParams &sp, const uint32_t (&key)[8],
                            const double (&scale)[MAX_DOF], const WorkQueue &wq,
@@ -309,7 +300,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
             for (int r = 0; r < 2 * N; ++r) y[r] = 0.0;
             int nmode = 1;
             double rnorm = 1.0;
-            const int nq = lane64_quads();
+            const int nq = wave_quads();  // (16; the emulation of tests/emu runs partial waves)
             const int qi = lane >> 2, ql = lane & 3;
 #ifdef OPTIK_LANE_EXP_DUP_NNLS
           for (int dup_ = 0; dup_ < 2; ++dup_) {

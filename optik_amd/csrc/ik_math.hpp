@@ -12,15 +12,7 @@
 // kinematics.rs:123-196, 243-255, objective.rs:7-110.
 #pragma once
 
-#ifdef OPTIK_LANE_EMU
-// tests/emu/: the same headers compiled for the host with the wave emulated by threads, so that the
-// CPU-side tests can compare the lane-distributed solver with the oracle bit for bit.  Test
-// infrastructure: the library is never built with this macro.
-#include "lane_emu.hpp"
-#else
-#include <hip/hip_runtime.h>
-#endif
-#include <stdint.h>
+#include "ik_platform.hpp"  // (the HIP runtime header -- or, for tests/emu only, its host emulation)
 
 namespace optik {
 

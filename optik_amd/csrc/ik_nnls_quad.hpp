@@ -48,7 +48,7 @@ constexpr int nnls_quad_wave_lds() { return 16 * NnlsQuadGeom<N>::STRIDE + 16; }
 // -DOPTIK_PROFILE: wave cycles per part of the loop below, summed over all waves into g_quad_nnls_prof
 // (tools/phase_profile.py): 0 steps two-four, 1 step five, 2 steps six-ten, 3 step eleven, 4 loop trips,
 // 5 calls, 6 Givens steps
-#if defined(OPTIK_PROFILE) && !defined(OPTIK_LANE_EMU)
+#ifdef OPTIK_DEVICE_PROFILE
 __device__ unsigned long long g_quad_nnls_prof[8];
 // [0, 17): loop trips by the number of quads still solving; [17, 49): calls by loop trips; [49, 66): calls by quads taking part
 __device__ unsigned long long g_quad_nnls_hist[66];
@@ -131,12 +131,12 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
 #pragma unroll
         for (int k = 0; k < CPL; ++k) col[k] = lds_col_load<N>(colp[k]);
     }
-#if defined(OPTIK_PROFILE) && !defined(OPTIK_LANE_EMU)
+#ifdef OPTIK_DEVICE_PROFILE
     unsigned long long np_[8] = {0, 0, 0, 0, 0, 1, 0, 0};
     unsigned long long nt_ = __builtin_readcyclecounter();
 #endif
 
-#if defined(OPTIK_PROFILE) && !defined(OPTIK_LANE_EMU)
+#ifdef OPTIK_DEVICE_PROFILE
     int trips_ = 0;
     {
         const int n_live_ = __popcll(__ballot(live)) / 4;
@@ -145,7 +145,7 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
 #endif
     while (wave_any(phase < 4)) {
         QNNLS_COUNT(4, 1);
-#if defined(OPTIK_PROFILE) && !defined(OPTIK_LANE_EMU)
+#ifdef OPTIK_DEVICE_PROFILE
         ++trips_;
         {
             const int n_run_ = __popcll(__ballot(phase < 4)) / 4;
@@ -516,7 +516,7 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
             QNNLS_PROBE(3);
         }
     }
-#if defined(OPTIK_PROFILE) && !defined(OPTIK_LANE_EMU)
+#ifdef OPTIK_DEVICE_PROFILE
     if ((threadIdx.x & 63u) == 0) {
         for (int i_ = 0; i_ < 7; ++i_) atomicAdd(&g_quad_nnls_prof[i_], np_[i_]);
         atomicAdd(&g_quad_nnls_hist[17 + (trips_ < 31 ? trips_ : 31)], 1ull);

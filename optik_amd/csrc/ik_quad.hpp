@@ -117,38 +117,18 @@ OPTIK_DEV Pose pose_sel(bool c, const Pose a, const Pose b) {
 // instead of keeping the first load's registers alive in between)
 template <class T>
 OPTIK_DEV const T *reload_barrier(const T *p) {
-#ifdef OPTIK_LANE_EMU
-    asm volatile("" : "+r"(p));
-#else
-    asm volatile("" : "+v"(p));
-#endif
+    asm volatile("" : OPTIK_REG_INOUT(p));
     return p;
 }
 
-// The same for a pointer INTO LDS: only the offset is laundered, the address space is kept.  (A generic pointer
-// laundered whole comes back as FLAT accesses: the LDS is reached through the aperture check of the vector-memory
-// path, every access counts on both wait counters, and nothing the LDS returns can be waited for selectively.)
+// The same for a pointer INTO LDS: only the offset is laundered, the address space is kept (ik_platform.hpp).
 template <class T>
-OPTIK_DEV const T *reload_barrier_lds(const T *p) {
-#ifdef OPTIK_LANE_EMU
-    asm volatile("" : "+r"(p));
-    return p;
-#else
-    typedef const T __attribute__((address_space(3))) *lds_cptr;
-    unsigned off = (unsigned)(__UINTPTR_TYPE__)(lds_cptr)p;
-    asm volatile("" : "+v"(off));
-    return (const T *)(lds_cptr)(__UINTPTR_TYPE__)off;
-#endif
-}
+OPTIK_DEV const T *reload_barrier_lds(const T *p) { return launder_lds(p); }
 
 // (the same for an integer: what is computed from the result is computed where it is used, not hoisted out
 // of the solver loop as an invariant -- and then spilled for the whole loop)
 OPTIK_DEV int opaque_int(int v) {
-#ifdef OPTIK_LANE_EMU
-    asm volatile("" : "+r"(v));
-#else
-    asm volatile("" : "+v"(v));
-#endif
+    asm volatile("" : OPTIK_REG_INOUT(v));
     return v;
 }
 

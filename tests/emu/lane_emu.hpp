@@ -122,6 +122,40 @@ inline unsigned long long __ballot(bool p) {
     return m;
 }
 
+// ---- the DPP moves and lane counters of optik_amd/csrc/ik_lane.hpp, under their device names -------------------
+// __builtin_amdgcn_update_dpp(old, v, dpp_ctrl, row_mask, bank_mask, bound_ctrl) with a quad_perm control (dpp_ctrl
+// 0x00 .. 0xFF, the only kind the solvers use): lane i of every quad of four reads the lane (dpp_ctrl >> 2 (i & 3)) & 3
+// of ITS quad -- the hardware's own decoding of the eight control bits, so that the control constants in ik_lane.hpp
+// (0x00 / 0x55 / 0xAA / 0xFF broadcasts, 0xB1 / 0x4E butterflies, 0x39 / 0x4E / 0x93 rotations) are what the CPU suite
+// checks, not a re-statement of what they are meant to do.  row_mask = bank_mask = 0xf and bound_ctrl = true are the only
+// form used (every lane of a full quad has a valid source; `old` is never taken); anything else aborts.
+namespace optik_emu {
+template <class T>
+inline T dpp_quad_perm(T v, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    if (ctrl < 0 || ctrl > 0xff || row_mask != 0xf || bank_mask != 0xf || !bound_ctrl) {
+        std::fprintf(stderr, "lane_emu: update_dpp form not emulated (ctrl 0x%x)\n", ctrl);
+        std::abort();
+    }
+    const int lane = (int)(threadIdx_x() & 63u);
+    return __shfl(v, (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3));
+}
+// v_mbcnt_lo / v_mbcnt_hi: add + the number of set mask bits below the lane in the low / high half of the wave
+inline unsigned mbcnt_lo(unsigned mask, unsigned add) {
+    const unsigned lane = threadIdx_x() & 63u;
+    const unsigned below = lane >= 32u ? 0xffffffffu : ((1u << lane) - 1u);
+    return add + (unsigned)__builtin_popcount(mask & below);
+}
+inline unsigned mbcnt_hi(unsigned mask, unsigned add) {
+    const unsigned lane = threadIdx_x() & 63u;
+    const unsigned below = lane <= 32u ? 0u : ((1u << (lane - 32u)) - 1u);
+    return add + (unsigned)__builtin_popcount(mask & below);
+}
+}  // namespace optik_emu
+#define __builtin_amdgcn_update_dpp(old, v, ctrl, row_mask, bank_mask, bound_ctrl) \
+    optik_emu::dpp_quad_perm((v), (ctrl), (row_mask), (bank_mask), (bound_ctrl))
+#define __builtin_amdgcn_mbcnt_lo(mask, add) optik_emu::mbcnt_lo((mask), (add))
+#define __builtin_amdgcn_mbcnt_hi(mask, add) optik_emu::mbcnt_hi((mask), (add))
+
 // LDS hand-over points: fence + wave barrier on the device, a real barrier between the threads here
 #define __builtin_amdgcn_fence(...) ((void)0)
 #define __builtin_amdgcn_wave_barrier() optik_emu::barrier()

@@ -57,6 +57,29 @@ void run_wave_lane64(const ChainDev &ch, const EvalParams &ep, const SolveParams
 
 extern "C" {
 
+// The cross-lane moves of ik_lane.hpp on an 8-lane partial wave, every lane holding its own number: out[m * 8 + lane]
+// for m = quad_get(., 0..3), quad_xor(., 1), quad_xor(., 2), quad_rot(., 1..3) -- through the same DPP controls the
+// device executes, decoded as the hardware decodes them (lane_emu.hpp).
+int quad_emu_lane_moves(int *out) {
+    optik_emu::Wave wave;
+    wave.lanes = 8;
+    std::vector<std::thread> th;
+    for (int lane = 0; lane < wave.lanes; ++lane) {
+        th.emplace_back([&, lane]() {
+            optik_emu::t_wave = &wave;
+            threadIdx.x = (unsigned)lane;
+            const int me = wave_lane_now();
+            for (int k = 0; k < 4; ++k) out[k * 8 + lane] = quad_get(me, k);
+            out[4 * 8 + lane] = quad_xor(me, 1);
+            out[5 * 8 + lane] = quad_xor(me, 2);
+            for (int r = 1; r <= 3; ++r) out[(5 + r) * 8 + lane] = (int)quad_rot((uint32_t)me, r);
+            out[9 * 8 + lane] = (int)quad_get(1.5 * me, 2) == (int)(1.5 * ((me & ~3) | 2)) ? 1 : 0;  // (a 64-bit value: both halves)
+        });
+    }
+    for (auto &t : th) t.join();
+    return 0;
+}
+
 // origins [J][7] (t, quat ijkw), axes [n][3], J = n or n + 1; restarts [begin, end) of ONE target.
 // out_x [n][R], out_f / out_key [R], out_status / out_evals [R].  quads: restarts in flight (1 .. 16).
 int quad_emu_solve(const double *origins, const double *axes, int n, int n_joints, const double *lb, const double *ub,

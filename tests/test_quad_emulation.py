@@ -20,6 +20,24 @@ def emu():
     return binding
 
 
+def test_lane_moves_follow_the_dpp_controls(emu):
+    """ik_lane.hpp's quad moves run in the emulation through the SAME __builtin_amdgcn_update_dpp controls the device
+    executes, decoded as the hardware decodes a quad_perm (lane i reads lane (ctrl >> 2 i) & 3 of its quad): broadcast
+    from lane k, the two butterflies, and the rotations the ChaCha diagonal rounds use."""
+    import ctypes as C
+    out = (C.c_int * 80)()
+    emu.lib().quad_emu_lane_moves(out)
+    got = np.array(list(out)).reshape(10, 8)
+    lanes = np.arange(8)
+    base = lanes & ~3
+    for k in range(4):
+        assert (got[k] == base + k).all()                       # quad_get(v, k): the value lane k of the quad holds
+    assert (got[4] == (lanes ^ 1)).all() and (got[5] == (lanes ^ 2)).all()   # quad_xor
+    for r in (1, 2, 3):
+        assert (got[5 + r] == base + ((lanes + r) & 3)).all()   # quad_rot(v, r): the value of lane (own + r) & 3
+    assert got[9].all()
+
+
 def _case(oracle, chains, robot, seed):
     d, ch = chains[robot]
     rng = np.random.default_rng(seed)
