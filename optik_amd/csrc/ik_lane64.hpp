@@ -66,15 +66,70 @@ constexpr int LANE64_CLASSES = 8;  // predicted pass classes 1 .. 7 (0: no bound
 #define OPTIK_LANE_REGCOLS 0      // 1: the NNLS keeps a lane's four columns in registers as well (ik_nnls_quad.hpp): slower
                                   // here -- 64 registers more across the rounds spill the lane's state (27.0 -> 24.4 M)
 #endif
+#ifndef OPTIK_LANE_PIPE
+#define OPTIK_LANE_PIPE 1         // 0: rounds of sixteen problems, each round to its end (comparisons)
+#endif
+#ifndef LANE64_MAX_RUNNING
+#define LANE64_MAX_RUNNING 8      // hand-over as soon as this few of the sixteen quads are still solving (and problems wait)
+#endif
 #ifndef OPTIK_LANE_REFILL
 #define OPTIK_LANE_REFILL 4       // idle lanes a wave accumulates before it refills (the seed generation runs for the whole wave)
 #endif
+
+// The wave's problems in rank order through its sixteen quads (ik_nnls_quad.hpp: Pipe): what lane64_wave hands to the
+// NNLS -- the answers of finished quads back to their owner lanes, the next problems into the idle quads.
+template <int N, class Expand, class ReadBack>
+struct Lane64Pipe {
+    static constexpr bool on = true;
+    static constexpr int MAX_RUNNING = LANE64_MAX_RUNNING;
+    int n_prob, next, hold;  // problems, the next rank to hand out (wave-uniform), the rank the quad holds or -1
+    int qi, ql, lane, rank;
+    bool has, got;
+    double *bk;
+    int *lor, *where;
+    Expand *expand_fn;
+    ReadBack *read_fn;
+    OPTIK_DEV bool more() const { return next < n_prob; }
+    OPTIK_DEV bool event(bool idle, int mode, double rn, int passes) {
+        const bool fin = idle && hold >= 0;
+        if (wave_any(fin)) {
+            // (the multipliers are in the block by column id; mode, rnorm and the pass count next to them)
+            if (fin && ql == 0) {
+                bk[Lane64Geom<N>::META] = (double)mode;
+                bk[Lane64Geom<N>::META + 1] = rn;
+                bk[Lane64Geom<N>::META + 2] = (double)passes;
+                where[hold] = 0x100 | qi;
+            }
+            lds_sync();
+            if (has && !got) {
+                const int w = where[rank];
+                if (w & 0x100) { (*read_fn)(w & 0xff); got = true; }
+            }
+            lds_sync();  // (before the blocks are rewritten)
+            if (fin) hold = -1;
+        }
+        const bool free_q = idle && hold < 0;
+        const unsigned long long fm = __ballot(free_q);
+        const int mine = (int)__popcll(fm & ((1ull << (lane & ~3)) - 1ull)) / QUAD;
+        const int pr = next + mine;
+        const bool live = free_q && pr < n_prob;
+        next += (int)__popcll(fm) / QUAD;
+        next = next < n_prob ? next : n_prob;
+        if (wave_any(live)) {
+            const int p = lor[live ? pr : 0];
+            (*expand_fn)(live, p);
+            if (live) hold = pr;
+        }
+        return live;
+    }
+};
 
 template <int N, bool TIP>
 OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const SolveParams &sp, const uint32_t (&key)[8],
                            const double (&scale)[MAX_DOF], const WorkQueue &wq,
                            double *nnls_lds /* lane64_block_lds<N>() doubles, the last 16 zero */,
-                           double *rec_lds /* lane64_rec_lds<N>() doubles */, int *lor_lds /* 64 ints: lane of rank */) {
+                           double *rec_lds /* lane64_rec_lds<N>() doubles */, int *lor_lds /* 64 ints: lane of rank */,
+                           int *where_lds /* 64 ints: by rank, 0x100 | the quad whose block holds the problem's answer */) {
     typedef Lane64Geom<N> G;
     constexpr int NL = N * (N + 1) / 2;
     constexpr int NS = (N > 4) ? 2 : 1;
@@ -293,6 +348,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
                 }
             }
             if (has) lor_lds[rank] = lane;
+            where_lds[lane] = 0;  // (no problem of this trip is solved yet)
             lds_sync();
 
             double y[2 * N];
@@ -302,26 +358,22 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
             double rnorm = 1.0;
             const int nq = wave_quads();  // (16; the emulation of tests/emu runs partial waves)
             const int qi = lane >> 2, ql = lane & 3;
-#ifdef OPTIK_LANE_EXP_DUP_NNLS
-          for (int dup_ = 0; dup_ < 2; ++dup_) {
-            asm volatile("" : "+s"(dup_));
-#endif
-            for (int r0 = 0; r0 < n_prob; r0 += nq) {
-                // quad qi takes the problem of rank r0 + qi: its columns from the owner's packed record
-                const int pr = r0 + qi;
-                const bool live = pr < n_prob;
-                const int p = lor_lds[live ? pr : 0];
-                double *const bk = nnls_lds + (unsigned)qi * NnlsQuadGeom<N>::STRIDE;
+            // quad qi's columns of the problem of lane p: from the owner's packed record into the quad's block
+            int ids[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int sl = k & 1, rr = ql + 4 * sl;
+                ids[k] = (sl < NS && rr < N) ? ((k >= 2) ? N : 0) + rr + 1 : 0x7fff;
+            }
+            double *const bk = nnls_lds + (unsigned)qi * NnlsQuadGeom<N>::STRIDE;
+            auto expand = [&](bool live, int p) {
                 const double *const rq = rec_lds + p;
-                int ids[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int sl = k & 1;
                     const bool neg = k >= 2;
-                    ids[k] = 0x7fff;
                     if (sl < NS) {
                         const int rr = ql + 4 * sl;
-                        ids[k] = (rr < N) ? (neg ? N : 0) + rr + 1 : 0x7fff;
                         if (live && rr < N) {
                             double *c = bk + CS * (ids[k] - 1);
                             // (row rr of E^-1 is zero before column rr; entry (rr, j) of the packed triangle otherwise)
@@ -336,10 +388,42 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
                         }
                     }
                 }
+            };
+            // the owner of a solved problem reads its answer back from the block of the quad that solved it
+            auto read_back = [&](int q) {
+                const double *ob = nnls_lds + (unsigned)q * NnlsQuadGeom<N>::STRIDE;
+#pragma unroll
+                for (int r = 0; r < 2 * N; ++r) y[r] = ob[NnlsQuadGeom<N>::XS + r];
+                nmode = (int)ob[G::META];
+                rnorm = ob[G::META + 1];
+                pred = (int)ob[G::META + 2];
+            };
+#ifdef OPTIK_LANE_EXP_DUP_NNLS
+          for (int dup_ = 0; dup_ < 2; ++dup_) {
+            asm volatile("" : "+s"(dup_));
+#endif
+#if OPTIK_LANE_PIPE
+            {
+                // The wave's problems in rank order through its sixteen quads, the rounds overlapping: whenever at most
+                // LANE64_MAX_RUNNING quads are still solving, the answers of the finished ones go back to their owners
+                // and the idle quads take the next problems -- a problem that needs more passes than its class
+                // predicted keeps ITS quad busy, not the wave (ik_nnls_quad.hpp: Pipe).
+                typedef Lane64Pipe<N, decltype(expand), decltype(read_back)> Pipe;
+                Pipe pipe{n_prob, 0, -1, qi, ql, lane, rank, has, false, bk, lor_lds, where_lds, &expand, &read_back};
+                int iters, qmode;
+                double xv[4], qrnorm;
+                nnls_quad<N, OPTIK_LANE_REGCOLS != 0, Pipe>(false, ids, bk, nnls_lds + 16 * NnlsQuadGeom<N>::STRIDE, xv, qmode,
+                                                            qrnorm, iters, &pipe);
+            }
+#else
+            for (int r0 = 0; r0 < n_prob; r0 += nq) {
+                // quad qi takes the problem of rank r0 + qi
+                const int pr = r0 + qi;
+                const bool live = pr < n_prob;
+                expand(live, lor_lds[live ? pr : 0]);
                 int iters, qmode;
                 double xv[4], qrnorm;
                 nnls_quad<N, OPTIK_LANE_REGCOLS != 0>(live, ids, bk, nnls_lds + 16 * NnlsQuadGeom<N>::STRIDE, xv, qmode, qrnorm, iters);
-                // the multipliers are in the block (by column id); mode, rnorm and the pass count next to them
                 if (live && ql == 0) {
                     bk[G::META] = (double)qmode;
                     bk[G::META + 1] = qrnorm;
@@ -347,16 +431,10 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
                 }
                 lds_sync();
                 // the owners of this round's problems read their answers back
-                if (has && rank >= r0 && rank < r0 + nq) {
-                    const double *ob = nnls_lds + (unsigned)(rank - r0) * NnlsQuadGeom<N>::STRIDE;
-#pragma unroll
-                    for (int r = 0; r < 2 * N; ++r) y[r] = ob[NnlsQuadGeom<N>::XS + r];
-                    nmode = (int)ob[G::META];
-                    rnorm = ob[G::META + 1];
-                    pred = (int)ob[G::META + 2];
-                }
+                if (has && rank >= r0 && rank < r0 + nq) read_back(rank - r0);
                 lds_sync();  // (before the next round rewrites the blocks)
             }
+#endif
 #ifdef OPTIK_LANE_EXP_DUP_NNLS
           }
 #endif

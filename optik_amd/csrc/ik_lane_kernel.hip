@@ -15,7 +15,7 @@ __global__ __launch_bounds__(64, 1) void ik_lane_kernel(const SolveLaunch a) {
     __shared__ ChainDev sch;
     __shared__ __attribute__((aligned(16))) double nnls_lds[lane64_block_lds<N>()];
     __shared__ __attribute__((aligned(16))) double rec_lds[lane64_rec_lds<N>()];
-    __shared__ int lor_lds[64];
+    __shared__ int lor_lds[64], where_lds[64];
     // (the launch parameters in LDS, as in ik_quad_kernel: ~125 SGPRs otherwise)
     __shared__ __attribute__((aligned(8))) uint32_t launch_lds[(sizeof(SolveLaunch) + 3) / 4];
     {
@@ -24,18 +24,19 @@ __global__ __launch_bounds__(64, 1) void ik_lane_kernel(const SolveLaunch a) {
     }
     if (threadIdx.x < 16) nnls_lds[lane64_block_lds<N>() - 16 + threadIdx.x] = 0.0;  // the column of zeros
     lor_lds[threadIdx.x & 63u] = 0;
+    where_lds[threadIdx.x & 63u] = 0;
     stage_chain(sch, a.chain);
     SolveLaunch &L = *reinterpret_cast<SolveLaunch *>(launch_lds);
     if (threadIdx.x == 0) L.wq.deadline = L.deadline_ticks ? wall_clock64() + L.deadline_ticks : 0ull;
     __syncthreads();
-    lane64_wave<N, TIP>(sch, L.ep, L.sp, L.key, L.scale, L.wq, nnls_lds, rec_lds, lor_lds);
+    lane64_wave<N, TIP>(sch, L.ep, L.sp, L.key, L.scale, L.wq, nnls_lds, rec_lds, lor_lds, where_lds);
 }
 
 int lane_solve_waves_per_cu() { return 4; }
 
 hipError_t lane_solve_launch(int n, bool tip, int grid, hipStream_t stream, const SolveLaunch &a, int *lds_bytes) {
     if (lds_bytes)
-        *lds_bytes = (int)(sizeof(ChainDev) + sizeof(SolveLaunch) + 64 * sizeof(int)
+        *lds_bytes = (int)(sizeof(ChainDev) + sizeof(SolveLaunch) + 128 * sizeof(int)
                            + sizeof(double) * (lane64_block_lds<7>() + lane64_rec_lds<7>()));
 #define CALL_LANE(NN)                                                                                  \
     case NN:                                                                                           \

@@ -87,9 +87,24 @@ OPTIK_DEV void lds_col_store(double *p, const typename NnlsQuadGeom<N>::rowvec v
 // back when Givens steps have rewritten the block.  For a kernel with one wave per SIMD (ik_lane64.hpp): the eight
 // column loads of a loop trip, each with its LDS latency exposed, are most of what such a wave waits for; the quad
 // solver (two waves per SIMD at 256 registers) has no room for it and hides the latency behind its other wave.
-template <int N, bool REGCOLS = false>
+//
+// Pipe (ik_lane64.hpp): a wave with MORE problems than quads.  With a pipe the call starts with every quad idle and,
+// whenever at most Pipe::MAX_RUNNING quads are still solving while problems wait (and when none is solving at all),
+// calls pipe.event(idle, mode, rnorm, passes): the pipe takes the answers of the quads that have just finished,
+// gives the idle quads their next problems -- it writes their blocks -- and returns whether the caller's quad got
+// one; that quad starts over from step two while the others carry on where they were.  A problem's arithmetic does
+// not depend on what the other quads are doing, so this only changes how many loop trips the wave runs: a straggler
+// no longer holds fifteen finished quads until it is done.  The call returns when nothing runs and nothing waits.
+struct NoPipe {
+    static constexpr bool on = false;
+    static constexpr int MAX_RUNNING = 0;
+    OPTIK_DEV bool more() const { return false; }
+    OPTIK_DEV bool event(bool, int, double, int) { return false; }
+};
+
+template <int N, bool REGCOLS = false, class Pipe = NoPipe>
 OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const double *zeros, double (&xv)[4], int &mode_out,
-                         double &rnorm_out, int &iters_out) {
+                         double &rnorm_out, int &iters_out, Pipe *pipe = nullptr) {
     constexpr int m = N + 1, n = 2 * N;
     constexpr int CPL = 4;
     static_assert(m <= 9 && n <= 16, "row vectors hold up to sixteen entries, the permutation sixteen nibbles");
@@ -125,6 +140,29 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
     // phases: 0 = step two (recompute duals, then choose), 1 = step three (choose again),
     // 2 = step six (solve), 3 = step eleven (remove), 4 = done
     int phase = live ? 0 : 4;
+    // rnorm = ||b(npp1..m)|| of the quad's problem as it stands
+    auto residual_norm = [&]() {
+        const int k0 = (npp1 < m) ? npp1 : m;
+        const int cnt = m - nsetp;
+        double xmax = 0.0;
+#pragma unroll
+        for (int r = 1; r <= m; ++r) {
+            const double av = __builtin_fabs(b[r - 1]);
+            if (r >= k0 && r < k0 + cnt && av > xmax) xmax = av;
+        }
+        double rn = 0.0;
+        if (xmax != 0.0) {
+            const double scale = 1.0 / xmax;
+            double sum = 0.0;
+#pragma unroll
+            for (int r = 1; r <= m; ++r) {
+                const double xsr = scale * b[r - 1];
+                if (r >= k0 && r < k0 + cnt) sum += xsr * xsr;
+            }
+            rn = xmax * __builtin_sqrt(sum);
+        }
+        return rn;
+    };
     lds_sync();
     dvecm col[REGCOLS ? CPL : 1];
     if constexpr (REGCOLS) {
@@ -143,7 +181,40 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
         if ((threadIdx.x & 63u) == 0) atomicAdd(&g_quad_nnls_hist[49 + n_live_], 1ull);
     }
 #endif
-    while (wave_any(phase < 4)) {
+    for (;;) {
+        if constexpr (Pipe::on) {
+            const int n_run = (int)__popcll(__ballot(phase < 4)) / QUAD;
+            if (n_run == 0 || (n_run <= Pipe::MAX_RUNNING && pipe->more())) {
+                // hand-over: answers out of the quads that are done, the next problems into the idle ones
+                const bool fresh = pipe->event(phase == 4, mode, residual_norm(), iter);
+                if (fresh) {
+                    // (the pipe has written the quad's block: the state of a problem at step two)
+                    b = 0.0;
+                    b[m - 1] = 1.0;
+                    indx.v = 0xFEDCBA9876543210ull;
+                    nsetp = 0; npp1 = 1; iter = 0; mode = 1;
+                    up = 0.0;
+                    rem_jj = 0;
+                    phase = 0;
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k) {
+                        pos[k] = ids[k];
+                        inZ[k] = isc[k];
+                        wv[k] = 0.0;
+                        xv[k] = 0.0;
+                        if (isc[k]) xs[ids[k] - 1] = 0.0;
+                    }
+                }
+                lds_sync();
+                if constexpr (REGCOLS) {
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k) col[k] = fresh ? lds_col_load<N>(colp[k]) : col[k];
+                }
+                if (!wave_any(phase < 4)) break;
+            }
+        } else {
+            if (!wave_any(phase < 4)) break;
+        }
         QNNLS_COUNT(4, 1);
 #ifdef OPTIK_DEVICE_PROFILE
         ++trips_;
@@ -522,29 +593,7 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
         atomicAdd(&g_quad_nnls_hist[17 + (trips_ < 31 ? trips_ : 31)], 1ull);
     }
 #endif
-    // rnorm = ||b(npp1..m)||
-    {
-        const int k0 = (npp1 < m) ? npp1 : m;
-        const int cnt = m - nsetp;
-        double xmax = 0.0;
-#pragma unroll
-        for (int r = 1; r <= m; ++r) {
-            const double av = __builtin_fabs(b[r - 1]);
-            if (r >= k0 && r < k0 + cnt && av > xmax) xmax = av;
-        }
-        double rn = 0.0;
-        if (xmax != 0.0) {
-            const double scale = 1.0 / xmax;
-            double sum = 0.0;
-#pragma unroll
-            for (int r = 1; r <= m; ++r) {
-                const double xsr = scale * b[r - 1];
-                if (r >= k0 && r < k0 + cnt) sum += xsr * xsr;
-            }
-            rn = xmax * __builtin_sqrt(sum);
-        }
-        rnorm_out = rn;
-    }
+    rnorm_out = residual_norm();
     mode_out = mode;
     iters_out = iter;
 }

@@ -41,13 +41,13 @@ void run_wave_lane64(const ChainDev &ch, const EvalParams &ep, const SolveParams
     optik_emu::Wave wave;
     wave.lanes = lanes;
     std::vector<double> lds((size_t)lane64_block_lds<N>(), 0.0), rec((size_t)lane64_rec_lds<N>(), 0.0);
-    std::vector<int> lor(64, 0);
+    std::vector<int> lor(64, 0), where(64, 0);
     std::vector<std::thread> th;
     for (int lane = 0; lane < wave.lanes; ++lane) {
         th.emplace_back([&, lane]() {
             optik_emu::t_wave = &wave;
             threadIdx.x = (unsigned)lane;
-            lane64_wave<N, TIP>(ch, ep, sp, key, scale, wq, lds.data(), rec.data(), lor.data());
+            lane64_wave<N, TIP>(ch, ep, sp, key, scale, wq, lds.data(), rec.data(), lor.data(), where.data());
         });
     }
     for (auto &t : th) t.join();
