@@ -62,10 +62,6 @@ template <int N>
 constexpr int lane64_rec_lds() { return Lane64Geom<N>::REC * 64; }
 
 constexpr int LANE64_CLASSES = 8;  // predicted pass classes 1 .. 7 (0: no bounded problem this trip)
-#ifndef OPTIK_LANE_REGCOLS
-#define OPTIK_LANE_REGCOLS 0      // 1: the NNLS keeps a lane's four columns in registers as well (ik_nnls_quad.hpp): slower
-                                  // here -- 64 registers more across the rounds spill the lane's state (27.0 -> 24.4 M)
-#endif
 #ifndef OPTIK_LANE_PIPE
 #define OPTIK_LANE_PIPE 1         // 0: rounds of sixteen problems, each round to its end (comparisons)
 #endif
@@ -412,7 +408,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
                 Pipe pipe{n_prob, 0, -1, qi, ql, lane, rank, has, false, bk, lor_lds, where_lds, &expand, &read_back};
                 int iters, qmode;
                 double xv[4], qrnorm;
-                nnls_quad<N, OPTIK_LANE_REGCOLS != 0, Pipe>(false, ids, bk, nnls_lds + 16 * NnlsQuadGeom<N>::STRIDE, xv, qmode,
+                nnls_quad<N, Pipe>(false, ids, bk, nnls_lds + 16 * NnlsQuadGeom<N>::STRIDE, xv, qmode,
                                                             qrnorm, iters, &pipe);
             }
 #else
@@ -423,7 +419,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
                 expand(live, lor_lds[live ? pr : 0]);
                 int iters, qmode;
                 double xv[4], qrnorm;
-                nnls_quad<N, OPTIK_LANE_REGCOLS != 0>(live, ids, bk, nnls_lds + 16 * NnlsQuadGeom<N>::STRIDE, xv, qmode, qrnorm, iters);
+                nnls_quad<N>(live, ids, bk, nnls_lds + 16 * NnlsQuadGeom<N>::STRIDE, xv, qmode, qrnorm, iters);
                 if (live && ql == 0) {
                     bk[G::META] = (double)qmode;
                     bk[G::META + 1] = qrnorm;

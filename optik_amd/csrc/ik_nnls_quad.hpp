@@ -81,13 +81,6 @@ OPTIK_DEV void lds_col_store(double *p, const typename NnlsQuadGeom<N>::rowvec v
 // multiplier of the lane's k-th column; quad-uniform: mode (1 ok, 3 iteration cap), rnorm, and the
 // number of solve passes.
 //
-// REGCOLS: the lane also keeps its four columns in REGISTERS (64 VGPRs) and works on those -- the block stays the
-// copy every lane of the quad can index (the chosen column, set P by position, Givens pivots), written through on
-// every change; a lane's copy of a column that sits in set P may be stale (nothing reads it there) and is read
-// back when Givens steps have rewritten the block.  For a kernel with one wave per SIMD (ik_lane64.hpp): the eight
-// column loads of a loop trip, each with its LDS latency exposed, are most of what such a wave waits for; the quad
-// solver (two waves per SIMD at 256 registers) has no room for it and hides the latency behind its other wave.
-//
 // Pipe (ik_lane64.hpp): a wave with MORE problems than quads.  With a pipe the call starts with every quad idle and,
 // whenever at most Pipe::MAX_RUNNING quads are still solving while problems wait (and when none is solving at all),
 // calls pipe.event(idle, mode, rnorm, passes): the pipe takes the answers of the quads that have just finished,
@@ -102,7 +95,10 @@ struct NoPipe {
     OPTIK_DEV bool event(bool, int, double, int) { return false; }
 };
 
-template <int N, bool REGCOLS = false, class Pipe = NoPipe>
+// (Tried for the one-wave-per-SIMD kernel and dropped: the lane's four columns kept in registers as well, and a step's
+// four column loads issued together -- both cost it more in spilled state than the exposed LDS latency they save:
+// 27.0 -> 24.4 M and 28.2 -> 27.6 M restarts/s.)
+template <int N, class Pipe = NoPipe>
 OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const double *zeros, double (&xv)[4], int &mode_out,
                          double &rnorm_out, int &iters_out, Pipe *pipe = nullptr) {
     constexpr int m = N + 1, n = 2 * N;
@@ -164,11 +160,6 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
         return rn;
     };
     lds_sync();
-    dvecm col[REGCOLS ? CPL : 1];
-    if constexpr (REGCOLS) {
-#pragma unroll
-        for (int k = 0; k < CPL; ++k) col[k] = lds_col_load<N>(colp[k]);
-    }
 #ifdef OPTIK_DEVICE_PROFILE
     unsigned long long np_[8] = {0, 0, 0, 0, 0, 1, 0, 0};
     unsigned long long nt_ = __builtin_readcyclecounter();
@@ -206,10 +197,6 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
                     }
                 }
                 lds_sync();
-                if constexpr (REGCOLS) {
-#pragma unroll
-                    for (int k = 0; k < CPL; ++k) col[k] = fresh ? lds_col_load<N>(colp[k]) : col[k];
-                }
                 if (!wave_any(phase < 4)) break;
             }
         } else {
@@ -236,9 +223,7 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
                 for (int r = 1; r <= m; ++r) bm[r - 1] = (r >= npp1) ? b[r - 1] : 0.0;
 #pragma unroll
                 for (int k = 0; k < CPL; ++k) {
-                    dvecm cv;
-                    if constexpr (REGCOLS) cv = col[k];
-                    else cv = lds_col_load<N>(colp[k]);
+                    const dvecm cv = lds_col_load<N>(colp[k]);
                     double sdot = 0.0;
 #pragma unroll
                     for (int r = 1; r <= m; ++r) sdot += cv[r - 1] * bm[r - 1];
@@ -398,19 +383,9 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
                     if (found && ql == 0) lds_col_store<N>(blk + CS * (j - 1), nc);
                 }
                 // the transformation applied to the lane's columns still in Z (pivot row nsetp, rows below)
-                if constexpr (REGCOLS) {
-                    // (a quad that applies nothing this trip multiplies its columns' zero weights into zeros, not into
-                    // whatever the rejected column held: `found` implies every entry of w is finite, this makes it so
-                    // for the others)
-                    const bool applies = found && apply_live;
-#pragma unroll
-                    for (int r = 1; r <= m; ++r) w[r - 1] = applies ? w[r - 1] : 0.0;
-                }
 #pragma unroll
                 for (int k = 0; k < CPL; ++k) {
-                    dvecm cv;
-                    if constexpr (REGCOLS) cv = col[k];
-                    else cv = lds_col_load<N>(colp[k]);
+                    dvecm cv = lds_col_load<N>(colp[k]);
                     double sm = 0.0;
 #pragma unroll
                     for (int r = 1; r <= m; ++r) {
@@ -419,17 +394,13 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
                     }
                     const bool act = found && apply_live && inZ[k] && sm != 0.0;
                     const double smh = act ? sm * hb : 0.0;
-                    // (REGCOLS: a column the transformation does not touch adds -0.0 everywhere -- smh is an exact zero
-                    // there, and x + (-0.0) is x bit for bit -- so the register copy needs no select)
-                    const unsigned colkeep = (REGCOLS && !act) ? 0x80000000u : 0u;
 #pragma unroll
                     for (int r = 1; r <= m; ++r) {
                         const double add = smh * w[r - 1];
-                        const double addz = __hiloint2double((int)((unsigned)__double2hiint(add) | rowkeep[r - 1] | colkeep),
+                        const double addz = __hiloint2double((int)((unsigned)__double2hiint(add) | rowkeep[r - 1]),
                                                              __double2loint(add));
                         cv[r - 1] = cv[r - 1] + addz;
                     }
-                    if constexpr (REGCOLS) col[k] = cv;
                     if (act) lds_col_store<N>(colp[k], cv);
                     wv[k] = (cand && hitk[k]) ? 0.0 : wv[k];
                 }
@@ -579,11 +550,6 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
                 }
             }
             lds_sync();
-            if constexpr (REGCOLS) {
-                // (Givens steps rewrote rows of the block: the lane's copies follow it)
-#pragma unroll
-                for (int k = 0; k < CPL; ++k) col[k] = lds_col_load<N>(colp[k]);
-            }
             QNNLS_PROBE(3);
         }
     }
