@@ -488,6 +488,44 @@ def test_engine_deadline_abandons_and_keeps_what_was_found(dev, oracle, chains, 
     assert int(out["win_idx"].cpu()[0]) == (ok.min() if len(ok) else -1)
 
 
+@pytest.mark.parametrize("path", ["kernel", "lane64"])
+def test_single_launch_deadline_abandons_and_keeps_what_was_found(dev, oracle, chains, hip_chains, path):
+    """optik_hip_ik_batch(deadline_s): every lane / quad checks the device clock before its evaluation -- restarts in
+    flight at the deadline end FORCED_STOP with their best point so far, the rest of the queue is abandoned unstarted;
+    what finished before is the oracle's result.  Both single-launch solvers (2^20 restarts: the lane-per-restart form
+    by default; the quad solver forced)."""
+    import time
+    from optik_amd import _native as nat
+    d, ch = chains["panda"]
+    rng = np.random.default_rng(31)
+    tg, x0 = make_targets(oracle, d, ch, rng, 1)
+    cfg = nat.make_config(solution_mode="speed")
+    hc = hip_chains["panda"]
+    R = 1 << 20
+    tgd, x0d = torch.tensor(tg, device="cuda"), torch.tensor(x0, device="cuda")
+    with nat.options(solve_kernel="quad" if path == "kernel" else "lane64"):
+        bufs = hc.alloc_ik_buffers(1, R)
+        hc.ik_batch(cfg, tgd, x0d, 0, 1 << 16, bufs=hc.alloc_ik_buffers(1, 1 << 16))   # (first-launch costs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = hc.ik_batch(cfg, tgd, x0d, 0, R, deadline_s=0.010, bufs=bufs)
+        torch.cuda.synchronize()
+        took = time.perf_counter() - t0
+    status = out["status"].cpu().numpy()
+    evals = out["evals"].cpu().numpy()
+    forced = status == nat.RES_FORCED_STOP
+    assert forced.any() and (~forced).any(), "the deadline should fall inside the launch"
+    assert took < 0.025, took                        # (the whole launch takes 60 - 70 ms)
+    assert (forced & (evals == 0)).sum() > R // 4    # never started
+    xs = out["x"].cpu().numpy()
+    for i in np.flatnonzero(~forced)[:200:10]:
+        r = oracle.solve_restart(ch, oracle.make_config("speed"), tg[0], x0[0], int(i))
+        assert r.result == status[i] and r.n_evals == evals[i]
+        assert_bit_equal(xs[:, i], np.array(r.x[:7]), f"restart {i}")
+    ok = np.flatnonzero(status == nat.RES_STOPVAL)
+    assert int(out["win_idx"].cpu()[0]) == (ok.min() if len(ok) else -1)
+
+
 def test_prismatic_chain_has_forward_kinematics_only(dev, oracle, chains, hip_chains):
     """kinematics.rs:243-255 handles prismatic joints in FK; the Jacobian is todo!() (:185), so
     ik() on such a chain panics in the reference -- here FK matches the oracle bit for bit and
