@@ -273,6 +273,18 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
 #pragma unroll
                         for (int i = 0; i < N; ++i) { u[i] = gn[i] - g[i]; g[i] = gn[i]; }
                         OPTIK_SCHED_FENCE();
+#ifdef OPTIK_LANE_EXP_DUP_BFGS
+                        {
+                            double l2[NL], u2[N];
+#pragma unroll
+                            for (int i = 0; i < NL; ++i) { l2[i] = l[i]; asm volatile("" : "+v"(l2[i])); }
+#pragma unroll
+                            for (int i = 0; i < N; ++i) u2[i] = u[i];
+                            bfgs_update<N>(l2, s, u2);
+#pragma unroll
+                            for (int i = 0; i < NL; ++i) asm volatile("" :: "v"(l2[i]));
+                        }
+#endif
                         bfgs_update<N>(l, s, u);
                         OPTIK_SCHED_FENCE();
                         need_dir = true;
@@ -306,6 +318,27 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
 #pragma unroll
                 for (int j = 0; j < N; ++j) E[i][j] = 0.0;
             }
+#ifdef OPTIK_LANE_EXP_DUP_LSQ
+            {
+                double gg[N], E0[N][N], f0_[N], lo[N], hi[N];
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    gg[i] = g[i]; asm volatile("" : "+v"(gg[i]));
+                    f0_[i] = 0.0; lo[i] = ch.lb[i] - x[i]; hi[i] = ch.ub[i] - x[i];
+#pragma unroll
+                    for (int j = 0; j < N; ++j) E0[i][j] = 0.0;
+                }
+                const int m0 = lsq_factor<N>(l, gg, E0, f0_);
+                double acc_ = 0.0;
+                const bool n0 = lsq_bound_rows<N>(E0, f0_, lo, hi, [&](int i, const double (&row)[N], double h_lo, double h_hi) {
+#pragma unroll
+                    for (int j = i; j < N; ++j) acc_ += row[j];
+                    acc_ += h_lo + h_hi;
+                });
+                asm volatile("" :: "v"(m0), "v"((int)n0), "v"(acc_));
+            }
+            OPTIK_SCHED_FENCE();
+#endif
             int lmode = lsq_factor<N>(l, g, E, fv);
             OPTIK_SCHED_FENCE();
             // rows of E^-1 and the bound rows they give: into the lane's packed problem in LDS
