@@ -1225,7 +1225,7 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     // one-wave-per-SIMD build -- no scratch, the lowest latency per iteration; anything bigger on the
     // two-waves-per-SIMD build)
     const long long wide_waves_per_cu = 8;  // resident waves per CU of the general solver (two per SIMD)
-    const bool quad_latency = quadk && (long long)cols <= (long long)cus * 4;
+    const bool quad_latency = quadk && (long long)cols <= (long long)cus * 4 && !lane_forced;
     // (not for a Speed batch's latency-sized rounds: restart-major hand-out with early exit keeps a few restarts per
     // target in flight and abandons most of the rest -- the quad solver's shorter trip wins there)
     lanek = lanek && !quad_latency

@@ -1,5 +1,5 @@
-// ik_lane64.hpp -- the restart solver with one restart per LANE and the wave's bounded sub-problems solved
-// sixteen at a time, in class order, by quads of lanes.
+// ik_lane64.hpp -- the restart solver with one restart per LANE and the wave's bounded sub-problems pipelined,
+// in class order, through its sixteen quads of lanes.
 //
 // Where the quad solver (ik_quad.hpp) spends a wave's instructions (MI355X, cost of every phase by
 // duplication, profiles/r4a_defer_experiment.txt): every scalar of Kraft's / NLopt's state machine, the
@@ -17,12 +17,13 @@
 //                                                      packed problem (rows of E^-1, h: 42 doubles) in LDS; the
 //                                                      wave ranks them by predicted pass count (what the restart's
 //                                                      previous problem took, or the number of violated bounds if
-//                                                      larger: 76 % repeat it, 92 % within one) and solves them in
-//                                                      rounds of sixteen -- quad q of round r takes the problem of
-//                                                      rank 16 r + q, expands it into its 1 KB block and runs
-//                                                      ik_nnls_quad.hpp on it; the owner lane reads the multipliers
-//                                                      back.  A round's sixteen problems take similar numbers of
-//                                                      passes, and the long ones share a round.
+//                                                      larger: 76 % repeat it, 92 % within one) and PIPELINES them
+//                                                      through its sixteen quads: a quad expands the next problem of
+//                                                      the ranking into its 1 KB block and runs ik_nnls_quad.hpp on it;
+//                                                      whenever eight or fewer quads are still solving, the finished
+//                                                      ones' answers go back to their owner lanes and the idle quads
+//                                                      take the next problems (Lane64Pipe).  A problem that needs more
+//                                                      passes than predicted keeps its quad busy, not the wave.
 //
 // The price: the per-lane state (~80 doubles) plus the working set of an evaluation need more than 256
 // registers, and 16 blocks + 64 packed problems fill 38 KB of LDS: ONE wave per SIMD (four per CU).
