@@ -44,7 +44,7 @@ def test_seeds_match_fixture(hip_chains, robot, rule):
 
 @pytest.mark.parametrize("robot", ["ur3e", "panda", "ur10", "arm10"])
 @pytest.mark.parametrize("rule", ["single_inclusive", "new_inclusive"])
-@pytest.mark.parametrize("path", ["kernel", "engine"])
+@pytest.mark.parametrize("path", ["kernel", "engine", "lane64"])
 def test_restarts_and_winners_match_fixture(hip_chains, robot, rule, path):
     from optik_amd import _native as nat
     doc = _load(robot)
@@ -60,6 +60,10 @@ def test_restarts_and_winners_match_fixture(hip_chains, robot, rule, path):
                 cfg = nat.make_config(solution_mode=mode, tol_f=tol_f)
                 if path == "kernel":
                     out = hc.ik_batch(cfg, tgd, x0d, 0, R)
+                elif path == "lane64":  # (the lane-per-restart form, forced at the fixture's size; arm10: the general solver)
+                    with nat.options(solve_kernel="lane64"):
+                        out = hc.ik_batch(cfg, tgd, x0d, 0, R)
+                        torch.cuda.synchronize()
                 else:
                     out = hc.engine_submit(cfg, tgd, x0d, 0, R)
                     hc.engine_run()
