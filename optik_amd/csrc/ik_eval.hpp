@@ -18,7 +18,11 @@
 // Keeps the machine scheduler from interleaving the iterations of the fully
 // unrolled per-joint loops: without it every joint's temporaries are live at once
 // (2x the registers of the rolled loop) and the restart kernel spills.
+#ifdef OPTIK_NO_SCHED_FENCE
+#define OPTIK_SCHED_FENCE()
+#else
 #define OPTIK_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 
 namespace optik {
 

@@ -105,6 +105,10 @@ struct SelectLaunch {
     double *win_f;
     unsigned long long *win_idx;
     double *win_key;
+    // the launch's work-item counter and first-success words, put back to their initial values by the last
+    // kernel of the launch so that the next launch needs no fill commands in front of it (null: leave them)
+    unsigned long long *reset_queue;
+    unsigned long long *reset_fs;  // [T]
 };
 
 // Stage 1 of the selection (lib.rs:397-413): per-block argmin of the keys of one
@@ -143,6 +147,23 @@ __global__ __launch_bounds__(256) void ik_tile_argmin_kernel(const SelectLaunch 
     }
 }
 
+// The winner of target t goes out (one thread), and the launch's queue / first-success words go back to their
+// initial values for the next launch.
+__device__ void select_publish(const SelectLaunch &a, int t, double key, unsigned long long idx) {
+    if (a.win_idx) a.win_idx[t] = idx;
+    if (a.win_key) a.win_key[t] = key;
+    const bool found = idx != ~0ull;
+    const size_t col = (size_t)t * a.n_restarts + (found ? (size_t)(idx - a.restart_begin) : 0);
+    if (a.win_f) a.win_f[t] = (found && a.out_f) ? a.out_f[col] : __builtin_nan("");
+    if (a.win_x) {
+        for (int i = 0; i < a.n; ++i)
+            a.win_x[(size_t)t * a.n + i] =
+                (found && a.out_x) ? a.out_x[(size_t)i * a.ld + col] : __builtin_nan("");
+    }
+    if (a.reset_fs) a.reset_fs[t] = ~0ull;
+    if (a.reset_queue && t == 0) *a.reset_queue = 0ull;
+}
+
 // Stage 2: one 64-lane block per target reduces the tile records and gathers the winner.
 __global__ __launch_bounds__(WAVE) void ik_select_kernel(const SelectLaunch a) {
     const int t = blockIdx.x;
@@ -154,17 +175,34 @@ __global__ __launch_bounds__(WAVE) void ik_select_kernel(const SelectLaunch a) {
         if (take) { key = r.key; idx = r.idx; }
     }
     wave_argmin(key, idx);
+    if (threadIdx.x == 0) select_publish(a, t, key, idx);
+}
+
+// Both stages in one kernel for a launch of at most one tile of restarts per target (a single ik() call's first
+// launches, a Speed batch's rounds): one 256-thread block per target.
+__global__ __launch_bounds__(256) void ik_select_small_kernel(const SelectLaunch a) {
+    __shared__ double s_key[4];
+    __shared__ unsigned long long s_idx[4];
+    const int t = blockIdx.x;
+    double key = 0.0;
+    unsigned long long idx = ~0ull;
+    for (unsigned long long r = threadIdx.x; r < a.n_restarts; r += blockDim.x) {
+        const double k = a.out_key[(size_t)t * a.n_restarts + r];
+        const unsigned long long i = a.restart_begin + r;
+        const bool ok = k < __builtin_huge_val();
+        if (ok && (idx == ~0ull || k < key || (k == key && i < idx))) { key = k; idx = i; }
+    }
+    wave_argmin(key, idx);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_key[wave] = key; s_idx[wave] = idx; }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        if (a.win_idx) a.win_idx[t] = idx;
-        if (a.win_key) a.win_key[t] = key;
-        const bool found = idx != ~0ull;
-        const size_t col = (size_t)t * a.n_restarts + (found ? (size_t)(idx - a.restart_begin) : 0);
-        if (a.win_f) a.win_f[t] = (found && a.out_f) ? a.out_f[col] : __builtin_nan("");
-        if (a.win_x) {
-            for (int i = 0; i < a.n; ++i)
-                a.win_x[(size_t)t * a.n + i] =
-                    (found && a.out_x) ? a.out_x[(size_t)i * a.ld + col] : __builtin_nan("");
+        for (int w = 1; w < 4; ++w) {
+            const bool take = (s_idx[w] != ~0ull)
+                              && (idx == ~0ull || s_key[w] < key || (s_key[w] == key && s_idx[w] < idx));
+            if (take) { key = s_key[w]; idx = s_idx[w]; }
         }
+        select_publish(a, t, key, idx);
     }
 }
 
@@ -572,6 +610,10 @@ struct optik_hip_chain {
     size_t tile_cap = 0;
     unsigned long long *first_success = nullptr;
     size_t fs_cap = 0;
+    // (what the last launch's selection kernel left behind: the work-item counter at 0, this many leading
+    // first-success words at ~0 -- a launch that finds them so skips its fill commands)
+    bool queue_clean = false;
+    size_t fs_clean = 0;
     // scratch per-restart buffers when the caller does not provide them
     double *tmp_x = nullptr, *tmp_f = nullptr, *tmp_key = nullptr;
     size_t tmp_cols = 0;
@@ -1114,17 +1156,23 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         HIP_TRY(hipMalloc(&ch->tile_recs, sizeof(TileRec) * (size_t)n_tiles));
         ch->tile_cap = (size_t)n_tiles;
     }
-    if (!ch->queue) HIP_TRY(hipMalloc(&ch->queue, sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(ch->queue, 0, sizeof(unsigned long long), stream));
+    if (!ch->queue) { HIP_TRY(hipMalloc(&ch->queue, sizeof(unsigned long long))); ch->queue_clean = false; }
+    if (!ch->queue_clean) HIP_TRY(hipMemsetAsync(ch->queue, 0, sizeof(unsigned long long), stream));
+    ch->queue_clean = false;  // (until this launch's selection kernel has put it back)
     const bool early = (flags & OPTIK_HIP_IK_EARLY_EXIT) && cfg->solution_mode == 2;
+    size_t fs_clean_after = ch->fs_clean;  // (a launch without early exit leaves the words alone)
     if (early) {
         if ((size_t)T > ch->fs_cap) {
             if (ch->first_success) HIP_TRY(hipFree(ch->first_success));
             ch->first_success = nullptr;
+            ch->fs_clean = 0;
             HIP_TRY(hipMalloc(&ch->first_success, sizeof(unsigned long long) * (size_t)T));
             ch->fs_cap = (size_t)T;
         }
-        HIP_TRY(hipMemsetAsync(ch->first_success, 0xff, sizeof(unsigned long long) * (size_t)T, stream));
+        if (ch->fs_clean < (size_t)T)
+            HIP_TRY(hipMemsetAsync(ch->first_success, 0xff, sizeof(unsigned long long) * (size_t)T, stream));
+        fs_clean_after = std::max(ch->fs_clean, (size_t)T);  // once the selection kernel has put words [0, T) back
+        ch->fs_clean = 0;
     }
     // the selection needs the per-restart x / f / key: scratch if the caller skips them
     const bool want_win = out->d_win_x || out->d_win_f || out->d_win_idx || out->d_win_key;
@@ -1337,10 +1385,19 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         s.ld = cols;
         s.win_x = out->d_win_x; s.win_f = out->d_win_f;
         s.win_idx = (unsigned long long *)out->d_win_idx; s.win_key = out->d_win_key;
-        hipLaunchKernelGGL(ik_tile_argmin_kernel, dim3((unsigned)n_tiles), dim3(256), 0, stream, s);
-        HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(ik_select_kernel, dim3(T), dim3(WAVE), 0, stream, s);
-        HIP_TRY(hipGetLastError());
+        s.reset_queue = ch->queue;
+        s.reset_fs = early ? ch->first_success : nullptr;
+        if (tiles_per_target == 1) {
+            hipLaunchKernelGGL(ik_select_small_kernel, dim3(T), dim3(256), 0, stream, s);
+            HIP_TRY(hipGetLastError());
+        } else {
+            hipLaunchKernelGGL(ik_tile_argmin_kernel, dim3((unsigned)n_tiles), dim3(256), 0, stream, s);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(ik_select_kernel, dim3(T), dim3(WAVE), 0, stream, s);
+            HIP_TRY(hipGetLastError());
+        }
+        ch->queue_clean = true;
+        ch->fs_clean = fs_clean_after;
     }
     return 0;
 }
@@ -1595,6 +1652,7 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
         HIP_TRY(hipMemcpyAsync(ch->eng_djobs, hj.data(), sizeof(EngJob) * n_jobs, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));  // hj goes out of scope; tiny copy
         HIP_TRY(hipMemsetAsync(ch->queue, 0, sizeof(unsigned long long), stream));
+        ch->queue_clean = false;  // (the engine's kernels leave the counter where the run ended)
         for (size_t ji = g0; ji < g1; ++ji) {
             auto &j = ch->eng_jobs[ji];
             if (j.own_fs) {

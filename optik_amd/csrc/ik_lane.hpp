@@ -21,7 +21,9 @@ OPTIK_DEV int quad_base() { return (int)(threadIdx.x & 63u) & ~3; }
 // an invariant and spilled for its whole length.
 OPTIK_DEV int wave_lane_now() {
     int v = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+#ifndef OPTIK_NO_LAUNDER
     asm volatile("" : OPTIK_REG_INOUT(v));
+#endif
     return v;
 }
 OPTIK_DEV int quad_lane_now() { return wave_lane_now() & 3; }

@@ -117,18 +117,28 @@ OPTIK_DEV Pose pose_sel(bool c, const Pose a, const Pose b) {
 // instead of keeping the first load's registers alive in between)
 template <class T>
 OPTIK_DEV const T *reload_barrier(const T *p) {
+#ifndef OPTIK_NO_LAUNDER
     asm volatile("" : OPTIK_REG_INOUT(p));
+#endif
     return p;
 }
 
 // The same for a pointer INTO LDS: only the offset is laundered, the address space is kept (ik_platform.hpp).
 template <class T>
-OPTIK_DEV const T *reload_barrier_lds(const T *p) { return launder_lds(p); }
+OPTIK_DEV const T *reload_barrier_lds(const T *p) {
+#ifndef OPTIK_NO_LAUNDER
+    return launder_lds(p);
+#else
+    return p;
+#endif
+}
 
 // (the same for an integer: what is computed from the result is computed where it is used, not hoisted out
 // of the solver loop as an invariant -- and then spilled for the whole loop)
 OPTIK_DEV int opaque_int(int v) {
+#ifndef OPTIK_NO_LAUNDER
     asm volatile("" : OPTIK_REG_INOUT(v));
+#endif
     return v;
 }
 

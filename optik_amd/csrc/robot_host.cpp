@@ -406,8 +406,14 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
     // budget) is throughput-bound: rounds of 1 M restarts per GPU on the streaming engine (46 ms
     // against 118 on the solve kernel).
     const uint64_t cus = (uint64_t)(c0->num_cus > 0 ? c0->num_cus : 256);
-    const uint64_t first_per_cu = 2;  // restarts per CU in the first, latency-sized launch
-    const uint64_t first_batch = cus * first_per_cu, later_batch = cus * 2 * 64 * 2;
+    // restarts of the first, latency-sized launch: two per CU under the first-success rule (the more restarts race,
+    // the sooner the first one succeeds: the fastest of 512 needs 18.6 evaluations on average, of 1024 17.9, but
+    // 1024 waves run each a little slower: 261 / 257 us per call); 128 under the deterministic rule (parallelism 1:
+    // the answer is the lowest successful index, nearly always below ten, and only the restarts below it decide
+    // when the launch ends: 685 -> 660 us per call, tools/single_call_variants.sh)
+    const uint64_t first_per_cu = 2;
+    const uint64_t first_batch = (!quality && r->parallelism == 1) ? 128 : cus * first_per_cu;
+    const uint64_t later_batch = cus * 2 * 64 * 2;
     const uint64_t engine_batch = (uint64_t)1 << 20;  // restarts per GPU per engine round
     const bool engine_ok = engine_batch > 0 && r->n <= 7;
     // One job of this many restarts is where the engine's ~10 ms floor is amortised against the solve kernel
