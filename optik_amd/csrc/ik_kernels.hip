@@ -646,6 +646,14 @@ struct optik_hip_chain {
     unsigned int *eng_cont = nullptr;      // continuation lists: [C] entries (a sub-pool's shards share its range), then [ENG_MAX_POOLS][NN_CONT_SHARDS] counters
     double *hw_dev = nullptr, *hw_pin = nullptr;  // optik_hip_ik_host: device block and pinned staging
     size_t hw_cap = 0;                            // doubles
+    // optik_hip_ik_host, one target under the first-success rule: the block the first successful restart writes its
+    // answer to (WorkQueue::claim; pinned, host-coherent), the sequence number of the last launch that used it, the
+    // request optik_hip_ik_host leaves for the launch it is about to make and whether that launch took it up
+    unsigned long long *hw_claim = nullptr;
+    unsigned long long claim_seq = 0;
+    bool claim_request = false, claim_armed = false;
+    bool claim_pending = false;  // such a call returned early: its launch may still be running on the null stream
+    unsigned hw_flip = 0;  // which half of the pinned block the next zero-copy call uses
     unsigned long long *nnls_trace = nullptr;  // OPTIK_NNLS_TRACE builds
     unsigned int *eng_trip_log = nullptr;      // OPTIK_ENG_TRIP_LOG diagnostics
     unsigned int *eng_compact = nullptr;       // [ENG_MAX_POOLS][2] counters, then free list [C], move list [C]
@@ -940,6 +948,7 @@ int optik_hip_chain_create(const double *origins, const double *axes, const int3
 void optik_hip_chain_destroy(optik_hip_chain *ch) {
     if (!ch) return;
     optik::DeviceScope dev_scope(ch->device_id);  // frees and the pool's last sync run on the chain's device
+    if (ch->claim_pending) (void)hipStreamSynchronize(nullptr);
     if (ch->dev) hipFree(ch->dev);
     if (ch->wdev) hipFree(ch->wdev);
     if (ch->wide_ws) hipFree(ch->wide_ws);
@@ -961,6 +970,7 @@ void optik_hip_chain_destroy(optik_hip_chain *ch) {
     if (ch->eng_deadline) hipFree(ch->eng_deadline);
     if (ch->hw_dev) hipFree(ch->hw_dev);
     if (ch->hw_pin) hipHostFree(ch->hw_pin);
+    if (ch->hw_claim) hipHostFree(ch->hw_claim);
     if (ch->eng_pinned) hipHostFree(ch->eng_pinned);
     for (auto &pe : ch->eng_pool_ev) for (auto &e : pe) if (e) hipEventDestroy(e);
     if (ch->eng_fork_ev) hipEventDestroy(ch->eng_fork_ev);
@@ -1139,6 +1149,10 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         return fail(OPTIK_HIP_EUNSUPPORTED,
                     "prismatic joints: only forward kinematics is available (the reference's Jacobian panics, kinematics.rs:185)");
     BIND_DEVICE(ch);
+    // (a single call that returned on its first success may have left its launch running on the null stream: a
+    // launch on another stream shares the chain's workspace with it and waits; on the null stream it queues behind)
+    if (ch->claim_pending && stream != nullptr) HIP_TRY(hipStreamSynchronize(nullptr));
+    ch->claim_pending = false;
 
     // selection tiles: 4096 restarts per 256-thread block
     constexpr int SEL_TILE = 4096;
@@ -1211,6 +1225,9 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     a.wq.x0 = d_x0;
     a.wq.first_success = early ? ch->first_success : nullptr;
     a.wq.find_any = (early && (flags & OPTIK_HIP_IK_FIND_ANY)) ? 1 : 0;
+    a.wq.claim = nullptr;
+    a.wq.claim_seq = 0;
+    ch->claim_armed = false;
     a.wq.restart_major = (flags & OPTIK_HIP_IK_RESTART_MAJOR) ? 1 : 0;
     a.wq.n_targets = (unsigned long long)T;
     a.wq.deadline = 0;
@@ -1310,6 +1327,12 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         if (wide_lds) lanes = 1;
     }
     a.wq.lanes = (int)lanes;
+    // a single call under the first-success rule on the quad solver: the first success goes to the host at once
+    if (ch->claim_request && quadk && !lanek && a.wq.find_any && T == 1 && ch->hw_claim) {
+        a.wq.claim = ch->hw_claim;
+        a.wq.claim_seq = ++ch->claim_seq;
+        ch->claim_armed = true;
+    }
     long long grid_ll = (resident + lanes - 1) / lanes;
     if (grid_ll > cap) grid_ll = cap;
     const int grid = (int)grid_ll;
@@ -1558,6 +1581,8 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
     std::lock_guard<std::mutex> lock(ch->mu);
     BIND_DEVICE(ch);
     if (ch->eng_jobs.empty()) return 0;
+    if (ch->claim_pending && stream != nullptr) HIP_TRY(hipStreamSynchronize(nullptr));  // (see ik_batch_locked)
+    ch->claim_pending = false;
     const auto t_call = std::chrono::steady_clock::now();
     auto since_call = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_call).count(); };
     int rc = 0;
@@ -2322,35 +2347,80 @@ int optik_hip_ik_host(optik_hip_chain *ch, const optik_solver_config *cfg, const
     // out = win_x [T][n], win_f [T], win_key [T], win_idx [T]
     const size_t n_in = (size_t)(7 + n) * (size_t)T, n_out = (size_t)(n + 3) * (size_t)T;
     if (n_in + n_out > ch->hw_cap) {
+        if (ch->claim_pending) (void)hipStreamSynchronize(nullptr);  // (its launch reads the block about to go)
         if (ch->hw_dev) (void)hipFree(ch->hw_dev);
         if (ch->hw_pin) (void)hipHostFree(ch->hw_pin);
         ch->hw_dev = nullptr; ch->hw_pin = nullptr; ch->hw_cap = 0;
         HIP_TRY(hipMalloc(&ch->hw_dev, sizeof(double) * (n_in + n_out)));
-        HIP_TRY(hipHostMalloc(&ch->hw_pin, sizeof(double) * (n_in + n_out)));
+        HIP_TRY(hipHostMalloc(&ch->hw_pin, sizeof(double) * 2 * (n_in + n_out)));  // (two blocks, see below)
         ch->hw_cap = n_in + n_out;
     }
     // A few targets (Robot::ik: one): the kernels read the inputs from and write the winners to the
-    // pinned block directly -- no copy commands around the launch.
+    // pinned block directly -- no copy commands around the launch.  (Two such blocks, used in turn: a call
+    // that returned on the first success -- below -- leaves a launch behind whose last restarts still read theirs.)
     const bool zero_copy = T <= 16;
-    double *io = zero_copy ? ch->hw_pin : ch->hw_dev;
+    double *pin = ch->hw_pin;
+    if (zero_copy) {
+        pin += (ch->hw_flip & 1u) * ch->hw_cap;
+        ch->hw_flip ^= 1u;
+    }
+    double *io = zero_copy ? pin : ch->hw_dev;
     double *d_t = io, *d_x0 = d_t + (size_t)7 * T;
     double *d_wx = io + n_in, *d_wf = d_wx + (size_t)n * T, *d_wk = d_wf + T;
     uint64_t *d_wi = reinterpret_cast<uint64_t *>(d_wk + T);
-    std::memcpy(ch->hw_pin, targets, sizeof(double) * 7 * (size_t)T);
-    std::memcpy(ch->hw_pin + (size_t)7 * T, x0, sizeof(double) * (size_t)n * (size_t)T);
+    std::memcpy(pin, targets, sizeof(double) * 7 * (size_t)T);
+    std::memcpy(pin + (size_t)7 * T, x0, sizeof(double) * (size_t)n * (size_t)T);
     if (!zero_copy)
-        HIP_TRY(hipMemcpyAsync(ch->hw_dev, ch->hw_pin, sizeof(double) * n_in, hipMemcpyHostToDevice, nullptr));
+        HIP_TRY(hipMemcpyAsync(ch->hw_dev, pin, sizeof(double) * n_in, hipMemcpyHostToDevice, nullptr));
     optik_hip_ik_outputs o;
     std::memset(&o, 0, sizeof o);
     o.d_win_x = d_wx; o.d_win_f = d_wf; o.d_win_idx = d_wi; o.d_win_key = d_wk;
+    // One target under the first-success rule (lib.rs:409-412, the reference's default): the first restart to
+    // succeed writes its answer to a host-coherent block and the call returns as soon as it is there; the launch's
+    // other restarts notice the flag at their next evaluation and the launch ends behind the caller's back (the
+    // next launch of the chain queues behind it).  Without a success the call ends with the launch, as before.
+    const bool claim = T == 1 && (flags & OPTIK_HIP_IK_FIND_ANY) && (flags & OPTIK_HIP_IK_EARLY_EXIT)
+                       && !(flags & OPTIK_HIP_IK_ENGINE) && cfg->solution_mode == 2;
+    if (claim && !ch->hw_claim) {
+        HIP_TRY(hipHostMalloc(&ch->hw_claim, sizeof(unsigned long long) * (3 + MAX_DOF), hipHostMallocCoherent));
+        std::memset(ch->hw_claim, 0, sizeof(unsigned long long) * (3 + MAX_DOF));
+    }
+    ch->claim_request = claim;
     const int rc = (flags & OPTIK_HIP_IK_ENGINE)
                        ? optik_hip_engine_solve(ch, cfg, d_t, d_x0, T, ee_offset7, restart_begin, restart_end,
                                                 flags & ~OPTIK_HIP_IK_ENGINE, deadline_s, &o, nullptr)
                        : optik_hip_ik_batch(ch, cfg, d_t, d_x0, T, ee_offset7, restart_begin, restart_end, flags,
                                             deadline_s, &o, nullptr);
+    ch->claim_request = false;
     if (rc) return rc;
-    double *h_out = ch->hw_pin + n_in;
+    double *h_out = pin + n_in;
     if (!zero_copy) HIP_TRY(hipMemcpyAsync(h_out, d_wx, sizeof(double) * n_out, hipMemcpyDeviceToHost, nullptr));
+    if (ch->claim_armed) {
+        const unsigned long long seq = ch->claim_seq;
+        volatile unsigned long long *cw = ch->hw_claim;
+        for (unsigned spin = 1;; ++spin) {
+            if (__atomic_load_n(ch->hw_claim, __ATOMIC_ACQUIRE) == seq) {
+                if (win_x) std::memcpy(win_x, (const void *)(cw + 3), sizeof(double) * (size_t)n);
+                if (win_f) std::memcpy(win_f, (const void *)(cw + 2), sizeof(double));
+                if (win_idx) *win_idx = cw[1];
+                if (win_key) *win_key = (double)cw[1];
+                ch->claim_pending = true;
+                return 0;
+            }
+            if ((spin & 63u) == 0) {
+                const hipError_t q = hipStreamQuery(nullptr);
+                if (q == hipSuccess) break;  // the launch is over and nobody succeeded (or the word is about to land)
+                if (q != hipErrorNotReady) HIP_TRY(q);
+            }
+        }
+        if (__atomic_load_n(ch->hw_claim, __ATOMIC_ACQUIRE) == seq) {
+            if (win_x) std::memcpy(win_x, (const void *)(cw + 3), sizeof(double) * (size_t)n);
+            if (win_f) std::memcpy(win_f, (const void *)(cw + 2), sizeof(double));
+            if (win_idx) *win_idx = cw[1];
+            if (win_key) *win_key = (double)cw[1];
+            return 0;
+        }
+    }
     HIP_TRY(hipStreamSynchronize(nullptr));
     if (win_x) std::memcpy(win_x, h_out, sizeof(double) * (size_t)n * (size_t)T);
     if (win_f) std::memcpy(win_f, h_out + (size_t)n * T, sizeof(double) * (size_t)T);

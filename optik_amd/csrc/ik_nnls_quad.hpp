@@ -95,12 +95,21 @@ struct NoPipe {
     OPTIK_DEV bool event(bool, int, double, int) { return false; }
 };
 
+// Stop (ik_quad.hpp): launches with early exit.  stop->poll(running) is called once per loop trip; it says whether
+// the quad's restart has been overtaken (another restart of its target succeeded) -- decided on a word it asked
+// for one trip earlier, so the answer is there without a wait -- and the quad then leaves the loop at once: the
+// caller abandons the restart, the multipliers are not used.
+struct NoStop {
+    static constexpr bool on = false;
+    OPTIK_DEV bool poll(bool) { return false; }
+};
+
 // (Tried for the one-wave-per-SIMD kernel and dropped: the lane's four columns kept in registers as well, and a step's
 // four column loads issued together -- both cost it more in spilled state than the exposed LDS latency they save:
 // 27.0 -> 24.4 M and 28.2 -> 27.6 M restarts/s.)
-template <int N, class Pipe = NoPipe>
+template <int N, class Pipe = NoPipe, class Stop = NoStop>
 OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const double *zeros, double (&xv)[4], int &mode_out,
-                         double &rnorm_out, int &iters_out, Pipe *pipe = nullptr) {
+                         double &rnorm_out, int &iters_out, Pipe *pipe = nullptr, Stop *stop = nullptr) {
     constexpr int m = N + 1, n = 2 * N;
     constexpr int CPL = 4;
     static_assert(m <= 9 && n <= 16, "row vectors hold up to sixteen entries, the permutation sixteen nibbles");
@@ -200,6 +209,9 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
                 if (!wave_any(phase < 4)) break;
             }
         } else {
+            if constexpr (Stop::on) {
+                if (stop->poll(phase < 4)) phase = 4;
+            }
             if (!wave_any(phase < 4)) break;
         }
         QNNLS_COUNT(4, 1);

@@ -643,6 +643,32 @@ struct NoTail {
     static constexpr bool on = false;
 };
 
+// Early exit inside a trip (ik_nnls_quad.hpp: Stop): the restart's first-success word is looked at once per
+// direction pass and once per loop trip of the NNLS as well -- a trip with a direction reset or a long active-set
+// search takes several times an evaluation, and a launch with early exit ends when its slowest abandoned restart
+// has noticed.  Every look uses the word asked for at the previous one (no wait) and asks again.  The reference
+// abandons a restart at its next objective evaluation (lib.rs:308); abandoning it sooner changes nothing it returns.
+struct QuadStop {
+    static constexpr bool on = true;
+    const WorkQueue *wq;       // the launch's queue record (LDS)
+    const int &ia, &ib;        // the quad's keepers of the target slot and the restart number (ik_quad.hpp: quad_wave)
+    bool enabled;              // the launch has first-success words (wave-uniform)
+    bool hit;                  // the quad's restart has been overtaken
+    unsigned long long seen;   // the word as last read
+    OPTIK_DEV bool poll(bool running) {
+        if (!enabled) return false;
+        const WorkQueue &q = *launder_lds(wq);
+        const unsigned long long index =
+            q.restart_begin + (((unsigned long long)(unsigned)quad_get(ib, 1) << 32) | (unsigned)quad_get(ib, 0));
+        const unsigned long long below = q.find_any ? ~0ull : index;
+        const unsigned ts = (unsigned)quad_get(ia, 3);
+        const bool now = running && seen < below;
+        hit = hit || now;
+        if (running && !now) seen = __hip_atomic_load(q.first_success + ts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return now;
+    }
+};
+
 template <int N, bool TIP, class Tail = NoTail>
 OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const SolveParams &sp_in, const uint32_t (&key)[8],
                          const double (&scale)[MAX_DOF], const WorkQueue &wq_in,
@@ -683,6 +709,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
     OPTIK_PROF_DECL;  // (-DOPTIK_PROFILE: slots 0 refill, 1 eval, 4 bookkeeping + BFGS, 5 direction, 6 NNLS of it, 3 publish, 7 trips)
 
     unsigned n_exec = 0;  // (Tail) evaluations the wave's quads executed
+    QuadStop st{&wq_in, ia, ib, false, false, ~0ull};
     for (;;) {
         OPTIK_PROF_BEGIN();
         int32_t ret = 0;
@@ -785,10 +812,13 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                     const unsigned long long fs = __hip_atomic_load(wq.first_success + tslot, __ATOMIC_RELAXED,
                                                                     __HIP_MEMORY_SCOPE_AGENT);
                     stop = wq.find_any ? (fs != ~0ull) : (fs < index);
+                    st.seen = fs;
                 }
                 if (wq.deadline && (unsigned long long)wall_clock64() > wq.deadline) stop = true;
                 if (stop) ret = RES_FORCED_STOP;
             }
+            st.enabled = (*reload_barrier_lds(&wq_in)).first_success != nullptr;
+            st.hit = false;
         }
         // (the four lanes may have read first_success / the clock at different moments: the leader decides)
         ret = quad_get(ret, 0);
@@ -966,6 +996,10 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
         while (wave_any(need_dir)) {
             OPTIK_PROF_COUNT(2, 1);  // (direction passes: more than one per trip when some quad has to reset and search again)
             const SolveParams &sp = *reload_barrier_lds(&sp_in);
+            if constexpr (!Tail::on) {
+                if (st.poll(need_dir)) { ret = RES_FORCED_STOP; need_dir = false; }
+                if (!wave_any(need_dir)) break;
+            }
             bool pass = need_dir;
             const bool sx0 = stop_x_quad<N>(sp, x, x0);
             const int qd = quad_lane_now();
@@ -1082,7 +1116,11 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                 int iters;
                 double xv[CPL];
 #ifndef OPTIK_QUAD_EXP_NO_NNLS
-                nnls_quad<N>(need_nnls, ids, bk, nnls_lds + QUADS_PER_WAVE * NnlsQuadGeom<N>::STRIDE, xv, nmode, rnorm, iters);
+                if constexpr (Tail::on)
+                    nnls_quad<N>(need_nnls, ids, bk, nnls_lds + QUADS_PER_WAVE * NnlsQuadGeom<N>::STRIDE, xv, nmode, rnorm, iters);
+                else
+                    nnls_quad<N, NoPipe, QuadStop>(need_nnls, ids, bk, nnls_lds + QUADS_PER_WAVE * NnlsQuadGeom<N>::STRIDE, xv,
+                                                   nmode, rnorm, iters, nullptr, &st);
 #else
                 for (int k = 0; k < CPL; ++k) xv[k] = bk[k]; iters = 0;
 #endif
@@ -1095,6 +1133,8 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                 OPTIK_PROF_COUNT(6, __builtin_readcyclecounter() - t_nn);
 #endif
             }
+            // (a restart overtaken while its sub-problem was being solved: abandoned here, its multipliers unused)
+            if (st.hit && pass) { ret = RES_FORCED_STOP; need_dir = false; pass = false; }
             OPTIK_SCHED_FENCE();
             double sn[NS];
 #pragma unroll
@@ -1223,6 +1263,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                     for (int s = 0; s < NS; ++s)
                         if (val[s]) o_x[(size_t)jc[s] * o_stride + item] = xb[s * 64];
                 }
+                int first_in = 0;  // (leader) this restart is the first of its target to succeed
                 if (qf == 0) {
                     if (o_f) o_f[item] = minf;
                     if (o_status) o_status[item] = ret;
@@ -1232,11 +1273,31 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                         if (o_quality) k = kq;
                         else {
                             k = (double)index;
-                            if (o_fs) atomicMin(o_fs + tslot, index);
+                            if (o_fs) first_in = atomicMin(o_fs + tslot, index) == ~0ull ? 1 : 0;
                         }
                     }
                     if (o_key) o_key[item] = k;
                     if constexpr (Tail::on) (*reload_barrier_lds(tail_in)).template release<N>(slot_u);
+                }
+                if constexpr (!Tail::on) {
+                    // a single call under the first-success rule: the answer goes to the host right away (WorkQueue::claim)
+                    const WorkQueue &wqc = *reload_barrier_lds(&wq_in);
+                    if (wqc.claim) {
+                        first_in = quad_get(first_in, 0);
+                        if (first_in) {
+                            double *cx = reinterpret_cast<double *>(wqc.claim) + 3;
+#pragma unroll
+                            for (int s = 0; s < NS; ++s)
+                                if (val[s]) cx[jc[s]] = xb[s * 64];
+                            if (qf == 0) {
+                                wqc.claim[1] = index;
+                                reinterpret_cast<double *>(wqc.claim)[2] = minf;
+                            }
+                            __threadfence_system();
+                            if (qf == 0)
+                                __hip_atomic_store(wqc.claim, wqc.claim_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                    }
                 }
                 active = false;
                 want = true;

@@ -176,6 +176,12 @@ struct WorkQueue {
     int32_t *out_status;                 // [T*R]
     int32_t *out_evals;                  // [T*R]
     unsigned long long *prof;            // [8] phase cycle totals (OPTIK_PROFILE builds), else null
+    // find_any launches of ONE target (a single Robot::ik call): the first restart to succeed also writes its answer
+    // to this host-visible block and then stores claim_seq into its first word, so that the host can return while
+    // the other restarts are still noticing the flag (quad solver; null: no such block).
+    // Layout: [0] sequence word, [1] restart index, [2] f (as a double), [3 .. 3 + n) x
+    unsigned long long *claim;
+    unsigned long long claim_seq;
 };
 
 // Wave-aggregated fetch of one work item per requesting lane: one atomic per wave.

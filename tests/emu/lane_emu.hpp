@@ -183,4 +183,7 @@ inline unsigned long long atomicMin(unsigned long long *p, unsigned long long v)
     return cur;
 }
 #define __HIP_MEMORY_SCOPE_AGENT 0
+#define __HIP_MEMORY_SCOPE_SYSTEM 1
 #define __hip_atomic_load(ptr, order, scope) __atomic_load_n((ptr), (order))
+#define __hip_atomic_store(ptr, val, order, scope) __atomic_store_n((ptr), (val), (order))
+inline void __threadfence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
