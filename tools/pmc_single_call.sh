@@ -20,19 +20,25 @@ for P in "$P1" "$P2" "$P3"; do
 done
 python3 - "$OUT" <<'PY' | tee "$OUT/summary.txt"
 import collections, csv, glob, sys
-tot = collections.defaultdict(float); n = 0
-for f in glob.glob(f"{sys.argv[1]}/p*/**/*counter_collection.csv", recursive=True):
-    seen = set()
-    for r in csv.DictReader(open(f)):
-        if "ik_quad_kernel" in r["Kernel_Name"]:
-            tot[r["Counter_Name"]] += float(r["Counter_Value"]); seen.add(r["Dispatch_Id"])
-    n = max(n, len(seen))
-print("dispatches", n)
-for k, v in sorted(tot.items()): print(f"  {k:32s} {v / max(n,1):14.1f} per call")
-g = lambda k: tot.get(k, 0.0)
-if g("SQC_ICACHE_REQ"): print("icache hit rate %.4f, misses per wave %.1f" % (g("SQC_ICACHE_HITS") / g("SQC_ICACHE_REQ"), g("SQC_ICACHE_MISSES") / max(g("SQ_WAVES") / 3, 1)))
-if g("SQ_WAVE_CYCLES"): print("VALU insts per wave %.0f, wave cycles per wave %.0f, cycles per VALU inst %.2f, wait_any %.3f, wait_inst_any %.3f" % (
-    g("SQ_INSTS_VALU") / (g("SQ_WAVES") / 3), g("SQ_WAVE_CYCLES") / 2 / (g("SQ_WAVES") / 3), (g("SQ_WAVE_CYCLES") / 2) / max(g("SQ_INSTS_VALU"), 1),
-    g("SQ_WAIT_ANY") / (g("SQ_WAVE_CYCLES") / 2), g("SQ_WAIT_INST_ANY") / (g("SQ_WAVE_CYCLES") / 2)))
+val = {}; calls = 0
+for d in sorted(glob.glob(f"{sys.argv[1]}/p[0-9]")):
+    tot = collections.defaultdict(float); seen = set()
+    for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "ik_quad_kernel" in r["Kernel_Name"]:
+                tot[r["Counter_Name"]] += float(r["Counter_Value"]); seen.add(r["Dispatch_Id"])
+    calls = max(calls, len(seen))
+    for k, v in tot.items(): val.setdefault(k, v / max(len(seen), 1))   # per launch; a counter of several passes: the first
+print(f"solve-kernel launches per pass: {calls}; per launch:")
+for k, v in sorted(val.items()): print(f"  {k:32s} {v:14.1f}")
+g = lambda k: val.get(k, 0.0)
+w = max(g("SQ_WAVES"), 1.0)
+if g("SQC_ICACHE_REQ"): print("instruction cache: hit rate %.4f, %.1f misses per wave" % (g("SQC_ICACHE_HITS") / g("SQC_ICACHE_REQ"), g("SQC_ICACHE_MISSES") / w))
+if g("SQ_WAVE_CYCLES"):
+    cyc = 4.0 * g("SQ_WAVE_CYCLES") / w   # (SQ_WAVE_CYCLES, SQ_WAIT_* count quad-cycles)
+    print("per wave: %.0f VALU + %.0f SALU + %.0f LDS + %.0f VMEM instructions in %.0f cycles = %.2f cycles per VALU instruction; "
+          "parked at s_waitcnt %.3f, issue stalls %.3f of the wave's cycles" % (
+          g("SQ_INSTS_VALU") / w, g("SQ_INSTS_SALU") / w, g("SQ_INSTS_LDS") / w, (g("SQ_INSTS_VMEM_RD") + g("SQ_INSTS_VMEM_WR")) / w, cyc,
+          cyc / max(g("SQ_INSTS_VALU") / w, 1.0), g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES")))
 PY
 rm -rf "$OUT"/p1 "$OUT"/p2 "$OUT"/p3
