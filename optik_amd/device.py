@@ -131,6 +131,22 @@ class HipChain:
             _stream_ptr()))
         return bufs
 
+    def ik_host(self, cfg, targets, x0, restart_begin, restart_end, flags=0, deadline_s=0.0, ee_offset7=None):
+        """optik_hip_ik_host: host arrays in (targets [T, 7], x0 [T, n]), the winners back as numpy arrays; blocking.
+        With IK_EARLY_EXIT | IK_FIND_ANY and one target the call returns when the first restart has succeeded."""
+        targets = np.ascontiguousarray(targets, dtype=np.float64)
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        T = targets.shape[0]
+        assert targets.shape == (T, 7) and x0.shape == (T, self.n)
+        win_x = np.zeros((T, self.n)); win_f = np.zeros(T); win_key = np.zeros(T)
+        win_idx = np.zeros(T, dtype=np.uint64)
+        ee = np.ascontiguousarray(ee_offset7, dtype=np.float64) if ee_offset7 is not None else None
+        nat.check(nat.lib().optik_hip_ik_host(
+            self._h, C.byref(cfg), _dp(targets), _dp(x0), T, _dp(ee) if ee is not None else None,
+            int(restart_begin), int(restart_end), int(flags), float(deadline_s), _dp(win_x), _dp(win_f),
+            win_idx.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(win_key)))
+        return dict(win_x=win_x, win_f=win_f, win_idx=win_idx.astype(np.int64), win_key=win_key)
+
     # -- the streaming engine (throughput path; same results) ---------------------
     def engine_submit(self, cfg, targets, x0, restart_begin, restart_end, flags=0, ee_offset7=None,
                       bufs=None, per_restart=True):

@@ -643,3 +643,64 @@ def test_set_parallelism_selects_find_any(oracle, chains):
     for t, o in enumerate(out):
         assert o is not None and o[1] < 1e-6
         np.testing.assert_allclose(np.array(r.fk(o[0]))[:3, 3], targets[t][:3, 3], atol=2e-3)
+
+
+def test_first_success_calls_return_early_and_leave_a_consistent_chain(oracle, chains):
+    """Under the first-success rule a single ik() returns when the first restart has succeeded and its launch ends
+    behind the call (ik_kernels.hip: optik_hip_ik_host, claim block).  Back-to-back calls, a call without any
+    solution (the launch then ends the ordinary way) and a deterministic call right behind an early return all give
+    answers the oracle reproduces by restart index."""
+    from optik_amd import Robot, SolverConfig
+    r = Robot.from_urdf_file(os.path.join(ROBOTS, "panda.urdf"), "panda_link0", "panda_link8")
+    _, ch = chains["panda"]
+    rng = np.random.default_rng(77)
+    lb, ub = (np.array(v) for v in r.joint_limits())
+    cfg = SolverConfig(max_time=0.0, max_restarts=2000)
+    cases = [(np.array(r.fk(rng.uniform(lb, ub))), rng.uniform(lb, ub)) for _ in range(24)]
+    got = [r.ik(cfg, t, x0.tolist(), return_index=True) for t, x0 in cases]  # back to back, nothing in between
+    for (t, x0), g in zip(cases, got):
+        assert g is not None
+        x, f, idx = g
+        ref = oracle.solve_restart(ch, oracle.make_config("speed"), _mat_to_pose7(t), x0, int(idx))
+        assert ref.success and abs(ref.f - f) < 1e-9
+        np.testing.assert_allclose(x, np.array(ref.x[:7]), atol=1e-6, rtol=0)
+    # out of reach: no restart succeeds, the call ends with its launches and says so
+    far = np.eye(4)
+    far[:3, 3] = [3.0, 0.0, 0.5]
+    assert r.ik(SolverConfig(max_time=0.0, max_restarts=600), far, cases[0][1].tolist()) is None
+    # ... and the next call is served as usual
+    assert r.ik(cfg, cases[0][0], cases[0][1].tolist()) is not None
+    # a deterministic call right behind an early return (its launch queues behind the one left running)
+    t, x0 = cases[1]
+    r.ik(cfg, t, x0.tolist())
+    r.set_parallelism(1)
+    x, f, idx = r.ik(cfg, t, x0.tolist(), return_index=True)
+    ref = oracle.ik(ch, oracle.make_config("speed"), _mat_to_pose7(t), x0, 0, 2000, n_threads=4, early_exit=False,
+                    per_restart=True)
+    assert ref["found"] and int(idx) == int(ref["winner"])
+
+
+def test_early_return_then_a_launch_on_another_stream(oracle, chains):
+    """A launch on a stream of its own shares the chain's workspace with the launch an early-returned call left
+    running on the null stream: it waits for that one (ik_kernels.hip: claim_pending) and gives the oracle's bits."""
+    import torch
+    from optik_amd import _native as nat
+    from optik_amd import device
+    d, ch = chains["panda"]
+    hc = device.HipChain(**d)
+    rng = np.random.default_rng(78)
+    cfg = nat.make_config(solution_mode="speed")
+    side = torch.cuda.Stream()
+    for trial in range(4):
+        _, tgt = oracle.fk(ch, rng.uniform(d["lb"], d["ub"]))
+        x0 = rng.uniform(d["lb"], d["ub"])
+        # a host call under the first-success rule: returns on the first success
+        early = hc.ik_host(cfg, tgt[None], x0[None], 0, 512, flags=nat.IK_EARLY_EXIT | nat.IK_FIND_ANY)
+        assert int(early["win_idx"][0]) >= 0
+        with torch.cuda.stream(side):
+            out = hc.ik_batch(cfg, torch.tensor(tgt[None], device="cuda:0"), torch.tensor(x0[None], device="cuda:0"), 0, 300)
+        side.synchronize()
+        ref = oracle.ik(ch, oracle.make_config(solution_mode="speed"), tgt, x0, 0, 300, n_threads=2, early_exit=False,
+                        per_restart=True)
+        assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
+        assert_bit_equal(out["x"].cpu().numpy(), ref["xs"].T.copy())
