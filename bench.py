@@ -510,8 +510,7 @@ def main():
         if args.path == "engine":
             st = hc.engine_stats()
             trips = int(nat.lib().optik_hip_engine_last_trips(hc._h))
-            per_kernel = {k: st[k + "_ms"] for k in (("slot", "bucket", "nnls") if st["fused"]
-                                                     else ("eval", "update", "nnls", "finish"))}
+            per_kernel = {k: st[k + "_ms"] for k in ("eval", "update", "nnls", "finish")}
             dom = max(per_kernel, key=per_kernel.get)
             if st.get("evals_executed") and not T:
                 mean_exec = st["evals_executed"] / (float(cols) * K)
@@ -526,16 +525,12 @@ def main():
                 nl = n * (n + 1) // 2
                 # planes read + written per slot-trip (update also writes the packed problem record,
                 # finish reads it back with the multipliers)
-                # planes read + written per slot-trip (update also writes the packed problem record,
-                # finish reads it back with the multipliers); the fused slot kernel does all three
-                # phases with x, the gradient and the factor read back from L2 between them
                 unit_bytes = {"eval": 8 * (2 * n + 6), "update": 8 * (3 * nl + 11 * n + 8),
-                              "finish": 8 * (2 * nl + 10 * n + 12),
-                              "slot": 8 * (3 * nl + 14 * n + 24), "bucket": 8}[dom]
+                              "finish": 8 * (2 * nl + 10 * n + 12)}[dom]
             kernel_ms = per_kernel[dom]
             achieved = unit_bytes * units / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
             kname = {"eval": "eng_eval_kernel", "update": "eng_update_kernel", "nnls": "eng_nnls_coop_kernel",
-                     "finish": "eng_finish_kernel", "slot": "eng_slot_kernel", "bucket": "eng_bucket_kernel"}[dom]
+                     "finish": "eng_finish_kernel"}[dom]
             traffic, traffic_note = None, f"no PMC pass of this command in {os.path.relpath(PMC_FILE, ROOT)} (key: {key})"
             if pmc and kname in pmc.get("kernels", {}):
                 kp = pmc["kernels"][kname]
@@ -551,10 +546,9 @@ def main():
                     "algorithmic_bytes_per_unit": unit_bytes, "units_per_launch": units,
                     "unit_name": "bounded sub-problem" if dom == "nnls" else "slot-trip",
                     "all_kernels_ms": per_kernel, "trips": trips, "sub_pools": st["pools"],
-                    # who finishes the run's last restarts once the queue is dry (ik_quad_tail.hpp / ik_tail.hpp)
+                    # who finishes the run's last restarts once the queue is dry (ik_quad_tail.hpp)
                     "tail": dict(zip(("solver", "restarts_taken_over"),
-                                     (lambda sv, nr: ({0: "none", 1: "per-lane kernel", 2: "cooperative kernel", 3: "quad solver"}[sv], nr))(
-                                         *hc.engine_last_tail()))),
+                                     (lambda sv, nr: ({0: "none", 3: "quad solver"}[sv], nr))(*hc.engine_last_tail()))),
                     "launches": st["launches"], "restart_output_bytes": out_bytes,
                     # the whole path at its boundary: SURVEY 8d's per-restart figure with in-kernel
                     # seeds (outputs only) and with the seeds counted as read (16n + 16)

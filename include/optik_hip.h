@@ -212,8 +212,7 @@ int optik_hip_engine_reserve(optik_hip_chain *chain, uint64_t slots, void *strea
 int optik_hip_engine_last_trips(const optik_hip_chain *chain);
 /* Who finished the last run's final restarts once its queue was dry: *restarts = how many (an upper bound:
  * the host's lagging count) were handed over from the slot pool; returns the solver -- 0 none (the
- * phase kernels ran every restart to its end), 1 the per-lane kernel, 2 the cooperative kernel, 3 the
- * quad solver (the default). */
+ * phase kernels ran every restart to its end), 3 the quad solver (1 and 2 named the kernels of rounds 1 and 2). */
 int optik_hip_engine_last_tail(const optik_hip_chain *chain, int32_t *restarts);
 /* The slot pool of a run is split into sub-pools (OPTIK_ENG_POOLS, default 3; at most 4),
  * each with its own HIP stream, so that kernels of different sub-pools overlap.  Returns
@@ -232,10 +231,6 @@ int optik_hip_engine_stats(const optik_hip_chain *chain, double *kernel_ms4, int
  * included).  d_evals reports NLopt's count per restart, which also includes the re-evaluation
  * of an accepted line-search point that was not the first trial; the kernels skip that one. */
 uint64_t optik_hip_engine_executed_evals(const optik_hip_chain *chain);
-/* 1 when the last run used fused trips (OPTIK_ENG_FUSED=1: bucket -> NNLS -> eng_slot_kernel): the
- * four durations of optik_hip_engine_stats are then {slot kernel, bucket, NNLS, 0}; 0 for the
- * default five-kernel trips ({eval, update, NNLS, finish}). */
-int optik_hip_engine_last_fused(const optik_hip_chain *chain);
 
 /* Tuning options of the kernel layer (diagnostics: tests and tools; the defaults are what the product runs with).
  * Each option's default comes from the environment variable named with it, read ONCE when the library first needs

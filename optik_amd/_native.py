@@ -100,7 +100,6 @@ def lib():
     L.optik_hip_engine_run_ex.argtypes = [vp, vp, C.c_double]
     L.optik_hip_engine_executed_evals.argtypes = [vp]
     L.optik_hip_engine_executed_evals.restype = C.c_uint64
-    L.optik_hip_engine_last_fused.argtypes = [vp]
     L.optik_hip_engine_reserve.argtypes = [vp, C.c_uint64, vp]
     L.optik_hip_engine_last_trips.argtypes = [vp]
     L.optik_hip_engine_last_tail.argtypes = [vp, C.POINTER(C.c_int32)]
@@ -133,7 +132,7 @@ def make_config(solution_mode="speed", max_time=0.0, max_restarts=0, tol_f=1e-6,
     return cfg
 
 
-SOLVE_KERNELS = {"auto": 0, "quad": 1, "lane64": 2, "general": 3, "coop": 4, "lane": 5}
+SOLVE_KERNELS = {"auto": 0, "quad": 1, "lane64": 2, "general": 3}
 WIDE_FORMS = {"lds": 0, "hbm": 1}
 
 

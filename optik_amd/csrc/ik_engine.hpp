@@ -22,9 +22,8 @@
 //                           (ik_nnls_coop.hpp)
 //       eng_finish_kernel   refill of finished slots from the work queue; LDP tail,
 //                           descent test and next trial point from the NNLS answers
-//     (the last restarts of a run -- up to 32 768 -- are finished by eng_tail_coop_kernel,
-//     ik_tail.hpp / ik_coop.hpp, without kernel boundaries; OPTIK_ENG_FUSED=1 runs finish, eval
-//     and update as one launch, eng_slot_kernel);
+//     (the last restarts of a run are finished by the quad solver without kernel boundaries:
+//     eng_tail_quad_kernel, ik_quad_tail.hpp);
 //   * jobs (one optik_hip_ik_batch call each) submitted before a run share the pool:
 //     a slot that finishes a restart of one job may continue with another job's.
 //
@@ -47,11 +46,6 @@ enum : int32_t {
     ST_NNLS = 5,           // direction needs the bounded solve (deferred to the NNLS kernel)
     ST_REFILL = 6,         // restart published; slot wants the next work item
     ST_DEAD = 7,           // terminated inside an update (status plane); publish next trip
-    // fused trips (eng_slot_kernel): a slot refilled by the slot kernel of a trip of parity p is
-    // ST_FRESH0 + p and gets its first evaluation from the NEXT trip's slot kernel -- the lane
-    // that owns the slot may be running its evaluation phase while another wave refills it
-    ST_FRESH0 = 8,
-    ST_FRESH1 = 9,
 };
 
 template <int N>
@@ -102,7 +96,7 @@ constexpr int ENG_MAX_POOLS = 4;
 // ones start first.  Scheduling only -- every problem is solved independently.
 constexpr int NN_CLASSES = 8;
 // counters of a sub-pool: class sizes per trip parity, then slots to refill, slots in use
-constexpr int ENG_POOL_COUNTERS = 2 * NN_CLASSES + 3;  // (+ the second refill count of fused trips)
+constexpr int ENG_POOL_COUNTERS = 2 * NN_CLASSES + 3;
 constexpr unsigned NN_NONE = 0xffffffffu;  // nn_cls entry of a slot without a problem
 // A problem that needs more than the launch's pass budget is suspended and continues in
 // the next trip's launch (its slot just stays in ST_NNLS): no launch waits for the rare
@@ -146,14 +140,13 @@ struct EngArgs {
     int nn_pred_viol;                   // prediction also from the number of violated bounds
     int pad5;
     int parity;                         // list consumed by this trip's NNLS kernel
-    int fused;                          // 1: trips are bucket -> NNLS -> eng_slot_kernel (finish + eval + update in one launch)
+    int pad6;
     unsigned int *n_active;             // slots holding a restart or waiting for one (bucket kernel; reset every trip)
     // slots whose restart was published this trip (or never started) and want the next work item:
     // listed by the bucket kernel, handed out one per lane by the finish kernel (a finished
     // restart per 39 evaluations would otherwise drag 4 of 5 waves through the refill code for
     // one or two lanes)
-    unsigned int *refill_count;         // (fused trips: the word of this trip's parity)
-    unsigned int *refill_count_next;    // fused trips: the other parity's word, zeroed by the slot kernel for the next bucket pass
+    unsigned int *refill_count;
     unsigned int *refill_list;          // [sub-pool size]
     unsigned int *host_in_use;          // pinned host word the finish kernel copies the in-use count to (last trip of a chunk), or null
     unsigned long long *nn_total;       // running count of bounded sub-problems solved
@@ -497,7 +490,6 @@ OPTIK_DEV bool eng_eval_body(const EngArgs &a, const ChainDev &ch, const EngJob 
     using E = EngLayout<N>;
     const double alfmin = 0.1;
     int st = ENG_I(E::STATE);
-    if (a.fused && st == ST_FRESH0 + (a.parity ^ 1)) st = ST_EVAL_FIRST;  // refilled by the previous trip
     if (st != ST_EVAL_FIRST && st != ST_EVAL_TRIAL && st != ST_DEAD) return false;
     const EngJob &J = jobs[ENG_I(E::JOB)];  // (job table staged in LDS: no dependent HBM round trip)
     const unsigned long long item = a.item[slot];
@@ -697,7 +689,7 @@ OPTIK_DEV bool refill_slot(const EngArgs &a, const ChainDev &ch, size_t slot, un
         ENG_I(E::NNIT) = 1;
         ENG_I(E::JOB) = job;
         a.item[slot] = item;
-        st = a.fused ? ST_FRESH0 + a.parity : ST_EVAL_FIRST;
+        st = ST_EVAL_FIRST;
     } else {
         st = ST_EMPTY;
     }
@@ -761,7 +753,7 @@ OPTIK_DEV void eng_update_body(const EngArgs &a, const ChainDev &ch, size_t slot
         ENG_PROBE(3);
 #ifdef OPTIK_PROFILE
         unsigned long long dpt[4] = {0, 0, 0, 0};
-        const int out = direction_search<N>(a, ch, slot, a.fused ? (a.parity ^ 1) : a.parity, false, l, g, x, f, ireset, iter,
+        const int out = direction_search<N>(a, ch, slot, a.parity, false, l, g, x, f, ireset, iter,
                                             st == ST_UPDATE_FIRST, s, h3, status, ENG_I(E::NNIT), rec, dpt);
         ENG_PROBE(5);  // (reused below: end of the search, before the stores)
         if (dpt[1] && dpt[0]) pt[0] += 0;  // keep dpt live
@@ -769,7 +761,7 @@ OPTIK_DEV void eng_update_body(const EngArgs &a, const ChainDev &ch, size_t slot
         prof_rows = (dpt[2] && dpt[1]) ? dpt[2] - dpt[1] : 0;
         prof_tail = dpt[2] ? pt[5] - dpt[2] : 0;
 #else
-        const int out = direction_search<N>(a, ch, slot, a.fused ? (a.parity ^ 1) : a.parity, false, l, g, x, f, ireset, iter,
+        const int out = direction_search<N>(a, ch, slot, a.parity, false, l, g, x, f, ireset, iter,
                                             st == ST_UPDATE_FIRST, s, h3, status, ENG_I(E::NNIT), rec);
 #endif
         emitted = out == DIR_DEFER;
@@ -1095,7 +1087,7 @@ struct CompactArgs {
     unsigned int *free_list, *move_list;
     // a slot waiting for the next NNLS launch takes its problem record and class entry along
     double *nn_prob, *nn_meta, *nn_carry;
-    double *nn_y;           // multipliers of an answered problem the slot kernel has not consumed yet (fused trips), or null
+    double *nn_y;           // multipliers that have to move with their slot, or null
     unsigned int *nn_cls;   // class entries of the next trip, by sub-pool slot
     int rec_len;            // doubles per problem record
     int ny;                 // doubles per multiplier vector (2n)

@@ -193,103 +193,4 @@ OPTIK_DEV double eval_fg(const ChainDev &ch, const EvalParams &ep, const Pose ta
     });
 }
 
-// The same evaluation shared by the lanes of a group (ik_coop.hpp: the four lanes of a restart):
-// every lane runs the forward pass and the error terms (identical values in all of them: no
-// extra time on a SIMD), leaves the joint frames in the group's LDS window `frames` (N x 7
-// doubles) and then computes only the Jacobian columns / gradient components k = gl, gl + G, ...
-// (lane_in_group + j G) -- two of seven instead of all seven for G = 4.  Component k is written to grad[k] (LDS, N
-// doubles); the caller makes them visible to the leader.  Each component is the operation
-// sequence of eval_fg_stream on the same operands: the same bits.  Returns f (in every lane).
-template <int N, bool TIP, int G>
-OPTIK_DEV double eval_fg_group(const ChainDev &ch, const EvalParams &ep, const Pose target, const double (&q)[N],
-                               int lane_in_group, double *frames, double *grad) {
-    Pose ee;  // kinematics.rs:163
-    {
-        Pose state;
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            double s, c;
-            sincos_dev(q[j] / 2.0, s, c);  // UnitQuaternion::from_axis_angle
-            const Q4 local{ch.axis[j][0] * s, ch.axis[j][1] * s, ch.axis[j][2] * s, c};
-            Pose jt;  // joint.origin * local_transform(q): the translation part is exact
-            jt.t = V3{ch.origin[j][0], ch.origin[j][1], ch.origin[j][2]};
-            jt.q = qmul(Q4{ch.origin[j][3], ch.origin[j][4], ch.origin[j][5], ch.origin[j][6]}, local);
-            state = (j == 0) ? jt : pose_mul(state, jt);  // identity * jt is exact
-            double *fr = frames + j * 7;
-            fr[0] = state.t.x; fr[1] = state.t.y; fr[2] = state.t.z;
-            fr[3] = state.q.i; fr[4] = state.q.j; fr[5] = state.q.k; fr[6] = state.q.w;
-            OPTIK_SCHED_FENCE();
-        }
-        if (TIP) state = pose_mul(state, load_pose(ch.origin[N]));
-        ee = ep.has_ee_offset ? pose_mul(state, load_pose(ep.ee_offset)) : state;
-    }
-
-    // X = T_target^-1 T_ee  (objective.rs:69-70)
-    const Pose X = pose_inv_mul(target, ee);
-    const V3 w = so3_log(X.q);
-    const RotTerms rt = rot_terms(w);
-    const M3 Jr = so3_right_jacobian(rt);          // math.rs:195
-    const M3 Qm = se3_q_matrix(rt, X.t, Jr);       // math.rs:196 (E = Jr, math.rs:167)
-    const V3 elin = se3_log_linear(rt, X.t);       // math.rs:120-122
-
-    // weighted error for the value (objective.rs:52) and for the gradient (:104)
-    V3 fl = elin, fa = w;
-    if (!ep.skip_lin) fl = weight_block(target.q, elin, ep.w_lin);
-    if (!ep.skip_ang) fa = weight_block(target.q, w, ep.w_ang);
-    V3 gl = fl, ga = fa;
-    if (!ep.grad_same_as_value) {
-        gl = elin; ga = w;
-        if (!ep.skip_lin2) gl = weight_block(target.q, elin, ep.w_lin2);
-        if (!ep.skip_ang2) ga = weight_block(target.q, w, ep.w_ang2);
-    }
-    const double e2[6] = {2.0 * gl.x, 2.0 * gl.y, 2.0 * gl.z, 2.0 * ga.x, 2.0 * ga.y, 2.0 * ga.z};
-    // f = ||e||^2 (objective.rs:56)
-    const double ef[6] = {fl.x, fl.y, fl.z, fa.x, fa.y, fa.z};
-    double f = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) f += ef[i] * ef[i];
-    OPTIK_SCHED_FENCE();
-
-    // the lane's joints: body-frame Jacobian column (kinematics.rs:173-184), then
-    // Jtask = Jlog6 * J (objective.rs:81) and g = (2 e') Jtask (objective.rs:106-109)
-    const Q4 eeqc = qconj(ee.q);
-#pragma unroll
-    for (int jj = 0; jj < (N + G - 1) / G; ++jj) {
-        const int k = lane_in_group + jj * G;
-        if (k < N) {
-            const double *fr = frames + k * 7;  // (what this lane wrote in its own forward pass)
-            const V3 tk{fr[0], fr[1], fr[2]};
-            const Q4 tq{fr[3], fr[4], fr[5], fr[6]};
-            const V3 ax{ch.axis[k][0], ch.axis[k][1], ch.axis[k][2]};
-            const V3 angular = qrot(tq, ax);
-            const V3 d{ee.t.x - tk.x, ee.t.y - tk.y, ee.t.z - tk.z};
-            const V3 linear = cross(angular, d);
-            const V3 al = qrot(eeqc, angular);
-            const V3 ll = qrot(eeqc, linear);
-            const double lin[3] = {ll.x, ll.y, ll.z};
-            const double ang[3] = {al.x, al.y, al.z};
-            double jt[6];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                double acc = 0.0;
-#pragma unroll
-                for (int m = 0; m < 3; ++m) acc += Jr.m[r][m] * lin[m];
-#pragma unroll
-                for (int m = 0; m < 3; ++m) acc += Qm.m[r][m] * ang[m];
-                jt[r] = acc;
-                double acc2 = 0.0;  // lower-left block of Jlog6 is zero
-#pragma unroll
-                for (int m = 0; m < 3; ++m) acc2 += Jr.m[r][m] * ang[m];
-                jt[r + 3] = acc2;
-            }
-            double acc = 0.0;
-#pragma unroll
-            for (int r = 0; r < 6; ++r) acc += e2[r] * jt[r];
-            grad[k] = acc;
-        }
-        OPTIK_SCHED_FENCE();
-    }
-    return f;
-}
-
 }  // namespace optik

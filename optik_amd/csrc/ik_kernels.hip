@@ -1,14 +1,16 @@
-// ik_kernels.hip -- gfx950 kernels and the C ABI of include/optik_hip.h.
+// ik_kernels.hip -- the C ABI of include/optik_hip.h and the kernels that are not solvers.
 //
-// Kernels (all f64, one configuration / restart per lane, 64-lane workgroups):
-//   ik_solve_kernel   the hot path: seed -> SLSQP restart -> status/x/f, plus the
-//                     per-wave argmin of the selection key (wavefront shuffles)
-//   ik_select_kernel  reduces the per-tile winners of each target (lib.rs:397-413)
-//   eval_batch_kernel objective + gradient for a batch of configurations
-//   fk_batch_kernel   end-effector pose (+ body Jacobian) for a batch
-//   seed_batch_kernel ChaCha8 restart seeds
-//   probe_kernel      elementary functions (test hook)
-// No CPU fallback exists: every entry point fails loudly without a device.
+//   single-launch solvers   launched from here, defined in their own translation units: the lane-per-restart form
+//                           (ik_lane_kernel.hip), the quad solver (ik_quad_kernel.hip), the general run-time-n solver
+//                           (ik_wide_kernel.hip); optik_hip_ik_batch picks one by launch size and joint count
+//   eng_*_kernel            the streaming engine's phase kernels (ik_engine.hpp, ik_nnls_coop.hpp)
+//   ik_tile_argmin_kernel, ik_select_kernel, ik_select_small_kernel
+//                           the selection of lib.rs:397-413 over the per-restart keys
+//   eval_batch_kernel       objective + gradient for a batch of configurations
+//   fk_batch_kernel         end-effector pose (+ body Jacobian) for a batch
+//   seed_batch_kernel       ChaCha8 restart seeds
+//   probe_kernel            elementary functions (test hook)
+// All f64.  No CPU fallback exists: every entry point fails loudly without a device.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <algorithm>
@@ -27,10 +29,6 @@
 #include "ik_launch.hpp"
 #include "ik_wide_launch.hpp"
 #include "ik_engine.hpp"
-#ifdef OPTIK_LEGACY_KERNELS  // rounds 1-2: the per-lane and leader-lane solvers, their engine tails, fused engine trips
-#include "ik_tail.hpp"       // (tools/build_lib_variant.py legacy -DOPTIK_LEGACY_KERNELS; not in the product library)
-#include "ik_coop.hpp"
-#endif
 
 using namespace optik;
 using namespace optik::hostparams;
@@ -61,33 +59,6 @@ __device__ __forceinline__ void wave_argmin(double &key, unsigned long long &idx
 
 constexpr int QUADS_PER_WAVE_HOST = 16;  // restarts a wave of the quad solver holds
 
-#ifdef OPTIK_LEGACY_KERNELS
-// Round 1: every wave pulls (target, restart) work items until the queue is dry, one restart per lane.
-template <int N, bool TIP>
-__global__ __launch_bounds__(WAVE) void ik_solve_kernel(const SolveLaunch a) {
-    __shared__ ChainDev sch;
-    __shared__ double nnls_lds[NnlsLayout<N>::SLOTS * WAVE];
-    stage_chain(sch, a.chain);
-    const NnlsWs<N> ws{nnls_lds + threadIdx.x};
-    WorkQueue wq = a.wq;
-    wq.deadline = a.deadline_ticks ? wall_clock64() + a.deadline_ticks : 0ull;
-    solve_wave<N, TIP>(sch, a.ep, a.sp, a.key, a.scale, wq, ws);
-}
-
-// The same restarts with one restart per group of four lanes and the cooperative NNLS
-// (ik_coop.hpp): the latency-oriented form, used whenever the chain has n <= 7 joints.
-template <int N, bool TIP>
-__global__ __launch_bounds__(WAVE) void ik_coop_kernel(const SolveLaunch a) {
-    __shared__ ChainDev sch;
-    __shared__ __attribute__((aligned(16))) double nnls_lds[coop_wave_lds<4>()];
-    __shared__ __attribute__((aligned(16))) double rec_lds[COOP_GROUPS_PER_WAVE * coop_rec_lds<N>()];
-    stage_chain(sch, a.chain);
-    if (threadIdx.x < 8) nnls_lds[coop_wave_lds<4>() - 8 + threadIdx.x] = 0.0;  // the column of zeros
-    WorkQueue wq = a.wq;
-    wq.deadline = a.deadline_ticks ? wall_clock64() + a.deadline_ticks : 0ull;
-    coop_wave<N, TIP>(sch, a.ep, a.sp, a.key, a.scale, wq, nnls_lds, rec_lds);
-}
-#endif  // OPTIK_LEGACY_KERNELS
 
 struct SelectLaunch {
     const double *out_key;   // [T*R] selection key, +inf unless the restart succeeded
@@ -303,74 +274,6 @@ __global__ __launch_bounds__(OPTIK_ENG_UPD_BLOCK, OPTIK_ENG_UPD_WAVES) void eng_
     eng_finish_body<N>(a, sch, local < a.n_slots ? slot : (size_t)a.slot_base, local, local < a.n_slots);
 }
 
-#ifdef OPTIK_LEGACY_KERNELS
-// Fused trips: everything a slot's owner lane does in a trip, in one launch -- the finishing pass of
-// the direction the NNLS kernel just answered (and the refill of the listed slots), the
-// evaluation of the trial point, and on an accepted step the BFGS update with the next
-// direction search.  Between the three phases nothing is kept in registers (a full memory
-// fence and a scheduling barrier: the register allocator sees three separate live ranges, 240
-// VGPRs, 2 waves per SIMD like the three kernels it replaces); what a phase wrote is read back
-// by the same wave from L2 instead of crossing a kernel boundary through HBM, and a trip is
-// three dependent launches (bucket, NNLS, slot) instead of five.
-#define OPTIK_PHASE_BOUNDARY() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-template <int N, bool TIP>
-__global__ __launch_bounds__(OPTIK_ENG_UPD_BLOCK, OPTIK_ENG_UPD_WAVES) void eng_slot_kernel(const EngArgs a) {
-    __shared__ ChainDev sch;
-    extern __shared__ __attribute__((aligned(16))) unsigned char slot_dyn_lds[];  // n_jobs job records
-    EngJob *sjobs = reinterpret_cast<EngJob *>(slot_dyn_lds);
-    __shared__ double rec_win[(OPTIK_ENG_UPD_BLOCK / 64) * RecIo<N>::WINDOW];
-    {
-        static_assert(sizeof(EngJob) % sizeof(double) == 0, "EngJob is a whole number of doubles");
-        const double *src = reinterpret_cast<const double *>(a.jobs);
-        double *dst = reinterpret_cast<double *>(sjobs);
-        const int nd = a.n_jobs * (int)(sizeof(EngJob) / sizeof(double));
-        for (int i = threadIdx.x; i < nd; i += blockDim.x) dst[i] = src[i];
-    }
-    stage_chain(sch, a.chain);
-    const size_t local = (size_t)blockIdx.x * OPTIK_ENG_UPD_BLOCK + threadIdx.x;
-    const size_t slot = (size_t)a.slot_base + local;
-    const bool in = local < a.n_slots;
-    if (blockIdx.x == 0) {
-        // the in-use count of this trip's bucket pass goes to the host; then the counters the next
-        // trip's bucket pass accumulates into are cleared (nothing in this launch reads them)
-        if (threadIdx.x == 0) {
-            if (a.host_in_use) __hip_atomic_store(a.host_in_use, *a.n_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            *a.n_active = 0u;
-            *a.refill_count_next = 0u;
-        }
-        if (threadIdx.x >= 8u && threadIdx.x < 8u + (unsigned)NN_CLASSES) a.nn_class_count[a.parity ^ 1][threadIdx.x - 8u] = 0u;
-    }
-    eng_finish_body<N>(a, sch, in ? slot : (size_t)a.slot_base, local, in);
-    OPTIK_PHASE_BOUNDARY();
-    const bool evaluated = in && eng_eval_body<N, TIP>(a, sch, sjobs, slot);
-    const unsigned long long em = __ballot(evaluated);
-    if (a.exec_evals && em && (threadIdx.x & 63u) == 0)
-        atomicAdd(a.exec_evals + (blockIdx.x % ENG_EXEC_SHARDS), (unsigned long long)__popcll(em));
-    OPTIK_PHASE_BOUNDARY();
-    eng_update_body<N>(a, sch, in ? slot : (size_t)a.slot_base, local, in, rec_win + (threadIdx.x / 64u) * RecIo<N>::WINDOW);
-}
-
-// the last restarts of a run, one per lane, to the end without kernel boundaries (ik_tail.hpp)
-template <int N, bool TIP>
-__global__ __launch_bounds__(WAVE) void eng_tail_kernel(const EngArgs a, const unsigned int *list,
-                                                        const unsigned int *count, int lanes) {
-    __shared__ ChainDev sch;
-    __shared__ double nnls_lds[NnlsLayout<N>::SLOTS * WAVE];
-    stage_chain(sch, a.chain);
-    const NnlsWs<N> ws{nnls_lds + threadIdx.x};
-    tail_wave<N, TIP>(a, sch, a.jobs, list, *count, lanes, ws);
-}
-template <int N, bool TIP>
-__global__ __launch_bounds__(WAVE) void eng_tail_coop_kernel(const EngArgs a, const unsigned int *list,
-                                                             const unsigned int *count, int groups) {
-    __shared__ ChainDev sch;
-    __shared__ __attribute__((aligned(16))) double nnls_lds[coop_wave_lds<4>()];
-    __shared__ __attribute__((aligned(16))) double rec_lds[COOP_GROUPS_PER_WAVE * coop_rec_lds<N>()];
-    stage_chain(sch, a.chain);
-    if (threadIdx.x < 8) nnls_lds[coop_wave_lds<4>() - 8 + threadIdx.x] = 0.0;  // the column of zeros
-    tail_wave_coop<N, TIP>(a, sch, a.jobs, list, *count, groups, nnls_lds, rec_lds);
-}
-#endif  // OPTIK_LEGACY_KERNELS
 __global__ __launch_bounds__(256) void eng_tail_list_kernel(const int32_t *state, unsigned long long n_slots,
                                                             unsigned int *count, unsigned int *list) {
     tail_list_body(state, n_slots, count, list);
@@ -661,7 +564,6 @@ struct optik_hip_chain {
     hipEvent_t eng_pool_ev[ENG_MAX_POOLS][8] = {};
     hipEvent_t eng_fork_ev = nullptr, eng_join_ev[ENG_MAX_POOLS] = {};
     int eng_pools = 1;
-    int eng_fused = 0;                         // the last run used fused trips (eng_kernel_ms = {slot, bucket, nnls, -})
     int eng_launches = 0;                      // NNLS launches of the last run, all sub-pools
     unsigned long long *eng_deadline = nullptr;  // device word: wall_clock64() value at which the run's max_time expires
     int eng_tail_restarts = 0;                 // restarts (upper bound) the tail kernel took over in the last run
@@ -681,8 +583,7 @@ struct optik_hip_chain {
     unsigned long long *eng_nn_total = nullptr;  // [0] problems solved by the NNLS kernel; [1 .. 64] executed evaluations (sharded)
     unsigned long long eng_nn_problems = 0;
     unsigned long long eng_exec_evals = 0;       // objective + gradient evaluations executed by the last run
-    int waves_per_cu = 2;                 // resident 64-lane workgroups per CU (LDS-bound)
-    // timing
+        // timing
     int timing = 0;
     static constexpr int EV_POOL = 256;  // event pairs recorded round-robin around the solve kernel
     hipEvent_t ev0[EV_POOL] = {}, ev1[EV_POOL] = {};
@@ -698,7 +599,7 @@ namespace {
 // Every tuning option of the kernel layer, in one place.  The defaults come from the environment ONCE, at the
 // first use (the OPTIK_* names below); tests and tools change them through optik_hip_set_option (optik_hip.h).
 // Nothing else in this library reads the environment (robot_host.cpp: OPTIK_HOST_THREADS, OPTIK_DEVICES).
-enum : int { SK_AUTO = 0, SK_QUAD = 1, SK_LANE64 = 2, SK_GENERAL = 3, SK_COOP = 4, SK_LANE = 5 };
+enum : int { SK_AUTO = 0, SK_QUAD = 1, SK_LANE64 = 2, SK_GENERAL = 3 };
 struct Options {
     int solve_kernel = SK_AUTO;      // OPTIK_SOLVE_KERNEL = quad | lane64 | general: which single-launch solver (auto: by size)
     long long engine_slots = 0;      // OPTIK_ENGINE_SLOTS: capacity of the engine's slot pool (0: 393 216, fewer for early-exit jobs)
@@ -716,10 +617,6 @@ int solve_kernel_from(const char *e) {
     if (!std::strcmp(e, "quad")) return SK_QUAD;
     if (!std::strcmp(e, "lane64")) return SK_LANE64;
     if (!std::strcmp(e, "general")) return SK_GENERAL;
-#ifdef OPTIK_LEGACY_KERNELS
-    if (!std::strcmp(e, "coop")) return SK_COOP;
-    if (!std::strcmp(e, "lane")) return SK_LANE;
-#endif
     return SK_AUTO;
 }
 Options &opt() {
@@ -1254,8 +1151,7 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     // quad of lanes, its state spread over the quad, NNLS matrix in LDS; n <= 8), from one full load of the chip
     // on the lane-per-restart form of ik_lane64.hpp (n <= 7), or -- `general` -- the run-time-n solver of
     // ik_wide.hpp on a chain of at most 8 joints too: a third, independently written device solver for the parity
-    // tests; chains of 9 .. 16 joints always run on it.  (-DOPTIK_LEGACY_KERNELS builds: `coop`, round 2's
-    // leader-lane solver of ik_coop.hpp, and `lane`, round 1's per-lane kernel with its per-lane LDS NNLS.)
+    // tests; chains of 9 .. 16 joints always run on it.
     const int sk = opt().solve_kernel;
     bool widek = ch->wide || sk == SK_GENERAL;
     if (widek && !ch->wide) {
@@ -1273,11 +1169,7 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         if (!ch->wdev) HIP_TRY(hipMalloc(&ch->wdev, sizeof(WideChainDev)));
         HIP_TRY(hipMemcpy(ch->wdev, &w, sizeof(WideChainDev), hipMemcpyHostToDevice));
     }
-    bool coop = false, quadk = !widek;
-#ifdef OPTIK_LEGACY_KERNELS
-    quadk = quadk && sk != SK_LANE && !(sk == SK_COOP && ch->n <= 7);
-    coop = !quadk && !widek && sk == SK_COOP;
-#endif
+    const bool quadk = !widek;
     // the throughput form for n <= 7: one restart per lane, bounded sub-problems in class order (ik_lane64.hpp)
     // (the default from one full load of the chip on -- 64 restarts for each of its four waves per CU: below that a
     // launch is as long as its longest restart, and the quad solver's trip is the shorter one; tools/lane_vs_quad_probe.py)
@@ -1296,8 +1188,8 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     lanek = lanek && !quad_latency
             && (lane_forced || ((long long)cols >= (long long)cus * lane_solve_waves_per_cu() * 64
                                 && !(early && (flags & OPTIK_HIP_IK_RESTART_MAJOR))));
-    long long cap = (long long)cus * (lanek ? lane_solve_waves_per_cu() : quadk ? (quad_latency ? 4 : quad_solve_waves_per_cu(ch->n)) : (coop ? 4 : (widek ? wide_waves_per_cu : ch->waves_per_cu)));
-    const long long per_wave_max = lanek ? WAVE : ((coop || quadk) ? QUADS_PER_WAVE_HOST : WAVE);
+    long long cap = (long long)cus * (lanek ? lane_solve_waves_per_cu() : quadk ? (quad_latency ? 4 : quad_solve_waves_per_cu(ch->n)) : wide_waves_per_cu);
+    const long long per_wave_max = (quadk && !lanek) ? QUADS_PER_WAVE_HOST : WAVE;
     // fewer work items than the chip holds: one restart per wave (or as few as fit).  A
     // restart-major Speed batch keeps about eight restarts per target in flight: the waves pull
     // the higher indices of the targets still unsolved as they go
@@ -1368,29 +1260,7 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     } else if (quadk) {
         HIP_TRY(quad_solve_launch(ch->n, ch->tip, grid, stream, a, &lds, quad_latency));
     }
-#ifdef OPTIK_LEGACY_KERNELS
-    else if (coop) {
-#define CALL_COOP(NN, TT)                                                                            \
-    lds = (int)(sizeof(ChainDev) + sizeof(double) * (coop_wave_lds<4>() + COOP_GROUPS_PER_WAVE * coop_rec_lds<NN>())); \
-    hipLaunchKernelGGL((ik_coop_kernel<NN, TT>), dim3(grid), dim3(WAVE), 0, stream, a)
-#define CALL_COOP_N(NN) do { if (ch->tip) { CALL_COOP(NN, true); } else { CALL_COOP(NN, false); } } while (0)
-        switch (ch->n) {
-        case 1: CALL_COOP_N(1); break; case 2: CALL_COOP_N(2); break; case 3: CALL_COOP_N(3); break;
-        case 4: CALL_COOP_N(4); break; case 5: CALL_COOP_N(5); break; case 6: CALL_COOP_N(6); break;
-        default: CALL_COOP_N(7); break;
-        }
-#undef CALL_COOP_N
-#undef CALL_COOP
-    } else {
-#define CALL(NN, TT)                                                                                 \
-    lds = (int)(sizeof(ChainDev) + sizeof(double) * NnlsLayout<NN>::SLOTS * WAVE);                   \
-    hipLaunchKernelGGL((ik_solve_kernel<NN, TT>), dim3(grid), dim3(WAVE), 0, stream, a)
-    OPTIK_DISPATCH(ch, CALL);
-#undef CALL
-    }
-#else
     else return fail(OPTIK_HIP_EUNSUPPORTED, "no solver for this chain in this build");
-#endif
     HIP_TRY(hipGetLastError());
     if (ch->timing) { HIP_TRY(hipEventRecord(ch->ev1[ev_slot], stream)); ch->ev_count += 1; }
     ch->last.grid = grid; ch->last.block = WAVE; ch->last.lds_bytes = lds; ch->last.tiles = n_tiles;
@@ -1714,21 +1584,6 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
         a.nn_slack = opt().engine_nnls_slack > 0 ? opt().engine_nnls_slack : 0;
         a.cont_pass = 0;
         a.cont_count = nullptr; a.cont_list = nullptr; a.cont_cap = 0;
-        // five-kernel trips (default), or fused trips (OPTIK_ENG_FUSED=1: bucket -> NNLS -> slot kernel).
-        // Measured (r2, Panda, 20 / 48 steps): fused 21.5 / 24.7 M restarts/s against 22.2 / 25.7 M --
-        // the slot kernel takes 150 us where eval + update + finish take 190, but its waves live three
-        // times as long, so the two small kernels of a trip wait longer for CU slots behind the other
-        // sub-pools' slot kernels (bucket 17 -> 55 us, NNLS 97 -> 110 us), and a refilled slot waits a
-        // trip for its first evaluation; HBM bytes per restart fall by 4 % only (111 -> 106 KB: the
-        // stores, 45 % of the traffic, go to memory either way and most loads are of lines the
-        // previous trip wrote).  Kept as a knob: identical results (tests/test_gpu_parity.py).
-#ifdef OPTIK_LEGACY_KERNELS
-        const bool fused = std::getenv("OPTIK_ENG_FUSED") && std::atoi(std::getenv("OPTIK_ENG_FUSED")) != 0;  // (legacy builds only)
-#else
-        const bool fused = false;
-#endif
-        a.fused = fused ? 1 : 0;
-        ch->eng_fused = a.fused;
         const unsigned cont_waves_per_cu = 4;  // grid of the continuation launch (it grid-strides over the lists)
         a.nn_total = ch->eng_nn_total;
         a.exec_evals = ch->eng_nn_total + 1;
@@ -1817,7 +1672,6 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
                     P.a.nn_cls[par] = ch->eng_list + (size_t)par * ch->eng_C + lo;
                 }
                 P.a.refill_count = cnt + 2 * NN_CLASSES;
-                P.a.refill_count_next = cnt + 2 * NN_CLASSES + 2;
                 P.a.n_active = cnt + 2 * NN_CLASSES + 1;
                 P.a.refill_list = ch->eng_refill + lo;
                 if (nn_cont) {
@@ -1889,31 +1743,6 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
 #define ENG_LAUNCH_LDS(kernel, grid, block, lds) do { if (tev0) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, tev0, tev1, 0, a); \
                                                        else hipLaunchKernelGGL(kernel, grid, block, lds, stream, a); } while (0)
 #define ENG_LAUNCH(kernel, grid, block) ENG_LAUNCH_LDS(kernel, grid, block, 0)
-#ifdef OPTIK_LEGACY_KERNELS
-                if (fused) {
-                    // trip t: bucket pass over what the previous slot kernel left, NNLS, slot kernel
-                    unsigned int *cnt = ch->eng_counters + (size_t)(&P - pools) * PCB;
-                    a.refill_count = cnt + 2 * NN_CLASSES + ((trip & 1) ? 2 : 0);
-                    a.refill_count_next = cnt + 2 * NN_CLASSES + ((trip & 1) ? 0 : 2);
-                    TEV(1);
-                    if (tev0) hipExtLaunchKernelGGL(eng_bucket_kernel, dim3((unsigned)cus), dim3(256), 0, stream, tev0, tev1, 0, a);
-                    else hipLaunchKernelGGL(eng_bucket_kernel, dim3((unsigned)cus), dim3(256), 0, stream, a);
-                    TEV(2);
-#define M_NNLS(NN) ENG_LAUNCH((eng_nnls_coop_kernel<NN>), dim3(nn_blocks), dim3(OPTIK_ENG_NNLS_BLOCK))
-                    DISPATCH_N(M_NNLS);
-#undef M_NNLS
-                    TEV(0);
-#define M_SLOT_T(NN) ENG_LAUNCH_LDS((eng_slot_kernel<NN, true>), dim3(blocks * (OPTIK_ENG_SLOT_BLOCK / OPTIK_ENG_UPD_BLOCK)), dim3(OPTIK_ENG_UPD_BLOCK), eval_lds)
-#define M_SLOT_F(NN) ENG_LAUNCH_LDS((eng_slot_kernel<NN, false>), dim3(blocks * (OPTIK_ENG_SLOT_BLOCK / OPTIK_ENG_UPD_BLOCK)), dim3(OPTIK_ENG_UPD_BLOCK), eval_lds)
-                    if (tip) DISPATCH_N(M_SLOT_T);
-                    else DISPATCH_N(M_SLOT_F);
-#undef M_SLOT_T
-#undef M_SLOT_F
-                    if (timed) ch->eng_tcount += 1;
-                    ch->eng_launches += 1;
-                    continue;
-                }
-#endif
                 TEV(0);
                 if (trip > 0) {
 #define M_EVAL_T(NN) ENG_LAUNCH_LDS((eng_eval_kernel<NN, true>), dim3(blocks), dim3(OPTIK_ENG_SLOT_BLOCK), eval_lds)
@@ -2013,20 +1842,10 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
             return 0;
         };
         ch->eng_launches = 0;
-        // hand-over to the tail kernel once this few restarts are left in all sub-pools together
-        // (the cooperative tail holds 16 restarts per wave, 16 384 resident at once -- its waves pull
-        // the rest of the list as groups finish -- at half the time per iteration of the per-lane
-        // one: measured best between 24 k and 48 k since the group evaluation, 24.3 against 23.9 M
-        // restarts/s at 16 k and 22.4 at 4 096 for a 20-step run)
-        // The tail is the quad solver (ik_quad_tail.hpp): it runs a restart ~2.7 times as fast as round 2's cooperative
-        // kernel, so it takes over early.  (-DOPTIK_LEGACY_KERNELS builds: solve_kernel = coop / lane select the
-        // tails of rounds 2 / 1.)
-        bool tail_quad = true;
+        // hand-over to the tail kernel -- the quad solver fed from the slot pool, ik_quad_tail.hpp -- once this few
+        // restarts are left in all sub-pools together (it runs a restart ~2.7 times as fast as a pool trip that
+        // is mostly empty, so it takes over early)
         unsigned long long tail_max = total / 8, tail_cap = 131072ull;
-#ifdef OPTIK_LEGACY_KERNELS
-        tail_quad = opt().solve_kernel != SK_COOP && opt().solve_kernel != SK_LANE;
-        if (!tail_quad) { tail_max = total / 16; tail_cap = opt().solve_kernel == SK_LANE ? 4096ull : 32768ull; }
-#endif
         if (tail_max > tail_cap) tail_max = tail_cap;
         if (tail_max < 64) tail_max = 64;
         if (opt().engine_tail_max >= 0) tail_max = (unsigned long long)opt().engine_tail_max;
@@ -2062,7 +1881,7 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
             HIP_TRY(hipMemsetAsync(t_count, 0, sizeof(unsigned int), stream));
             hipLaunchKernelGGL(eng_tail_list_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream,
                                ch->eng_i32, (unsigned long long)C, t_count, t_list);
-            if (tail_quad) {
+            {
                 // persistent waves of the quad solver, each quad pulling the next live slot of the list
                 TailLaunch tq;
                 std::memset(&tq, 0, sizeof tq);
@@ -2095,45 +1914,7 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
                 ch->eng_tail_solver = 3;
                 for (int p2 = 0; p2 < n_pools; ++p2) pools[p2].done = true;
                 all_done = true;
-                continue;
             }
-#ifdef OPTIK_LEGACY_KERNELS
-            bool tail_coop = true;  // (n <= 7 always here) the cooperative tail, unless the per-lane one is asked for
-            if (opt().solve_kernel == SK_LANE) tail_coop = false;
-            const unsigned long long cap_waves = (unsigned long long)cus * (unsigned long long)(tail_coop ? 4 : ch->waves_per_cu);
-            unsigned long long lanes = (left + cap_waves - 1) / cap_waves;
-            if (lanes < 1) lanes = 1;
-            if (lanes > (tail_coop ? (unsigned long long)COOP_GROUPS_PER_WAVE : (unsigned long long)WAVE)) lanes = tail_coop ? COOP_GROUPS_PER_WAVE : WAVE;
-            const unsigned t_grid = (unsigned)((left + lanes - 1) / lanes);
-            const int lanes_i = (int)lanes;
-            EngArgs ta = pools[0].a;
-            ta.slot_base = 0;
-            ta.n_slots = C;
-            ta.tail_deadline_ticks = 0;
-            if (deadline_s > 0.0) {
-                const double left_s = deadline_s - since_call();
-                const double khz = ch->wall_clock_khz > 0 ? (double)ch->wall_clock_khz : 100000.0;
-                ta.tail_deadline_ticks = left_s > 0.0 ? (unsigned long long)(left_s * khz * 1e3) + 1ull : 1ull;
-            }
-#define M_TAIL_T(NN) hipLaunchKernelGGL((eng_tail_kernel<NN, true>), dim3(t_grid), dim3(WAVE), 0, stream, ta, t_list, t_count, lanes_i)
-#define M_TAIL_F(NN) hipLaunchKernelGGL((eng_tail_kernel<NN, false>), dim3(t_grid), dim3(WAVE), 0, stream, ta, t_list, t_count, lanes_i)
-#define M_TAILC_T(NN) hipLaunchKernelGGL((eng_tail_coop_kernel<NN, true>), dim3(t_grid), dim3(WAVE), 0, stream, ta, t_list, t_count, lanes_i)
-#define M_TAILC_F(NN) hipLaunchKernelGGL((eng_tail_coop_kernel<NN, false>), dim3(t_grid), dim3(WAVE), 0, stream, ta, t_list, t_count, lanes_i)
-            if (tail_coop) { if (tip) DISPATCH_N(M_TAILC_T); else DISPATCH_N(M_TAILC_F); }
-            else if (tip) DISPATCH_N(M_TAIL_T);
-            else DISPATCH_N(M_TAIL_F);
-#undef M_TAILC_T
-#undef M_TAILC_F
-#undef M_TAIL_T
-#undef M_TAIL_F
-            HIP_TRY(hipGetLastError());
-            ch->eng_tail_restarts = (int)left;
-            ch->eng_tail_solver = tail_coop ? 2 : 1;
-            for (int p2 = 0; p2 < n_pools; ++p2) pools[p2].done = true;
-            all_done = true;
-#else
-            return fail(OPTIK_HIP_EUNSUPPORTED, "engine tail: no solver in this build");
-#endif
         }
         if (ENG_DEBUG_PRINTS)
             fprintf(stderr, "[optik engine] loop %.2f ms (drain from %.2f ms), host waited on the GPU %.2f ms (bulk) + %.2f ms (drain), %d launches\n",
@@ -2186,8 +1967,7 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
         for (int k = 0; k < 4; ++k) {
             double sum = 0.0;
             int cnt = 0;
-            // (fused trips time three kernels: [0] slot, [1] bucket, [2] NNLS)
-            for (int i = 0; i < ch->eng_tcount && !(fused && k == 3); ++i) {
+            for (int i = 0; i < ch->eng_tcount; ++i) {
                 const int trip_i = i + 1;  // sample i was taken on trip i + 1
                 if (k != 2 && trip_i % 8 != 2) continue;
                 float ms = 0.0f;
@@ -2208,7 +1988,7 @@ int optik_hip_engine_run_ex(optik_hip_chain *ch, void *stream_v, double deadline
                     const int i = t - 1;
                     if (i >= 0 && i < ch->eng_tcount)
                         for (int k = 0; k < 4; ++k)
-                            if ((k == 2 || t % 8 == 2) && !(fused && k == 3)) hipEventElapsedTime(&ms[k], ch->eng_tev[k][i][0], ch->eng_tev[k][i][1]);
+                            if (k == 2 || t % 8 == 2) hipEventElapsedTime(&ms[k], ch->eng_tev[k][i][0], ch->eng_tev[k][i][1]);
                     fprintf(fp, "%d,%u,%u,%.4f,%.4f,%.4f,%.4f\n", t, h[2 * t], h[2 * t + 1], ms[0], ms[1], ms[2], ms[3]);
                 }
                 fclose(fp);
@@ -2299,7 +2079,6 @@ int optik_hip_nnls_step_profile(unsigned long long *out8) {
     return hipMemcpyToSymbol(HIP_SYMBOL(optik::g_nnls_prof), z, sizeof z) == hipSuccess ? 0 : -1;
 }
 #endif
-int optik_hip_engine_last_fused(const optik_hip_chain *ch) { return ch ? ch->eng_fused : 0; }
 
 /* Tuning options (tests, tools): see `struct Options`.  Names: solve_kernel (0 auto, 1 quad, 2 lane64, 3 general),
  * engine_slots, engine_pools, engine_nnls_budget, engine_nnls_slack, engine_tail_max, engine_compact, wide_form

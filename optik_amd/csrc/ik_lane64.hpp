@@ -134,7 +134,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
     static_assert(N <= 7, "the throughput form of chains with at most seven joints");
     const double alfmin = 0.1;
     const int lane = (int)(threadIdx.x & 63u);
-    // SLSQP state of the lane's restart (names as in solve_wave)
+    // SLSQP state of the lane's restart (names as in the oracle)
     double x[N], x0[N], g[N], s[N], l[NL];
     double xbest[N], xprev[N];
     double f = 0.0, f0 = 0.0, t0 = 0.0, h3 = 0.0, alpha = 1.0;

@@ -1,8 +1,8 @@
 // ik_quad.hpp -- the restart solver with one restart per QUAD and its state SPREAD over the quad.
 //
-// ik_coop.hpp (round 2) already gives a restart four lanes, but keeps the whole SLSQP state in the
+// (Round 2's leader-lane solver gave a restart four lanes too, but kept the whole SLSQP state in the
 // quad's leader: 512 registers + 428 B of scratch, one wave per SIMD, three lanes idle outside the
-// NNLS and the Jacobian columns.  Here lane q of a quad owns joints / rows / columns q and q + 4:
+// NNLS and the Jacobian columns.)  Here lane q of a quad owns joints / rows / columns q and q + 4:
 //
 //   by joint (2 doubles per lane each)   x, x0, g, s, x_best, x_prev, lb, ub, f (LSQ right-hand side)
 //   row j of the packed LDL' factor      l(i, j), i < j, and the diagonal l(j, j)       (11 doubles, n = 7)
@@ -688,7 +688,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
     // parking place of what the evaluation does not touch (lane ql's i-th double at [4 i + ql])
 #define blk (nnls_lds + (unsigned)(wave_lane_now() >> 2) * NnlsQuadGeom<N>::STRIDE)
 
-    // SLSQP state of the quad's restart: by joint, by row, and the replicated scalars (names as in solve_wave)
+    // SLSQP state of the quad's restart: by joint, by row, and the replicated scalars (names as in the oracle)
     double x[NS], x0[NS], g[NS], sv[NS];
     double Lr[NS][NM], dg[NS];
     // The replicated scalars of the restart are the same in the four lanes of the quad, so each is kept
@@ -991,7 +991,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
         OPTIK_PROF_END(4);
 
         // ---- labels 110/130: (reset,) search direction, descent test: a wave-uniform loop, every
-        // quad that needs a direction takes part in every step of a round (ik_coop.hpp:coop_direction)
+        // quad that needs a direction takes part in every step of a round
         OPTIK_PROF_BEGIN();
         while (wave_any(need_dir)) {
             OPTIK_PROF_COUNT(2, 1);  // (direction passes: more than one per trip when some quad has to reset and search again)

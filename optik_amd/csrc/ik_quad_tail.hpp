@@ -1,18 +1,17 @@
 // ik_quad_tail.hpp -- the last restarts of an engine run, finished by the quad solver.
 //
 // When an engine run's queue is empty its slot pool drains: every trip of the five phase kernels
-// covers fewer slots at the same launch latencies.  ik_tail.hpp hands the last restarts to a kernel
-// without launch boundaries; this is the same hand-over onto the quad solver (ik_quad.hpp), which
-// runs a restart nearly three times as fast as round 2's cooperative kernel -- so the hand-over can
-// come earlier.  A quad that is free pulls the next entry of the list of live slots, reads the
+// covers fewer slots at the same launch latencies.  The last restarts are therefore handed to a kernel
+// without launch boundaries: the quad solver (ik_quad.hpp), fed from the slot pool instead of the work
+// queue.  A quad that is free pulls the next entry of the list of live slots, reads the
 // restart's state from the slot planes (each lane its own joints / rows; the restart's scalars one
 // per lane, as the solver keeps them) and carries on from the slot's state at the trip boundary:
-//   ST_EVAL_FIRST / ST_FRESH*  seeded, not evaluated yet
+//   ST_EVAL_FIRST              seeded, not evaluated yet
 //   ST_EVAL_TRIAL              line-search trial point waiting for its evaluation
 //   ST_NNLS                    direction deferred to an NNLS launch (pending or suspended): the LSQ
 //                              call is made again from (l, g, x) -- the carry record is not needed
 //   ST_DEAD                    terminated, waiting to be published
-// Results are published through the slot's job exactly as eng_eval_body / ik_tail.hpp do.
+// Results are published through the slot's job exactly as eng_eval_body does.
 // Arithmetic and decisions are quad_wave's: same bits as every other path.
 #pragma once
 
@@ -48,7 +47,7 @@ struct EngTail : EngTailData {
         pending = false;
         ret = 0;
         double f0v = 0.0, h3v = 0.0, alv = 1.0, fc = 0.0;
-        const bool fresh = st == ST_EVAL_FIRST || st == ST_FRESH0 || st == ST_FRESH1;
+        const bool fresh = st == ST_EVAL_FIRST;
         const bool has_factor = !fresh && st != ST_DEAD;
         const bool trial = has_factor && st != ST_NNLS;
 #pragma unroll

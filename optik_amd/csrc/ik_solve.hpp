@@ -1,17 +1,16 @@
-// ik_solve.hpp -- one random restart per lane: seed, SLSQP state machine, NLopt
-// stopping rules, classification.
+// ik_solve.hpp -- what every single-launch solver shares: NLopt's result codes and stopping rules, the restart seeds
+// (ChaCha8), the work queue of a launch.
 //
-// Restates the closure of /root/reference/crates/optik/src/lib.rs:301-391 and
-// the nlopt_slsqp() driver it calls (un-vendored).  Instead
-// of NLopt's reverse-communication call/return, every lane runs the same loop
+// Restates pieces of the closure of /root/reference/crates/optik/src/lib.rs:301-391 and of the nlopt_slsqp()
+// driver it calls (un-vendored).  Instead of NLopt's reverse-communication call/return, every
+// solver runs the same loop
 //
 //     evaluate f, g at x  ->  bookkeeping / stop tests  ->  (line search accepted:
 //     BFGS update + next search direction)  ->  next trial point
 //
-// so the whole wave executes one objective evaluation per trip regardless of
-// which restart is in which SLSQP phase; only the accept / reject branch
-// diverges.  Numerics and decisions are bit-identical to the oracle's
-// ok_solve_restart().
+// so a wave executes one objective evaluation per trip regardless of which restart is in which SLSQP phase
+// (ik_lane64.hpp: a restart per lane; ik_quad.hpp: a restart per quad of lanes).  Numerics and decisions are
+// bit-identical to the oracle's ok_solve_restart().
 #pragma once
 
 #include "ik_slsqp.hpp"
@@ -197,250 +196,6 @@ OPTIK_DEV unsigned long long fetch_items(unsigned long long *counter, bool want)
     }
     const unsigned rank = (unsigned)__popcll(mask & ((1ull << (threadIdx.x & 63u)) - 1ull));
     return base + rank;
-}
-
-// One 64-lane wave solving restarts until the queue is empty.
-template <int N, bool TIP>
-OPTIK_DEV void solve_wave(const ChainDev &ch, const EvalParams &ep, const SolveParams &sp,
-                          const uint32_t (&key)[8], const double (&scale)[MAX_DOF], const WorkQueue &wq,
-                          const NnlsWs<N> &ws) {
-    constexpr int NL = N * (N + 1) / 2;
-    const double alfmin = 0.1;
-    // SLSQP state of the lane's current restart
-    double x[N], x0[N], g[N], s[N], l[NL];
-    double xbest[N], xprev[N];
-    double f = 0.0, f0 = 0.0, t0 = 0.0, h3 = 0.0, alpha = 1.0;
-    double minf = __builtin_huge_val(), fprev = __builtin_huge_val();
-    int ireset = 0, line = 0, nevals = 0;  // (Kraft's iter only feeds maxiter, which NLopt leaves unbounded)
-    bool first = true;
-    // the work item
-    Pose target;
-    unsigned long long item = 0, index = 0;
-    unsigned tslot = 0;
-    bool active = false, want = (int)(threadIdx.x & 63u) < wq.lanes;
-#pragma unroll
-    for (int i = 0; i < N; ++i) { x[i] = 0.0; x0[i] = 0.0; g[i] = 0.0; s[i] = 0.0; xbest[i] = 0.0; xprev[i] = 0.0; }
-#pragma unroll
-    for (int i = 0; i < NL; ++i) l[i] = 0.0;
-    target.t = V3{0, 0, 0};
-    target.q = Q4{0, 0, 0, 1};
-    OPTIK_PROF_DECL;
-
-    for (;;) {
-        OPTIK_PROF_BEGIN();
-        // ---- refill: lanes without a restart pull the next work item -------------
-        // (the seed generation below runs for the whole wave, so wait until several lanes
-        // are idle -- or none is busy -- before paying for it)
-        const unsigned n_want = (unsigned)__popcll(__ballot(want));
-        if (n_want >= (unsigned)(wq.lanes < REFILL_BATCH ? wq.lanes : REFILL_BATCH) || (n_want > 0 && !wave_any(active))) {
-            const unsigned long long it = fetch_items(wq.next_item, want);
-            if (want) {
-                want = false;
-                if (it < wq.total_items) {
-                    unsigned long long r;
-                    if (wq.restart_major) { r = it / wq.n_targets; tslot = (unsigned)(it - r * wq.n_targets); }
-                    else { tslot = (unsigned)(it / wq.n_restarts); r = it - (unsigned long long)tslot * wq.n_restarts; }
-                    item = (unsigned long long)tslot * wq.n_restarts + r;  // output column
-                    index = wq.restart_begin + r;
-                    target = load_pose(wq.targets + (size_t)tslot * 7);
-                    // lib.rs:366-370: restart 0 starts from the caller's seed
-                    restart_seed<N>(key, ch.lb, scale, index, x);
-                    if (index == 0) {
-                        const double *x0p = wq.x0 + (size_t)tslot * N;
-#pragma unroll
-                        for (int i = 0; i < N; ++i) x[i] = x0p[i];
-                    }
-#pragma unroll
-                    for (int i = 0; i < N; ++i) { xbest[i] = x[i]; xprev[i] = x[i]; x0[i] = x[i]; s[i] = 0.0; g[i] = 0.0; }
-                    f = 0.0; f0 = 0.0; t0 = 0.0; h3 = 0.0; alpha = 1.0;
-                    minf = __builtin_huge_val(); fprev = __builtin_huge_val();
-                    ireset = 0; line = 0; nevals = 0;
-                    first = true;
-                    active = true;
-                }
-            }
-        }
-        OPTIK_PROF_END(0);  // refill
-        if (!wave_any(active)) break;
-        OPTIK_PROF_COUNT(7, 1);  // trips
-
-        int32_t ret = 0;
-        if (active) {
-            // lib.rs:308: abandon when timed out or a lower-index restart succeeded
-            bool stop = false;
-            if (wq.first_success) {
-                const unsigned long long fs = __hip_atomic_load(wq.first_success + tslot, __ATOMIC_RELAXED,
-                                                                __HIP_MEMORY_SCOPE_AGENT);
-                stop = wq.find_any ? (fs != ~0ull) : (fs < index);
-            }
-            if (wq.deadline && (unsigned long long)wall_clock64() > wq.deadline) stop = true;
-            if (stop) ret = RES_FORCED_STOP;
-        }
-        double gn[N];
-        double fn = 0.0;
-        const bool do_eval = active && ret == 0;
-        OPTIK_SCHED_FENCE();
-        OPTIK_PROF_BEGIN();
-        if (do_eval) fn = eval_fg<N, TIP>(ch, ep, target, x, gn);
-        OPTIK_PROF_END(1);  // eval
-        OPTIK_SCHED_FENCE();
-        OPTIK_PROF_BEGIN();
-        if (do_eval) {
-            f = fn;
-            ++nevals;
-            // NLopt: update best point so far; stopval is tested after every evaluation
-            if (f < minf) {
-                minf = f;
-#pragma unroll
-                for (int i = 0; i < N; ++i) xbest[i] = x[i];
-            }
-            bool need_dir = false, reset = false;
-            if (minf < sp.stopval) {
-                ret = RES_STOPVAL_REACHED;
-            } else if (nevals >= MAX_EVALS_CAP) {
-                ret = RES_ITER_CAP;
-            } else if (first) {
-                // SLSQPB label 100/110: initialise, reset the BFGS matrix
-                first = false;
-#pragma unroll
-                for (int i = 0; i < N; ++i) g[i] = gn[i];
-                need_dir = true;
-                reset = true;
-            } else {
-                // label 220: L1 merit (m = 0: the objective itself)
-                const double h1 = f - t0;
-                bool accept = false;
-                if (__builtin_isfinite(h1)) {
-                    if (h1 <= h3 / 10.0 || line > 10) accept = true;
-                    else {
-                        const double a = h3 / ((h3 - h1) * 2.0);
-                        alpha = (a > alfmin) ? a : alfmin;
-                    }
-                } else {
-                    const double a = alpha * 0.5;
-                    alpha = (a > alfmin) ? a : alfmin;
-                }
-                if (accept) {
-                    // line search complete (mode -1): NLopt re-evaluates f and the
-                    // gradient there unless the accepted trial was the first one
-                    if (line > 1) ++nevals;
-                    if (!__builtin_isinf(fprev)) {
-                        if (__builtin_fabs(f - fprev) < sp.ftol_abs) ret = RES_FTOL_REACHED;
-                        else if (stop_x<N>(sp, x, xprev)) ret = RES_XTOL_REACHED;
-                    }
-                    fprev = f;
-#pragma unroll
-                    for (int i = 0; i < N; ++i) xprev[i] = x[i];
-                    if (ret == 0 && nevals >= MAX_EVALS_CAP) ret = RES_ITER_CAP;
-                    if (ret == 0) {
-                        // label 260: BFGS update with u = g_new - g_old
-                        double u[N];
-#pragma unroll
-                        for (int i = 0; i < N; ++i) { u[i] = gn[i] - g[i]; g[i] = gn[i]; }
-                        OPTIK_SCHED_FENCE();
-                        OPTIK_PROF_SUB_BEGIN();
-                        bfgs_update<N>(l, s, u);
-                        OPTIK_PROF_SUB_END(4);  // BFGS (inside slot 2)
-                        OPTIK_SCHED_FENCE();
-                        need_dir = true;
-                    }
-                }
-            }
-            // labels 110/130: (reset,) search direction, descent test
-            while (need_dir) {
-                if (reset) {
-                    ++ireset;
-                    if (ireset > 5) {
-                        // label 255 with acc = 0 -> mode 8; NLopt's relaxed test vs (f0, x0)
-                        ret = RES_ROUNDOFF_LIMITED;
-                        if (__builtin_fabs(f - f0) < sp.ftol_abs && !__builtin_isinf(f0)) ret = RES_FTOL_REACHED;
-                        else if (stop_x<N>(sp, x, x0)) ret = RES_XTOL_REACHED;
-                        break;
-                    }
-#pragma unroll
-                    for (int i = 0; i < NL; ++i) l[i] = 0.0;
-#pragma unroll
-                    for (int i = 0; i < N; ++i) l[lidx<N>(i, i)] = 1.0;
-                }
-                double lo[N], hi[N];
-#pragma unroll
-                for (int i = 0; i < N; ++i) { lo[i] = ch.lb[i] - x[i]; hi[i] = ch.ub[i] - x[i]; }
-                OPTIK_SCHED_FENCE();
-                OPTIK_PROF_SUB_BEGIN();
-                unsigned long long nnls_cycles = 0;
-                const int lmode = lsq_box<N>(ws, l, g, lo, hi, s, nnls_cycles);
-                OPTIK_PROF_SUB_END(5);  // LSQ incl. NNLS (inside slot 2)
-                OPTIK_PROF_COUNT(6, nnls_cycles);
-                OPTIK_SCHED_FENCE();
-                if (lmode != 1) {
-                    // NLopt: modes 5,6,7 -> ROUNDOFF_LIMITED; 3,4,9 -> FAILURE
-                    ret = (lmode == 5 || lmode == 6 || lmode == 7) ? RES_ROUNDOFF_LIMITED : RES_FAILURE;
-                    break;
-                }
-                // (g is also Kraft's v: the gradient at the start of the line search)
-                double gs = 0.0;
-#pragma unroll
-                for (int i = 0; i < N; ++i) x0[i] = x[i];
-                f0 = f;
-#pragma unroll
-                for (int i = 0; i < N; ++i) gs += g[i] * s[i];
-                t0 = f;
-                h3 = gs;  // h3 = gs - h1 * h4 with h1 = 0 (no constraints)
-                if (h3 >= 0.0) { reset = true; continue; }
-                line = 0;
-                alpha = 1.0;
-                break;
-            }
-            if (ret == 0) {
-                // label 190: next trial point x = x0 + alpha * s, clipped (NLopt)
-                ++line;
-                h3 = alpha * h3;
-#pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    s[i] *= alpha;
-                    double xi = x0[i];
-                    xi += s[i];
-                    if (xi < ch.lb[i]) xi = ch.lb[i];
-                    else if (xi > ch.ub[i]) xi = ch.ub[i];
-                    x[i] = xi;
-                }
-            }
-        }
-        OPTIK_PROF_END(2);  // bookkeeping + BFGS + direction
-        OPTIK_PROF_BEGIN();
-        // ---- a restart ended: classify (lib.rs:376-379), publish, free the lane ----
-        if (active && ret != 0) {
-            const bool success = (sp.ok_stopval && ret == RES_STOPVAL_REACHED)
-                                 || (sp.ok_ftol && ret == RES_FTOL_REACHED)
-                                 || (sp.ok_xtol && ret == RES_XTOL_REACHED);
-            if (wq.out_x) {
-#pragma unroll
-                for (int i = 0; i < N; ++i) wq.out_x[(size_t)i * wq.total_items + item] = xbest[i];
-            }
-            if (wq.out_f) wq.out_f[item] = minf;
-            if (wq.out_status) wq.out_status[item] = ret;
-            if (wq.out_evals) wq.out_evals[item] = nevals;
-            // selection key (lib.rs:402-407): Quality = ||x - x0||_2, Speed = index
-            double k = __builtin_huge_val();
-            if (success) {
-                if (wq.quality) {
-                    const double *x0p = wq.x0 + (size_t)tslot * N;
-                    double acc = 0.0;
-#pragma unroll
-                    for (int i = 0; i < N; ++i) { const double d = xbest[i] - x0p[i]; acc += d * d; }
-                    k = __builtin_sqrt(acc);
-                } else {
-                    k = (double)index;
-                    if (wq.first_success) atomicMin(wq.first_success + tslot, index);
-                }
-            }
-            if (wq.out_key) wq.out_key[item] = k;
-            active = false;
-            want = true;
-        }
-        OPTIK_PROF_END(3);  // publish
-    }
-    OPTIK_PROF_FLUSH(wq.prof);
 }
 
 }  // namespace optik

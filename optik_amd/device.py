@@ -184,8 +184,8 @@ class HipChain:
         return int(nat.lib().optik_hip_engine_last_trips(self._h))
 
     def engine_last_tail(self):
-        """(solver, restarts) of the last engine_run's tail: solver 0 none, 1 per-lane kernel, 2 cooperative
-        kernel, 3 quad solver; restarts = how many (upper bound) were taken over from the slot pool."""
+        """(solver, restarts) of the last engine_run's tail: solver 0 none, 3 quad solver (1 and 2 were the kernels of
+        rounds 1 and 2); restarts = how many (upper bound) were taken over from the slot pool."""
         n = C.c_int32(0)
         solver = int(nat.lib().optik_hip_engine_last_tail(self._h, C.byref(n)))
         return solver, int(n.value)
@@ -200,11 +200,7 @@ class HipChain:
         launches = C.c_int32(0)
         pools = int(nat.lib().optik_hip_engine_last_pools(self._h, C.byref(launches)))
         executed = int(nat.lib().optik_hip_engine_executed_evals(self._h))
-        if int(nat.lib().optik_hip_engine_last_fused(self._h)):
-            return dict(slot_ms=ms[0], bucket_ms=ms[1], nnls_ms=ms[2], fused=True,
-                        sampled_trips=cnt.value, nnls_problems=prob.value, pools=pools,
-                        launches=launches.value, evals_executed=executed, slot_trips=executed)
-        return dict(eval_ms=ms[0], update_ms=ms[1], nnls_ms=ms[2], finish_ms=ms[3], fused=False,
+        return dict(eval_ms=ms[0], update_ms=ms[1], nnls_ms=ms[2], finish_ms=ms[3],
                     sampled_trips=cnt.value, nnls_problems=prob.value, pools=pools,
                     launches=launches.value, evals_executed=executed, slot_trips=executed)
 

@@ -53,10 +53,9 @@ def main():
     out = (C.c_ulonglong * 8)()
     nat.lib().optik_hip_phase_profile.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     nat.check(nat.lib().optik_hip_phase_profile(hc._h, out))
-    # cooperative kernel (n <= 7; OPTIK_SOLVE_KERNEL=lane profiles round 1's: slot 2 = its whole update)
-    names = ["refill", "eval", "update(lane krn)", "publish", "bookkeeping+bfgs", "direction(total)", "  nnls", "trips"]
+    names = ["refill", "eval", "(unused)", "publish", "bookkeeping+bfgs", "direction(total)", "  nnls", "trips"]
     v = list(out)
-    total = v[0] + v[1] + v[2] + v[3] + (0 if os.environ.get("OPTIK_SOLVE_KERNEL") == "lane" else v[4] + v[5])
+    total = v[0] + v[1] + v[2] + v[3] + v[4] + v[5]
     trips = max(v[7], 1)
     print(f"{robot}: R={R}, wave-trips={trips}, mean evals/restart={float(bufs['evals'].double().mean()):.1f}")
     for n_, c in zip(names[:7], v[:7]):

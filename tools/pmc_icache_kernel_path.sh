@@ -15,7 +15,7 @@ import collections, csv, glob, sys
 f = glob.glob(f"{sys.argv[1]}/**/*counter_collection.csv", recursive=True)[0]
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 for r in csv.DictReader(open(f)):
-    for nm in ("ik_quad_kernel", "ik_coop_kernel", "ik_solve_kernel"):
+    for nm in ("ik_quad_kernel", "ik_lane_kernel"):
         if nm in r["Kernel_Name"]:
             acc[int(r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
 last = acc[max(acc)]

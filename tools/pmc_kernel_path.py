@@ -18,7 +18,7 @@ out, cmd = sys.argv[1], sys.argv[2]
 line = json.loads([ln for ln in open(f"{out}/bench_unprofiled.json") if ln.startswith('{"metric"')][0])
 reps = line["config"]["reps"]
 per_launch = line["roofline"]["units_per_launch"]
-KERNELS = ("ik_quad_kernel", "ik_lane_kernel", "ik_coop_kernel", "ik_solve_kernel", "wide_solve_kernel", "wide_solve_coop_kernel")
+KERNELS = ("ik_quad_kernel", "ik_lane_kernel", "wide_solve_kernel", "wide_solve_coop_kernel")
 
 
 def timed_rows(d):

@@ -16,7 +16,7 @@ ev = sorted((int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0, r["Ke
             for r in run if "eng_" in r["Kernel_Name"])
 end = max(e for _, e, _, _ in ev)
 print(f"timed run: {end / 1e6:.2f} ms of engine kernels")
-for name in ("eng_tail_list_kernel", "eng_tail_coop_kernel", "eng_tail_kernel"):
+for name in ("eng_tail_list_kernel", "eng_tail_quad_kernel"):
     for s, e, k, _ in ev:
         if name in k:
             print(f"  {name}: starts {s / 1e6:.2f} ms, runs {(e - s) / 1e6:.2f} ms")
