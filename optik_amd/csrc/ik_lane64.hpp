@@ -398,24 +398,24 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
             double *const bk = nnls_lds + (unsigned)qi * NnlsQuadGeom<N>::STRIDE;
             auto expand = [&](bool live, int p) {
                 const double *const rq = rec_lds + p;
+                // (row rr of E^-1 goes out twice: as the lower bound's column and, negated, as the upper bound's --
+                // one read of every entry, two stores)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int sl = k & 1;
-                    const bool neg = k >= 2;
-                    if (sl < NS) {
-                        const int rr = ql + 4 * sl;
-                        if (live && rr < N) {
-                            double *c = bk + CS * (ids[k] - 1);
-                            // (row rr of E^-1 is zero before column rr; entry (rr, j) of the packed triangle otherwise)
-                            const int tri = rr * N - (rr * (rr - 1)) / 2 - rr;  // G::g(rr, j) - j
+                for (int sl = 0; sl < NS; ++sl) {
+                    const int rr = ql + 4 * sl;
+                    if (live && rr < N) {
+                        double *clo = bk + CS * (ids[sl] - 1), *chi = bk + CS * (ids[2 + sl] - 1);
+                        // (row rr of E^-1 is zero before column rr; entry (rr, j) of the packed triangle otherwise)
+                        const int tri = rr * N - (rr * (rr - 1)) / 2 - rr;  // G::g(rr, j) - j
 #pragma unroll
-                            for (int j = 0; j < N; ++j) {
-                                const double e = rq[64 * (j >= rr ? tri + j : 0)];
-                                const double v = (j >= rr) ? e : 0.0;
-                                c[j] = neg ? ((j >= rr) ? -v : 0.0) : v;
-                            }
-                            c[N] = neg ? rq[64 * (G::NG + N + rr)] : rq[64 * (G::NG + rr)];
+                        for (int j = 0; j < N; ++j) {
+                            const double e = rq[64 * (j >= rr ? tri + j : 0)];
+                            const double v = (j >= rr) ? e : 0.0;
+                            clo[j] = v;
+                            chi[j] = (j >= rr) ? -v : 0.0;
                         }
+                        clo[N] = rq[64 * (G::NG + rr)];
+                        chi[N] = rq[64 * (G::NG + N + rr)];
                     }
                 }
             };
