@@ -78,10 +78,11 @@ def _assert_every_restart_equals_oracle(out, ref, what):
     assert_bit_equal(out["x"].cpu().numpy(), ref["xs"].T, what + ": per-restart x")
 
 
-@pytest.mark.parametrize("path", ["kernel", "engine"])
+@pytest.mark.parametrize("path", ["kernel", "quad", "engine"])
 def test_config2_every_restart_equals_oracle(robots, oracle, chains, path):
     """Config 2 at its own size: all 65 536 Panda restarts of the headline workload -- status,
-    evaluation count, x, f -- and the Speed winner against the oracle, on both execution paths
+    evaluation count, x, f -- and the Speed winner against the oracle, on every execution path: the single launch
+    a batch of this size gets (the lane-per-restart form), the quad solver forced onto it, the streaming engine
     (lib.rs:297-413; the reference's own check of this shape is tests/test_ik.rs:91-130)."""
     from optik_amd import _native as nat
     robot = robots["panda"]
@@ -91,6 +92,11 @@ def test_config2_every_restart_equals_oracle(robots, oracle, chains, path):
     cfg = nat.make_config("speed", tol_f=1e-6)
     if path == "kernel":
         out = hc.ik_batch(cfg, tg, x0, 0, R)
+        assert hc.last_launch()["lds_bytes"] > 30000, "a launch of this size runs on the lane-per-restart form"
+    elif path == "quad":
+        with nat.options(solve_kernel="quad"):
+            out = hc.ik_batch(cfg, tg, x0, 0, R)
+        assert hc.last_launch()["lds_bytes"] < 30000
     else:
         out = hc.engine_submit(cfg, tg, x0, 0, R)
         hc.engine_run()
