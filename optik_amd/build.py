@@ -29,8 +29,10 @@ UNITS = [("ik_kernels.hip", "ik_kernels.o", []),
           ["-DOPTIK_QUAD_PART=2", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-use-amdgpu-trackers=1",
            "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
          # the throughput form for n <= 7: one restart per lane, one wave per SIMD (ik_lane64.hpp)
-         # (max-ILP scheduling: +2.3 % restarts/s, as on the quad solver's units)
-         ("ik_lane_kernel.hip", "ik_lane_kernel.o", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
+         # (max-ILP scheduling: +2.3 % restarts/s, as on the quad solver's units; the register allocator assigning
+         # local intervals in reverse order: +0.4 %, three of three interleaved runs -- 1 516 AGPR copies in the loop)
+         ("ik_lane_kernel.hip", "ik_lane_kernel.o", ["-mllvm", "-amdgpu-sched-strategy=max-ilp",
+                                                     "-mllvm", "-greedy-reverse-local-assignment=1"]),
          # chains with 9 .. 16 joint positions: one run-time-n body per kernel (ik_wide.hpp)
          ("ik_wide_kernel.hip", "ik_wide_kernel.o", []),
          ("robot_host.cpp", "robot_host.o", [])]
