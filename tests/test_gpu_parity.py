@@ -387,6 +387,38 @@ def test_early_exit_on_the_lane_per_restart_form(dev, oracle, chains, hip_chains
         assert torch.equal(full["win_x"], fast["win_x"])
 
 
+def test_launch_words_are_left_clean_for_the_next_launch(dev, oracle, chains, hip_chains):
+    """The selection kernel of a launch puts the work-item counter and the first-success words back, and the next launch
+    skips its fill commands when it finds them so (ik_kernels.hip: queue_clean / fs_clean).  A sequence of launches with
+    and without early exit, with growing and shrinking target counts, small (one selection kernel) and large (two),
+    must give the winners of the same launches made on a fresh chain each."""
+    from optik_amd import _native as nat
+    from optik_amd import device
+    d, ch = chains["panda"]
+    rng = np.random.default_rng(12)
+    cfg = nat.make_config(solution_mode="speed")
+    hc = device.HipChain(**d)
+    seq = [(3, 96, nat.IK_EARLY_EXIT), (9, 64, nat.IK_EARLY_EXIT), (2, 5000, nat.IK_EARLY_EXIT), (16, 40, 0),
+           (12, 128, nat.IK_EARLY_EXIT | nat.IK_RESTART_MAJOR), (1, 300, nat.IK_EARLY_EXIT | nat.IK_FIND_ANY),
+           (5, 8192, 0), (7, 100, nat.IK_EARLY_EXIT)]
+    for T, R, fl in seq:
+        tg, x0 = make_targets(oracle, d, ch, rng, T)
+        tgd, x0d = torch.tensor(tg, device="cuda"), torch.tensor(x0, device="cuda")
+        out = hc.ik_batch(cfg, tgd, x0d, 0, R, flags=fl)
+        fresh = device.HipChain(**d).ik_batch(cfg, tgd, x0d, 0, R)  # no early exit: every restart runs
+        torch.cuda.synchronize()
+        if fl & nat.IK_FIND_ANY:
+            ok = (fresh["status"] == nat.RES_STOPVAL).view(T, R)
+            for t in range(T):
+                w = int(out["win_idx"][t])
+                assert (w >= 0) == bool(ok[t].any()) and (w < 0 or bool(ok[t, w]))
+        else:
+            assert torch.equal(out["win_idx"], fresh["win_idx"]), (T, R, fl)
+            assert torch.equal(out["win_x"], fresh["win_x"])
+        # every restart was handed out exactly once: none is left unwritten (status 0 is not a result code)
+        assert int((out["status"] == 0).sum()) == 0
+
+
 def test_ftol_and_xtol_count_as_success_when_enabled(dev, oracle, chains, hip_chains):
     """tol_df >= 0 / tol_dx >= 0 (lib.rs:376-379): FTOL / XTOL exits become successes and
     return NLopt's best-so-far point."""
