@@ -190,11 +190,14 @@ def inprocess_main(args):
     targets = [robot.fk(q) for q in q_star]
     cfg = SolverConfig(solution_mode="quality", max_time=0.0, max_restarts=R * G, tol_f=1e-6)
 
+    parts_used = []  # devices every timed call was actually cut over (optik_robot_last_parts)
+
     def run_steps(first, count):
         out = []
         for k in range(first, first + count):
             r = robot.ik(cfg, targets[k], x0[k], return_index=True)
             out.append(-1 if r is None else int(r[2]))
+            parts_used.append(robot.last_parts())
         return out
 
     if W:
@@ -215,12 +218,16 @@ def inprocess_main(args):
     line = {
         "metric": "random-restart IK solves/sec (Panda 7-DoF, 1e-6 tol)" if args.robot == "panda"
                   else f"random-restart IK solves/sec ({args.robot}, 1e-6 tol)",
-        "value": total / elapsed, "unit": "restarts/s", "n_gpus": robot.num_devices(), "steps": K, "warmup": W,
+        "value": total / elapsed, "unit": "restarts/s", "n_gpus": min(parts_used[-K:]) if parts_used else 0, "steps": K, "warmup": W,
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.robot} {n}-DoF, {R} random restarts per GPU per step (one Robot.ik call over "
                                f"[0, {R * G})), one target per step, SolutionMode::Quality, every restart run to termination",
-                   "inprocess": True, "devices": devices, "world": 1, "backend": "host threads + host min (no collective)",
+                   "inprocess": True, "devices": devices, "devices_configured": robot.num_devices(),
+                   # (n_gpus above is what the calls were really cut over -- the host API keeps a range that is not worth
+                   # cutting on one device -- not what was configured)
+                   "parts_per_call": sorted(set(parts_used[-K:])), "world": 1,
+                   "backend": "host threads + host min (no collective)",
                    "reps": len(rep_elapsed), "rep_reported": "median", "value_reps": [total / e for e in rep_elapsed],
                    "restarts_per_gpu": R, "tol_f": 1e-6, "solution_mode": "quality",
                    "parallelism": f"restart-range x{G} (in-process)", "winner_index_per_step": winners[:64]},

@@ -92,6 +92,9 @@ int optik_robot_ik_batch_poses(const optik_robot *robot, const CSolverConfig *co
  * for robots created after it.  A device may be listed more than once. */
 int optik_robot_set_devices(optik_robot *robot, const int32_t *device_ids, int32_t count);
 int32_t optik_robot_num_devices(const optik_robot *robot);
+/* Over how many of the robot's devices the last _ik / _ik_batch call was actually cut (its widest round): 1 for a
+ * call that ended with its latency-sized first launch or whose range was too short to be worth cutting. */
+int32_t optik_robot_last_parts(const optik_robot *robot);
 /* Robot::diff_ik with its full signature: ee_offset and alpha.  rc 0 = solved, 1 = none. */
 int optik_robot_diff_ik_ex(const optik_robot *robot, const double *x0, const double *V_WE6,
                            const double *v_max, const double *ee_offset16, double *alpha_out,

@@ -67,6 +67,8 @@ struct optik_robot {
     // more than once (two contexts on one GPU: how the sharding is tested on a 1-GPU box).
     std::vector<int> device_ids;
     mutable std::vector<std::unique_ptr<DeviceCtx>> devs;
+    // over how many of them the widest round of the last ik / ik_batch call was actually cut (optik_robot_last_parts)
+    mutable std::atomic<int32_t> last_parts{0};
 };
 
 namespace {
@@ -324,6 +326,7 @@ int optik_robot_set_devices(optik_robot *r, const int32_t *device_ids, int32_t c
 }
 
 int32_t optik_robot_num_devices(const optik_robot *r) { return r ? (int32_t)device_count(r) : 0; }
+int32_t optik_robot_last_parts(const optik_robot *r) { return r ? r->last_parts.load() : 0; }
 
 void optik_robot_set_parallelism(optik_robot *r, unsigned int n) {
     // The GPU grid is sized from the device; n only selects Speed's early-exit rule (see optik_robot).
@@ -464,6 +467,7 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
             if (even < per_part) per_part = even;
         }
         std::vector<Part> parts;
+        const bool begin_was_zero = begin == 0;
         for (size_t g = 0; g < g_round && begin < max_restarts; ++g) {
             Part p;
             p.ctx = g == 0 ? c0 : device_ctx(r, g);
@@ -480,6 +484,8 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
                                      p.wx.data(), &p.wf, &p.widx, &p.wkey);
             if (p.rc) p.err = optik_hip_last_error();
         };
+        if (begin_was_zero) r->last_parts.store(0);
+        if ((int32_t)parts.size() > r->last_parts.load()) r->last_parts.store((int32_t)parts.size());
         if (parts.size() == 1) {
             run_part(parts[0]);
         } else {
@@ -743,6 +749,7 @@ int optik_robot_ik_batch_poses(const optik_robot *r, const CSolverConfig *config
         if (!p.ctx) return -1;
         parts.push_back(p);
     }
+    r->last_parts.store((int32_t)parts.size());
     auto run_part = [&](Part &p) {
         p.rc = ik_batch_on_device(r, p.ctx, config, p.t1 - p.t0, targets16 + (size_t)p.t0 * 16, row_major,
                                   x0 + (size_t)p.t0 * n, ee16 ? ee7 : nullptr, start,

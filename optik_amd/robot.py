@@ -38,6 +38,8 @@ def _bind(L):
     L.optik_robot_joint_jacobian_ex.argtypes = [vp, dp, dp, dp]
     L.optik_robot_set_devices.argtypes = [vp, C.POINTER(C.c_int32), C.c_int32]
     L.optik_robot_num_devices.argtypes = [vp]
+    L.optik_robot_last_parts.argtypes = [vp]
+    L.optik_robot_last_parts.restype = C.c_int32
     L.optik_robot_chain_tables.argtypes = [vp, C.POINTER(C.c_int32), dp, dp, C.POINTER(C.c_int32)]
     L.optik_robot_chain_tables_n.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), dp, dp, C.POINTER(C.c_int32)]
     L.optik_robot_hip_chain.argtypes = [vp]
@@ -158,6 +160,10 @@ class Robot:
 
     def num_devices(self) -> int:
         return int(self._L.optik_robot_num_devices(self._h))
+
+    def last_parts(self) -> int:
+        """Over how many of the robot's devices the last ik / ik_batch call was actually cut."""
+        return int(self._L.optik_robot_last_parts(self._h))
 
     def num_positions(self) -> int:
         return int(self._L.optik_robot_num_positions(self._h))

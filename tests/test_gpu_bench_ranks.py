@@ -113,19 +113,27 @@ def test_plain_gpus_flag_spawns_the_ranks_itself():
 @pytest.mark.gpu
 def test_inprocess_two_devices_reports_two_gpus():
     """`--inprocess --gpus 2`: one process, two device contexts (the test box's GPU listed twice)
-    behind optik_robot_set_devices; the winner is the one a single device finds in the same range."""
-    common = ["--inprocess", "--steps", "2", "--warmup", "1", "--reps", "1", "--restarts", "4096"]
+    behind optik_robot_set_devices; the winner is the one a single device finds in the same range.  n_gpus is what
+    the calls were really cut over (optik_robot_last_parts): a range too short to be worth cutting stays on one."""
+    common = ["--inprocess", "--steps", "2", "--warmup", "1", "--reps", "1", "--restarts", "16384"]
     env = dict(os.environ, OPTIK_BENCH_ONE_DEVICE="1")
     two = subprocess.run([sys.executable, "bench.py", "--gpus", "2", *common], cwd=ROOT, env=env,
                          capture_output=True, text=True, timeout=600)
     assert two.returncode == 0, two.stderr[-2000:]
-    common[-1] = "8192"
+    common[-1] = "32768"
     one = subprocess.run([sys.executable, "bench.py", "--gpus", "1", *common], cwd=ROOT, env=env,
                          capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     a, b = _line(one.stdout), _line(two.stdout)
     assert b["n_gpus"] == 2 and b["config"]["inprocess"] and b["config"]["devices"] == [0, 0]
+    assert b["config"]["parts_per_call"] == [2] and a["n_gpus"] == 1
     assert a["config"]["winner_index_per_step"] == b["config"]["winner_index_per_step"]
+    common[-1] = "2048"  # 4096 restarts over two devices: not worth cutting, and the line says so
+    small = subprocess.run([sys.executable, "bench.py", "--gpus", "2", *common], cwd=ROOT, env=env,
+                           capture_output=True, text=True, timeout=600)
+    assert small.returncode == 0, small.stderr[-2000:]
+    c = _line(small.stdout)
+    assert c["n_gpus"] == 1 and c["config"]["devices_configured"] == 2
 
 
 @pytest.mark.gpu
