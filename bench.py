@@ -272,6 +272,9 @@ def main():
     ap.add_argument("--force-distributed", action="store_true",
                     help="run the process-group path (init_process_group, the min / sum / max all-reduces, "
                          "all_gather_object) even with ONE rank: RCCL on a single GPU")
+    ap.add_argument("--set-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="a tuning option of the kernel layer for this run (include/optik_hip.h: optik_hip_set_option), "
+                         "e.g. engine_pools=2; experiments only -- the line records what was set")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -335,6 +338,9 @@ def main():
 
     from optik_amd import _native as nat
     from optik_amd.parallel import I64_MAX, shard_range, select_winner, gather_winner_x
+    for kv in args.set_option:
+        name, _, val = kv.partition("=")
+        nat.set_option(name, int(val) if val.lstrip("-").isdigit() else val)
 
     robot = load_chain(args.robot)
     hc = robot.hip_chain(dev)
@@ -681,6 +687,7 @@ def main():
                        "value_reps": [total / e for e in rep_elapsed],
                        "value_min": total / max(rep_elapsed), "value_max": total / min(rep_elapsed),
                        "path": args.path, "restarts_per_gpu": cols, "tol_f": 1e-6, "solution_mode": mode,
+                       "options_set": args.set_option or None,
                        "parallelism": (f"targets x{world}" if T else f"restart-range x{world}"),
                        "success_rate_last_step": (n_success / cols) if n_success is not None else None,
                        "solved_targets": solved_targets, "targets_per_step": per_step,
