@@ -662,7 +662,9 @@ struct QuadStop {
             q.restart_begin + (((unsigned long long)(unsigned)quad_get(ib, 1) << 32) | (unsigned)quad_get(ib, 0));
         const unsigned long long below = q.find_any ? ~0ull : index;
         const unsigned ts = (unsigned)quad_get(ia, 3);
-        const bool now = running && seen < below;
+        // (the quad's leader decides, as for the look before an evaluation: four lanes that saw different values
+        // of the word would split the quad over two restarts)
+        const bool now = quad_get((int)(running && seen < below), 0) != 0;
         hit = hit || now;
         if (running && !now) seen = __hip_atomic_load(q.first_success + ts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return now;
