@@ -553,6 +553,7 @@ struct optik_hip_chain {
     // answer to (WorkQueue::claim; pinned, host-coherent), the sequence number of the last launch that used it, the
     // request optik_hip_ik_host leaves for the launch it is about to make and whether that launch took it up
     unsigned long long *hw_claim = nullptr;
+    hipEvent_t claim_done = nullptr;  // recorded behind such a launch: what the polling host also looks at
     unsigned long long claim_seq = 0;
     bool claim_request = false, claim_armed = false;
     bool claim_pending = false;  // such a call returned early: its launch may still be running on the null stream
@@ -868,6 +869,7 @@ void optik_hip_chain_destroy(optik_hip_chain *ch) {
     if (ch->hw_dev) hipFree(ch->hw_dev);
     if (ch->hw_pin) hipHostFree(ch->hw_pin);
     if (ch->hw_claim) hipHostFree(ch->hw_claim);
+    if (ch->claim_done) hipEventDestroy(ch->claim_done);
     if (ch->eng_pinned) hipHostFree(ch->eng_pinned);
     for (auto &pe : ch->eng_pool_ev) for (auto &e : pe) if (e) hipEventDestroy(e);
     if (ch->eng_fork_ev) hipEventDestroy(ch->eng_fork_ev);
@@ -2163,6 +2165,7 @@ int optik_hip_ik_host(optik_hip_chain *ch, const optik_solver_config *cfg, const
     if (claim && !ch->hw_claim) {
         HIP_TRY(hipHostMalloc(&ch->hw_claim, sizeof(unsigned long long) * (3 + MAX_DOF), hipHostMallocCoherent));
         std::memset(ch->hw_claim, 0, sizeof(unsigned long long) * (3 + MAX_DOF));
+        HIP_TRY(hipEventCreateWithFlags(&ch->claim_done, hipEventDisableTiming));
     }
     ch->claim_request = claim;
     const int rc = (flags & OPTIK_HIP_IK_ENGINE)
@@ -2175,6 +2178,8 @@ int optik_hip_ik_host(optik_hip_chain *ch, const optik_solver_config *cfg, const
     double *h_out = pin + n_in;
     if (!zero_copy) HIP_TRY(hipMemcpyAsync(h_out, d_wx, sizeof(double) * n_out, hipMemcpyDeviceToHost, nullptr));
     if (ch->claim_armed) {
+        // (the end of THIS launch, not of the null stream: other chains' calls may keep that one busy)
+        HIP_TRY(hipEventRecord(ch->claim_done, nullptr));
         const unsigned long long seq = ch->claim_seq;
         volatile unsigned long long *cw = ch->hw_claim;
         for (unsigned spin = 1;; ++spin) {
@@ -2187,7 +2192,7 @@ int optik_hip_ik_host(optik_hip_chain *ch, const optik_solver_config *cfg, const
                 return 0;
             }
             if ((spin & 63u) == 0) {
-                const hipError_t q = hipStreamQuery(nullptr);
+                const hipError_t q = hipEventQuery(ch->claim_done);
                 if (q == hipSuccess) break;  // the launch is over and nobody succeeded (or the word is about to land)
                 if (q != hipErrorNotReady) HIP_TRY(q);
             }
