@@ -704,3 +704,45 @@ def test_early_return_then_a_launch_on_another_stream(oracle, chains):
                         per_restart=True)
         assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
         assert_bit_equal(out["x"].cpu().numpy(), ref["xs"].T.copy())
+
+
+def test_first_success_calls_from_many_threads_and_robots(oracle, chains):
+    """Early-return calls (first-success rule) from several host threads on several robots of one device: every
+    launch one of them leaves behind queues in front of the others' launches on the null stream.  Every answer is
+    a restart that succeeds on its own (the oracle's, by index); nothing hangs."""
+    import threading
+    from optik_amd import Robot, SolverConfig
+    _, ch = chains["panda"]
+    robots = [Robot.from_urdf_file(os.path.join(ROBOTS, "panda.urdf"), "panda_link0", "panda_link8") for _ in range(3)]
+    lb, ub = (np.array(v) for v in robots[0].joint_limits())
+    cfg = SolverConfig(max_time=0.0, max_restarts=2000)
+    errors, results = [], []
+    lock = threading.Lock()
+
+    def work(k):
+        try:
+            rng = np.random.default_rng(500 + k)
+            r = robots[k % len(robots)]
+            for _ in range(25):
+                tgt = np.array(r.fk(rng.uniform(lb, ub)))
+                x0 = rng.uniform(lb, ub)
+                got = r.ik(cfg, tgt, x0.tolist(), return_index=True)
+                with lock:
+                    results.append((tgt, x0, got))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=180)
+    assert not any(th.is_alive() for th in threads), "deadlock"
+    assert not errors, errors
+    assert len(results) == 150
+    for tgt, x0, got in results[::5]:
+        assert got is not None
+        x, f, idx = got
+        ref = oracle.solve_restart(ch, oracle.make_config("speed"), _mat_to_pose7(tgt), x0, int(idx))
+        assert ref.success and abs(ref.f - f) < 1e-9
+        np.testing.assert_allclose(x, np.array(ref.x[:7]), atol=1e-6, rtol=0)
