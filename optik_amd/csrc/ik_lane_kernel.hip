@@ -56,3 +56,14 @@ hipError_t lane_solve_launch(int n, bool tip, int grid, hipStream_t stream, cons
 }
 
 }  // namespace optik
+
+#ifdef OPTIK_PROFILE
+// diagnostic builds: the NNLS histograms of THIS object's calls (ik_nnls_quad.hpp: g_quad_nnls_hist -- every translation
+// unit has its own copy of the counters), then reset
+extern "C" int optik_hip_lane_nnls_hist(unsigned long long *out66) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out66, HIP_SYMBOL(optik::g_quad_nnls_hist), 66 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[66] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(optik::g_quad_nnls_hist), z, sizeof z) == hipSuccess ? 0 : -1;
+}
+#endif
