@@ -23,8 +23,10 @@ SOURCES = ["ik_kernels.hip", "ik_quad_kernel.hip", "ik_lane_kernel.hip", "ik_wid
 UNITS = [("ik_kernels.hip", "ik_kernels.o", []),
          # (the quad solver is issue-bound: the max-ILP scheduling strategy is worth +3 % restarts/s on the
          # throughput form and -3 % on a single ik()'s latency; on the engine's kernels it costs 6 %)
+         # (the latency forms without the machine-LICM pass as well since round 4: 206 -> 201 us per single ik() call,
+         # 673 -> 662 us deterministic, tools/single_call_variants.sh; in round 3 the default pipeline was the faster one there)
          ("ik_quad_kernel.hip", "ik_quad_latency.o",
-          ["-DOPTIK_QUAD_PART=1", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
+          ["-DOPTIK_QUAD_PART=1", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
          ("ik_quad_kernel.hip", "ik_quad_throughput.o",
           ["-DOPTIK_QUAD_PART=2", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-use-amdgpu-trackers=1",
            "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),

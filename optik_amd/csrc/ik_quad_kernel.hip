@@ -20,8 +20,8 @@ namespace optik {
 // -amdgpu-use-amdgpu-trackers=1` -- the machine-LICM pass hoists the ~60 double constants of sin / cos /
 // atan2 and LDS address variants out of the solver loop, and at 256 registers the allocator then spills
 // those loop invariants to scratch and reloads them every trip (412 -> 280 B of scratch, +4-5 %
-// restarts/s); OPTIK_QUAD_PART = 1 holds the latency forms (W = 1: no scratch either way, and the
-// default pipeline is the faster one there) and the launch function.
+// restarts/s); OPTIK_QUAD_PART = 1 holds the latency forms (W = 1: no scratch either way; built without the pass
+// too since round 4 -- 2 % off a single call's latency) and the launch function.
 #ifndef OPTIK_QUAD_PART
 #define OPTIK_QUAD_PART 0  // 0: everything in one object (tools/, experiments)
 #endif
