@@ -409,12 +409,17 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
     // budget) is throughput-bound: rounds of 1 M restarts per GPU on the streaming engine (46 ms
     // against 118 on the solve kernel).
     const uint64_t cus = (uint64_t)(c0->num_cus > 0 ? c0->num_cus : 256);
-    // restarts of the first, latency-sized launch: two per CU under the first-success rule (the more restarts race,
-    // the sooner the first one succeeds: the fastest of 512 needs 18.6 evaluations on average, of 1024 17.9, but
-    // 1024 waves run each a little slower: 261 / 257 us per call); 128 under the deterministic rule (parallelism 1:
-    // the answer is the lowest successful index, nearly always below ten, and only the restarts below it decide
-    // when the launch ends: 685 -> 660 us per call, tools/single_call_variants.sh)
-    const uint64_t first_per_cu = 2;
+    // restarts of the first, latency-sized launch: four per CU -- one per SIMD, the most the quad solver's one-restart-
+    // per-wave form takes -- under the first-success rule (the more restarts race, the sooner the first one succeeds: the
+    // fastest of 512 needs 18.6 evaluations on average, of 1024 17.9; 1024 waves run each a little slower, but since
+    // the call returns on the first success the launch's tail no longer counts: 201 -> 194 us per call, 221 -> 216 us
+    // back to back); 128 under the deterministic rule (parallelism 1: the answer is the lowest successful index,
+    // nearly always below ten, and only the restarts below it decide when the launch ends: 685 -> 660 us per call,
+    // tools/single_call_variants.sh)
+#ifndef OPTIK_FIRST_PER_CU
+#define OPTIK_FIRST_PER_CU 4  // (tools/build_lib_variant.py fpcN -DOPTIK_FIRST_PER_CU=N --only=robot_host.o: the comparison above)
+#endif
+    const uint64_t first_per_cu = OPTIK_FIRST_PER_CU;
     const uint64_t first_batch = (!quality && r->parallelism == 1) ? 128 : cus * first_per_cu;
     const uint64_t later_batch = cus * 2 * 64 * 2;
     const uint64_t engine_batch = (uint64_t)1 << 20;  // restarts per GPU per engine round
