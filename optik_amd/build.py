@@ -31,9 +31,10 @@ UNITS = [("ik_kernels.hip", "ik_kernels.o", []),
           ["-DOPTIK_QUAD_PART=2", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-use-amdgpu-trackers=1",
            "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
          # the throughput form for n <= 7: one restart per lane, one wave per SIMD (ik_lane64.hpp)
-         # (max-ILP scheduling: +2.3 % restarts/s, as on the quad solver's units; the register allocator assigning
-         # local intervals in reverse order: +0.4 %, three of three interleaved runs -- 1 516 AGPR copies in the loop)
-         ("ik_lane_kernel.hip", "ik_lane_kernel.o", ["-mllvm", "-amdgpu-sched-strategy=max-ilp",
+         # (scheduling strategy, tools/ab_kernel_path.sh, M restarts/s interleaved on one box: the default 27.8, max-ILP 28.5,
+         # iterative-ILP 29.2 (iterative-minreg 27.7, max-memory-clause 28.0); the register allocator assigning local
+         # intervals in reverse order: +0.4 %, three of three runs -- 1 516 AGPR copies in the loop)
+         ("ik_lane_kernel.hip", "ik_lane_kernel.o", ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
                                                      "-mllvm", "-greedy-reverse-local-assignment=1"]),
          # chains with 9 .. 16 joint positions: one run-time-n body per kernel (ik_wide.hpp)
          ("ik_wide_kernel.hip", "ik_wide_kernel.o", []),
