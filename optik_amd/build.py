@@ -22,7 +22,9 @@ SOURCES = ["ik_kernels.hip", "ik_quad_kernel.hip", "ik_lane_kernel.hip", "ik_wid
 # (csrc/ik_quad_kernel.hip), its latency forms and the launch function with the default pipeline.
 UNITS = [("ik_kernels.hip", "ik_kernels.o", []),
          # (the quad solver is issue-bound: the max-ILP scheduling strategy is worth +3 % restarts/s on the
-         # throughput form and -3 % on a single ik()'s latency; on the engine's kernels it costs 6 %)
+         # throughput form and -3 % on a single ik()'s latency; on the engine's kernels it costs 6 %.  The
+         # iterative-ILP strategy the lane kernel is built with: together with -disable-machine-licm it crashes this
+         # compiler on the quad kernel and on ik_kernels.hip; without, it compiles and is 3 % slower on both quad objects)
          # (the latency forms without the machine-LICM pass as well since round 4: 206 -> 201 us per single ik() call,
          # 673 -> 662 us deterministic, tools/single_call_variants.sh; in round 3 the default pipeline was the faster one there)
          ("ik_quad_kernel.hip", "ik_quad_latency.o",
