@@ -23,6 +23,26 @@
 #else
 #define OPTIK_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
+// (by file, for experiments: -DOPTIK_NOFENCE_EVAL / _SLSQP drop the fences of ik_eval.hpp / ik_slsqp.hpp alone: the
+// first costs the lane kernel a quarter of its rate, the second ~0.5 %)
+#ifdef OPTIK_NOFENCE_EVAL
+#define OPTIK_SCHED_FENCE_EVAL()
+#else
+#define OPTIK_SCHED_FENCE_EVAL() OPTIK_SCHED_FENCE()
+#endif
+#ifdef OPTIK_NOFENCE_SLSQP
+#define OPTIK_SCHED_FENCE_SLSQP()
+#else
+#define OPTIK_SCHED_FENCE_SLSQP() OPTIK_SCHED_FENCE()
+#endif
+// (the thirteen fences between the phases of ik_lane64.hpp's trip are OFF since the lane kernel is scheduled with the
+// iterative-ILP strategy: 29.16 -> 29.48 M restarts/s without them, tools/ab_kernel_path.sh; -DOPTIK_FENCE_LANE64 puts
+// them back)
+#ifdef OPTIK_FENCE_LANE64
+#define OPTIK_SCHED_FENCE_LANE64() OPTIK_SCHED_FENCE()
+#else
+#define OPTIK_SCHED_FENCE_LANE64()
+#endif
 
 namespace optik {
 
@@ -80,7 +100,7 @@ OPTIK_DEV void forward_kinematics(const ChainDev &ch, const EvalParams &ep, cons
         jt.q = qmul(Q4{ch.origin[j][3], ch.origin[j][4], ch.origin[j][5], ch.origin[j][6]}, local);
         state = (j == 0) ? jt : pose_mul(state, jt);  // identity * jt is exact
         kin.tf[j] = state;
-        OPTIK_SCHED_FENCE();
+        OPTIK_SCHED_FENCE_EVAL();
     }
     if (TIP) state = pose_mul(state, load_pose(ch.origin[N]));
     kin.ee = ep.has_ee_offset ? pose_mul(state, load_pose(ep.ee_offset)) : state;
@@ -110,7 +130,7 @@ OPTIK_DEV double eval_fg_stream(const ChainDev &ch, const EvalParams &ep, const 
             jt.q = qmul(Q4{ch.origin[j][3], ch.origin[j][4], ch.origin[j][5], ch.origin[j][6]}, local);
             state = (j == 0) ? jt : pose_mul(state, jt);  // identity * jt is exact
             tfq[j] = state.q;
-            OPTIK_SCHED_FENCE();
+            OPTIK_SCHED_FENCE_EVAL();
         }
         if (TIP) state = pose_mul(state, load_pose(ch.origin[N]));
         ee = ep.has_ee_offset ? pose_mul(state, load_pose(ep.ee_offset)) : state;
@@ -140,7 +160,7 @@ OPTIK_DEV double eval_fg_stream(const ChainDev &ch, const EvalParams &ep, const 
     double f = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) f += ef[i] * ef[i];
-    OPTIK_SCHED_FENCE();
+    OPTIK_SCHED_FENCE_EVAL();
 
     // per joint: body-frame Jacobian column (kinematics.rs:173-184), then
     // Jtask = Jlog6 * J (objective.rs:81) and g = (2 e') Jtask (objective.rs:106-109)
@@ -178,7 +198,7 @@ OPTIK_DEV double eval_fg_stream(const ChainDev &ch, const EvalParams &ep, const 
 #pragma unroll
         for (int r = 0; r < 6; ++r) acc += e2[r] * jt[r];
         gsink(k, acc);
-        OPTIK_SCHED_FENCE();
+        OPTIK_SCHED_FENCE_EVAL();
     }
     return f;
 }

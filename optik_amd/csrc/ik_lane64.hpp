@@ -205,7 +205,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
         const bool do_eval = stepping && !again;
         double gn[N];
         double fn = 0.0;
-        OPTIK_SCHED_FENCE();
+        OPTIK_SCHED_FENCE_LANE64();
 #ifdef OPTIK_LANE_EXP_DUP_EVAL  // (cost-by-duplication experiments, tools/lane_dup_costs.sh: same results, the phase runs twice)
         if (do_eval) {
             double xx[N], g0[N];
@@ -214,10 +214,10 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
             const double f0_ = eval_fg<N, TIP>(ch, ep, target, xx, g0);
             asm volatile("" :: "v"(f0_), "v"(g0[0]), "v"(g0[N - 1]));
         }
-        OPTIK_SCHED_FENCE();
+        OPTIK_SCHED_FENCE_LANE64();
 #endif
         if (do_eval) fn = eval_fg<N, TIP>(ch, ep, target, x, gn);
-        OPTIK_SCHED_FENCE();
+        OPTIK_SCHED_FENCE_LANE64();
 
         // ---- NLopt bookkeeping and Kraft's line search (labels 100 / 220), per lane ---------------------
         bool need_dir = stepping && again, reset = stepping && again;
@@ -273,7 +273,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
                         double u[N];
 #pragma unroll
                         for (int i = 0; i < N; ++i) { u[i] = gn[i] - g[i]; g[i] = gn[i]; }
-                        OPTIK_SCHED_FENCE();
+                        OPTIK_SCHED_FENCE_LANE64();
 #ifdef OPTIK_LANE_EXP_DUP_BFGS
                         {
                             double l2[NL], u2[N];
@@ -287,13 +287,13 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
                         }
 #endif
                         bfgs_update<N>(l, s, u);
-                        OPTIK_SCHED_FENCE();
+                        OPTIK_SCHED_FENCE_LANE64();
                         need_dir = true;
                     }
                 }
             }
         }
-        OPTIK_SCHED_FENCE();
+        OPTIK_SCHED_FENCE_LANE64();
 
         // ---- labels 110/130: (reset,) search direction, descent test -- one pass per trip -----------------
         if (wave_any(need_dir)) {
@@ -338,10 +338,10 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
                 });
                 asm volatile("" :: "v"(m0), "v"((int)n0), "v"(acc_));
             }
-            OPTIK_SCHED_FENCE();
+            OPTIK_SCHED_FENCE_LANE64();
 #endif
             int lmode = lsq_factor<N>(l, g, E, fv);
-            OPTIK_SCHED_FENCE();
+            OPTIK_SCHED_FENCE_LANE64();
             // rows of E^-1 and the bound rows they give: into the lane's packed problem in LDS
             int nviol = 0;
             bool need_nnls;
@@ -359,7 +359,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
                 });
             }
             const bool has = need_dir && lmode == 1 && need_nnls;
-            OPTIK_SCHED_FENCE();
+            OPTIK_SCHED_FENCE_LANE64();
 
             // ---- the wave's bounded problems by predicted class, the largest first -----------------------
             int cls = 0;
@@ -468,7 +468,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
 #ifdef OPTIK_LANE_EXP_DUP_NNLS
           }
 #endif
-            OPTIK_SCHED_FENCE();
+            OPTIK_SCHED_FENCE_LANE64();
 
             // ---- LDP tail (lsq_dual), back-substitution, descent test, per lane ------------------------------
             double sn[N];
@@ -495,7 +495,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
 #pragma unroll
                             for (int r = 0; r <= j; ++r) acc += (-rp[64 * G::g(r, j)]) * y[N + r];
                             sn[j] = fac * acc;
-                            OPTIK_SCHED_FENCE();
+                            OPTIK_SCHED_FENCE_LANE64();
                         }
                     }
                 }
@@ -507,7 +507,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
                 for (int i = 0; i < N; ++i) { lo[i] = ch.lb[i] - x[i]; hi[i] = ch.ub[i] - x[i]; }
                 lsq_finish<N>(E, fv, lo, hi, sn);
             }
-            OPTIK_SCHED_FENCE();
+            OPTIK_SCHED_FENCE_LANE64();
             if (need_dir) {
                 if (lmode != 1) {
                     // NLopt: modes 5,6,7 -> ROUNDOFF_LIMITED; 3,4,9 -> FAILURE
@@ -532,7 +532,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
             }
             lds_sync();  // (the records are read: the next trip may rewrite them)
         }
-        OPTIK_SCHED_FENCE();
+        OPTIK_SCHED_FENCE_LANE64();
         if (stepping && ret == 0 && !again) {
             // label 190: next trial point x = x0 + alpha * s, clipped (NLopt)
             ++line;

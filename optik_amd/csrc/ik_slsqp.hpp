@@ -96,7 +96,7 @@ OPTIK_DEV int lsq_factor(const double (&l)[N * (N + 1) / 2], const double (&g)[N
 #pragma unroll
         for (int k = 0; k < i; ++k) acc += E[k][i] * f[k];
         f[i] = (g[i] - acc) / diag;
-        OPTIK_SCHED_FENCE();
+        OPTIK_SCHED_FENCE_SLSQP();
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) f[i] = -f[i];
@@ -127,7 +127,7 @@ OPTIK_DEV int lsq_factor(const double (&l)[N * (N + 1) / 2], const double (&g)[N
                 if (sm != 0.0) { sm *= b; f[i] += sm * up; }
             }
         }
-        OPTIK_SCHED_FENCE();
+        OPTIK_SCHED_FENCE_SLSQP();
     }
     bool singular = false;
 #pragma unroll
@@ -166,7 +166,7 @@ OPTIK_DEV bool lsq_bound_rows(const double (&E)[N][N], const double (&f)[N], con
         sink(i, row, h_lo, h_hi);
         // rows are independent recurrences (each a chain of divisions): letting the scheduler
         // interleave OPTIK_ROWS_GROUP of them hides the division latency at 2 waves per SIMD
-        if (i % OPTIK_ROWS_GROUP == OPTIK_ROWS_GROUP - 1) OPTIK_SCHED_FENCE();
+        if (i % OPTIK_ROWS_GROUP == OPTIK_ROWS_GROUP - 1) OPTIK_SCHED_FENCE_SLSQP();
     }
     return need;
 }
@@ -184,7 +184,7 @@ OPTIK_DEV void lsq_finish(const double (&E)[N][N], const double (&f)[N], const d
 #pragma unroll
         for (int j = i + 1; j < N; ++j) acc += E[i][j] * s[j];
         s[i] = (s[i] - acc) / E[i][i];
-        OPTIK_SCHED_FENCE();
+        OPTIK_SCHED_FENCE_SLSQP();
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -208,7 +208,7 @@ OPTIK_DEV void ldl_update(double (&a)[N * (N + 1) / 2], double (&z)[N], double s
             t += v * v / a[lidx<N>(i, i)];
 #pragma unroll
             for (int j = i + 1; j < N; ++j) w[j] -= v * a[lidx<N>(i, j)];
-            OPTIK_SCHED_FENCE();
+            OPTIK_SCHED_FENCE_SLSQP();
         }
         if (t >= 0.0) t = EPMACH / sigma;
 #pragma unroll
@@ -245,7 +245,7 @@ OPTIK_DEV void ldl_update(double (&a)[N * (N + 1) / 2], double (&z)[N], double s
             }
             t = tp;
         }
-        OPTIK_SCHED_FENCE();
+        OPTIK_SCHED_FENCE_SLSQP();
     }
 }
 
@@ -285,11 +285,11 @@ OPTIK_DEV void bfgs_update(double (&l)[N * (N + 1) / 2], const double (&s)[N], d
 #pragma unroll
         for (int i = 0; i < N; ++i) u[i] += (1.0 - h4) * v[i];
     }
-    OPTIK_SCHED_FENCE();
+    OPTIK_SCHED_FENCE_SLSQP();
     ldl_update<N>(l, u, 1.0 / h1);
-    OPTIK_SCHED_FENCE();
+    OPTIK_SCHED_FENCE_SLSQP();
     ldl_update<N>(l, v, -1.0 / h2);
-    OPTIK_SCHED_FENCE();
+    OPTIK_SCHED_FENCE_SLSQP();
 }
 
 }  // namespace optik
