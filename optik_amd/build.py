@@ -36,7 +36,8 @@ UNITS = [("ik_kernels.hip", "ik_kernels.o", []),
          # (scheduling strategy, tools/ab_kernel_path.sh, M restarts/s interleaved on one box: the default 27.8, max-ILP 28.5,
          # iterative-ILP 29.2 (iterative-minreg 27.7, max-memory-clause 28.0); the register allocator assigning local
          # intervals in reverse order: +0.4 %, three of three runs -- 1 516 AGPR copies in the loop)
-         ("ik_lane_kernel.hip", "ik_lane_kernel.o", ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
+         # (-O2, overriding FLAGS' -O3: 29.48 -> 29.85 M, three of three runs; -O1 28.2, -Os 29.5)
+         ("ik_lane_kernel.hip", "ik_lane_kernel.o", ["-O2", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
                                                      "-mllvm", "-greedy-reverse-local-assignment=1"]),
          # chains with 9 .. 16 joint positions: one run-time-n body per kernel (ik_wide.hpp)
          ("ik_wide_kernel.hip", "ik_wide_kernel.o", []),
