@@ -62,7 +62,10 @@ constexpr int lane64_block_lds() { return nnls_quad_wave_lds<N>(); }
 template <int N>
 constexpr int lane64_rec_lds() { return Lane64Geom<N>::REC * 64; }
 
-constexpr int LANE64_CLASSES = 8;  // predicted pass classes 1 .. 7 (0: no bounded problem this trip)
+#ifndef OPTIK_LANE_CLASSES
+#define OPTIK_LANE_CLASSES 8
+#endif
+constexpr int LANE64_CLASSES = OPTIK_LANE_CLASSES;  // predicted pass classes 1 .. 7 (0: no bounded problem this trip)
 #ifndef OPTIK_LANE_PIPE
 #define OPTIK_LANE_PIPE 1         // 0: rounds of sixteen problems, each round to its end (comparisons)
 #endif
