@@ -689,6 +689,14 @@ static void rot(int n, double *x, int incx, double *y, int incy, double c, doubl
     }
 }
 
+/* Diagnostic: how the NNLS calls ended -- [iter][nsetp] counts, iter capped at 15 (ok_nnls_hist reads and clears them;
+ * tools/nnls_pass_hist.py).  Not part of any result. */
+static unsigned long long g_nnls_hist[16][16];
+void ok_nnls_hist(unsigned long long *out256) {
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j) out256[i * 16 + j] = __atomic_exchange_n(&g_nnls_hist[i][j], 0ull, __ATOMIC_RELAXED);
+}
+
 /* Lawson-Hanson NNLS:  min ||A x - b||  s.t. x >= 0.   A is m x n column-major,
  * leading dimension mda.  Returns mode: 1 ok, 2 bad dims, 3 iteration count. */
 static int nnls(double *a, int mda, int m, int n, double *b, double *x, double *rnorm, double *w,
@@ -815,6 +823,7 @@ done: {
         *rnorm = bl_nrm2(m - nsetp, &b[k - 1], 1);
         if (npp1 > m) for (int i = 0; i < n; ++i) w[i] = 0.0;
     }
+    __atomic_fetch_add(&g_nnls_hist[iter < 15 ? iter : 15][nsetp < 15 ? nsetp : 15], 1ull, __ATOMIC_RELAXED);
     return mode;
 #undef A
 }
