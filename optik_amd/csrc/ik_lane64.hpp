@@ -56,6 +56,14 @@ struct Lane64Geom {
     static_assert(NnlsQuadGeom<N>::XS + 2 * N + 3 <= NnlsQuadGeom<N>::STRIDE, "three spare doubles per block");
 };
 
+}  // namespace optik
+#include "ik_nnls_first.hpp"
+namespace optik {
+
+#ifndef OPTIK_LANE_FIRST_PASS
+#define OPTIK_LANE_FIRST_PASS 1   // every lane runs the first NNLS pass on its own problem; only the unsolved ones go through the quads
+#endif
+
 // doubles of LDS per wave: the NNLS blocks of its 16 quads (+ the column of zeros), the 64 packed problems
 template <int N>
 constexpr int lane64_block_lds() { return nnls_quad_wave_lds<N>(); }
@@ -361,7 +369,18 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
                     nviol += (h_lo > 0.0 ? 1 : 0) + (h_hi > 0.0 ? 1 : 0);
                 });
             }
-            const bool has = need_dir && lmode == 1 && need_nnls;
+            const bool has_any = need_dir && lmode == 1 && need_nnls;
+            // 45 % of the bounded problems end after ONE pass with one active bound: that pass per lane, on the lane's own
+            // record (ik_nnls_first.hpp: the same numbers as the quads would form); the rest through the quads
+            bool solved1 = false;
+            int y1_id = 1;
+            double y1_val = 0.0, rn1 = 1.0;
+#if OPTIK_LANE_FIRST_PASS
+            OPTIK_SCHED_FENCE();  // (a phase of its own: interleaved with its neighbours it costs them their registers)
+            if (has_any) solved1 = nnls_first_pass<N>(rec_lds + lane, y1_id, y1_val, rn1);
+            OPTIK_SCHED_FENCE();
+#endif
+            const bool has = has_any && !solved1;
             OPTIK_SCHED_FENCE_LANE64();
 
             // ---- the wave's bounded problems by predicted class, the largest first -----------------------
@@ -477,7 +496,15 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
             double sn[N];
 #pragma unroll
             for (int j = 0; j < N; ++j) sn[j] = 0.0;
-            if (has) {
+            if (solved1) {
+                // (what a quad would have handed back: one multiplier, mode 1, one pass)
+#pragma unroll
+                for (int r = 0; r < 2 * N; ++r) y[r] = (r == y1_id - 1) ? y1_val : 0.0;
+                nmode = 1;
+                rnorm = rn1;
+                pred = 1;
+            }
+            if (has_any) {
                 const double *const rp = rec_lds + lane;
                 int mode = nmode;
                 if (mode == 1 && rnorm <= 0.0) mode = 4;

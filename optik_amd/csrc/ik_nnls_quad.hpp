@@ -359,10 +359,14 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
 #pragma unroll
                 for (int r = 1; r <= m; ++r) rowkeep[r - 1] = (r < npp1) ? 0x80000000u : 0u;
                 {
+                    // (a column the test above rejects leaves b as it was -- oracle: z is only copied back to b when the
+                    // column is found: the factor is zeroed as well as the sign forced, or a rejected column with a
+                    // non-zero factor would still move b)
                     const unsigned allkeep = (found && actb) ? 0u : 0x80000000u;
+                    const double smhb_b = (found && actb) ? smhb : 0.0;
 #pragma unroll
                     for (int r = 1; r <= m; ++r) {
-                        const double add = smhb * w[r - 1];
+                        const double add = smhb_b * w[r - 1];
                         const double addz = __hiloint2double((int)((unsigned)__double2hiint(add) | rowkeep[r - 1] | allkeep),
                                                              __double2loint(add));
                         b[r - 1] = b[r - 1] + addz;
