@@ -60,6 +60,9 @@ struct Lane64Geom {
 #include "ik_nnls_first.hpp"
 namespace optik {
 
+#ifndef OPTIK_LANE_FIRST_PASS_MIN
+#define OPTIK_LANE_FIRST_PASS_MIN 24  // (0 / 16 / 20 / 24 / 28 / 32: Panda 30.93 / 30.99 / 30.95 / 31.08 / 30.95 / 30.69 M, UR10 52.3 / 52.9 / -- / 53.4 / -- / 53.0)
+#endif
 #ifndef OPTIK_LANE_FIRST_PASS
 #define OPTIK_LANE_FIRST_PASS 1   // every lane runs the first NNLS pass on its own problem; only the unsolved ones go through the quads
 #endif
@@ -78,7 +81,8 @@ constexpr int LANE64_CLASSES = OPTIK_LANE_CLASSES;  // predicted pass classes 1 
 #define OPTIK_LANE_PIPE 1         // 0: rounds of sixteen problems, each round to its end (comparisons)
 #endif
 #ifndef LANE64_MAX_RUNNING
-#define LANE64_MAX_RUNNING 10     // hand-over as soon as this few of the sixteen quads are still solving (and problems wait; 8: -0.8 %, 12: the same)
+#define LANE64_MAX_RUNNING 14     // hand-over as soon as this few of the sixteen quads are still solving (and problems wait).  Since the first pass
+                                  // runs per lane a call seldom has more problems than quads: 6: -1 %, 10: -0.4 %, 13 .. 15: the same
 #endif
 #ifndef OPTIK_LANE_REFILL
 #define OPTIK_LANE_REFILL 4       // idle lanes a wave accumulates before it refills (the seed generation runs for the whole wave)
@@ -377,7 +381,12 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
             double y1_val = 0.0, rn1 = 1.0;
 #if OPTIK_LANE_FIRST_PASS
             OPTIK_SCHED_FENCE();  // (a phase of its own: interleaved with its neighbours it costs them their registers)
-            if (has_any) solved1 = nnls_first_pass<N>(rec_lds + lane, y1_id, y1_val, rn1);
+            // (only when the wave has well more problems than quads: a call with about sixteen is as long as its longest
+            // problem whatever else is taken out of it, and the pass costs the whole wave ~800 instructions -- UR10, whose
+            // wide joint limits leave fewer problems per trip, lost 2.3 % to an unconditional first pass)
+            if ((int)__popcll(__ballot(has_any)) > OPTIK_LANE_FIRST_PASS_MIN) {
+                if (has_any) solved1 = nnls_first_pass<N>(rec_lds + lane, y1_id, y1_val, rn1);
+            }
             OPTIK_SCHED_FENCE();
 #endif
             const bool has = has_any && !solved1;

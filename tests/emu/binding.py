@@ -31,7 +31,10 @@ def build(force=False):
     if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
         return LIB
     subprocess.check_call([_clang(), "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
-                           "-I", HERE, "-I", CSRC, "-Wno-unused-value", "-Wno-psabi", SRC, "-o", LIB])
+                           "-I", HERE, "-I", CSRC, "-Wno-unused-value", "-Wno-psabi",
+                           # (the emulated waves are a few lanes wide: the per-lane first NNLS pass of ik_nnls_first.hpp, which the
+                           # device only runs on trips with more than 24 problems, runs on every trip here)
+                           "-DOPTIK_LANE_FIRST_PASS_MIN=0", SRC, "-o", LIB])
     return LIB
 
 
