@@ -63,6 +63,9 @@ namespace optik {
 #ifndef OPTIK_LANE_FIRST_PASS_MIN
 #define OPTIK_LANE_FIRST_PASS_MIN 24  // (0 / 16 / 20 / 24 / 28 / 32: Panda 30.93 / 30.99 / 30.95 / 31.08 / 30.95 / 30.69 M, UR10 52.3 / 52.9 / -- / 53.4 / -- / 53.0)
 #endif
+#ifndef OPTIK_LANE_WARM_START
+#define OPTIK_LANE_WARM_START 1   // a problem the first pass does not end starts in its quad AFTER that pass (the quad re-forms the state)
+#endif
 #ifndef OPTIK_LANE_FIRST_PASS
 #define OPTIK_LANE_FIRST_PASS 1   // every lane runs the first NNLS pass on its own problem; only the unsolved ones go through the quads
 #endif
@@ -93,6 +96,7 @@ constexpr int LANE64_CLASSES = OPTIK_LANE_CLASSES;  // predicted pass classes 1 
 template <int N, class Expand, class ReadBack>
 struct Lane64Pipe {
     static constexpr bool on = true;
+    static constexpr bool warm_start = true;
     static constexpr int MAX_RUNNING = LANE64_MAX_RUNNING;
     int n_prob, next, hold;  // problems, the next rank to hand out (wave-uniform), the rank the quad holds or -1
     int qi, ql, lane, rank;
@@ -102,7 +106,11 @@ struct Lane64Pipe {
     Expand *expand_fn;
     ReadBack *read_fn;
     OPTIK_DEV bool more() const { return next < n_prob; }
-    OPTIK_DEV bool event(bool idle, int mode, double rn, int passes) {
+    // (warm start, ik_nnls_first.hpp: wst receives Q e_m, the pivot weight and the multiplier of a problem whose first
+    // column is already in, wj that column's id -- 0: the problem starts at step two)
+    template <bool WARM>
+    OPTIK_DEV bool event(bool idle, int mode, double rn, int passes, double *wst, int &wj) {
+        wj = 0;
         const bool fin = idle && hold >= 0;
         if (wave_any(fin)) {
             // (the multipliers are in the block by column id; mode, rnorm and the pass count next to them)
@@ -129,7 +137,7 @@ struct Lane64Pipe {
         next = next < n_prob ? next : n_prob;
         if (wave_any(live)) {
             const int p = lor[live ? pr : 0];
-            (*expand_fn)(live, p);
+            (*expand_fn)(std::integral_constant<bool, WARM>{}, live, p, wst, wj);
             if (live) hold = pr;
         }
         return live;
@@ -376,7 +384,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
             const bool has_any = need_dir && lmode == 1 && need_nnls;
             // 45 % of the bounded problems end after ONE pass with one active bound: that pass per lane, on the lane's own
             // record (ik_nnls_first.hpp: the same numbers as the quads would form); the rest through the quads
-            bool solved1 = false;
+            bool solved1 = false, warm1 = false;  // (warm: the first column is in, a quad continues from there)
             int y1_id = 1;
             double y1_val = 0.0, rn1 = 1.0;
 #if OPTIK_LANE_FIRST_PASS
@@ -385,7 +393,11 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
             // problem whatever else is taken out of it, and the pass costs the whole wave ~800 instructions -- UR10, whose
             // wide joint limits leave fewer problems per trip, lost 2.3 % to an unconditional first pass)
             if ((int)__popcll(__ballot(has_any)) > OPTIK_LANE_FIRST_PASS_MIN) {
-                if (has_any) solved1 = nnls_first_pass<N>(rec_lds + lane, y1_id, y1_val, rn1);
+                if (has_any) {
+                    const int fp = nnls_first_pass<N>(rec_lds + lane, y1_id, y1_val, rn1);
+                    solved1 = fp == FIRST_SOLVED;
+                    warm1 = OPTIK_LANE_WARM_START && fp == FIRST_WARM;
+                }
             }
             OPTIK_SCHED_FENCE();
 #endif
@@ -408,7 +420,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
                     n_prob += (int)__popcll(mc);
                 }
             }
-            if (has) lor_lds[rank] = lane;
+            if (has) lor_lds[rank] = lane | (warm1 ? (y1_id << 8) : 0);  // (lane of rank; the column that is already in, or 0)
             where_lds[lane] = 0;  // (no problem of this trip is solved yet)
             lds_sync();
 
@@ -427,8 +439,48 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
                 ids[k] = (sl < NS && rr < N) ? ((k >= 2) ? N : 0) + rr + 1 : 0x7fff;
             }
             double *const bk = nnls_lds + (unsigned)qi * NnlsQuadGeom<N>::STRIDE;
-            auto expand = [&](bool live, int p) {
+            // (what a warm start hands to nnls_quad's state: Q e_m, the transformation's pivot weight, the multiplier and
+            // the id of the column that is in -- quad-uniform; wj = 0: a cold start)
+            // (wst: N + 1 doubles of Q e_m, then up, then the multiplier; wj: the column that is in, 0 for a cold start --
+            // locals of nnls_quad's hand-over, not carried through its loop)
+            auto expand = [&](auto warm_tag, bool live_any, int enc, double *wst, int &wj) {
+                constexpr bool WARM = decltype(warm_tag)::value;
+                const int p = enc & 0xff;
                 const double *const rq = rec_lds + p;
+                const int jw = (WARM && live_any) ? (enc >> 8) : 0;
+                wj = live_any ? jw : wj;
+                if (WARM && wave_any(live_any && jw != 0)) {
+                    // warm: column jw is in (ik_nnls_first.hpp: the owner lane's own first pass, formed again here from
+                    // the same record -- the same numbers), the quad's block gets the columns as that pass leaves them
+                    const bool wq = live_any && jw != 0;
+                    OPTIK_SCHED_FENCE();
+                    double w[N + 1], bq[N + 1], up, ulp, hb, yv;
+                    bool al;
+                    (void)first_pass_column<N>(rq, wq ? jw : 1, w, bq, up, ulp, hb, al, yv);
+                    if (wq) {
+                        wst[N + 1] = up;
+                        wst[N + 2] = yv;
+#pragma unroll
+                        for (int r = 0; r <= N; ++r) wst[r] = bq[r];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int sl = k & 1;
+                        if (sl < NS && ql + 4 * sl < N) {
+                            double nv[N + 1];
+                            first_pass_other_column<N>(rq, ids[k], w, hb, al, nv);
+                            OPTIK_SCHED_FENCE();  // (a column at a time)
+                            if (wq) {
+                                double *c = bk + CS * (ids[k] - 1);
+                                const bool isj = ids[k] == jw;
+#pragma unroll
+                                for (int r = 0; r <= N; ++r) c[r] = isj ? ((r == 0) ? ulp : 0.0) : nv[r];
+                            }
+                        }
+                    }
+                    OPTIK_SCHED_FENCE();
+                }
+                const bool live = live_any && jw == 0;
                 // (row rr of E^-1 goes out twice: as the lower bound's column and, negated, as the upper bound's --
                 // one read of every entry, two stores)
 #pragma unroll
@@ -481,7 +533,9 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
                 // quad qi takes the problem of rank r0 + qi
                 const int pr = r0 + qi;
                 const bool live = pr < n_prob;
-                expand(live, lor_lds[live ? pr : 0]);
+                double wdummy[N + 3];
+                int wjd = 0;
+                expand(std::false_type{}, live, lor_lds[live ? pr : 0] & 0xff, wdummy, wjd);  // (rounds: every problem from step two)
                 int iters, qmode;
                 double xv[4], qrnorm;
                 nnls_quad<N>(live, ids, bk, nnls_lds + 16 * NnlsQuadGeom<N>::STRIDE, xv, qmode, qrnorm, iters);

@@ -25,6 +25,8 @@
 // hand-over is wave-uniform (tests/emu runs this file on the host).
 #pragma once
 
+#include <type_traits>
+
 #include "ik_lane.hpp"
 #include "ik_slsqp.hpp"
 
@@ -90,9 +92,11 @@ OPTIK_DEV void lds_col_store(double *p, const typename NnlsQuadGeom<N>::rowvec v
 // no longer holds fifteen finished quads until it is done.  The call returns when nothing runs and nothing waits.
 struct NoPipe {
     static constexpr bool on = false;
+    static constexpr bool warm_start = false;
     static constexpr int MAX_RUNNING = 0;
     OPTIK_DEV bool more() const { return false; }
-    OPTIK_DEV bool event(bool, int, double, int) { return false; }
+    template <bool WARM>
+    OPTIK_DEV bool event(bool, int, double, int, double *, int &) { return false; }
 };
 
 // Stop (ik_quad.hpp): launches with early exit.  stop->poll(running) is called once per loop trip; it says whether
@@ -181,31 +185,63 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
         if ((threadIdx.x & 63u) == 0) atomicAdd(&g_quad_nnls_hist[49 + n_live_], 1ull);
     }
 #endif
+    // hand-over (Pipe): answers out of the quads that are done, the next problems into the idle ones.  WARM: the
+    // problems may start after their first pass (ik_nnls_first.hpp) -- only the hand-over in front of the loop does
+    // that, where no quad holds a problem yet and the registers its state takes inside the loop are free
+    auto hand_over = [&](auto warm_tag) {
+        constexpr bool WARM = decltype(warm_tag)::value;
+        double wst[m + 2];
+        int wj = 0;
+        const bool fresh = pipe->template event<WARM>(phase == 4, mode, residual_norm(), iter, wst, wj);
+        if (fresh) {
+            // (the pipe has written the quad's block: the state of a problem at step two)
+            b = 0.0;
+            b[m - 1] = 1.0;
+            indx.v = 0xFEDCBA9876543210ull;
+            nsetp = 0; npp1 = 1; iter = 0; mode = 1;
+            up = 0.0;
+            rem_jj = 0;
+            phase = 0;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                pos[k] = ids[k];
+                inZ[k] = isc[k];
+                wv[k] = 0.0;
+                xv[k] = 0.0;
+                if (isc[k]) xs[ids[k] - 1] = 0.0;
+            }
+            if constexpr (WARM) {
+                // Warm start: the owner lane's first pass already brought column wj in with a positive multiplier; the
+                // pipe has written the block as that pass leaves it.  The state of the problem after steps five .. ten
+                // of its first trip, as the code below would have left it:
+                if (wj != 0) {
+#pragma unroll
+                    for (int r = 0; r < m; ++r) b[r] = wst[r];
+                    // column wj took position 1, the column there (id 1) took wj's
+                    indx.set(wj, indx.get(1));
+                    indx.set(1, wj);
+                    nsetp = 1; npp1 = 2; iter = 1;
+                    up = wst[m];
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k) {
+                        const bool hit = ids[k] == wj;
+                        const bool other = isc[k] && ids[k] == 1 && !hit;
+                        pos[k] = hit ? 1 : (other ? wj : pos[k]);
+                        inZ[k] = hit ? false : inZ[k];
+                        xv[k] = hit ? wst[m + 1] : 0.0;
+                        if (hit) xs[ids[k] - 1] = xv[k];
+                    }
+                }
+            }
+        }
+        lds_sync();
+    };
+    if constexpr (Pipe::on && Pipe::warm_start) hand_over(std::true_type{});
     for (;;) {
         if constexpr (Pipe::on) {
             const int n_run = (int)__popcll(__ballot(phase < 4)) / QUAD;
             if (n_run == 0 || (n_run <= Pipe::MAX_RUNNING && pipe->more())) {
-                // hand-over: answers out of the quads that are done, the next problems into the idle ones
-                const bool fresh = pipe->event(phase == 4, mode, residual_norm(), iter);
-                if (fresh) {
-                    // (the pipe has written the quad's block: the state of a problem at step two)
-                    b = 0.0;
-                    b[m - 1] = 1.0;
-                    indx.v = 0xFEDCBA9876543210ull;
-                    nsetp = 0; npp1 = 1; iter = 0; mode = 1;
-                    up = 0.0;
-                    rem_jj = 0;
-                    phase = 0;
-#pragma unroll
-                    for (int k = 0; k < CPL; ++k) {
-                        pos[k] = ids[k];
-                        inZ[k] = isc[k];
-                        wv[k] = 0.0;
-                        xv[k] = 0.0;
-                        if (isc[k]) xs[ids[k] - 1] = 0.0;
-                    }
-                }
-                lds_sync();
+                hand_over(std::false_type{});
                 if (!wave_any(phase < 4)) break;
             }
         } else {
