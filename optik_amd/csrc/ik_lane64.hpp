@@ -61,7 +61,7 @@ struct Lane64Geom {
 namespace optik {
 
 #ifndef OPTIK_LANE_FIRST_PASS_MIN
-#define OPTIK_LANE_FIRST_PASS_MIN 24  // (0 / 16 / 20 / 24 / 28 / 32: Panda 30.93 / 30.99 / 30.95 / 31.08 / 30.95 / 30.69 M, UR10 52.3 / 52.9 / -- / 53.4 / -- / 53.0)
+#define OPTIK_LANE_FIRST_PASS_MIN 16  // (with the warm start, 0 / 8 / 16 / 24: Panda 32.10 / 32.29 / 32.30 / 32.16 M, UR10 54.7 / 54.3 / 54.8 / 53.9 M)
 #endif
 #ifndef OPTIK_LANE_WARM_START
 #define OPTIK_LANE_WARM_START 1   // a problem the first pass does not end starts in its quad AFTER that pass (the quad re-forms the state)
@@ -389,9 +389,8 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
             double y1_val = 0.0, rn1 = 1.0;
 #if OPTIK_LANE_FIRST_PASS
             OPTIK_SCHED_FENCE();  // (a phase of its own: interleaved with its neighbours it costs them their registers)
-            // (only when the wave has well more problems than quads: a call with about sixteen is as long as its longest
-            // problem whatever else is taken out of it, and the pass costs the whole wave ~800 instructions -- UR10, whose
-            // wide joint limits leave fewer problems per trip, lost 2.3 % to an unconditional first pass)
+            // (only when the wave has more problems than quads: with fewer, a call is as long as its longest problem
+            // whatever is taken out of it, and the pass costs the whole wave ~800 instructions)
             if ((int)__popcll(__ballot(has_any)) > OPTIK_LANE_FIRST_PASS_MIN) {
                 if (has_any) {
                     const int fp = nnls_first_pass<N>(rec_lds + lane, y1_id, y1_val, rn1);
