@@ -406,8 +406,7 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
     // (lib.rs:297-300 shards the same range over rayon workers) and the host keeps the
     // minimum of the G (key, index) records.
     // A call that is still running after those two launches (a hard target, or Quality with a large
-    // budget) is throughput-bound: rounds of 1 M restarts per GPU on the streaming engine (46 ms
-    // against 118 on the solve kernel).
+    // budget) is throughput-bound: rounds of 1 M restarts per GPU, each one launch of the lane-per-restart form.
     const uint64_t cus = (uint64_t)(c0->num_cus > 0 ? c0->num_cus : 256);
     // restarts of the first, latency-sized launch: four per CU -- one per SIMD, the most the quad solver's one-restart-
     // per-wave form takes -- under the first-success rule (the more restarts race, the sooner the first one succeeds: the
@@ -422,12 +421,14 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
     const uint64_t first_per_cu = OPTIK_FIRST_PER_CU;
     const uint64_t first_batch = (!quality && r->parallelism == 1) ? 128 : cus * first_per_cu;
     const uint64_t later_batch = cus * 2 * 64 * 2;
-    const uint64_t engine_batch = (uint64_t)1 << 20;  // restarts per GPU per engine round
-    const bool engine_ok = engine_batch > 0 && r->n <= 7;
-    // One job of this many restarts is where the engine's ~10 ms floor is amortised against the solve kernel
-    // (tools/kernel_vs_engine_probe.py, quad kernel: 131 072 restarts 12.0 against 15.2 ms, 262 144: 20.2
-    // against 20.8, 524 288: 37.7 against 34.3; with round 2's kernel the two met at ~100 000)
-    const uint64_t engine_from = 262144;
+    const uint64_t engine_batch = (uint64_t)1 << 20;  // restarts per GPU per big round
+    // Rounds 2-3 ran the big rounds on the streaming engine (from 262 144 restarts on it beat the quad solver's single
+    // launch).  Since the lane-per-restart form a single launch wins at every size (tools/kernel_vs_engine_probe.py,
+    // ms per job, kernel / engine: 131 072 restarts 9.5 / 14.2, 262 144: 15.2 / 20.1, 1 048 576: 50.4 / 59.6,
+    // 2 097 152: 97 / 111): the big rounds are single launches too, and a round is worth ~1 M restarts because every
+    // launch pays its own ~4 ms of drain.
+    const bool engine_ok = false;
+    const uint64_t engine_from = 262144;  // (from this many restarts left on: rounds of engine_batch)
     const size_t G = device_count(r);
     const uint32_t speed_flags = OPTIK_HIP_IK_EARLY_EXIT | (r->parallelism != 1 ? OPTIK_HIP_IK_FIND_ANY : 0u);
     struct Part {
@@ -452,7 +453,7 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
         // Quality with a restart budget and no time budget runs every restart whatever happens: no
         // latency-sized first launches (each of them waits for its slowest restart -- 1 000 restarts
         // took two launches of 2.7 ms), the whole range at once: one launch of the solve kernel
-        // below ~260 000 restarts (engine_from), engine rounds from index 0 above.
+        // below ~260 000 restarts (engine_from), rounds of 1 M from index 0 above.
         // (with a time budget too when the whole range is one solve-kernel launch: its waves watch the clock)
         const bool all_at_once = quality && config->max_restarts > 0
                                  && (config->max_time <= 0.0 || config->max_restarts < engine_from);
@@ -460,9 +461,9 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
         // soon as every part is a few waves per CU -- decided on its own, not by the engine / kernel crossover)
         const size_t g_round = (begin == 0 && !(all_at_once && max_restarts / G >= cus * 64)) ? 1 : G;
         // (what is left must be worth an engine run: below engine_from restarts the solve kernel is faster)
-        const bool on_engine = engine_ok && max_restarts - begin >= engine_from
-                               && (all_at_once || begin >= first_batch + later_batch);
-        const uint64_t batch = on_engine ? engine_batch
+        const bool big_round = max_restarts - begin >= engine_from && (all_at_once || begin >= first_batch + later_batch);
+        const bool on_engine = engine_ok && big_round;
+        const uint64_t batch = big_round ? engine_batch
                                : all_at_once ? engine_from
                                : begin == 0 ? first_batch : later_batch;
         // (several GPUs: what is left is cut evenly when it is less than a full round of each)

@@ -497,12 +497,12 @@ def test_diff_ik_six_dof_solution_is_the_unique_ray(ur3e):
         np.testing.assert_allclose(v, alpha_ref * w, atol=1e-8, rtol=0)
 
 
-def test_long_calls_move_to_the_engine_with_the_same_answer(panda):
-    """Throughput-bound calls run on the streaming engine -- Quality with a restart budget of
-    ~100 000 or more from index 0, any call still running after 512 + 65 536 restarts in rounds of
-    1 M: Quality over 300 000 restarts returns the restart a solve-kernel launch around it
-    selects; an unreachable Speed target comes back None after all of them; max_time ends an
-    engine round early."""
+def test_long_calls_move_to_big_rounds_with_the_same_answer(panda):
+    """Throughput-bound calls run in rounds of 1 M restarts (single launches of the lane-per-restart form; rounds 2-3:
+    the streaming engine) -- Quality with a restart budget of ~260 000 or more from index 0, any call still running
+    after its first two launches: Quality over 300 000 restarts returns the restart a solve-kernel launch around it
+    selects; an unreachable Speed target comes back None after all of them; max_time ends a
+    round early."""
     import torch
     from optik_amd import SolverConfig
     rng = np.random.default_rng(77)
