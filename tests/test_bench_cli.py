@@ -39,3 +39,17 @@ def test_inprocess_refuses_a_multi_rank_launcher():
     r = subprocess.run([sys.executable, "bench.py", "--inprocess", "--gpus", "2"], cwd=ROOT, capture_output=True,
                        text=True, env=_clean_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=300)
     assert r.returncode != 0 and "one process" in r.stderr
+
+
+def test_pmc_record_of_the_default_command_has_the_shape_bench_reads():
+    """bench.py takes roofline.traffic and the f64 VALU scalars of the driver's command from profiles/: the record must sit
+    under its command key as {"kernel_path": {...}} with the fields the line quotes (written flat once, the line said null)."""
+    import json
+    import bench
+    with open(bench.PMC_FILES[0]) as fh:
+        recs = json.load(fh)["commands"]
+    key = "robot=panda,restarts=65536,steps=20,warmup=5,mode=speed,scaling=weak,targets=0,path=kernel,gpus=1"
+    assert key in recs and "kernel_path" in recs[key]
+    kp = recs[key]["kernel_path"]
+    for f in ("hbm_bytes_per_restart", "f64_flops_per_restart", "launches", "valu_busy", "valu_active_lane_frac"):
+        assert f in kp, f
