@@ -13,14 +13,17 @@
 //   evaluation, NLopt bookkeeping, BFGS, LSQ factor,   per lane on the lane's own restart: no replication, no
 //   rows of E^-1, LDP tail, back-substitution          cross-lane traffic; the building blocks of ik_slsqp.hpp /
 //                                                      ik_eval.hpp that the engine's phase kernels use
-//   bounded dual problems (NNLS)                       the lanes that need one (~46 of 64 per trip) leave the
-//                                                      packed problem (rows of E^-1, h: 42 doubles) in LDS; the
-//                                                      wave ranks them by predicted pass count (what the restart's
+//   bounded dual problems (NNLS)                       the lanes that need one (~30 of 64 per trip) leave the
+//                                                      packed problem (rows of E^-1, h: 42 doubles) in LDS and run
+//                                                      Lawson-Hanson's FIRST pass on it themselves
+//                                                      (ik_nnls_first.hpp): 45 % of the problems end there, the
+//                                                      others start in a quad after that pass; the
+//                                                      wave ranks those by predicted pass count (what the restart's
 //                                                      previous problem took, or the number of violated bounds if
 //                                                      larger: 76 % repeat it, 92 % within one) and PIPELINES them
 //                                                      through its sixteen quads: a quad expands the next problem of
 //                                                      the ranking into its 1 KB block and runs ik_nnls_quad.hpp on it;
-//                                                      whenever eight or fewer quads are still solving, the finished
+//                                                      whenever fourteen or fewer quads are still solving, the finished
 //                                                      ones' answers go back to their owner lanes and the idle quads
 //                                                      take the next problems (Lane64Pipe).  A problem that needs more
 //                                                      passes than predicted keeps its quad busy, not the wave.
