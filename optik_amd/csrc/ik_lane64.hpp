@@ -180,11 +180,22 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
     target.t = V3{0, 0, 0};
     target.q = Q4{0, 0, 0, 1};
 
+    // (-DOPTIK_PROFILE: wave cycles per part of a trip -- 0 refill, 1 evaluation, 4 bookkeeping + BFGS, 5 LSQ factor +
+    // records, 2 first NNLS pass, 6 ranking + NNLS, 3 LDP tail .. publish, 7 trips; tools/phase_profile.py lane)
+#ifdef OPTIK_PROFILE
+    unsigned long long lp_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long lt_ = __builtin_readcyclecounter();
+#define LANE_PROF(slot) do { const unsigned long long n_ = __builtin_readcyclecounter(); lp_[slot] += n_ - lt_; lt_ = n_; } while (0)
+#else
+#define LANE_PROF(slot)
+#endif
     for (;;) {
         // ---- refill: lanes without a restart pull the next work item ----------------------------------
         // (the seed generation runs for the whole wave: wait until several lanes are idle -- or none is busy)
         const unsigned n_want = (unsigned)__popcll(__ballot(want));
         if (n_want >= (unsigned)(wq.lanes < OPTIK_LANE_REFILL ? wq.lanes : OPTIK_LANE_REFILL) || (n_want > 0 && !wave_any(active))) {
+            // (asking for the items one refill ahead, so that no refill waits for its own atomic add on the launch's one
+            // counter, measured nothing: 32.35 against 32.29 M restarts/s)
             const unsigned long long it = fetch_items(wq.next_item, want);
             if (want) {
                 want = false;
@@ -214,6 +225,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
             }
         }
         if (!wave_any(active)) break;
+        LANE_PROF(0);
 
         int32_t ret = 0;
         if (active) {
@@ -244,6 +256,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
 #endif
         if (do_eval) fn = eval_fg<N, TIP>(ch, ep, target, x, gn);
         OPTIK_SCHED_FENCE_LANE64();
+        LANE_PROF(1);
 
         // ---- NLopt bookkeeping and Kraft's line search (labels 100 / 220), per lane ---------------------
         bool need_dir = stepping && again, reset = stepping && again;
@@ -321,6 +334,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
         }
         OPTIK_SCHED_FENCE_LANE64();
 
+        LANE_PROF(4);
         // ---- labels 110/130: (reset,) search direction, descent test -- one pass per trip -----------------
         if (wave_any(need_dir)) {
             if (need_dir && reset) {
@@ -390,6 +404,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
             bool solved1 = false, warm1 = false;  // (warm: the first column is in, a quad continues from there)
             int y1_id = 1;
             double y1_val = 0.0, rn1 = 1.0;
+            LANE_PROF(5);
 #if OPTIK_LANE_FIRST_PASS
             OPTIK_SCHED_FENCE();  // (a phase of its own: interleaved with its neighbours it costs them their registers)
             // (only when the wave has more problems than quads: with fewer, a call is as long as its longest problem
@@ -405,6 +420,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
 #endif
             const bool has = has_any && !solved1;
             OPTIK_SCHED_FENCE_LANE64();
+            LANE_PROF(2);
 
             // ---- the wave's bounded problems by predicted class, the largest first -----------------------
             int cls = 0;
@@ -556,6 +572,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
           }
 #endif
             OPTIK_SCHED_FENCE_LANE64();
+            LANE_PROF(6);
 
             // ---- LDP tail (lsq_dual), back-substitution, descent test, per lane ------------------------------
             double sn[N];
@@ -673,7 +690,16 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
             want = true;
             again = false;
         }
+#ifdef OPTIK_PROFILE
+        LANE_PROF(3);
+        lp_[7] += 1;
+#endif
     }
+#ifdef OPTIK_PROFILE
+    if (wq.prof && (threadIdx.x & 63u) == 0)
+        for (int i_ = 0; i_ < 8; ++i_) atomicAdd(wq.prof + i_, lp_[i_]);
+#endif
+#undef LANE_PROF
 }
 
 }  // namespace optik
