@@ -426,6 +426,8 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
             int cls = 0;
             if (has) {
                 cls = nviol > pred ? nviol : pred;
+                // (after the first pass: one pass done + one per dual still positive; +0.9 %, three of three runs)
+                if (warm1) { const int c2 = 1 + (int)y1_val; cls = c2 > cls ? c2 : cls; }
                 cls = cls < 1 ? 1 : (cls > LANE64_CLASSES - 1 ? LANE64_CLASSES - 1 : cls);
             }
             int rank = 0, n_prob = 0;

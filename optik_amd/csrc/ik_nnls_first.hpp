@@ -178,6 +178,7 @@ OPTIK_DEV int nnls_first_pass(const double *rp, int &y_id, double &y_val, double
     // only when it is a zero itself -- and a zero sum decides the same way whatever its sign: `sm != 0`, `sdot > 0`.
     // An untouched column -- sm == 0 -- gets smh = 0 and cv + 0 w = cv up to the sign of a zero.)
     bool more = false;
+    int npos = 0;  // duals that are positive after the pass: how many more columns are likely to enter
 #pragma unroll
     for (int c = 1; c <= n; ++c) {
         const int rr = (c > N) ? c - N - 1 : c - 1;
@@ -204,10 +205,11 @@ OPTIK_DEV int nnls_first_pass(const double *rp, int &y_id, double &y_val, double
             sdot += nv * ((r >= 1) ? b[r] : 0.0);
         }
         more = more || (c != j && sdot > 0.0);
+        npos += (c != j && sdot > 0.0) ? 1 : 0;
         OPTIK_SCHED_FENCE();  // (one column at a time: interleaved, the fourteen of them keep ~100 doubles live)
     }
     y_id = j;
-    if (more) return FIRST_WARM;
+    if (more) { y_val = (double)npos; return FIRST_WARM; }  // (FIRST_WARM: y_val carries that count, for the ranking)
 
     // ---- rnorm = ||b(2 .. m)||, as residual_norm forms it
     double xmax = 0.0;
