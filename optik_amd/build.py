@@ -82,7 +82,8 @@ def _unit_stale(hipcc, src, objname, extra):
         return True
     t = os.path.getmtime(obj)
     flags_file = obj + ".flags"
-    if not (os.path.exists(flags_file) and open(flags_file).read() == " ".join(_unit_cmd(hipcc, src, objname, extra)[1:])):
+    if hipcc is not None and not (os.path.exists(flags_file)
+                                  and open(flags_file).read() == " ".join(_unit_cmd(hipcc, src, objname, extra)[1:])):
         return True
     deps = _dep_files(obj)
     if deps is None:
@@ -97,7 +98,12 @@ def _unit_stale(hipcc, src, objname, extra):
 def is_stale() -> bool:
     if not os.path.exists(LIB):
         return True
-    hipcc = _hipcc()
+    # (a runtime-only machine has the library and no compiler: the recorded command lines then cannot be
+    # compared -- the prerequisites' time stamps still are)
+    try:
+        hipcc = _hipcc()
+    except RuntimeError:
+        hipcc = None
     t = os.path.getmtime(LIB)
     for src, objname, extra in UNITS:
         if _unit_stale(hipcc, src, objname, extra) or os.path.getmtime(os.path.join(CSRC, objname)) > t:

@@ -515,8 +515,11 @@ struct optik_hip_chain {
     size_t fs_cap = 0;
     // (what the last launch's selection kernel left behind: the work-item counter at 0, this many leading
     // first-success words at ~0 -- a launch that finds them so skips its fill commands)
+    // (host-side knowledge that holds for launches ORDERED behind that selection kernel: the stream it ran on is kept
+    // with it, a launch on any other stream fills the words itself)
     bool queue_clean = false;
     size_t fs_clean = 0;
+    hipStream_t clean_stream = nullptr;
     // scratch per-restart buffers when the caller does not provide them
     double *tmp_x = nullptr, *tmp_f = nullptr, *tmp_key = nullptr;
     size_t tmp_cols = 0;
@@ -555,8 +558,9 @@ struct optik_hip_chain {
     unsigned long long *hw_claim = nullptr;
     hipEvent_t claim_done = nullptr;  // recorded behind such a launch: what the polling host also looks at
     unsigned long long claim_seq = 0;
-    bool claim_request = false, claim_armed = false;
-    bool claim_pending = false;  // such a call returned early: its launch may still be running on the null stream
+    // such a launch may still be running on the null stream (set, under `mu`, in the critical section that queues it;
+    // cleared by whoever has waited for the null stream)
+    bool claim_pending = false;
     unsigned hw_flip = 0;  // which half of the pinned block the next zero-copy call uses
     unsigned long long *nnls_trace = nullptr;  // OPTIK_NNLS_TRACE builds
     unsigned int *eng_trip_log = nullptr;      // OPTIK_ENG_TRIP_LOG diagnostics
@@ -1014,7 +1018,7 @@ int optik_hip_seed_batch(const optik_hip_chain *ch, uint64_t first, int64_t coun
 static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, const double *d_targets,
                            const double *d_x0, int32_t T, const double *ee_offset7, uint64_t restart_begin,
                            uint64_t restart_end, uint32_t flags, double deadline_s, const optik_hip_ik_outputs *out,
-                           void *stream_v);
+                           void *stream_v, bool claim_request = false, bool *claim_armed = nullptr);
 
 extern "C" {
 
@@ -1033,7 +1037,8 @@ int optik_hip_ik_batch(optik_hip_chain *ch, const optik_solver_config *cfg, cons
 static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, const double *d_targets,
                            const double *d_x0, int32_t T, const double *ee_offset7, uint64_t restart_begin,
                            uint64_t restart_end, uint32_t flags, double deadline_s, const optik_hip_ik_outputs *out,
-                           void *stream_v) {
+                           void *stream_v, bool claim_request, bool *claim_armed) {
+    if (claim_armed) *claim_armed = false;
     if (!ch || !cfg || !d_targets || !d_x0 || !out || T < 1) return fail(OPTIK_HIP_EINVAL, "bad argument");
     if (restart_end <= restart_begin) return fail(OPTIK_HIP_EINVAL, "empty restart range");
     if (cfg->solution_mode != 1 && cfg->solution_mode != 2)
@@ -1050,8 +1055,8 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     BIND_DEVICE(ch);
     // (a single call that returned on its first success may have left its launch running on the null stream: a
     // launch on another stream shares the chain's workspace with it and waits; on the null stream it queues behind)
-    if (ch->claim_pending && stream != nullptr) HIP_TRY(hipStreamSynchronize(nullptr));
-    ch->claim_pending = false;
+    // (on the null stream the flag stays: optik_hip_ik_host's staged path still has to know)
+    if (ch->claim_pending && stream != nullptr) { HIP_TRY(hipStreamSynchronize(nullptr)); ch->claim_pending = false; }
 
     // selection tiles: 4096 restarts per 256-thread block
     constexpr int SEL_TILE = 4096;
@@ -1070,6 +1075,8 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         ch->tile_cap = (size_t)n_tiles;
     }
     if (!ch->queue) { HIP_TRY(hipMalloc(&ch->queue, sizeof(unsigned long long))); ch->queue_clean = false; }
+    // (the words are only known to be clean to a launch queued behind the selection kernel that cleaned them)
+    if (stream != ch->clean_stream) { ch->queue_clean = false; ch->fs_clean = 0; }
     if (!ch->queue_clean) HIP_TRY(hipMemsetAsync(ch->queue, 0, sizeof(unsigned long long), stream));
     ch->queue_clean = false;  // (until this launch's selection kernel has put it back)
     const bool early = (flags & OPTIK_HIP_IK_EARLY_EXIT) && cfg->solution_mode == 2;
@@ -1126,7 +1133,6 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     a.wq.find_any = (early && (flags & OPTIK_HIP_IK_FIND_ANY)) ? 1 : 0;
     a.wq.claim = nullptr;
     a.wq.claim_seq = 0;
-    ch->claim_armed = false;
     a.wq.restart_major = (flags & OPTIK_HIP_IK_RESTART_MAJOR) ? 1 : 0;
     a.wq.n_targets = (unsigned long long)T;
     a.wq.deadline = 0;
@@ -1222,10 +1228,11 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     }
     a.wq.lanes = (int)lanes;
     // a single call under the first-success rule on the quad solver: the first success goes to the host at once
-    if (ch->claim_request && quadk && !lanek && a.wq.find_any && T == 1 && ch->hw_claim) {
+    if (claim_request && quadk && !lanek && a.wq.find_any && T == 1 && ch->hw_claim) {
         a.wq.claim = ch->hw_claim;
         a.wq.claim_seq = ++ch->claim_seq;
-        ch->claim_armed = true;
+        if (claim_armed) *claim_armed = true;
+        if (stream == nullptr) ch->claim_pending = true;  // (the caller may return before this launch has ended)
     }
     long long grid_ll = (resident + lanes - 1) / lanes;
     if (grid_ll > cap) grid_ll = cap;
@@ -1293,6 +1300,7 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         }
         ch->queue_clean = true;
         ch->fs_clean = fs_clean_after;
+        ch->clean_stream = stream;
     }
     return 0;
 }
@@ -2127,8 +2135,10 @@ int optik_hip_ik_host(optik_hip_chain *ch, const optik_solver_config *cfg, const
     // six hipMalloc / hipFree pairs and six copies): in = targets [T][7], x0 [T][n];
     // out = win_x [T][n], win_f [T], win_key [T], win_idx [T]
     const size_t n_in = (size_t)(7 + n) * (size_t)T, n_out = (size_t)(n + 3) * (size_t)T;
+    // (`mu` from here to the launch: the claim state and the staging blocks belong to the launch workspace)
+    std::unique_lock<std::mutex> launch_lock(ch->mu);
     if (n_in + n_out > ch->hw_cap) {
-        if (ch->claim_pending) (void)hipStreamSynchronize(nullptr);  // (its launch reads the block about to go)
+        if (ch->claim_pending) { (void)hipStreamSynchronize(nullptr); ch->claim_pending = false; }  // (its launch reads the block about to go)
         if (ch->hw_dev) (void)hipFree(ch->hw_dev);
         if (ch->hw_pin) (void)hipHostFree(ch->hw_pin);
         ch->hw_dev = nullptr; ch->hw_pin = nullptr; ch->hw_cap = 0;
@@ -2144,6 +2154,12 @@ int optik_hip_ik_host(optik_hip_chain *ch, const optik_solver_config *cfg, const
     if (zero_copy) {
         pin += (ch->hw_flip & 1u) * ch->hw_cap;
         ch->hw_flip ^= 1u;
+    } else if (ch->claim_pending) {
+        // The staged path always uses block 0.  A launch that a first-success call left running may have been given
+        // that block: its selection kernel still writes its winner there -- inside the region the targets are about
+        // to be staged in -- so it has to end first (the two-block flip only protects the zero-copy calls).
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        ch->claim_pending = false;
     }
     double *io = zero_copy ? pin : ch->hw_dev;
     double *d_t = io, *d_x0 = d_t + (size_t)7 * T;
@@ -2167,20 +2183,25 @@ int optik_hip_ik_host(optik_hip_chain *ch, const optik_solver_config *cfg, const
         std::memset(ch->hw_claim, 0, sizeof(unsigned long long) * (3 + MAX_DOF));
         HIP_TRY(hipEventCreateWithFlags(&ch->claim_done, hipEventDisableTiming));
     }
-    ch->claim_request = claim;
-    const int rc = (flags & OPTIK_HIP_IK_ENGINE)
-                       ? optik_hip_engine_solve(ch, cfg, d_t, d_x0, T, ee_offset7, restart_begin, restart_end,
-                                                flags & ~OPTIK_HIP_IK_ENGINE, deadline_s, &o, nullptr)
-                       : optik_hip_ik_batch(ch, cfg, d_t, d_x0, T, ee_offset7, restart_begin, restart_end, flags,
-                                            deadline_s, &o, nullptr);
-    ch->claim_request = false;
+    bool armed = false;
+    unsigned long long seq = 0;
+    int rc;
+    if (flags & OPTIK_HIP_IK_ENGINE) {
+        launch_lock.unlock();  // (an engine run takes the lock itself)
+        rc = optik_hip_engine_solve(ch, cfg, d_t, d_x0, T, ee_offset7, restart_begin, restart_end,
+                                    flags & ~OPTIK_HIP_IK_ENGINE, deadline_s, &o, nullptr);
+    } else {
+        rc = ik_batch_locked(ch, cfg, d_t, d_x0, T, ee_offset7, restart_begin, restart_end, flags, deadline_s, &o, nullptr,
+                             claim, &armed);
+        seq = ch->claim_seq;
+        // (the end of THIS launch, not of the null stream: other chains' calls may keep that one busy)
+        if (!rc && armed && hipEventRecord(ch->claim_done, nullptr) != hipSuccess) rc = fail(OPTIK_HIP_ENODEVICE, "hipEventRecord failed");
+        launch_lock.unlock();
+    }
     if (rc) return rc;
     double *h_out = pin + n_in;
     if (!zero_copy) HIP_TRY(hipMemcpyAsync(h_out, d_wx, sizeof(double) * n_out, hipMemcpyDeviceToHost, nullptr));
-    if (ch->claim_armed) {
-        // (the end of THIS launch, not of the null stream: other chains' calls may keep that one busy)
-        HIP_TRY(hipEventRecord(ch->claim_done, nullptr));
-        const unsigned long long seq = ch->claim_seq;
+    if (armed) {
         volatile unsigned long long *cw = ch->hw_claim;
         for (unsigned spin = 1;; ++spin) {
             if (__atomic_load_n(ch->hw_claim, __ATOMIC_ACQUIRE) == seq) {
@@ -2188,8 +2209,7 @@ int optik_hip_ik_host(optik_hip_chain *ch, const optik_solver_config *cfg, const
                 if (win_f) std::memcpy(win_f, (const void *)(cw + 2), sizeof(double));
                 if (win_idx) *win_idx = cw[1];
                 if (win_key) *win_key = (double)cw[1];
-                ch->claim_pending = true;
-                return 0;
+                return 0;  // (claim_pending stays set: the launch ends behind the caller's back)
             }
             if ((spin & 63u) == 0) {
                 const hipError_t q = hipEventQuery(ch->claim_done);
@@ -2206,6 +2226,11 @@ int optik_hip_ik_host(optik_hip_chain *ch, const optik_solver_config *cfg, const
         }
     }
     HIP_TRY(hipStreamSynchronize(nullptr));
+    if (armed) {
+        // (nothing of this call is left on the null stream -- unless a later launch of the chain armed a claim meanwhile)
+        std::lock_guard<std::mutex> relock(ch->mu);
+        if (ch->claim_seq == seq) ch->claim_pending = false;
+    }
     if (win_x) std::memcpy(win_x, h_out, sizeof(double) * (size_t)n * (size_t)T);
     if (win_f) std::memcpy(win_f, h_out + (size_t)n * T, sizeof(double) * (size_t)T);
     if (win_key) std::memcpy(win_key, h_out + (size_t)(n + 1) * T, sizeof(double) * (size_t)T);

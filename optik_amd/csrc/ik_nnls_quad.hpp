@@ -396,16 +396,16 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
                 for (int r = 1; r <= m; ++r) rowkeep[r - 1] = (r < npp1) ? 0x80000000u : 0u;
                 {
                     // (a column the test above rejects leaves b as it was -- oracle: z is only copied back to b when the
-                    // column is found: the factor is zeroed as well as the sign forced, or a rejected column with a
-                    // non-zero factor would still move b)
-                    const unsigned allkeep = (found && actb) ? 0u : 0x80000000u;
-                    const double smhb_b = (found && actb) ? smhb : 0.0;
+                    // column is found.  A select, not a zeroed factor: 0 * w would still be NaN for a column that has
+                    // overflowed, and the oracle does not touch b then)
+                    const bool moves = found && actb;
 #pragma unroll
                     for (int r = 1; r <= m; ++r) {
-                        const double add = smhb_b * w[r - 1];
-                        const double addz = __hiloint2double((int)((unsigned)__double2hiint(add) | rowkeep[r - 1] | allkeep),
+                        const double add = smhb * w[r - 1];
+                        const double addz = __hiloint2double((int)((unsigned)__double2hiint(add) | rowkeep[r - 1]),
                                                              __double2loint(add));
-                        b[r - 1] = b[r - 1] + addz;
+                        const double nb = b[r - 1] + addz;
+                        b[r - 1] = moves ? nb : b[r - 1];
                     }
                 }
                 // column j takes position iz1 = nsetp + 1, the column there takes j's

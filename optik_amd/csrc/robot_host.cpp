@@ -595,7 +595,7 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
             if (deadline <= 0.0) break;  // lib.rs:393
         }
         const size_t L = live.size();
-        const bool big_speed = !quality && L >= engine_min;
+        const bool big_speed = !quality && L >= engine_min && std::getenv("OPTIK_BATCH_NO_ENGINE") == nullptr;
         uint64_t round = quality ? 256 : speed_round;
         // (~4 M work items per round at most -- 288 MB of per-restart keys, points and residuals --
         // down to 64 indices per target, which still leave no reachable target unsolved)
@@ -639,8 +639,9 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
         // (one job of ~260 000 restarts is where the engine overtakes the quad solve kernel: 131 072 take 12.0
         // against 15.2 ms, 524 288 take 37.7 against 34.3 ms; n = 8 has no engine)
         const uint64_t kernel_below = 262144;
-        const bool kernel_path = r->n <= 7 && !big_speed && L <= small_batch
-                                 && ((!quality && begin < 256) || (uint64_t)L * (end - begin) < kernel_below);
+        static const bool no_engine_ = std::getenv("OPTIK_BATCH_NO_ENGINE") != nullptr;  // (round 5 measurement, temporary)
+        const bool kernel_path = no_engine_ || (r->n <= 7 && !big_speed && L <= small_batch
+                                 && ((!quality && begin < 256) || (uint64_t)L * (end - begin) < kernel_below));
         const uint32_t mode_flags =
             quality ? 0u : (OPTIK_HIP_IK_EARLY_EXIT | (r->parallelism != 1 ? OPTIK_HIP_IK_FIND_ANY : 0u));
         if (kernel_path) {
