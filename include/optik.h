@@ -59,13 +59,28 @@ const char *optik_robot_last_error(void);
 int optik_robot_ik_ex(const optik_robot *robot, const CSolverConfig *config, const double *target16,
                       const double *x0, const double *ee_offset16, double *x_out, double *f_out,
                       uint64_t *winner_out);
+/* How a 4x4 target becomes the (translation, unit quaternion) pose Robot::ik takes.  The reference has two readings:
+ * its C path (optik-cpp/src/lib.rs:137-144) runs nalgebra's ITERATIVE UnitQuaternion::from_matrix on the 3x3 block,
+ * its Python path (optik-py/src/lib.rs:8-15) nalgebra's try_convert = the closed-form from_rotation_matrix.  Both give
+ * the same rotation for a rotation matrix, last bits apart -- and last bits decide which restart wins (DESIGN.md
+ * section 2).  optik_robot_ik (the reference's C symbol) uses the iterative form, as liboptikcpp does;
+ * optik_robot_ik_ex (what the Python front end calls; ee_offset only exists there) the closed form;
+ * optik_robot_ik_pose takes the choice as a flag: OPTIK_POSE_FROM_MATRIX = the iterative form.
+ * optik_pose_from_matrix: the conversion alone (host code, no GPU): m16 column-major -> pose7 [t, qi, qj, qk, qw]. */
+#define OPTIK_POSE_FROM_MATRIX 4u
+int optik_robot_ik_pose(const optik_robot *robot, const CSolverConfig *config, const double *target16,
+                        uint32_t flags, const double *x0, const double *ee_offset16, double *x_out,
+                        double *f_out, uint64_t *winner_out);
+int optik_pose_from_matrix(const double *m16, uint32_t flags, double *pose7);
 /* T independent ik() calls with one SolverConfig: targets16 [T][16] (4x4 col-major each),
  * x0 [T][n] -> x_out [T][n], f_out [T], found_out [T] (0/1).  Every target gets Robot::ik's
  * semantics (config 5 of BASELINE.json: many targets x a few hundred restarts).  Scheduling
- * (robot_host.cpp:ik_batch_on_device): a Speed batch's first round of 256 restart indices per
- * target runs on the cooperative solve kernel, restart-major -- from 40 960 targets on the
- * streaming engine, 16 indices per target; what it leaves unsolved runs in rounds four times as
- * long each; Quality batches and rounds of ~100 000 restarts or more run on the engine.
+ * (robot_host.cpp:ik_batch_on_device): every round is ONE launch of optik_hip_ik_batch over the
+ * targets still unsolved.  Speed: a first round of 128 restart indices per target, restart-major
+ * with early exit (64 when the round would exceed ~4 M work items, down to 8 for batches of more
+ * than 65 536 targets); what it leaves unsolved runs in rounds four times as long each.  Quality:
+ * every restart of every target, as many indices per round as ~4 M work items allow, on the
+ * lane-per-restart form.
  * rc 0 = ran, < 0 = error. */
 int optik_robot_ik_batch_ex(const optik_robot *robot, const CSolverConfig *config, int32_t T,
                             const double *targets16, const double *x0, const double *ee_offset16,
@@ -74,7 +89,9 @@ int optik_robot_ik_batch_ex(const optik_robot *robot, const CSolverConfig *confi
  * 4x4 is row-major (optik-py/src/lib.rs:8-15 reads nested rows), OPTIK_BATCH_VALIDATE_POSES =
  * apply parse_pose's isometry test to every target (bottom row exactly 0 0 0 1, R'R = I within
  * 100 * DBL_EPSILON per entry, det R > 0) and return -3 with "invalid target transform
- * specified" before any GPU work if one fails.  flags = 0 is optik_robot_ik_batch_ex. */
+ * specified" before any GPU work if one fails; OPTIK_POSE_FROM_MATRIX = convert every target with the iterative
+ * UnitQuaternion::from_matrix (the C path's reading; optik_robot_ik_batch_ex passes it, the Python front end does
+ * not). */
 #define OPTIK_BATCH_ROW_MAJOR 1u
 #define OPTIK_BATCH_VALIDATE_POSES 2u
 int optik_robot_ik_batch_poses(const optik_robot *robot, const CSolverConfig *config, int32_t T,

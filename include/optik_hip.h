@@ -79,8 +79,8 @@ const char *optik_hip_last_error(void);
  * each chain joint, ignored for fixed), types: OPTIK_JOINT_*, lb/ub: n limits
  * (Robot::joint_limits, lib.rs:78-84).  Supported: 1 <= n <= 16 positional joints plus
  * an optional trailing fixed joint (what from_urdf's folding produces).  n <= 8 runs on the
- * tuned solvers (the streaming engine covers n <= 7, an 8-DoF chain's engine jobs run on the
- * quad solver); 9 <= n <= 16 runs on one general kernel per entry point (joint count at run
+ * tuned solvers (the lane-per-restart form for n <= 7 from one full load of the chip on, the
+ * quad solver otherwise); 9 <= n <= 16 runs on one general kernel per entry point (joint count at run
  * time; the solver keeps one restart per wave in LDS with the wave's 64 lanes working on it
  * together: the same results as the CPU oracle bit for bit, a fraction of the tuned solvers'
  * rate) -- the reference itself has no limit
@@ -137,16 +137,6 @@ int optik_hip_seed_batch(const optik_hip_chain *chain, uint64_t first, int64_t c
  * higher indices are never started.  Scheduling only: per-restart results and winners are the
  * same (an abandoned restart's status is FORCED_STOP either way). */
 #define OPTIK_HIP_IK_RESTART_MAJOR 4u
-/* optik_hip_ik_host only: run the call as one job of the streaming engine
- * (optik_hip_engine_solve) instead of the single solve kernel -- same results; faster from
- * ~100 000 restarts (1 M restarts: 46 against 118 ms), slower below (16 384: 9.8 against 3.9 ms). */
-#define OPTIK_HIP_IK_ENGINE 8u
-/* Engine jobs with EARLY_EXIT: a run whose jobs all have early exit uses a pool of about eight
- * slots per target (most restarts above a target's first success are abandoned, and the phase
- * kernels cost per slot scanned).  FULL_POOL keeps the whole pool: for jobs whose targets are
- * known to be hard -- the later rounds of a call, where nearly every restart runs to the end. */
-#define OPTIK_HIP_IK_FULL_POOL 16u
-
 /* Outputs of optik_hip_ik_batch; any pointer may be NULL to skip that output.
  * R = restart_end - restart_begin. */
 typedef struct optik_hip_ik_outputs {
@@ -174,79 +164,14 @@ int optik_hip_ik_batch(optik_hip_chain *chain, const optik_solver_config *cfg,
                        uint32_t flags, double deadline_s, const optik_hip_ik_outputs *out,
                        void *stream);
 
-/* Streaming engine (throughput path): the same restarts, the same arithmetic and the
- * same results as optik_hip_ik_batch, executed as phase kernels over a pool of restart
- * slots in HBM with continuous refill (optik_amd/csrc/ik_engine.hpp).  submit() only
- * records a job (arguments as optik_hip_ik_batch; all jobs of one run must share
- * tolerances, weights and ee_offset; buffers must stay valid until run() returns);
- * run() executes every pending job, runs their selections and blocks until done (it
- * uses the given stream and up to three internal ones, joined before it returns).
- * With OPTIK_HIP_IK_EARLY_EXIT a restart whose target already has a lower-index success
- * when its turn comes is never started: its status is FORCED_STOP, evals 0, key +inf,
- * and its x / f entries are left as they were.
- * Any number of jobs may be submitted; at most 256 of them share one run of the slot pool
- * (more are executed as consecutive runs inside engine_run). */
-int optik_hip_engine_submit(optik_hip_chain *chain, const optik_solver_config *cfg,
-                            const double *d_targets, const double *d_x0, int32_t T,
-                            const double *ee_offset7, uint64_t restart_begin, uint64_t restart_end,
-                            uint32_t flags, const optik_hip_ik_outputs *out);
-int optik_hip_engine_run(optik_hip_chain *chain, void *stream);
-/* The same with max_time (lib.rs:260-264, 308, 393): `deadline_s` > 0 seconds after the call
- * starts, restarts still in flight are abandoned at their next evaluation (status FORCED_STOP,
- * x / f = their best point so far, never a success) and restarts not yet started are not
- * started (FORCED_STOP, 0 evaluations); solutions published before the deadline stay and are
- * selected as usual.  The host checks the clock between chunks of four trips. */
-int optik_hip_engine_run_ex(optik_hip_chain *chain, void *stream, double deadline_s);
-/* One job, submitted and run in one call that other optik_hip_engine_solve callers of the
- * chain cannot interleave with (submit + run_ex under one lock): what a re-entrant host API
- * (Robot::ik is, lib.rs:241) calls.  Do not mix with jobs left pending by optik_hip_engine_submit. */
-int optik_hip_engine_solve(optik_hip_chain *chain, const optik_solver_config *cfg,
-                           const double *d_targets, const double *d_x0, int32_t T,
-                           const double *ee_offset7, uint64_t restart_begin, uint64_t restart_end,
-                           uint32_t flags, double deadline_s, const optik_hip_ik_outputs *out,
-                           void *stream);
-/* Allocates the engine's slot pool and work buffers for up to `slots` slots (0 = the default
- * capacity, 393 216) ahead of the first run -- set-up a caller does once; runs allocate on
- * demand otherwise. */
-int optik_hip_engine_reserve(optik_hip_chain *chain, uint64_t slots, void *stream);
-int optik_hip_engine_last_trips(const optik_hip_chain *chain);
-/* Who finished the last run's final restarts once its queue was dry: *restarts = how many (an upper bound:
- * the host's lagging count) were handed over from the slot pool; returns the solver -- 0 none (the
- * phase kernels ran every restart to its end), 3 the quad solver (1 and 2 named the kernels of rounds 1 and 2). */
-int optik_hip_engine_last_tail(const optik_hip_chain *chain, int32_t *restarts);
-/* The slot pool of a run is split into sub-pools (OPTIK_ENG_POOLS, default 3; at most 4),
- * each with its own HIP stream, so that kernels of different sub-pools overlap.  Returns
- * the number of sub-pools of the last run; *launches = launches of each phase kernel,
- * all sub-pools together (last_trips is the trip count of sub-pool 0). */
-int optik_hip_engine_last_pools(const optik_hip_chain *chain, int32_t *launches);
-/* Last run, when timing is enabled (optik_hip_set_timing): mean duration in ms of the four
- * phase kernels {eval, update, nnls, finish} over the trips of sub-pool 0 (HIP start / stop events
- * attached to the dispatches on its launch stream, first 1024 trips; kernels of the other
- * sub-pools run concurrently), and
- * the number of bounded sub-problems solved by all sub-pools. */
-int optik_hip_engine_stats(const optik_hip_chain *chain, double *kernel_ms4, int32_t *sampled_trips,
-                           uint64_t *nnls_problems);
-
-/* Objective + gradient evaluations the last engine run executed (all sub-pools, tail kernel
- * included).  d_evals reports NLopt's count per restart, which also includes the re-evaluation
- * of an accepted line-search point that was not the first trial; the kernels skip that one. */
-uint64_t optik_hip_engine_executed_evals(const optik_hip_chain *chain);
-
 /* Tuning options of the kernel layer (diagnostics: tests and tools; the defaults are what the product runs with).
  * Each option's default comes from the environment variable named with it, read ONCE when the library first needs
  * an option; afterwards only this call changes it.  Not synchronised with calls in flight.
  *   solve_kernel        OPTIK_SOLVE_KERNEL = quad | lane64 | general   0 auto (by launch size), 1 quad solver
  *                                                                       (ik_quad.hpp), 2 lane-per-restart form
  *                                                                       (ik_lane64.hpp), 3 general solver (ik_wide.hpp)
- *   engine_slots        OPTIK_ENGINE_SLOTS       capacity of the streaming engine's slot pool (0: default)
- *   engine_pools        OPTIK_ENG_POOLS          sub-pools of an engine run (0: default)
- *   engine_nnls_budget  OPTIK_ENG_NNLS_BUDGET    solve passes per bounded sub-problem per NNLS launch (default 6)
- *   engine_nnls_slack   OPTIK_ENG_NNLS_SLACK     ... and per problem: its predicted count + this (default 1)
- *   engine_tail_max     OPTIK_ENG_TAIL_MAX       restarts left at which the quad solver takes an engine run over
- *                                                (-1: default, 0: never)
  *   wide_form           OPTIK_WIDE_FORM = lds | hbm   form of the general solver (0 lds, 1 hbm)
  *   range_rule          OPTIK_RANDOM_RANGE_RULE = new_inclusive   OPTIK_HIP_RANGE_* of chains created afterwards
- *   engine_compact      (none)                   0: no drain compaction of an engine run's sub-pools
  *   stop_x_legacy       (none)                   1: nlopt_stop_x of NLopt 2.5 (no zero-step rule)
  * The host layer (optik.h) reads OPTIK_HOST_THREADS and OPTIK_DEVICES; nothing else in the library reads the
  * environment.  Returns 0, or OPTIK_HIP_EINVAL for an unknown name; optik_hip_get_option returns -1 for one. */

@@ -19,8 +19,6 @@ MAX_DOF = 8
 IK_EARLY_EXIT = 1
 IK_FIND_ANY = 2
 IK_RESTART_MAJOR = 4
-IK_ENGINE = 8      # optik_hip_ik_host only: run the call as one engine job
-IK_FULL_POOL = 16  # engine jobs with early exit: keep the whole slot pool (hard targets)
 UINT64_MAX = 0xFFFFFFFFFFFFFFFF
 
 RES_FAILURE, RES_ROUNDOFF, RES_FORCED_STOP, RES_ITER_CAP = -1, -4, -5, -100
@@ -94,17 +92,6 @@ def lib():
     L.optik_hip_ik_host.argtypes = [vp, C.POINTER(SolverConfigC), dp, dp, C.c_int32, dp,
                                     C.c_uint64, C.c_uint64, C.c_uint32, C.c_double, dp, dp,
                                     C.POINTER(C.c_uint64), dp]
-    L.optik_hip_engine_submit.argtypes = [vp, C.POINTER(SolverConfigC), vp, vp, C.c_int32, dp,
-                                          C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(IkOutputs)]
-    L.optik_hip_engine_run.argtypes = [vp, vp]
-    L.optik_hip_engine_run_ex.argtypes = [vp, vp, C.c_double]
-    L.optik_hip_engine_executed_evals.argtypes = [vp]
-    L.optik_hip_engine_executed_evals.restype = C.c_uint64
-    L.optik_hip_engine_reserve.argtypes = [vp, C.c_uint64, vp]
-    L.optik_hip_engine_last_trips.argtypes = [vp]
-    L.optik_hip_engine_last_tail.argtypes = [vp, C.POINTER(C.c_int32)]
-    L.optik_hip_engine_last_pools.argtypes = [vp, C.POINTER(C.c_int32)]
-    L.optik_hip_engine_stats.argtypes = [vp, dp, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
     L.optik_hip_probe.argtypes = [C.c_int32, dp, dp, C.c_int64, dp]
     L.optik_hip_probe_math.argtypes = [C.c_int32, dp, C.c_int64, dp]
     L.optik_hip_set_timing.argtypes = [vp, C.c_int32]
@@ -149,7 +136,7 @@ def get_option(name):
 
 
 class options:
-    """``with options(solve_kernel="lane64", engine_slots=4096): ...`` -- set for the block, restored after it."""
+    """``with options(solve_kernel="lane64"): ...`` -- set for the block, restored after it."""
 
     def __init__(self, **kw):
         self.kw = kw

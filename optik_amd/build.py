@@ -15,16 +15,19 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "liboptik_amd.so")
-SOURCES = ["ik_kernels.hip", "ik_quad_kernel.hip", "ik_lane_kernel.hip", "ik_wide_kernel.hip", "robot_host.cpp"]
+SOURCES = ["ik_capi.hip", "ik_select.hip", "ik_batch_ops.hip", "ik_quad_kernel.hip", "ik_lane_kernel.hip", "ik_wide_kernel.hip",
+           "robot_host.cpp"]
 # translation units: (source, object, extra flags).  ik_quad_kernel.hip is compiled twice -- its
 # throughput form (two waves per SIMD) without the machine-LICM pass, which otherwise hoists constants and
 # LDS addresses out of the solver loop only for the register allocator to spill them to scratch
 # (csrc/ik_quad_kernel.hip), its latency forms and the launch function with the default pipeline.
-UNITS = [("ik_kernels.hip", "ik_kernels.o", []),
+UNITS = [("ik_capi.hip", "ik_capi.o", []),          # chains, options, the restart launch (host code only)
+         ("ik_select.hip", "ik_select.o", []),      # selection kernels
+         ("ik_batch_ops.hip", "ik_batch_ops.o", []),  # objective / FK / seed batches, probes
          # (the quad solver is issue-bound: the max-ILP scheduling strategy is worth +3 % restarts/s on the
-         # throughput form and -3 % on a single ik()'s latency; on the engine's kernels it costs 6 %.  The
-         # iterative-ILP strategy the lane kernel is built with: together with -disable-machine-licm it crashes this
-         # compiler on the quad kernel and on ik_kernels.hip; without, it compiles and is 3 % slower on both quad objects)
+         # throughput form and -3 % on a single ik()'s latency.  The iterative-ILP strategy the lane kernel is built
+         # with: together with -disable-machine-licm it crashes this compiler on the quad kernel; without, it compiles
+         # and is 3 % slower on both quad objects)
          # (the latency forms without the machine-LICM pass as well since round 4: 206 -> 201 us per single ik() call,
          # 673 -> 662 us deterministic, tools/single_call_variants.sh; in round 3 the default pipeline was the faster one there)
          ("ik_quad_kernel.hip", "ik_quad_latency.o",
@@ -47,8 +50,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
 # What a translation unit depends on is what the compiler says it read: every object is compiled with
 # -MD and its dependency file (<object>.d) is kept next to it; an object is stale when any file listed
 # there is newer than it, when the list is missing, or when it was compiled with other flags.  (Rounds
-# 1-3 kept the header lists by hand, and they drifted: ik_quad_kernel.hip's list missed ik_quad_tail.hpp
-# and ik_engine.hpp.)
+# 1-3 kept the header lists by hand, and they drifted.)
 
 
 def _hipcc():

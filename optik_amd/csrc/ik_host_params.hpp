@@ -1,7 +1,7 @@
 // ik_host_params.hpp -- host-side derivation of what a launch passes to the kernels as wave-uniform
 // parameters: the ChaCha key of seed_from_u64(42), rand's uniform scale per joint, the objective
 // weights with nalgebra's is_identity decision, NLopt's stopping parameters.  Plain C++ (no HIP):
-// shared by ik_kernels.hip and by the host emulation of the quad solver under tests/emu/.
+// shared by ik_capi.hip / ik_batch_ops.hip and by the host emulation of the quad solver under tests/emu/.
 #pragma once
 
 #include <cmath>

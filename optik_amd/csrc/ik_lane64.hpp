@@ -12,7 +12,7 @@
 //
 //   evaluation, NLopt bookkeeping, BFGS, LSQ factor,   per lane on the lane's own restart: no replication, no
 //   rows of E^-1, LDP tail, back-substitution          cross-lane traffic; the building blocks of ik_slsqp.hpp /
-//                                                      ik_eval.hpp that the engine's phase kernels use
+//                                                      ik_eval.hpp
 //   bounded dual problems (NNLS)                       the lanes that need one (~30 of 64 per trip) leave the
 //                                                      packed problem (rows of E^-1, h: 42 doubles) in LDS and run
 //                                                      Lawson-Hanson's FIRST pass on it themselves
@@ -31,8 +31,7 @@
 // The price: the per-lane state (~80 doubles) plus the working set of an evaluation need more than 256
 // registers, and 16 blocks + 64 packed problems fill 38 KB of LDS: ONE wave per SIMD (four per CU).
 //
-// Bit-exactness: the per-lane blocks execute the oracle's operation sequence as they do
-// in the engine; the NNLS is ik_nnls_quad.hpp's; the LDP tail is lsq_dual's.  A direction that is not a descent
+// Bit-exactness: the per-lane blocks execute the oracle's operation sequence ; the NNLS is ik_nnls_quad.hpp's; the LDP tail is lsq_dual's.  A direction that is not a descent
 // direction (Kraft: reset B and search again, 5e-5 of the trips) repeats in the wave's NEXT trip instead of a
 // second pass of this one -- the lane sits out one evaluation, its arithmetic is the same.
 //

@@ -8,6 +8,22 @@
 
 namespace optik {
 
+// Where the lane-per-restart kernel leaves the restarts still running when its queue is dry, for the quad solver to
+// finish (ik_spill.hpp).  Plain data: planes of doubles / ints over C slots (slot = a lane's global number), the
+// list of slots that hold a restart and its length.  d == nullptr: the launch does not spill.
+struct SpillPool {
+    double *d;                   // [SpillLayout::ND][C]
+    int32_t *i32;                // [SpillLayout::NI][C]
+    unsigned long long *item;    // [C] output column of the slot's restart (target * n_restarts + restart)
+    unsigned long long C;
+    unsigned int *list;          // [C] slots holding a restart ...
+    unsigned int *count;         // ... how many (appended to by the spilling waves; zero before the launch)
+    unsigned long long *cursor;  // the tail kernel's hand-out counter (zero before the launch)
+    unsigned long long *deadline;  // the lane kernel's absolute deadline (wall_clock64 ticks, 0 = none), for the tail
+    int spill_at;                // a wave spills when at most this many of its lanes still hold a restart
+    int pad;
+};
+
 struct SolveLaunch {
     const ChainDev *chain;
     EvalParams ep;
@@ -16,27 +32,7 @@ struct SolveLaunch {
     double scale[MAX_DOF];  // rand UniformFloat scale per joint
     WorkQueue wq;
     unsigned long long deadline_ticks;  // relative to kernel start, 0 = none
-};
-
-// The engine's drain handed to the quad solver (ik_quad_tail.hpp): the slot planes of the pool, the
-// run's job table and the list of slots that still hold a restart.  Plain data: filled by the host
-// (ik_kernels.hip), read by eng_tail_quad_kernel (ik_quad_kernel.hip).
-struct EngJob;
-struct EngTailData {
-    double *d;                      // slot planes (EngArgs::d / i32 / item / C)
-    int32_t *i32;
-    unsigned long long *item;
-    unsigned long long C;
-    const EngJob *jobs;
-    const unsigned int *list;       // slots holding a restart ...
-    const unsigned int *count;      // ... how many (written by eng_tail_list_kernel)
-    unsigned long long *cursor;     // next list entry to hand out, zeroed before the launch
-    unsigned long long *exec_evals; // [ENG_EXEC_SHARDS] or null
-    unsigned long long deadline;    // wall_clock64() ticks (set by the kernel from SolveLaunch::deadline_ticks), 0 = none
-};
-struct TailLaunch {
-    SolveLaunch base;               // chain, weights, tolerances; wq.lanes = restarts (quads) a wave holds at a time
-    EngTailData tail;
+    SpillPool spill;        // (lane-per-restart kernel and its tail)
 };
 
 __device__ __forceinline__ void stage_chain(ChainDev &dst, const ChainDev *src) {
@@ -59,7 +55,8 @@ int quad_solve_waves_per_cu(int n);
 // per SIMD
 hipError_t lane_solve_launch(int n, bool tip, int grid, hipStream_t stream, const SolveLaunch &a, int *lds_bytes);
 int lane_solve_waves_per_cu();
-// the engine's tail on the quad solver (n <= 7, the two-waves-per-SIMD build)
-hipError_t quad_tail_launch(int n, bool tip, int grid, hipStream_t stream, const TailLaunch &a);
+// the spilled restarts of a lane-per-restart launch on the quad solver (n <= 7, the two-waves-per-SIMD build): queued
+// behind that launch on the same stream; `a` is the launch's own record (a.wq.lanes is set to 16 quads per wave here)
+hipError_t quad_tail_launch(int n, bool tip, int grid, hipStream_t stream, const SolveLaunch &a);
 
 }  // namespace optik

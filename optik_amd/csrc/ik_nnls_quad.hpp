@@ -1,9 +1,9 @@
 // ik_nnls_quad.hpp -- Lawson-Hanson NNLS of the LSQ dual for the quad solver: matrix in LDS.
 //
-// ik_nnls_coop.hpp keeps the (n+1) x 2n matrix in REGISTERS, four columns per lane (64 VGPRs) plus
-// ~120 more for the masked copies of the Householder vector: 242 VGPRs on its own, which is what
-// holds every kernel that contains it at two waves per SIMD at best -- and the quad solver, whose
-// own state lives next to it, at one.  A register file cannot be indexed per lane; LDS can.  Here
+// Rounds 1-2 kept the (n+1) x 2n matrix in REGISTERS, four columns per lane (64 VGPRs) plus ~120 more for
+// the masked copies of the Householder vector: 242 VGPRs on its own, which held every kernel that
+// contained it at two waves per SIMD at best -- and the quad solver, whose own state lives next to it,
+// at one.  A register file cannot be indexed per lane; LDS can.  Here
 // the quad's matrix lives in a 1 KB block of LDS, column-major (column id c at doubles [8 (c-1),
 // 8 c)), next to the multipliers x by column id:
 //
@@ -20,7 +20,7 @@
 // granules apart, so a wave-wide ds_read_b128 of "my k-th column" (lanes of a quad on four
 // consecutive columns) touches 64 distinct granules of every 256-byte row: conflict-free.
 //
-// Arithmetic per matrix element, its order, and every decision are those of nnls_coop and of
+// Arithmetic per matrix element, its order, and every decision are those of
 // oracle/optik_oracle.c:nnls: same bits.  Control flow around every cross-lane move and LDS
 // hand-over is wave-uniform (tests/emu runs this file on the host).
 #pragma once
@@ -346,7 +346,7 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
                     up = (cand && pivot) ? asave - c2 : up;
                     ulp = pivot ? c2 : ulp;
                 }
-                // diff(unorm + factor |ulp|, unorm) > 0 (see nnls_coop: decided by t > 3 * 2^-52 * xmax whenever
+                // diff(unorm + factor |ulp|, unorm) > 0 (decided by t > 3 * 2^-52 * xmax whenever
                 // that holds; otherwise by the norm of the column above the pivot row, re-read from the block)
                 const double t = factor * __builtin_fabs(ulp);
                 bool ok1 = t > 6.7e-16 * xmax;

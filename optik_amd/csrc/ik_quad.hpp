@@ -16,8 +16,8 @@
 // quad_perm moves (ik_lane.hpp), never through LDS; the LDS of the solver is the 1 KB block per quad
 // that holds the matrix of the bounded dual problem while ik_nnls_quad.hpp solves it -- and, while
 // the quad evaluates, what the evaluation does not touch -- plus x_best / x_prev of every lane.
-// The restarts come from the launch's work queue, or (ik_quad_tail.hpp) mid-flight from the slot pool
-// of an engine run that is draining.
+// The restarts come from the launch's work queue, or (a Tail: ik_spill.hpp) mid-flight from the spill pool
+// of a lane-per-restart launch whose last restarts are handed over.
 //
 // Bit-exactness (the contract of DESIGN.md section 2): every sum the reference / oracle forms
 // sequentially is formed here in the SAME ORDER from the same products -- either inside one lane
@@ -558,7 +558,7 @@ OPTIK_DEV bool bound_rows_quad(const double (&Ec)[QuadDims<N>::NS][QuadDims<N>::
     return quad_any(need);
 }
 
-// LDP tail from the NNLS multipliers (ik_engine.hpp:ldp_from_record): the transformed-space step,
+// LDP tail from the NNLS multipliers (oracle: lsq_dual): the transformed-space step,
 // by joint.  ylo / yhi: multipliers of the lane's lower- / upper-bound columns.  Returns the mode.
 template <int N>
 OPTIK_DEV int ldp_quad(int mode, double rnorm, const double (&row)[QuadDims<N>::NS][N], const double (&h_lo)[QuadDims<N>::NS],
@@ -637,8 +637,8 @@ constexpr int quad_wave_lds() { return nnls_quad_wave_lds<N>(); }
 // eight registers for the whole life of the kernel)
 constexpr int quad_lane_lds() { return 4 * 64; }
 
-// Where the restarts come from: the work queue of a launch (NoTail: seeds drawn in the kernel), or the slot
-// pool of an engine run that is draining (ik_quad_tail.hpp: restarts taken over mid-flight).
+// Where the restarts come from: the work queue of a launch (NoTail: seeds drawn in the kernel), or a pool
+// of restarts spilled mid-flight by another kernel (a Tail: see ik_spill.hpp).
 struct NoTail {
     static constexpr bool on = false;
 };

@@ -3,12 +3,11 @@
 // with 16 restarts per wave, a throughput path whose per-restart state never touches HBM.
 //
 // Its own translation unit: the kernel is tuned against the register allocator (waves per SIMD), and
-// rebuilding it must not wait for the streaming engine's two minutes of template instantiations.
+// rebuilding it must not wait for the other solvers' template instantiations.
 #include <hip/hip_runtime.h>
 
 #include "ik_launch.hpp"
 #include "ik_quad.hpp"
-#include "ik_quad_tail.hpp"
 
 namespace optik {
 
@@ -53,49 +52,9 @@ __global__ __launch_bounds__(64, W) void ik_quad_kernel(const SolveLaunch a) {
     quad_wave<N, TIP>(sch, L.ep, L.sp, L.key, L.scale, L.wq, nnls_lds, lane_lds);
 }
 
-// The same body fed from a draining engine run's slot pool instead of the work queue (ik_quad_tail.hpp):
-// the engine's tail.  Throughput build only (n <= 7).
-template <int N, bool TIP>
-__global__ __launch_bounds__(64, OPTIK_QUAD_WAVES) void eng_tail_quad_kernel(const TailLaunch a) {
-    __shared__ ChainDev sch;
-    __shared__ __attribute__((aligned(16))) double nnls_lds[quad_wave_lds<N>()];
-    __shared__ double lane_lds[quad_lane_lds()];
-    __shared__ __attribute__((aligned(8))) uint32_t launch_lds[(sizeof(TailLaunch) + 3) / 4];  // (as in ik_quad_kernel)
-    {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(&a);
-        for (unsigned i = threadIdx.x; i < sizeof(TailLaunch) / 4; i += 64) launch_lds[i] = src[i];
-    }
-    if (threadIdx.x < 16) nnls_lds[quad_wave_lds<N>() - 16 + threadIdx.x] = 0.0;  // the column of zeros
-    stage_chain(sch, a.base.chain);
-    TailLaunch &L = *reinterpret_cast<TailLaunch *>(launch_lds);
-    if (threadIdx.x == 0) L.tail.deadline = L.base.deadline_ticks ? wall_clock64() + L.base.deadline_ticks : 0ull;
-    __syncthreads();
-    static_assert(sizeof(EngTail) == sizeof(EngTailData), "EngTail adds no data");
-    quad_wave<N, TIP, EngTail>(sch, L.base.ep, L.base.sp, L.base.key, L.base.scale, L.base.wq, nnls_lds, lane_lds,
-                               static_cast<const EngTail *>(&L.tail));
-}
-
 // (n = 8: nine-row columns make the blocks 22 KB per wave: six waves per CU of the throughput form --
 // 236 B of scratch, 12.1 against 9.3 M restarts/s with four waves of the latency form)
 #if OPTIK_QUAD_PART != 1
-hipError_t quad_tail_launch(int n, bool tip, int grid, hipStream_t stream, const TailLaunch &a) {
-#define CALL_TAIL(NN)                                                                                   \
-    case NN:                                                                                            \
-        if (tip) hipLaunchKernelGGL((eng_tail_quad_kernel<NN, true>), dim3(grid), dim3(64), 0, stream, a);   \
-        else hipLaunchKernelGGL((eng_tail_quad_kernel<NN, false>), dim3(grid), dim3(64), 0, stream, a);      \
-        break;
-    switch (n) {
-#ifdef OPTIK_QUAD_ONLY_N
-        CALL_TAIL(OPTIK_QUAD_ONLY_N)
-#else
-        CALL_TAIL(1) CALL_TAIL(2) CALL_TAIL(3) CALL_TAIL(4) CALL_TAIL(5) CALL_TAIL(6) CALL_TAIL(7)
-#endif
-    default: return hipErrorInvalidValue;
-    }
-#undef CALL_TAIL
-    return hipGetLastError();
-}
-
 // the throughput form, reached through one entry point per (n, tip) so that it can live in its own object
 hipError_t quad_solve_launch_w2(int n, bool tip, int grid, hipStream_t stream, const SolveLaunch &a) {
 #define CALL_QUAD2(NN)                                                                                  \

@@ -8,10 +8,10 @@
 // f = -E^-T g), Kraft's transformation of the 2n bound rows to a least-distance problem
 // (G E^-1 = +-E^-1 because G = [I; -I]; zeros are skipped, which leaves every non-zero
 // bit-identical), the back-substitution, the Fletcher-Powell LDL' update and the damped BFGS
-// update.  Their users: the lane-per-restart form (ik_lane64.hpp) and the streaming engine
-// (ik_engine.hpp); the quad solver (ik_quad.hpp) spreads the same arithmetic over four lanes.
+// update.  Their user: the lane-per-restart form (ik_lane64.hpp); the quad solver (ik_quad.hpp) spreads the
+// same arithmetic over four lanes.
 // The NNLS of the dual problem -- Lawson-Hanson's active-set iteration, whose column choices are
-// data dependent -- is ik_nnls_quad.hpp (matrix in LDS) and ik_nnls_coop.hpp (matrix in registers).
+// data dependent -- is ik_nnls_quad.hpp (matrix in LDS).
 //
 // Operation order equals oracle/optik_oracle.c everywhere a non-zero flows, so
 // kernel results are bit-identical to the CPU oracle (-ffp-contract=off).
@@ -77,7 +77,7 @@ OPTIK_DEV constexpr int lidx(int i, int j) { return i * N - (i * (i - 1)) / 2 + 
 // bound through the NNLS:
 //   lsq_factor        E = D^1/2 L', f, Kraft's Householder pass
 //   lsq_bound_rows    G E^-1 = +-E^-1 and h: the rows of the dual problem (handed to a sink: LDS record, HBM slot)
-//   (NNLS, then the LDP tail: ik_engine.hpp:ldp_from_record, ik_lane64.hpp)
+//   (NNLS, then the LDP tail: ik_lane64.hpp)
 //   lsq_finish        s = E^-1 (y + f), clipped
 
 // E = D^1/2 L', f = -E^-T g, then Kraft's LSI Householder pass.  Returns 1, or 5 when E is

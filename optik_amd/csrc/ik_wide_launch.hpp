@@ -1,6 +1,6 @@
 // ik_wide_launch.hpp -- chains with 9 .. 16 joint positions (ik_wide.hpp): the chain table and what
 // the launches of ik_wide_kernel.hip receive.  Plain data shared by that translation unit and the
-// host code of ik_kernels.hip.
+// host code of ik_capi.hip / ik_batch_ops.hip.
 #pragma once
 
 #include <hip/hip_runtime.h>

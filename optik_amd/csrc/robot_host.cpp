@@ -5,7 +5,7 @@
 // What stays on the host is what the reference does once per call or per robot:
 // URDF loading, the seed-limit check, the restart/time budget and the loop over
 // launches.  FK, Jacobian, the restarts and the selection all run in the kernels
-// of ik_kernels.hip -- there is no CPU implementation of them in this library.
+// of ik_capi.hip / ik_batch_ops.hip -- there is no CPU implementation of them in this library.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -198,10 +198,9 @@ std::vector<int> devices_from_env() {
     return ids;
 }
 
-// 4x4 column-major homogeneous matrix -> pose7, with nalgebra's
-// UnitQuaternion::from_rotation_matrix branches (optik-py/src/lib.rs:8-15; the C
-// path's iterative from_matrix, optik-cpp/src/lib.rs:141-142, converges to the same
-// rotation for a proper rotation matrix).
+// 4x4 column-major homogeneous matrix -> pose7 as the pyo3 path does it (optik-py/src/lib.rs:8-15:
+// try_convert::<Matrix4, Isometry3> = UnitQuaternion::from_rotation_matrix's closed-form branches).  The C path's
+// iterative UnitQuaternion::from_matrix is pose7_from_mat16_iterative below: the same rotation, last bits apart.
 void pose7_from_mat16(const double *m, double *p) {
     auto M = [&](int r, int c) { return m[c * 4 + r]; };
     p[0] = M(0, 3); p[1] = M(1, 3); p[2] = M(2, 3);
@@ -222,6 +221,124 @@ void pose7_from_mat16(const double *m, double *p) {
     }
     const double nrm = std::sqrt(w * w + i * i + j * j + k * k);  // UnitQuaternion::new_normalize
     p[3] = i / nrm; p[4] = j / nrm; p[5] = k / nrm; p[6] = w / nrm;
+}
+
+// UnitQuaternion::from_rotation_matrix (nalgebra 0.34, not vendored): the four closed-form branches, no normalisation.
+void quat_from_rotation(const double R[3][3], double &w, double &i, double &j, double &k) {
+    const double tr = R[0][0] + R[1][1] + R[2][2];
+    if (tr > 0.0) {
+        const double d = std::sqrt(tr + 1.0) * 2.0;
+        w = 0.25 * d; i = (R[2][1] - R[1][2]) / d; j = (R[0][2] - R[2][0]) / d; k = (R[1][0] - R[0][1]) / d;
+    } else if (R[0][0] > R[1][1] && R[0][0] > R[2][2]) {
+        const double d = std::sqrt(1.0 + R[0][0] - R[1][1] - R[2][2]) * 2.0;
+        w = (R[2][1] - R[1][2]) / d; i = 0.25 * d; j = (R[0][1] + R[1][0]) / d; k = (R[0][2] + R[2][0]) / d;
+    } else if (R[1][1] > R[2][2]) {
+        const double d = std::sqrt(1.0 + R[1][1] - R[0][0] - R[2][2]) * 2.0;
+        w = (R[0][2] - R[2][0]) / d; i = (R[0][1] + R[1][0]) / d; j = 0.25 * d; k = (R[1][2] + R[2][1]) / d;
+    } else {
+        const double d = std::sqrt(1.0 + R[2][2] - R[0][0] - R[1][1]) * 2.0;
+        w = (R[1][0] - R[0][1]) / d; i = (R[0][2] + R[2][0]) / d; j = (R[1][2] + R[2][1]) / d; k = 0.25 * d;
+    }
+}
+
+// Rotation3::from_axis_angle (nalgebra: Rodrigues' formula entry by entry; angle == 0 -> identity).
+void rot_from_axis_angle(const double u[3], double angle, double O[3][3]) {
+    if (angle == 0.0) {
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) O[r][c] = r == c ? 1.0 : 0.0;
+        return;
+    }
+    const double ux = u[0], uy = u[1], uz = u[2];
+    const double sqx = ux * ux, sqy = uy * uy, sqz = uz * uz;
+    double sn, cs;  // (f64::sin_cos: platform libm; ONE sincos call here and in the oracle -- sin + cos can differ from it in the last bit)
+    ::sincos(angle, &sn, &cs);
+    const double omc = 1.0 - cs;
+    O[0][0] = sqx + (1.0 - sqx) * cs; O[0][1] = ux * uy * omc - uz * sn; O[0][2] = ux * uz * omc + uy * sn;
+    O[1][0] = ux * uy * omc + uz * sn; O[1][1] = sqy + (1.0 - sqy) * cs; O[1][2] = uy * uz * omc - ux * sn;
+    O[2][0] = ux * uz * omc - uy * sn; O[2][1] = uy * uz * omc + ux * sn; O[2][2] = sqz + (1.0 - sqz) * cs;
+}
+
+// 3x3 product as nalgebra forms it (gemv per column: the terms of an entry accumulated in order k = 0, 1, 2).
+void mat3_mul(const double A[3][3], const double B[3][3], double O[3][3]) {
+    double T[3][3];
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) {
+            double acc = A[r][0] * B[0][c];
+            acc = A[r][1] * B[1][c] + acc;
+            acc = A[r][2] * B[2][c] + acc;
+            T[r][c] = acc;
+        }
+    std::memcpy(O, T, sizeof T);
+}
+
+// ||M - R||_F^2, column by column (Matrix::norm_squared).
+double diff_norm_squared(const double M[3][3], const double R[3][3]) {
+    double res = 0.0;
+    for (int c = 0; c < 3; ++c) {
+        const double d0 = M[0][c] - R[0][c], d1 = M[1][c] - R[1][c], d2 = M[2][c] - R[2][c];
+        res += d0 * d0 + d1 * d1 + d2 * d2;
+    }
+    return res;
+}
+
+// UnitQuaternion::from_matrix (optik-cpp/src/lib.rs:141-142) = Rotation3::from_matrix_eps(m, f64::EPSILON, 0 =
+// unlimited, identity) -- nalgebra 0.34 (Cargo.lock:579-581, not vendored), "A Robust Method to Extract the
+// Rotational Part of Deformations" (Mueller et al.) with nalgebra's perturbation step at a stalled iterate --
+// followed by from_rotation_matrix.  Restated from the crate's published source; the iteration cap is this
+// implementation's (nalgebra's is usize::MAX: a rotation matrix converges in a few dozen steps).
+void quat_from_matrix_iterative(const double M[3][3], double &w, double &i, double &j, double &k) {
+    const double eps = 2.220446049250313e-16;
+    const double eps_disturbance = std::fmax(std::sqrt(eps), eps * eps);
+    double axes[3] = {1.0, 0.0, 0.0};  // perturbation_axes = Vector3::x_axis()
+    double rot[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int it = 0; it < 100000; ++it) {
+        // axis = sum_c rot.col(c) x m.col(c), denom = sum_c rot.col(c) . m.col(c)
+        double axis[3] = {0, 0, 0}, denom = 0.0;
+        for (int c = 0; c < 3; ++c) {
+            const double a0 = rot[0][c], a1 = rot[1][c], a2 = rot[2][c], b0 = M[0][c], b1 = M[1][c], b2 = M[2][c];
+            const double cr[3] = {a1 * b2 - a2 * b1, a2 * b0 - a0 * b2, a0 * b1 - a1 * b0};
+            const double dt = a0 * b0 + a1 * b1 + a2 * b2;
+            if (c == 0) { axis[0] = cr[0]; axis[1] = cr[1]; axis[2] = cr[2]; denom = dt; }
+            else { axis[0] += cr[0]; axis[1] += cr[1]; axis[2] += cr[2]; denom += dt; }
+        }
+        const double dv = std::fabs(denom) + eps;
+        double aa[3] = {axis[0] / dv, axis[1] / dv, axis[2] / dv};
+        // Unit::try_new_and_get(axisangle, eps)
+        const double sq = aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2];
+        if (sq > eps * eps) {
+            const double nrm = std::sqrt(sq);
+            const double u[3] = {aa[0] / nrm, aa[1] / nrm, aa[2] / nrm};
+            double Rd[3][3];
+            rot_from_axis_angle(u, nrm, Rd);
+            mat3_mul(Rd, rot, rot);
+        } else {
+            // stuck at a stationary point of ||m - rot||: a maximum, unless a small rotation makes it worse
+            double pert[3][3];
+            std::memcpy(pert, rot, sizeof pert);
+            const double n0 = diff_norm_squared(M, rot);
+            double n1;
+            for (;;) {
+                double Rp[3][3];
+                rot_from_axis_angle(axes, eps_disturbance, Rp);
+                mat3_mul(pert, Rp, pert);
+                n1 = diff_norm_squared(M, pert);
+                if (std::fabs(n0 - n1) > eps) break;  // abs_diff_ne!(.., epsilon = f64::EPSILON)
+            }
+            if (n0 < n1) break;  // a minimum: done
+            const double t = axes[0];  // perturbation_axes.yzx()
+            axes[0] = axes[1]; axes[1] = axes[2]; axes[2] = t;
+            std::memcpy(rot, pert, sizeof pert);
+        }
+    }
+    quat_from_rotation(rot, w, i, j, k);
+}
+
+// 4x4 column-major -> pose7 as the C path of the reference does it (optik-cpp/src/lib.rs:137-144).
+void pose7_from_mat16_iterative(const double *m, double *p) {
+    double M[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) M[r][c] = m[c * 4 + r];
+    p[0] = m[12]; p[1] = m[13]; p[2] = m[14];
+    quat_from_matrix_iterative(M, p[6], p[3], p[4], p[5]);
 }
 
 // pose7 -> 4x4 column-major (Isometry3::to_matrix, optik-cpp/src/lib.rs:115).
@@ -381,7 +498,20 @@ const double *optik_robot_random_configuration(const optik_robot *r) {
 int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const double *target16,
                       const double *x0, const double *ee16, double *x_out, double *f_out,
                       uint64_t *winner_out) {
+    return optik_robot_ik_pose(r, config, target16, 0u, x0, ee16, x_out, f_out, winner_out);
+}
+
+int optik_pose_from_matrix(const double *m16, uint32_t flags, double *pose7) {
+    if (!m16 || !pose7) return set_err(-1, "null argument");
+    if (flags & OPTIK_POSE_FROM_MATRIX) pose7_from_mat16_iterative(m16, pose7);
+    else pose7_from_mat16(m16, pose7);
+    return 0;
+}
+
+int optik_robot_ik_pose(const optik_robot *r, const CSolverConfig *config, const double *target16, uint32_t flags,
+                        const double *x0, const double *ee16, double *x_out, double *f_out, uint64_t *winner_out) {
     if (!r || !config || !target16 || !x0) return set_err(-1, "null argument");
+    const bool iterative = (flags & OPTIK_POSE_FROM_MATRIX) != 0;
     // lib.rs:251-254
     for (int i = 0; i < r->n; ++i)
         if (x0[i] < r->lb[i] || x0[i] > r->ub[i])
@@ -389,7 +519,8 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
     DeviceCtx *c0 = device_ctx(r);
     if (!c0) return -1;
     double tgt7[7], ee7[7];
-    pose7_from_mat16(target16, tgt7);
+    if (iterative) pose7_from_mat16_iterative(target16, tgt7);
+    else pose7_from_mat16(target16, tgt7);
     if (ee16) pose7_from_mat16(ee16, ee7);
 
     const auto start = std::chrono::steady_clock::now();
@@ -421,14 +552,11 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
     const uint64_t first_per_cu = OPTIK_FIRST_PER_CU;
     const uint64_t first_batch = (!quality && r->parallelism == 1) ? 128 : cus * first_per_cu;
     const uint64_t later_batch = cus * 2 * 64 * 2;
-    const uint64_t engine_batch = (uint64_t)1 << 20;  // restarts per GPU per big round
-    // Rounds 2-3 ran the big rounds on the streaming engine (from 262 144 restarts on it beat the quad solver's single
-    // launch).  Since the lane-per-restart form a single launch wins at every size (tools/kernel_vs_engine_probe.py,
-    // ms per job, kernel / engine: 131 072 restarts 9.5 / 14.2, 262 144: 15.2 / 20.1, 1 048 576: 50.4 / 59.6,
-    // 2 097 152: 97 / 111): the big rounds are single launches too, and a round is worth ~1 M restarts because every
-    // launch pays its own ~4 ms of drain.
-    const bool engine_ok = false;
-    const uint64_t engine_from = 262144;  // (from this many restarts left on: rounds of engine_batch)
+    // (a big round is one launch of the lane-per-restart form and worth ~1 M restarts, because every launch pays its
+    // own few ms of drain; rounds 1-3 ran them on a streaming engine that the lane form beat at every size in round 4
+    // and that was retired in round 5: profiles/r5a_engine_retire_probe.txt)
+    const uint64_t big_batch = (uint64_t)1 << 20;  // restarts per GPU per big round
+    const uint64_t big_from = 262144;              // (from this many restarts left on: rounds of big_batch)
     const size_t G = device_count(r);
     const uint32_t speed_flags = OPTIK_HIP_IK_EARLY_EXIT | (r->parallelism != 1 ? OPTIK_HIP_IK_FIND_ANY : 0u);
     struct Part {
@@ -453,18 +581,16 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
         // Quality with a restart budget and no time budget runs every restart whatever happens: no
         // latency-sized first launches (each of them waits for its slowest restart -- 1 000 restarts
         // took two launches of 2.7 ms), the whole range at once: one launch of the solve kernel
-        // below ~260 000 restarts (engine_from), rounds of 1 M from index 0 above.
+        // below ~260 000 restarts (big_from), rounds of 1 M from index 0 above.
         // (with a time budget too when the whole range is one solve-kernel launch: its waves watch the clock)
         const bool all_at_once = quality && config->max_restarts > 0
-                                 && (config->max_time <= 0.0 || config->max_restarts < engine_from);
+                                 && (config->max_time <= 0.0 || config->max_restarts < big_from);
         // (the latency-sized first launch stays on one GPU; a Quality range run at once is cut over the G devices as
-        // soon as every part is a few waves per CU -- decided on its own, not by the engine / kernel crossover)
+        // soon as every part is a few waves per CU)
         const size_t g_round = (begin == 0 && !(all_at_once && max_restarts / G >= cus * 64)) ? 1 : G;
-        // (what is left must be worth an engine run: below engine_from restarts the solve kernel is faster)
-        const bool big_round = max_restarts - begin >= engine_from && (all_at_once || begin >= first_batch + later_batch);
-        const bool on_engine = engine_ok && big_round;
-        const uint64_t batch = big_round ? engine_batch
-                               : all_at_once ? engine_from
+        const bool big_round = max_restarts - begin >= big_from && (all_at_once || begin >= first_batch + later_batch);
+        const uint64_t batch = big_round ? big_batch
+                               : all_at_once ? big_from
                                : begin == 0 ? first_batch : later_batch;
         // (several GPUs: what is left is cut evenly when it is less than a full round of each)
         uint64_t per_part = batch;
@@ -486,7 +612,7 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
         }
         auto run_part = [&](Part &p) {
             p.rc = optik_hip_ik_host(p.ctx->chain, config, tgt7, x0, 1, ee16 ? ee7 : nullptr, p.begin, p.end,
-                                     (quality ? 0u : speed_flags) | (on_engine ? (OPTIK_HIP_IK_ENGINE | OPTIK_HIP_IK_FULL_POOL) : 0u), deadline,
+                                     quality ? 0u : speed_flags, deadline,
                                      p.wx.data(), &p.wf, &p.widx, &p.wkey);
             if (p.rc) p.err = optik_hip_last_error();
         };
@@ -522,11 +648,11 @@ int optik_robot_ik_ex(const optik_robot *r, const CSolverConfig *config, const d
 namespace {
 
 // optik_robot_ik_batch_ex for the targets of one GPU: rounds of `round` restart indices per
-// target (sizes and the kernel each round runs on: see the loop); targets already solved
-// (Speed) drop out of later rounds; max_time is enforced inside a launch / engine run and
-// between rounds.
+// target (sizes: see the loop), each round ONE launch of optik_hip_ik_batch (which picks the solver by
+// launch size); targets already solved (Speed) drop out of later rounds; max_time is enforced inside a
+// launch and between rounds.
 int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *config, int32_t T,
-                       const double *targets16, bool row_major, const double *x0, const double *ee7,
+                       const double *targets16, bool row_major, bool iterative, const double *x0, const double *ee7,
                        std::chrono::steady_clock::time_point start, double *x_out, double *f_out,
                        int32_t *found_out, std::string &err) {
     const int n = r->n;
@@ -535,15 +661,8 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
     };
     const uint64_t max_restarts = config->max_restarts > 0 ? config->max_restarts : UINT64_MAX;
     const bool quality = config->solution_mode == 1;
-    // restart indices per target per round: 256, fewer for a Speed batch of very many targets on
-    // the engine -- nearly all of a round's higher indices are abandoned unissued (a third to a half
-    // of the restarts succeed), and skipping an item still costs the refilling lane a queue fetch:
-    // with 262 144 targets x 256 indices the finish kernel spent 0.55 instead of 0.07 ms per trip
-    // on 66 M such fetches.  Rounds of ~4 M items keep that below a few percent; the handful of
-    // targets a short round leaves unsolved go through the next round (on the cooperative kernel).
+    // work items (target x restart index) per round: ~4 M -- 288 MB of per-restart keys, points and residuals
     const uint64_t round_items = (uint64_t)4 << 20;
-    const uint64_t engine_first_round = 16;
-    const size_t engine_min = 40960;  // Speed batches from this many targets: engine (32 768 targets: 16.8 (kernel) against 18.5 ms, 49 152: 24.7 against 22.7)
     std::lock_guard<std::mutex> lock(c->batch_mu);
     optik::DeviceScope dev_scope(c->device);
     if (!dev_scope.ok()) { err = "hipSetDevice failed"; return -1; }
@@ -559,7 +678,8 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
                     for (int b = 0; b < 4; ++b) cm[b * 4 + a] = m[a * 4 + b];
                 m = cm;
             }
-            pose7_from_mat16(m, &tgt7[t * 7]);
+            if (iterative) pose7_from_mat16_iterative(m, &tgt7[t * 7]);
+            else pose7_from_mat16(m, &tgt7[t * 7]);
         }
     });
     std::vector<int> live((size_t)T);
@@ -595,18 +715,17 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
             if (deadline <= 0.0) break;  // lib.rs:393
         }
         const size_t L = live.size();
-        const bool big_speed = !quality && L >= engine_min && std::getenv("OPTIK_BATCH_NO_ENGINE") == nullptr;
         uint64_t round = quality ? 256 : speed_round;
-        // (~4 M work items per round at most -- 288 MB of per-restart keys, points and residuals --
-        // down to 64 indices per target, which still leave no reachable target unsolved)
-        while (round > (big_speed ? 16u : (first_round < 64 ? first_round : 64u)) && round * (uint64_t)L > round_items) round >>= 1;
-        // (from ~500 000 targets the queue fetches of the abandoned indices outweigh the second round
-        // that 8 indices leave 1.7 % of the targets for: 1 M targets 163 against 194 ms)
-        if (big_speed && begin == 0) round = (L >= 524288 && engine_first_round > 8) ? 8 : engine_first_round;
-        else if (speed_round < ((uint64_t)1 << 40)) speed_round *= 4;  // (the round after a short engine round is 256 again)
-        // Quality runs every restart of every target to the end: nothing to gain from short rounds,
-        // and an engine run has a ~10 ms floor -- as many indices per round as ~4 M items allow
-        // (288 MB of per-restart keys, points and residuals)
+        // (a round's items are capped -- down to 64 indices per target, which still leave no reachable target
+        // unsolved; batches of more than 65 536 targets down to 8: nearly all of a round's higher indices are
+        // abandoned unissued -- a third to a half of the restarts succeed -- and skipping an item still costs the
+        // refilling wave a queue fetch; the handful of targets a short round leaves unsolved go through the next)
+        const uint64_t min_round = L <= 65536 ? (first_round < 64 ? first_round : 64u) : 8u;
+        const uint64_t cap_items = L <= 65536 ? round_items : 2 * round_items;
+        while (round > min_round && round * (uint64_t)L > cap_items) round >>= 1;
+        if (!quality && speed_round < ((uint64_t)1 << 40)) speed_round *= 4;
+        // Quality runs every restart of every target to the end: nothing to gain from short rounds -- as many
+        // indices per round as ~4 M items allow
         if (quality)
             while (round * 2 * (uint64_t)L <= round_items && round < max_restarts - begin) round <<= 1;
         const uint64_t end = (max_restarts - begin > round) ? begin + round : max_restarts;
@@ -627,38 +746,20 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
         optik_hip_ik_outputs o;
         std::memset(&o, 0, sizeof o);
         o.d_win_x = d_wx; o.d_win_f = d_wf; o.d_win_idx = d_wi; o.d_win_key = d_wk;
-        // Which path.  The first round of a Speed batch is latency-bound -- early exit abandons most of
-        // its restarts, what is left is each target's few first restarts run to the end: the
-        // cooperative single-kernel solver with restart-major hand-out (no trips of five dependent
-        // launches) beats the engine from 1 target (0.5 against 2.1 ms) to ~50 000 (measured, Panda:
-        // 64 targets 1.0 against 2.9 ms, 4 096: 1.1 M against 324 k calls/s, 16 384: 1.68 M against
-        // 1.05 M).  Everything else -- a Quality batch, the later rounds of a Speed batch (whatever
-        // 256 restarts did not solve runs nearly all of its restarts) -- is throughput-bound: the
-        // engine's domain, unless the round is a few launches' worth of restarts.
-        const size_t small_batch = (size_t)-1;
-        // (one job of ~260 000 restarts is where the engine overtakes the quad solve kernel: 131 072 take 12.0
-        // against 15.2 ms, 524 288 take 37.7 against 34.3 ms; n = 8 has no engine)
-        const uint64_t kernel_below = 262144;
-        static const bool no_engine_ = std::getenv("OPTIK_BATCH_NO_ENGINE") != nullptr;  // (round 5 measurement, temporary)
-        const bool kernel_path = no_engine_ || (r->n <= 7 && !big_speed && L <= small_batch
-                                 && ((!quality && begin < 256) || (uint64_t)L * (end - begin) < kernel_below));
+        // One launch per round.  The first rounds of a Speed batch are latency-bound -- early exit abandons most of
+        // their restarts, what is left is each target's few first restarts run to the end: restart-major hand-out
+        // keeps only a few restarts per target in flight (optik_hip_ik_batch then stays on the quad solver's shorter
+        // trip).  Everything else -- a Quality batch, the later rounds of a Speed batch (whatever 256 restarts did
+        // not solve runs nearly all of its restarts) -- is throughput-bound: target-major, the lane-per-restart form
+        // from one full load of the chip on.  (Rounds 1-4 ran those rounds, and the first round of batches of 40 960
+        // targets or more, on a streaming engine: retired in round 5, the single launch is 15 - 28 % faster at every
+        // size where the engine was used -- profiles/r5a_engine_retire_probe.txt.)
         const uint32_t mode_flags =
             quality ? 0u : (OPTIK_HIP_IK_EARLY_EXIT | (r->parallelism != 1 ? OPTIK_HIP_IK_FIND_ANY : 0u));
-        if (kernel_path) {
-            // (restart-major hand-out keeps only a few restarts per target in flight -- right while
-            // early exit abandons most of them, i.e. for the first 256 indices of a target (the
-            // leftovers of a 16-index engine round are unlucky, not hard); later rounds fill the chip)
-            const int rck = optik_hip_ik_batch(c->chain, config, d_t, d_x0, (int32_t)L, ee7, begin, end,
-                                               mode_flags | (begin < 256 ? OPTIK_HIP_IK_RESTART_MAJOR : 0u), deadline,
-                                               &o, nullptr);
-            if (rck) { err = optik_hip_last_error(); return -1; }
-        } else {
-            // (later rounds: the targets still unsolved run nearly all of their restarts -- the whole pool)
-            const int rc = optik_hip_engine_solve(c->chain, config, d_t, d_x0, (int32_t)L, ee7, begin, end,
-                                                  mode_flags | (begin >= 256 ? OPTIK_HIP_IK_FULL_POOL : 0u), deadline, &o,
-                                                  nullptr);
-            if (rc) { err = optik_hip_last_error(); return -1; }
-        }
+        const int rck = optik_hip_ik_batch(c->chain, config, d_t, d_x0, (int32_t)L, ee7, begin, end,
+                                           mode_flags | ((!quality && begin < 256) ? OPTIK_HIP_IK_RESTART_MAJOR : 0u),
+                                           deadline, &o, nullptr);
+        if (rck) { err = optik_hip_last_error(); return -1; }
         if (hipMemcpyAsync(h_out, d_wx, sizeof(double) * (size_t)(n + 3) * L, hipMemcpyDeviceToHost, nullptr) != hipSuccess
             || hipStreamSynchronize(nullptr) != hipSuccess) {
             err = "download failed";
@@ -703,7 +804,7 @@ int ik_batch_on_device(const optik_robot *r, DeviceCtx *c, const CSolverConfig *
 int optik_robot_ik_batch_ex(const optik_robot *r, const CSolverConfig *config, int32_t T,
                             const double *targets16, const double *x0, const double *ee16, double *x_out,
                             double *f_out, int32_t *found_out) {
-    return optik_robot_ik_batch_poses(r, config, T, targets16, 0u, x0, ee16, x_out, f_out, found_out);
+    return optik_robot_ik_batch_poses(r, config, T, targets16, OPTIK_POSE_FROM_MATRIX, x0, ee16, x_out, f_out, found_out);
 }
 
 int optik_robot_ik_batch_poses(const optik_robot *r, const CSolverConfig *config, int32_t T,
@@ -759,6 +860,7 @@ int optik_robot_ik_batch_poses(const optik_robot *r, const CSolverConfig *config
     r->last_parts.store((int32_t)parts.size());
     auto run_part = [&](Part &p) {
         p.rc = ik_batch_on_device(r, p.ctx, config, p.t1 - p.t0, targets16 + (size_t)p.t0 * 16, row_major,
+                                  (flags & OPTIK_POSE_FROM_MATRIX) != 0,
                                   x0 + (size_t)p.t0 * n, ee16 ? ee7 : nullptr, start,
                                   x_out ? x_out + (size_t)p.t0 * n : nullptr, f_out ? f_out + p.t0 : nullptr,
                                   found_out ? found_out + p.t0 : nullptr, p.err);
@@ -779,7 +881,8 @@ int optik_robot_ik_batch_poses(const optik_robot *r, const CSolverConfig *config
 const double *optik_robot_ik(const optik_robot *r, const CSolverConfig *config, const double *target,
                              const double *x0) {
     std::vector<double> x((size_t)r->n);
-    const int rc = optik_robot_ik_ex(r, config, target, x0, nullptr, x.data(), nullptr, nullptr);
+    // (the C path converts the target with the iterative UnitQuaternion::from_matrix: optik-cpp/src/lib.rs:141-142)
+    const int rc = optik_robot_ik_pose(r, config, target, OPTIK_POSE_FROM_MATRIX, x0, nullptr, x.data(), nullptr, nullptr);
     if (rc < 0) panic(g_robot_err);
     if (rc == 1) return nullptr;  // optik-cpp/src/lib.rs:158-160
     return malloc_copy(x.data(), x.size());

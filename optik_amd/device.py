@@ -2,7 +2,7 @@
 
 PyTorch is used only as plumbing: HBM allocation, streams, and (in ``bench.py``)
 ``torch.distributed``.  All arithmetic happens in the HIP kernels of
-``csrc/ik_kernels.hip``; nothing here computes on the CPU.
+``csrc/ik_capi.hip``; nothing here computes on the CPU.
 """
 from __future__ import annotations
 
@@ -146,63 +146,6 @@ class HipChain:
             int(restart_begin), int(restart_end), int(flags), float(deadline_s), _dp(win_x), _dp(win_f),
             win_idx.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(win_key)))
         return dict(win_x=win_x, win_f=win_f, win_idx=win_idx.astype(np.int64), win_key=win_key)
-
-    # -- the streaming engine (throughput path; same results) ---------------------
-    def engine_submit(self, cfg, targets, x0, restart_begin, restart_end, flags=0, ee_offset7=None,
-                      bufs=None, per_restart=True):
-        """Queue one job for the next engine_run().  Same arguments / buffers as ik_batch;
-        the tensors must stay alive until engine_run() returns."""
-        assert targets.is_cuda and targets.dtype == torch.float64 and targets.is_contiguous()
-        assert x0.is_cuda and x0.dtype == torch.float64 and x0.is_contiguous()
-        T = targets.shape[0]
-        assert targets.shape == (T, 7) and x0.shape == (T, self.n)
-        R = int(restart_end - restart_begin)
-        if bufs is None:
-            bufs = self.alloc_ik_buffers(T, R, per_restart)
-        o = nat.IkOutputs()
-        o.d_x, o.d_f = _ptr(bufs.get("x")), _ptr(bufs.get("f"))
-        o.d_status, o.d_evals = _ptr(bufs.get("status")), _ptr(bufs.get("evals"))
-        o.d_win_x, o.d_win_f = _ptr(bufs["win_x"]), _ptr(bufs["win_f"])
-        o.d_win_idx, o.d_win_key = _ptr(bufs["win_idx"]), _ptr(bufs["win_key"])
-        ee = np.ascontiguousarray(ee_offset7, dtype=np.float64) if ee_offset7 is not None else None
-        nat.check(nat.lib().optik_hip_engine_submit(
-            self._h, C.byref(cfg), _ptr(targets), _ptr(x0), T, _dp(ee) if ee is not None else None,
-            int(restart_begin), int(restart_end), int(flags), C.byref(o)))
-        self._pending = getattr(self, "_pending", [])
-        self._pending.append((targets, x0, bufs))  # keep the buffers alive
-        return bufs
-
-    def engine_reserve(self, slots=0):
-        """Allocate the engine's slot pool ahead of the first run (0 = default capacity)."""
-        nat.check(nat.lib().optik_hip_engine_reserve(self._h, int(slots), _stream_ptr()))
-
-    def engine_run(self, deadline_s=0.0):
-        """Run every submitted job to completion (blocking) and their selections.  deadline_s > 0:
-        max_time -- restarts still running that long after the call started are abandoned."""
-        nat.check(nat.lib().optik_hip_engine_run_ex(self._h, _stream_ptr(), float(deadline_s)))
-        self._pending = []
-        return int(nat.lib().optik_hip_engine_last_trips(self._h))
-
-    def engine_last_tail(self):
-        """(solver, restarts) of the last engine_run's tail: solver 0 none, 3 quad solver (1 and 2 were the kernels of
-        rounds 1 and 2); restarts = how many (upper bound) were taken over from the slot pool."""
-        n = C.c_int32(0)
-        solver = int(nat.lib().optik_hip_engine_last_tail(self._h, C.byref(n)))
-        return solver, int(n.value)
-
-    def engine_stats(self):
-        """Per-kernel mean ms {eval, update, nnls, finish} over the sampled trips of sub-pool 0 of
-        the last engine_run (needs set_timing(True)), sampled trips, NNLS problems solved, the
-        number of sub-pools and the launches of each phase kernel over all of them."""
-        ms = (C.c_double * 4)()
-        cnt, prob = C.c_int32(0), C.c_uint64(0)
-        nat.check(nat.lib().optik_hip_engine_stats(self._h, ms, C.byref(cnt), C.byref(prob)))
-        launches = C.c_int32(0)
-        pools = int(nat.lib().optik_hip_engine_last_pools(self._h, C.byref(launches)))
-        executed = int(nat.lib().optik_hip_engine_executed_evals(self._h))
-        return dict(eval_ms=ms[0], update_ms=ms[1], nnls_ms=ms[2], finish_ms=ms[3],
-                    sampled_trips=cnt.value, nnls_problems=prob.value, pools=pools,
-                    launches=launches.value, evals_executed=executed, slot_trips=executed)
 
     def set_timing(self, enabled=True):
         nat.lib().optik_hip_set_timing(self._h, 1 if enabled else 0)

@@ -118,6 +118,39 @@ def use_portable_build():
     _lib, _lib_path = None, _LIB_PATH
 
 
+FLOPS_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fpermissive", "-w", "-pthread"]
+
+
+def use_flops_build() -> str:
+    """Compile optik_oracle_flops.cpp (the oracle with a counting double: every f64 + - * / sqrt it executes is
+    counted) into liboptik_oracle_flops.so and make lib() load it.  Same results bit for bit, ~10 x slower, counters
+    process-wide: call ik(..., n_threads=1) between flop_reset() and flop_counts().  Raises if g++ is missing."""
+    global _lib, _lib_path
+    out = os.path.join(_HERE, "liboptik_oracle_flops.so")
+    src = os.path.join(_HERE, "optik_oracle_flops.cpp")
+    deps = (src, os.path.join(_HERE, "optik_oracle.c"), os.path.join(_HERE, "optik_oracle.h"))
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.check_call(["g++", *FLOPS_FLAGS, "-shared", "-o", out, src, "-lm", "-lpthread"], cwd=_HERE)
+    _lib, _lib_path = None, out
+    return "g++ " + " ".join(FLOPS_FLAGS)
+
+
+FLOP_NAMES = ("add_sub", "mul", "div", "sqrt", "compare", "sign_abs_minmax", "int_conversions")
+
+
+def flop_reset():
+    lib().ok_flop_reset()
+
+
+def flop_counts() -> dict:
+    """Counters of the counting build since the last flop_reset(); `flops` = add_sub + mul + div + sqrt."""
+    out = (C.c_ulonglong * 8)()
+    lib().ok_flop_counts(out)
+    d = {k: int(out[i]) for i, k in enumerate(FLOP_NAMES)}
+    d["flops"] = d["add_sub"] + d["mul"] + d["div"] + d["sqrt"]
+    return d
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -130,6 +163,7 @@ def lib():
         L.ok_se3_log.argtypes = [C.POINTER(Pose), dp]
         L.ok_se3_right_jacobian.argtypes = [C.POINTER(Pose), dp]
         L.ok_pose_from_rpy.argtypes = [dp, dp, C.POINTER(Pose)]
+        L.ok_quat_from_matrix.argtypes = [dp, C.c_int, dp]
         L.ok_fk.argtypes = [C.POINTER(Chain), dp, C.POINTER(Pose), C.POINTER(Pose), C.POINTER(Pose)]
         L.ok_joint_jacobian.argtypes = [C.POINTER(Chain), C.POINTER(Pose), C.POINTER(Pose), dp]
         L.ok_eval.argtypes = [C.POINTER(Chain), C.POINTER(Pose), C.POINTER(Pose), dp, dp, dp, dp]
@@ -226,6 +260,14 @@ def se3_right_jacobian(t, q):
     p = Pose.make(t, q); out = np.zeros(36)
     lib().ok_se3_right_jacobian(C.byref(p), _dp(out))
     return out.reshape(6, 6).T
+
+
+def quat_from_matrix(R, iterative: bool):
+    """3x3 rotation (row, col) -> [i, j, k, w] by the reference's C-binding (iterative) or Python-binding reading."""
+    m = _f64(np.asarray(R, dtype=np.float64).T).ravel()  # column-major
+    q = np.zeros(4)
+    lib().ok_quat_from_matrix(_dp(m), int(bool(iterative)), _dp(q))
+    return q
 
 
 def fk(chain: Chain, q, ee_offset=None):

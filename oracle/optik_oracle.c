@@ -12,6 +12,9 @@
 #include "optik_oracle.h"
 
 #include <math.h>
+#ifndef sincos
+void sincos(double x, double *s, double *c); /* glibc (GNU extension; not declared under -std=c11) */
+#endif
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
@@ -347,6 +350,122 @@ void ok_pose_from_rpy(const double xyz[3], const double rpy[3], ok_pose *out) {
     out->q[1] = cr * sp * cy + sr * cp * sy;
     out->q[2] = cr * cp * sy - sr * sp * cy;
     out->t[0] = xyz[0]; out->t[1] = xyz[1]; out->t[2] = xyz[2];
+}
+
+/* ---- target matrix -> pose, the two readings of the reference's bindings ------------------------------
+ * nalgebra 0.34.0 (Cargo.lock:579-581; not vendored: restated from the crate's published source, PARITY
+ * UNPINNED).  m: 3x3 rotation block, column-major (m[3 c + r]); q out as [i, j, k, w]. */
+
+/* UnitQuaternion::from_rotation_matrix: what try_convert::<Matrix4, Isometry3> ends in
+ * (optik-py/src/lib.rs:8-15). */
+static void quat_from_rot(const double *m, double q[4]) {
+#define RM(r, c) m[3 * (c) + (r)]
+    const double tr = RM(0, 0) + RM(1, 1) + RM(2, 2);
+    double den;
+    if (tr > 0.0) {
+        den = sqrt(tr + 1.0) * 2.0;
+        q[3] = 0.25 * den;
+        q[0] = (RM(2, 1) - RM(1, 2)) / den; q[1] = (RM(0, 2) - RM(2, 0)) / den; q[2] = (RM(1, 0) - RM(0, 1)) / den;
+    } else if (RM(0, 0) > RM(1, 1) && RM(0, 0) > RM(2, 2)) {
+        den = sqrt(1.0 + RM(0, 0) - RM(1, 1) - RM(2, 2)) * 2.0;
+        q[3] = (RM(2, 1) - RM(1, 2)) / den;
+        q[0] = 0.25 * den; q[1] = (RM(0, 1) + RM(1, 0)) / den; q[2] = (RM(0, 2) + RM(2, 0)) / den;
+    } else if (RM(1, 1) > RM(2, 2)) {
+        den = sqrt(1.0 + RM(1, 1) - RM(0, 0) - RM(2, 2)) * 2.0;
+        q[3] = (RM(0, 2) - RM(2, 0)) / den;
+        q[0] = (RM(0, 1) + RM(1, 0)) / den; q[1] = 0.25 * den; q[2] = (RM(1, 2) + RM(2, 1)) / den;
+    } else {
+        den = sqrt(1.0 + RM(2, 2) - RM(0, 0) - RM(1, 1)) * 2.0;
+        q[3] = (RM(1, 0) - RM(0, 1)) / den;
+        q[0] = (RM(0, 2) + RM(2, 0)) / den; q[1] = (RM(1, 2) + RM(2, 1)) / den; q[2] = 0.25 * den;
+    }
+#undef RM
+}
+
+/* Rotation3::from_axis_angle, column-major out. */
+static void rot_axis_angle(const double u[3], double angle, double *o) {
+    if (angle == 0.0) {
+        for (int e = 0; e < 9; ++e) o[e] = (e % 4 == 0) ? 1.0 : 0.0;
+        return;
+    }
+    const double sx = u[0] * u[0], sy = u[1] * u[1], sz = u[2] * u[2];
+    double sn, cs; /* f64::sin_cos: platform libm -- ONE sincos call on both sides (glibc's sin + cos differ from its
+                    * sincos in the last bit for ~0.5 % of arguments, and compilers merge the pair or not as they like) */
+    sincos(angle, &sn, &cs);
+    const double omc = 1.0 - cs;
+    o[0] = sx + (1.0 - sx) * cs;            o[3] = u[0] * u[1] * omc - u[2] * sn; o[6] = u[0] * u[2] * omc + u[1] * sn;
+    o[1] = u[0] * u[1] * omc + u[2] * sn;   o[4] = sy + (1.0 - sy) * cs;          o[7] = u[1] * u[2] * omc - u[0] * sn;
+    o[2] = u[0] * u[2] * omc - u[1] * sn;   o[5] = u[1] * u[2] * omc + u[0] * sn; o[8] = sz + (1.0 - sz) * cs;
+}
+
+/* o = a * b (nalgebra gemm for small static matrices: column by column, axpy over k in order). */
+static void m3_mul(const double *a, const double *b, double *o) {
+    double t[9];
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) {
+            double y = a[r] * b[3 * c];
+            y = a[3 + r] * b[3 * c + 1] + y;
+            y = a[6 + r] * b[3 * c + 2] + y;
+            t[3 * c + r] = y;
+        }
+    memcpy(o, t, sizeof t);
+}
+
+static double m3_diff_norm2(const double *a, const double *b) {
+    double res = 0.0;
+    for (int c = 0; c < 3; ++c) {
+        const double d0 = a[3 * c] - b[3 * c], d1 = a[3 * c + 1] - b[3 * c + 1], d2 = a[3 * c + 2] - b[3 * c + 2];
+        res += d0 * d0 + d1 * d1 + d2 * d2;
+    }
+    return res;
+}
+
+/* iterative != 0: UnitQuaternion::from_matrix = Rotation3::from_matrix_eps(m, EPSILON, 0, identity) then
+ * from_rotation_matrix -- the C path, optik-cpp/src/lib.rs:141-142; iterative == 0: from_rotation_matrix alone. */
+void ok_quat_from_matrix(const double m[9], int iterative, double q[4]) {
+    if (!iterative) { quat_from_rot(m, q); return; }
+    const double eps = 2.220446049250313e-16;
+    const double sq_eps = sqrt(eps), eps2 = eps * eps;
+    const double disturb = sq_eps > eps2 ? sq_eps : eps2;
+    double ax[3] = {1.0, 0.0, 0.0};
+    double rot[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (long it = 0; it < 100000; ++it) { /* (nalgebra: usize::MAX) */
+        double axis[3], denom;
+        for (int c = 0; c < 3; ++c) {
+            const double *a = rot + 3 * c, *b = m + 3 * c;
+            double cr[3];
+            v3_cross(a, b, cr);
+            const double d = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+            if (c == 0) { axis[0] = cr[0]; axis[1] = cr[1]; axis[2] = cr[2]; denom = d; }
+            else { axis[0] += cr[0]; axis[1] += cr[1]; axis[2] += cr[2]; denom += d; }
+        }
+        const double dv = fabs(denom) + eps;
+        const double aa[3] = {axis[0] / dv, axis[1] / dv, axis[2] / dv};
+        const double sq = aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2];
+        if (sq > eps * eps) { /* Unit::try_new_and_get */
+            const double nrm = sqrt(sq);
+            const double u[3] = {aa[0] / nrm, aa[1] / nrm, aa[2] / nrm};
+            double rd[9];
+            rot_axis_angle(u, nrm, rd);
+            m3_mul(rd, rot, rot);
+        } else {
+            double pert[9];
+            memcpy(pert, rot, sizeof pert);
+            const double n0 = m3_diff_norm2(m, rot);
+            double n1;
+            for (;;) {
+                double rp[9];
+                rot_axis_angle(ax, disturb, rp);
+                m3_mul(pert, rp, pert);
+                n1 = m3_diff_norm2(m, pert);
+                if (fabs(n0 - n1) > eps) break;
+            }
+            if (n0 < n1) break;
+            const double t = ax[0]; ax[0] = ax[1]; ax[1] = ax[2]; ax[2] = t; /* yzx */
+            memcpy(rot, pert, sizeof pert);
+        }
+    }
+    quat_from_rot(rot, q);
 }
 
 /* JointType::local_transform, kinematics.rs:243-255. */

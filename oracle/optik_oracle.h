@@ -99,6 +99,10 @@ void ok_se3_right_jacobian(const ok_pose *X, double J[36]);      /* math.rs:191-
 
 /* ---- kinematics.rs ---------------------------------------------------- */
 void ok_pose_from_rpy(const double xyz[3], const double rpy[3], ok_pose *out); /* :263-267 */
+/* 3x3 rotation block (column-major) -> unit quaternion [i, j, k, w]: iterative != 0 as the reference's C binding
+ * (optik-cpp/src/lib.rs:141-142, nalgebra UnitQuaternion::from_matrix), 0 as its Python binding
+ * (optik-py/src/lib.rs:8-15, from_rotation_matrix). */
+void ok_quat_from_matrix(const double m[9], int iterative, double q[4]);
 void ok_fk(const ok_chain *c, const double *q, const ok_pose *ee_offset,
            ok_pose *joint_tfms /* [J] */, ok_pose *ee_tfm);      /* :123-164 */
 void ok_joint_jacobian(const ok_chain *c, const ok_pose *joint_tfms,

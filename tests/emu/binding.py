@@ -27,7 +27,7 @@ def _clang():
 def build(force=False):
     deps = [SRC, os.path.join(HERE, "lane_emu.hpp")] + [
         os.path.join(CSRC, h) for h in ("ik_quad.hpp", "ik_lane64.hpp", "ik_lane.hpp", "ik_platform.hpp", "ik_math.hpp", "ik_eval.hpp", "ik_slsqp.hpp",
-                                        "ik_solve.hpp", "ik_nnls_coop.hpp", "ik_nnls_quad.hpp", "ik_nnls_first.hpp", "ik_host_params.hpp")]
+                                        "ik_solve.hpp", "ik_nnls_quad.hpp", "ik_nnls_first.hpp", "ik_host_params.hpp")]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
         return LIB
     subprocess.check_call([_clang(), "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",

@@ -1,15 +1,15 @@
 """-m gpu: BASELINE.json's configurations at their full sizes.
 
-Every restart of config 2 (65 536 Panda restarts, both execution paths), of config 3 (2^20 UR10
-restarts at tol_f = 1e-12) and every target of one GPU's share of config 5 (512 targets x 256
-restarts) is compared with the CPU oracle bit for bit -- status, evaluation count, x, f, winner
-(the oracle runs 20-30 k restarts/s per host thread: a second or two for config 2, well under a
-minute for config 3 on the box's cores).  Config 4 (2^22 restarts, 8 shards) and the properties
-below hold at any size:
+Every restart of config 2 (65 536 Panda restarts, both solvers), of config 3 (2^20 UR10 restarts at
+tol_f = 1e-12, one launch of the default solver), of config 4 (2^22 Panda restarts as 8 shards of
+524 288, Quality, each shard one launch of the default solver) and every target of one GPU's share of
+config 5 (512 targets x 256 restarts) is compared with the CPU oracle bit for bit -- status, evaluation
+count, x, f, winner (the oracle runs 20-30 k restarts/s per host thread: a second or two for config 2,
+~4 s for config 3 and ~15 s for config 4 on the box's 16 cores).  The properties below hold at any size:
 
   * round trip: every restart reported as solved satisfies FK(x) == target to the pose
     tolerance implied by tol_f, and respects the joint limits;
-  * the two GPU execution paths (single kernel / streaming engine) agree bit for bit --
+  * the two single-launch solvers (lane-per-restart form / quad solver) agree bit for bit --
     a checksum over every per-restart output;
   * selection: the reported winner is the lowest solved index (Speed) / the solved restart
     closest to the seed (Quality), recomputed from the per-restart outputs;
@@ -78,11 +78,11 @@ def _assert_every_restart_equals_oracle(out, ref, what):
     assert_bit_equal(out["x"].cpu().numpy(), ref["xs"].T, what + ": per-restart x")
 
 
-@pytest.mark.parametrize("path", ["kernel", "quad", "engine"])
+@pytest.mark.parametrize("path", ["kernel", "quad"])
 def test_config2_every_restart_equals_oracle(robots, oracle, chains, path):
     """Config 2 at its own size: all 65 536 Panda restarts of the headline workload -- status,
-    evaluation count, x, f -- and the Speed winner against the oracle, on every execution path: the single launch
-    a batch of this size gets (the lane-per-restart form), the quad solver forced onto it, the streaming engine
+    evaluation count, x, f -- and the Speed winner against the oracle, on both solvers: the single launch
+    a batch of this size gets (the lane-per-restart form) and the quad solver forced onto it
     (lib.rs:297-413; the reference's own check of this shape is tests/test_ik.rs:91-130)."""
     from optik_amd import _native as nat
     robot = robots["panda"]
@@ -93,13 +93,10 @@ def test_config2_every_restart_equals_oracle(robots, oracle, chains, path):
     if path == "kernel":
         out = hc.ik_batch(cfg, tg, x0, 0, R)
         assert hc.last_launch()["lds_bytes"] > 30000, "a launch of this size runs on the lane-per-restart form"
-    elif path == "quad":
+    else:
         with nat.options(solve_kernel="quad"):
             out = hc.ik_batch(cfg, tg, x0, 0, R)
         assert hc.last_launch()["lds_bytes"] < 30000
-    else:
-        out = hc.engine_submit(cfg, tg, x0, 0, R)
-        hc.engine_run()
     torch.cuda.synchronize()
     _, ch = chains["panda"]
     ref = oracle.ik(ch, oracle.make_config(solution_mode="speed", tol_f=1e-6), tg[0].cpu().numpy(), x0[0].cpu().numpy(),
@@ -111,32 +108,94 @@ def test_config2_every_restart_equals_oracle(robots, oracle, chains, path):
 
 
 def test_config3_every_restart_equals_oracle(robots, oracle, chains):
-    """Config 3 at its own size: 2^20 UR10 restarts at tol_f = 1e-12, Quality -- every restart and the
-    winner (the solved restart closest to the seed) against the oracle."""
+    """Config 3 at its own size on the DEFAULT solver: 2^20 UR10 restarts at tol_f = 1e-12, Quality, as ONE launch
+    of optik_hip_ik_batch (the lane-per-restart form at this size) -- every restart and the winner (the solved
+    restart closest to the seed) against the oracle.  ~4 s of oracle time on 16 threads."""
     from optik_amd import _native as nat
     robot = robots["ur10"]
     hc = robot.hip_chain("cuda:0")
     tg, x0, lb, ub = _targets(robot, hc, 1, 3)
     R = 1 << 20
-    out = hc.engine_submit(nat.make_config("quality", tol_f=1e-12), tg, x0, 0, R)
-    hc.engine_run()
+    out = hc.ik_batch(nat.make_config("quality", tol_f=1e-12), tg, x0, 0, R)
     torch.cuda.synchronize()
+    assert hc.last_launch()["lds_bytes"] > 30000, "a launch of this size runs on the lane-per-restart form"
     _, ch = chains["ur10"]
     ref = oracle.ik(ch, oracle.make_config(solution_mode="quality", tol_f=1e-12), tg[0].cpu().numpy(),
                     x0[0].cpu().numpy(), 0, R, n_threads=_threads(), early_exit=False, per_restart=True)
     _assert_every_restart_equals_oracle(out, ref, "config 3")
     assert ref["found"] and int(out["win_idx"][0]) == ref["winner"]
     assert_bit_equal(out["win_x"].cpu().numpy()[0], ref["x"], "winner x")
-    # ... and an eighth of it (one GPU's contiguous index range, section 8e) through the single-launch path
+    # ... and an eighth of it (one GPU's contiguous index range, section 8e) on the quad solver
     g = 5
-    part = hc.ik_batch(nat.make_config("quality", tol_f=1e-12), tg, x0, g * (R // 8), (g + 1) * (R // 8))
-    torch.cuda.synchronize()
+    with nat.options(solve_kernel="quad"):
+        part = hc.ik_batch(nat.make_config("quality", tol_f=1e-12), tg, x0, g * (R // 8), (g + 1) * (R // 8))
+        torch.cuda.synchronize()
     sl = slice(g * (R // 8), (g + 1) * (R // 8))
     sub = {k: ref[k][sl] for k in ("status", "evals", "fs", "xs")}
-    _assert_every_restart_equals_oracle(part, sub, "config 3, shard 5 on the kernel path")
+    _assert_every_restart_equals_oracle(part, sub, "config 3, shard 5 on the quad solver")
 
 
-@pytest.mark.parametrize("path", ["kernel", "engine"])
+def _quality_keys(xs, x0):
+    """||x - x0||_2 as the kernels and the oracle form it (lib.rs:402-407): squares summed in joint order."""
+    acc = np.zeros(xs.shape[0])
+    for i in range(xs.shape[1]):
+        d = xs[:, i] - x0[i]
+        acc = acc + d * d
+    return np.sqrt(acc)
+
+
+def test_config4_every_restart_equals_oracle(robots, oracle, chains):
+    """Config 4 at its own size on the DEFAULT solver: Panda, 2^22 restarts as 8 contiguous shards of 524 288 (one
+    per GPU), SolutionMode::Quality.  Every shard is one launch of optik_hip_ik_batch (the lane-per-restart form);
+    every restart of every shard -- status, evaluation count, x, f -- and every shard's (key, index) record equal
+    the oracle's on that index range; the winner the two min-all-reduces of optik_amd.parallel pick from the eight
+    records is the oracle's winner over the 4 M restarts (lib.rs:397-413; the reference's own check of the Quality
+    rule is a property, tests/test_ik.rs:132-182).  ~15 s of oracle time on 16 threads."""
+    from optik_amd import _native as nat
+    from optik_amd.parallel import I64_MAX, local_key
+    robot = robots["panda"]
+    hc = robot.hip_chain("cuda:0")
+    tg, x0, lb, ub = _targets(robot, hc, 1, 4)
+    cfg = nat.make_config("quality", tol_f=1e-6)
+    ocfg = oracle.make_config(solution_mode="quality", tol_f=1e-6)
+    _, ch = chains["panda"]
+    tgn, x0n = tg[0].cpu().numpy(), x0[0].cpu().numpy()
+    R, G = 1 << 22, 8
+    S = R // G
+    keys, idxs, recs = [], [], []
+    best = (np.inf, -1, None)  # the oracle's winner over all shards: (key, index, x)
+    bufs = hc.alloc_ik_buffers(1, S)
+    for g in range(G):
+        sh = hc.ik_batch(cfg, tg, x0, g * S, (g + 1) * S, bufs=dict(bufs))
+        torch.cuda.synchronize()
+        assert hc.last_launch()["lds_bytes"] > 30000, "a shard of this size runs on the lane-per-restart form"
+        ref = oracle.ik(ch, ocfg, tgn, x0n, g * S, (g + 1) * S, n_threads=_threads(), early_exit=False, per_restart=True)
+        _assert_every_restart_equals_oracle(sh, ref, f"config 4, shard {g}")
+        assert ref["found"] and int(sh["win_idx"][0]) == ref["winner"], g
+        assert_bit_equal(sh["win_x"].cpu().numpy()[0], ref["x"], f"shard {g} winner x")
+        rk = _quality_keys(ref["xs"], x0n)
+        ok = ref["success"] != 0
+        kmin = rk[ok].min()
+        assert ref["winner"] == g * S + int(np.nonzero(ok & (rk == kmin))[0][0])  # (ties to the lower index)
+        assert_bit_equal(sh["win_key"].cpu().numpy(), [kmin], f"shard {g} key")
+        if kmin < best[0]:
+            best = (kmin, ref["winner"], ref["x"].copy())
+        k, i = local_key(sh, "quality")
+        keys.append(k.clone()); idxs.append(i.clone())
+        recs.append({kk: sh[kk].clone() for kk in ("win_x", "win_key", "win_idx")})
+    key = torch.stack(keys).min(0).values                      # all-reduce MIN of the keys
+    cand = [torch.where(k == key, i, torch.full_like(i, I64_MAX)) for k, i in zip(keys, idxs)]
+    win = torch.stack(cand).min(0).values                      # all-reduce MIN of the indices
+    assert int(win[0]) == best[1] >= 0
+    owner = int(win[0]) // S
+    assert_bit_equal(recs[owner]["win_x"].cpu().numpy()[0], best[2], "config 4 winner x")
+    # the winner is a solution: FK(x) == target to the tolerance tol_f implies, inside the limits
+    x = recs[owner]["win_x"][0]
+    assert _pose_error(hc, x.view(-1, 1), tg[0]).max().item() < 2e-3
+    assert (x >= torch.tensor(lb, device="cuda")).all() and (x <= torch.tensor(ub, device="cuda")).all()
+
+
+@pytest.mark.parametrize("path", ["kernel", "rounds"])
 def test_config5_share_winners_equal_oracle(robots, oracle, chains, path):
     """Config 5, one GPU's share (targets 512 .. 1023 of the 4096, 256 restarts each, Speed): the winner
     index, x and f of EVERY target against the oracle's 1-thread run of that target (lowest solved
@@ -152,8 +211,18 @@ def test_config5_share_winners_equal_oracle(robots, oracle, chains, path):
     if path == "kernel":
         out = hc.ik_batch(cfg, tg, x0, 0, R, flags=nat.IK_EARLY_EXIT | nat.IK_RESTART_MAJOR, per_restart=False)
     else:
-        out = hc.engine_submit(cfg, tg, x0, 0, R, flags=nat.IK_EARLY_EXIT, per_restart=False)
-        hc.engine_run()
+        # the product's round scheduling (robot_host.cpp:ik_batch_on_device): 128 indices restart-major, then the
+        # unsolved targets' next 128 -- the deterministic rule (no FIND_ANY)
+        out = hc.ik_batch(cfg, tg, x0, 0, 128, flags=nat.IK_EARLY_EXIT | nat.IK_RESTART_MAJOR, per_restart=False)
+        torch.cuda.synchronize()
+        out = {k: v.clone() for k, v in out.items()}
+        left = torch.nonzero(out["win_idx"] < 0).flatten()
+        if left.numel():
+            more = hc.ik_batch(cfg, tg[left].contiguous(), x0[left].contiguous(), 128, R,
+                               flags=nat.IK_EARLY_EXIT | nat.IK_RESTART_MAJOR, per_restart=False)
+            torch.cuda.synchronize()
+            for k in ("win_idx", "win_x", "win_f"):
+                out[k][left] = more[k]
     torch.cuda.synchronize()
     _, ch = chains["panda"]
     ocfg = oracle.make_config(solution_mode="speed", tol_f=1e-6)
@@ -183,9 +252,9 @@ def test_config2_panda_65536_speed(robots):
     cfg = nat.make_config("speed", tol_f=1e-6)
     R = 65536
     a = hc.ik_batch(cfg, tg, x0, 0, R)
-    b = hc.engine_submit(cfg, tg, x0, 0, R)
-    hc.engine_run()
-    torch.cuda.synchronize()
+    with nat.options(solve_kernel="quad"):
+        b = hc.ik_batch(cfg, tg, x0, 0, R)
+        torch.cuda.synchronize()
     assert _checksum(a) == _checksum(b)
     assert torch.equal(a["win_idx"], b["win_idx"]) and torch.equal(a["win_x"], b["win_x"])
     ok = a["status"] == nat.RES_STOPVAL
@@ -209,8 +278,7 @@ def test_config3_ur10_one_million_tight_tolerance(robots):
     tg, x0, lb, ub = _targets(robot, hc, 1, 3)
     cfg = nat.make_config("quality", tol_f=1e-12)
     R = 1 << 20
-    out = hc.engine_submit(cfg, tg, x0, 0, R)
-    hc.engine_run()
+    out = hc.ik_batch(cfg, tg, x0, 0, R)
     torch.cuda.synchronize()
     ok = out["status"] == nat.RES_STOPVAL
     assert ok.sum().item() > 1000
@@ -248,12 +316,14 @@ def test_config4_panda_four_million_sharded_quality(robots):
     tg, x0, lb, ub = _targets(robot, hc, 1, 4)
     cfg = nat.make_config("quality", tol_f=1e-6)
     R, G = 1 << 22, 8
-    whole = hc.engine_submit(cfg, tg, x0, 0, R, per_restart=False)
-    hc.engine_run()
+    whole = hc.ik_batch(cfg, tg, x0, 0, R, per_restart=False)
     torch.cuda.synchronize()
-    shards = [hc.engine_submit(cfg, tg, x0, g * (R // G), (g + 1) * (R // G), per_restart=False) for g in range(G)]
-    hc.engine_run()
-    torch.cuda.synchronize()
+    whole = {k: v.clone() for k, v in whole.items()}
+    shards = []
+    for g in range(G):
+        sh = hc.ik_batch(cfg, tg, x0, g * (R // G), (g + 1) * (R // G), per_restart=False)
+        torch.cuda.synchronize()
+        shards.append({k: v.clone() for k, v in sh.items()})
     keys, idxs = zip(*(local_key(sh, "quality") for sh in shards))
     key = torch.stack(keys).min(0).values                      # all-reduce MIN of the keys
     cand = [torch.where(k == key, i, torch.full_like(i, I64_MAX)) for k, i in zip(keys, idxs)]
@@ -276,8 +346,7 @@ def test_config5_motion_planning_batch(robots):
     T, R = 4096, 256
     tg, x0, lb, ub = _targets(robot, hc, T, 5)
     cfg = nat.make_config("speed", tol_f=1e-6)
-    out = hc.engine_submit(cfg, tg, x0, 0, R)
-    hc.engine_run()
+    out = hc.ik_batch(cfg, tg, x0, 0, R)
     torch.cuda.synchronize()
     st = out["status"].view(T, R)
     ok = st == nat.RES_STOPVAL
@@ -292,9 +361,10 @@ def test_config5_motion_planning_batch(robots):
     dt = (pose[:3] - t[:3]).abs().amax(0)
     dq = torch.minimum((pose[3:] - t[3:]).abs().amax(0), (pose[3:] + t[3:]).abs().amax(0))
     assert torch.maximum(dt, dq).max().item() < 2e-3
-    # one GPU's share (targets 512..1023) through the other path: identical winners
-    sub = hc.ik_batch(cfg, tg[512:1024].contiguous(), x0[512:1024].contiguous(), 0, R)
-    torch.cuda.synchronize()
+    # one GPU's share (targets 512..1023) on the quad solver: identical winners
+    with nat.options(solve_kernel="quad"):
+        sub = hc.ik_batch(cfg, tg[512:1024].contiguous(), x0[512:1024].contiguous(), 0, R)
+        torch.cuda.synchronize()
     assert torch.equal(sub["win_idx"], out["win_idx"][512:1024])
     assert torch.equal(sub["win_x"], out["win_x"][512:1024])
     # the random seeds are the same for every target (lib.rs:360): restart i of any two targets

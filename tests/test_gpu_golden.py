@@ -44,7 +44,7 @@ def test_seeds_match_fixture(hip_chains, robot, rule):
 
 @pytest.mark.parametrize("robot", ["ur3e", "panda", "ur10", "arm10"])
 @pytest.mark.parametrize("rule", ["single_inclusive", "new_inclusive"])
-@pytest.mark.parametrize("path", ["kernel", "engine", "lane64"])
+@pytest.mark.parametrize("path", ["kernel", "quad", "lane64"])
 def test_restarts_and_winners_match_fixture(hip_chains, robot, rule, path):
     from optik_amd import _native as nat
     doc = _load(robot)
@@ -64,9 +64,10 @@ def test_restarts_and_winners_match_fixture(hip_chains, robot, rule, path):
                     with nat.options(solve_kernel="lane64"):
                         out = hc.ik_batch(cfg, tgd, x0d, 0, R)
                         torch.cuda.synchronize()
-                else:
-                    out = hc.engine_submit(cfg, tgd, x0d, 0, R)
-                    hc.engine_run()
+                else:  # (the quad solver forced; arm10: the general solver)
+                    with nat.options(solve_kernel="quad"):
+                        out = hc.ik_batch(cfg, tgd, x0d, 0, R)
+                        torch.cuda.synchronize()
                 torch.cuda.synchronize()
                 rs = blk["restarts"]
                 assert out["status"].cpu().tolist() == [r["status"] for r in rs]

@@ -124,7 +124,7 @@ def _oracle_all(oracle, ch, cfg_kw, tgt, x0, begin, end):
 def _run(hc, path, cfg, tgd, x0d, begin, end, flags=0):
     """The GPU paths: the single-launch solvers -- `kernel`: what a launch of this size gets (the quad solver below
     one full load of the chip), `lane64`: the lane-per-restart form (ik_lane64.hpp), the default from there on,
-    forced here at the test's size -- and the streaming engine."""
+    forced here at the test's size -- and `quad`: the quad solver forced whatever the size."""
     from optik_amd import _native as nat
     if path == "lane64":
         with nat.options(solve_kernel="lane64"):
@@ -133,8 +133,9 @@ def _run(hc, path, cfg, tgd, x0d, begin, end, flags=0):
     elif path == "kernel":
         out = hc.ik_batch(cfg, tgd, x0d, begin, end, flags=flags)
     else:
-        out = hc.engine_submit(cfg, tgd, x0d, begin, end, flags=flags)
-        hc.engine_run()
+        with nat.options(solve_kernel="quad"):
+            out = hc.ik_batch(cfg, tgd, x0d, begin, end, flags=flags)
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     return out
 
@@ -142,7 +143,7 @@ def _run(hc, path, cfg, tgd, x0d, begin, end, flags=0):
 @pytest.mark.parametrize("robot,tol_f,R", [("panda", 1e-6, 4096), ("ur10", 1e-12, 2048),
                                            ("ur3e", 1e-6, 2048), ("panda_hand", 1e-8, 2048)])
 @pytest.mark.parametrize("mode", ["speed", "quality"])
-@pytest.mark.parametrize("path", ["kernel", "engine", "lane64"])
+@pytest.mark.parametrize("path", ["kernel", "lane64"])
 def test_every_restart_bit_exact(dev, oracle, chains, hip_chains, robot, tol_f, R, mode, path):
     """One target, restarts 0..R-1: status, evaluation count, returned x and f of EVERY
     restart equal the oracle's, and so does the selected winner."""
@@ -167,11 +168,11 @@ def test_every_restart_bit_exact(dev, oracle, chains, hip_chains, robot, tol_f, 
 
 
 @pytest.mark.parametrize("robot", ["panda1", "panda2", "panda3", "panda4", "panda5", "arm8"])
-@pytest.mark.parametrize("path", ["kernel", "engine", "lane64"])
+@pytest.mark.parametrize("path", ["kernel", "lane64"])
 def test_other_joint_counts_bit_exact(dev, oracle, chains, hip_chains, robot, path):
     """Kernels are instantiated for 1 <= n <= 8: sub-chains of the Panda (no trailing fixed
     joint) and a synthetic 8-joint arm through both paths, every restart against the oracle
-    (an 8-DoF chain's engine jobs run on the single-kernel path: the engine's NNLS holds 8 rows)."""
+    (an 8-DoF chain always runs on the quad solver: the lane-per-restart form is built for n <= 7)."""
     from optik_amd import _native as nat
     d, ch = chains[robot]
     rng = np.random.default_rng(17)
@@ -211,7 +212,7 @@ def test_restart_ranges_compose(dev, oracle, chains, hip_chains):
     assert int(idxs[best]) == int(full["win_idx"][0])
 
 
-@pytest.mark.parametrize("path", ["kernel", "engine", "lane64"])
+@pytest.mark.parametrize("path", ["kernel", "lane64"])
 def test_many_targets_batch(dev, oracle, chains, hip_chains, path):
     """Config-5 shape: T targets x R restarts each; per-target winners match the oracle
     run target by target (Speed: lowest successful index)."""
@@ -234,107 +235,6 @@ def test_many_targets_batch(dev, oracle, chains, hip_chains, path):
             assert_bit_equal(wx[t], ref["x"], f"winner x target {t}")
         else:
             assert win[t] == -1
-
-
-def test_engine_pools_jobs_and_matches_the_single_kernel_path(dev, oracle, chains, hip_chains):
-    """Several jobs submitted before one engine run share the slot pool (continuous
-    batching); every job's outputs equal the single-kernel path's bit for bit, also when
-    the pool is much smaller than the work (slots are refilled many times)."""
-    import os
-    from optik_amd import _native as nat
-    d, ch = chains["panda"]
-    hc = hip_chains["panda"]
-    rng = np.random.default_rng(31)
-    cfg = nat.make_config(solution_mode="quality")
-    jobs = []
-    for T, begin, end in [(1, 0, 3000), (3, 5, 700), (1, 100000, 101000)]:
-        tg, x0 = make_targets(oracle, d, ch, rng, T)
-        jobs.append((torch.tensor(tg, device="cuda"), torch.tensor(x0, device="cuda"), begin, end))
-    ref = [hc.ik_batch(cfg, t, x, b, e) for t, x, b, e in jobs]
-    torch.cuda.synchronize()
-    with nat.options(engine_slots=1024):
-        outs = [hc.engine_submit(cfg, t, x, b, e) for t, x, b, e in jobs]
-        trips = hc.engine_run()
-    torch.cuda.synchronize()
-    assert trips > 50
-    for r, o in zip(ref, outs):
-        for k in ("status", "evals", "win_idx"):
-            assert torch.equal(r[k], o[k]), k
-        for k in ("x", "f", "win_x", "win_f", "win_key"):
-            assert torch.equal(r[k].view(torch.int64), o[k].view(torch.int64)), k
-
-
-@pytest.mark.parametrize("knobs", [
-    dict(engine_pools=3, engine_slots=3072),                           # three sub-pools, refilled many times
-    dict(engine_pools=4, engine_slots=8192, engine_nnls_budget=1),     # every solve suspended each pass
-    dict(engine_pools=2, engine_slots=4096, engine_nnls_budget=2),
-    dict(engine_pools=1, engine_compact=0),                            # no drain compaction
-    dict(engine_pools=1, engine_slots=2048, engine_nnls_budget=3),
-    dict(engine_slots=1000, engine_pools=1),                           # pool that is not a whole number of 64-slot tiles
-    dict(engine_slots=1900, engine_pools=3),
-    dict(engine_nnls_slack=0, engine_slots=4096),                      # every solve capped at its predicted pass count
-    dict(engine_nnls_slack=100),                                       # ... or only by the launch budget
-    dict(engine_tail_max=0),                                           # the engine finishes every restart itself
-    dict(engine_tail_max=100000, engine_slots=4096),                   # the quad solver takes over as soon as the queue is empty
-    dict(engine_tail_max=7, engine_pools=2),                           # ... or only for the last handful
-    dict(engine_tail_max=100000, engine_slots=4096, engine_nnls_budget=1),  # quad tail taking over slots with suspended solves
-])
-def test_engine_scheduling_does_not_change_results(dev, oracle, chains, hip_chains, knobs):
-    """Sub-pools, the per-launch NNLS pass budget (suspend / resume), pool size (refills) and
-    drain compaction only decide WHERE and WHEN a restart's arithmetic runs: every restart's
-    status, evaluation count, x and f equal the oracle's under any setting."""
-    import os
-    from optik_amd import _native as nat
-    d, ch = chains["panda"]
-    rng = np.random.default_rng(41)
-    tg, x0 = make_targets(oracle, d, ch, rng, 1)
-    kw = dict(solution_mode="quality", tol_f=1e-6)
-    cfg = nat.make_config(**kw)
-    R = 6000
-    with nat.options(**knobs):
-        out = _run(hip_chains["panda"], "engine", cfg, torch.tensor(tg, device="cuda"),
-                   torch.tensor(x0, device="cuda"), 0, R)
-        tail_solver, tail_restarts = hip_chains["panda"].engine_last_tail()
-    # the hand-over really happened where the setting asks for it (solver 3 = the quad solver)
-    if knobs.get("engine_tail_max") == 0:
-        assert tail_solver == 0 and tail_restarts == 0
-    elif knobs.get("engine_tail_max") == 100000:
-        assert tail_restarts > 0 and tail_solver == 3, (tail_solver, tail_restarts)
-    ref = _oracle_all(oracle, ch, kw, tg[0], x0[0], 0, R)
-    assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
-    assert np.array_equal(out["evals"].cpu().numpy(), ref["evals"])
-    assert_bit_equal(out["f"].cpu().numpy(), ref["fs"], "per-restart f")
-    assert_bit_equal(out["x"].cpu().numpy(), ref["xs"].T, "per-restart x")
-    assert int(out["win_idx"].cpu()[0]) == ref["winner"]
-
-
-@pytest.mark.parametrize("robot,tol_f", [("panda", 1e-6), ("ur10", 1e-8), ("ur3e", 1e-6), ("panda_hand", 1e-6)])
-def test_engine_many_targets_pooled_bit_exact(dev, oracle, chains, hip_chains, robot, tol_f):
-    """Eight targets submitted as eight jobs of one engine run (restart ranges that do not start
-    at 0, weights other than the default): every restart of every job equals the oracle's."""
-    from optik_amd import _native as nat
-    d, ch = chains[robot]
-    rng = np.random.default_rng(97)
-    kw = dict(solution_mode="quality", tol_f=tol_f, linear_weight=(1.0, 2.0, 0.5), angular_weight=(0.7, 1.0, 1.3))
-    cfg = nat.make_config(**kw)
-    jobs = []
-    for j in range(8):
-        tg, x0 = make_targets(oracle, d, ch, rng, 1)
-        begin = int(rng.integers(0, 5000))
-        end = begin + int(rng.integers(300, 900))
-        out = hip_chains[robot].engine_submit(cfg, torch.tensor(tg, device="cuda"), torch.tensor(x0, device="cuda"),
-                                              begin, end)
-        jobs.append((tg, x0, begin, end, out))
-    hip_chains[robot].engine_run()
-    torch.cuda.synchronize()
-    for tg, x0, begin, end, out in jobs:
-        ref = _oracle_all(oracle, ch, kw, tg[0], x0[0], begin, end)
-        assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
-        assert np.array_equal(out["evals"].cpu().numpy(), ref["evals"])
-        assert_bit_equal(out["f"].cpu().numpy(), ref["fs"], "per-restart f")
-        assert_bit_equal(out["x"].cpu().numpy(), ref["xs"].T, "per-restart x")
-        want = ref["winner"] if ref["found"] else -1
-        assert int(out["win_idx"].cpu()[0]) == want
 
 
 def test_early_exit_keeps_the_winner(dev, oracle, chains, hip_chains):
@@ -438,7 +338,7 @@ def test_ftol_and_xtol_count_as_success_when_enabled(dev, oracle, chains, hip_ch
     assert int(out["win_idx"].cpu()[0]) == ref["winner"]
 
 
-@pytest.mark.parametrize("path", ["kernel", "engine", "lane64"])
+@pytest.mark.parametrize("path", ["kernel", "lane64"])
 @pytest.mark.parametrize("tol_dx", [-1.0, 0.0])
 def test_zero_step_counts_as_xtol(dev, oracle, chains, hip_chains, path, tol_dx):
     """ftol_abs = 0 (tol_f = tol_df = 0): neither stopval nor ftol can fire, and restarts end
@@ -460,64 +360,6 @@ def test_zero_step_counts_as_xtol(dev, oracle, chains, hip_chains, path, tol_dx)
     assert_bit_equal(out["x"].cpu().numpy(), ref["xs"].T, "per-restart x")
     assert int(out["win_idx"].cpu()[0]) == (ref["winner"] if ref["found"] else -1)
     assert ref["found"] == (tol_dx >= 0.0)
-
-
-def test_more_jobs_than_the_pool_table_holds(dev, oracle, chains, hip_chains):
-    """Any number of jobs may be submitted before a run: more than ENG_MAX_JOBS (256) are executed
-    as consecutive runs inside engine_run, each job's result what it is alone."""
-    from optik_amd import _native as nat
-    d, ch = chains["ur3e"]
-    rng = np.random.default_rng(23)
-    J, R = 300, 24
-    tg, x0 = make_targets(oracle, d, ch, rng, J)
-    cfg = nat.make_config(solution_mode="speed")
-    hc = hip_chains["ur3e"]
-    tgd, x0d = torch.tensor(tg, device="cuda"), torch.tensor(x0, device="cuda")
-    outs = [hc.engine_submit(cfg, tgd[j:j + 1], x0d[j:j + 1], 0, R) for j in range(J)]
-    hc.engine_run()
-    torch.cuda.synchronize()
-    for j in (0, 1, 128, 255, 256, 257, 299):
-        ref = _oracle_all(oracle, ch, dict(solution_mode="speed"), tg[j], x0[j], 0, R)
-        assert np.array_equal(outs[j]["status"].cpu().numpy(), ref["status"]), j
-        assert_bit_equal(outs[j]["x"].cpu().numpy(), ref["xs"].T, f"job {j}")
-        assert int(outs[j]["win_idx"].cpu()[0]) == (ref["winner"] if ref["found"] else -1)
-
-
-def test_engine_deadline_abandons_and_keeps_what_was_found(dev, oracle, chains, hip_chains):
-    """optik_hip_engine_run_ex(deadline): restarts in flight at the deadline end FORCED_STOP with
-    their best point so far, queued ones never start (0 evaluations); whatever finished before
-    is what the oracle computes for that restart, and the selection sees only those."""
-    from optik_amd import _native as nat
-    d, ch = chains["panda"]
-    rng = np.random.default_rng(29)
-    tg, x0 = make_targets(oracle, d, ch, rng, 1)
-    cfg = nat.make_config(solution_mode="speed")
-    hc = hip_chains["panda"]
-    R = 1 << 20
-    tgd, x0d = torch.tensor(tg, device="cuda"), torch.tensor(x0, device="cuda")
-    import time
-    hc.engine_reserve()                                   # pool allocation and first-launch costs
-    hc.engine_submit(cfg, tgd, x0d, 0, 1 << 17)           # are not part of what is timed
-    hc.engine_run()
-    out = hc.engine_submit(cfg, tgd, x0d, 0, R)
-    t0 = time.perf_counter()
-    hc.engine_run(deadline_s=0.010)
-    took = time.perf_counter() - t0
-    torch.cuda.synchronize()
-    status = out["status"].cpu().numpy()
-    evals = out["evals"].cpu().numpy()
-    forced = status == nat.RES_FORCED_STOP
-    assert forced.any() and (~forced).any(), "the deadline should fall inside the run"
-    assert took < 0.020, took                      # a full run of 2^20 restarts takes ~45 ms; the deadline is checked on the device clock at every evaluation / refill
-    assert (evals[forced & (evals == 0)] == 0).all() and (forced & (evals == 0)).sum() > R // 4  # never started
-    done = np.flatnonzero(~forced)[:200]
-    xs = out["x"].cpu().numpy()
-    for i in done[::10]:
-        r = oracle.solve_restart(ch, oracle.make_config("speed"), tg[0], x0[0], int(i))
-        assert r.result == status[i] and r.n_evals == evals[i]
-        assert_bit_equal(xs[:, i], np.array(r.x[:7]), f"restart {i}")
-    ok = np.flatnonzero(status == nat.RES_STOPVAL)
-    assert int(out["win_idx"].cpu()[0]) == (ok.min() if len(ok) else -1)
 
 
 @pytest.mark.parametrize("path", ["kernel", "lane64"])

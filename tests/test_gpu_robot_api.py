@@ -202,9 +202,9 @@ def test_c_abi_ik_returns_malloced_buffer(ur3e):
     assert not bool(L.optik_robot_ik(ur3e._h, C.byref(cfg), far, x0))   # NULL = no solution
 
 
-def test_ik_batch_on_the_engine_equals_individual_calls(panda):
-    """A Speed batch of 40 960 targets or more runs its first round on the streaming engine
-    (robot_host.cpp:ik_batch_on_device): the same answers as ik() target by target."""
+def test_ik_batch_of_41000_targets_equals_individual_calls(panda):
+    """A Speed batch of tens of thousands of targets (one launch per round, robot_host.cpp:ik_batch_on_device;
+    rounds 1-4 ran batches of this size on a streaming engine): the same answers as ik() target by target."""
     from optik_amd import SolverConfig
     rng = np.random.default_rng(18)
     lb, ub = (np.array(v) for v in panda.joint_limits())
@@ -248,7 +248,7 @@ def test_ik_batch_equals_individual_calls(panda, oracle, chains):
             assert ref["found"] == (batch[t] is not None)
             if ref["found"]:
                 np.testing.assert_allclose(batch[t][0], ref["x"], atol=1e-6, rtol=0)
-    # Quality with thousands of restarts per target: one engine round covers them all
+    # Quality with thousands of restarts per target: one round (one launch) covers them all
     cfg = SolverConfig(solution_mode="quality", max_time=0.0, max_restarts=3000)
     batch = panda.ik_batch(cfg, targets[:20], x0s[:20])
     for t in (0, 9, 19):
@@ -268,10 +268,10 @@ def test_ik_batch_equals_individual_calls(panda, oracle, chains):
         panda.ik_batch(SolverConfig(max_time=0.0, max_restarts=16), [targets[0], bad], x0s[:2])
 
 
-def test_big_speed_batch_on_the_engine_equals_individual_calls(panda):
-    """From 40 960 targets a Speed batch runs on the streaming engine in short rounds (16 restart
-    indices in the first, the unsolved rest goes through later rounds): the answers are
-    still those of ik() alone -- the lowest successful restart index with set_parallelism(1)."""
+def test_big_speed_batch_equals_individual_calls(panda):
+    """A Speed batch of 65 536 targets runs in rounds capped at ~4 M work items (64 restart indices per target in
+    the first, the unsolved rest goes through later rounds): the answers are still those of ik() alone -- the
+    lowest successful restart index with set_parallelism(1)."""
     from optik_amd import SolverConfig
     rng = np.random.default_rng(15)
     lb, ub = (np.array(v) for v in panda.joint_limits())
@@ -296,8 +296,7 @@ def test_big_speed_batch_on_the_engine_equals_individual_calls(panda):
 
 def test_speed_batch_with_hard_targets_runs_growing_rounds(panda):
     """A Speed batch's first round is 256 restart indices per target; what it leaves unsolved goes
-    through rounds four times as long each (on the engine with the whole pool once a round is
-    ~100 000 restarts): reachable targets keep the answer of ik() alone, unreachable ones come back
+    through rounds four times as long each: reachable targets keep the answer of ik() alone, unreachable ones come back
     None after all max_restarts -- in a time that shows the rounds grew (390 rounds of 256 took 0.8 s)."""
     from optik_amd import SolverConfig
     rng = np.random.default_rng(61)
@@ -309,7 +308,7 @@ def test_speed_batch_with_hard_targets_runs_growing_rounds(panda):
     targets[[2, 7]] = far
     x0s = rng.uniform(lb, ub, size=(T, 7))
     cfg = SolverConfig(solution_mode="speed", max_time=0.0, max_restarts=60_000)
-    panda.ik_batch_arrays(cfg, targets, x0s)  # (first engine use of this robot allocates the pool)
+    panda.ik_batch_arrays(cfg, targets, x0s)  # (the first call allocates the launch workspace)
     t0 = time.perf_counter()
     x, f, ok = panda.ik_batch_arrays(cfg, targets, x0s)
     dt = time.perf_counter() - t0
@@ -321,8 +320,8 @@ def test_speed_batch_with_hard_targets_runs_growing_rounds(panda):
 
 
 def test_eight_dof_batch_equals_individual_calls():
-    """n = 8 runs on the quad solve kernel (nine-row NNLS columns in LDS; the engine's register NNLS holds
-    n + 1 <= 8 rows, so engine jobs of such a chain go there too): a Speed batch is handed out
+    """n = 8 runs on the quad solve kernel (nine-row NNLS columns in LDS; the lane-per-restart form is built for
+    n <= 7): a Speed batch is handed out
     restart-major, same answers as ik() alone."""
     from conftest import TEST_ROBOTS
     from optik_amd import Robot, SolverConfig
@@ -426,7 +425,7 @@ def test_multi_device_sharding_gives_the_single_device_answers():
         cfg = SolverConfig(solution_mode=mode, max_time=0.0, max_restarts=300)
         assert one.ik_batch(cfg, targets, x0s) == two.ik_batch(cfg, targets, x0s)
     # a long Quality call: after 512 + 65 536 (x 2) restarts on the solve kernel the rounds of 1 M
-    # restarts per context run on each context's own engine; same winner, same numbers
+    # restarts per context are one launch on each context; same winner, same numbers
     cfg = SolverConfig(solution_mode="quality", max_time=0.0, max_restarts=2_400_000)
     a = one.ik(cfg, targets[1], x0s[1].tolist(), return_index=True)
     b = two.ik(cfg, targets[1], x0s[1].tolist(), return_index=True)
@@ -435,9 +434,9 @@ def test_multi_device_sharding_gives_the_single_device_answers():
         two.set_devices([0])  # only before the first GPU call
 
 
-def test_ik_batch_honours_max_time_inside_an_engine_run(panda):
+def test_ik_batch_honours_max_time_inside_a_launch(panda):
     """lib.rs:308: the time-out is checked at every evaluation, so a batch whose round would
-    run for tens of ms returns close to max_time (the engine abandons what is in flight)."""
+    run for tens of ms returns close to max_time (the launch's waves abandon what is in flight)."""
     from optik_amd import SolverConfig
     far = np.eye(4)
     far[:3, 3] = 50.0  # unreachable: every restart runs until it stalls
@@ -446,7 +445,7 @@ def test_ik_batch_honours_max_time_inside_an_engine_run(panda):
     lb, ub = (np.array(v) for v in panda.joint_limits())
     x0s = rng.uniform(lb, ub, size=(T, 7))
     cfg_free = SolverConfig(max_time=0.0, max_restarts=256)
-    panda.ik_batch(cfg_free, [far] * 64, x0s[:64])  # warm-up: pool allocation, module load
+    panda.ik_batch(cfg_free, [far] * 64, x0s[:64])  # warm-up: workspace allocation, module load
     t0 = time.perf_counter()
     res = panda.ik_batch(cfg_free, [far] * T, x0s)
     full = time.perf_counter() - t0
@@ -498,8 +497,7 @@ def test_diff_ik_six_dof_solution_is_the_unique_ray(ur3e):
 
 
 def test_long_calls_move_to_big_rounds_with_the_same_answer(panda):
-    """Throughput-bound calls run in rounds of 1 M restarts (single launches of the lane-per-restart form; rounds 2-3:
-    the streaming engine) -- Quality with a restart budget of ~260 000 or more from index 0, any call still running
+    """Throughput-bound calls run in rounds of 1 M restarts (single launches of the lane-per-restart form) -- Quality with a restart budget of ~260 000 or more from index 0, any call still running
     after its first two launches: Quality over 300 000 restarts returns the restart a solve-kernel launch around it
     selects; an unreachable Speed target comes back None after all of them; max_time ends a
     round early."""
@@ -535,7 +533,7 @@ def test_long_calls_move_to_big_rounds_with_the_same_answer(panda):
 def test_robot_is_reentrant(panda):
     """Robot::ik takes &self and is called from many host threads at once (lib.rs:241; SURVEY 8b
     "Threading"): concurrent ik / ik_batch / fk calls on ONE robot -- short ones on the solve
-    kernel, a long Quality call that moves to the engine, a batch -- return what they return alone."""
+    kernel, a long Quality call of 1 M-restart rounds, a batch -- return what they return alone."""
     import threading
     from optik_amd import SolverConfig
     rng = np.random.default_rng(31)
@@ -577,10 +575,9 @@ def test_robot_is_reentrant(panda):
     assert not errors, errors
 
 
-def test_robots_share_one_engine_pool_per_device():
-    """The streaming engine's slot pool (~1 GB) belongs to the device, not to the robot: several
-    robots -- different chains, used from different threads at once -- take turns on it, return
-    what they return alone, and do not multiply the memory."""
+def test_robots_on_one_device_from_many_threads():
+    """Several robots -- different chains, used from different threads at once -- share one device: each returns what
+    it returns alone, and the launch workspaces stay small (rounds 1-4 kept a ~1 GB slot pool per device here)."""
     import threading
     import torch
     from optik_amd import Robot, SolverConfig
@@ -588,7 +585,7 @@ def test_robots_share_one_engine_pool_per_device():
              ("panda.urdf", "panda_link0", "panda_link5"), ("panda.urdf", "panda_link0", "panda_hand")]
     robots = [Robot.from_urdf_file(os.path.join(ROBOTS, f), b, e) for f, b, e in specs]
     rng = np.random.default_rng(9)
-    cfg = SolverConfig(solution_mode="quality", max_time=0.0, max_restarts=150_000)  # an engine run each
+    cfg = SolverConfig(solution_mode="quality", max_time=0.0, max_restarts=150_000)
     cases = []
     for r in robots:
         lb, ub = (np.array(v) for v in r.joint_limits())
@@ -596,7 +593,7 @@ def test_robots_share_one_engine_pool_per_device():
     free0, _ = torch.cuda.mem_get_info()
     want = [r.ik(cfg, t, x0, return_index=True) for r, (t, x0) in zip(robots, cases)]
     free1, _ = torch.cuda.mem_get_info()
-    assert free0 - free1 < 2.2 * 2**30, (free0 - free1) / 2**30  # one pool (+ per-robot job buffers), not four
+    assert free0 - free1 < 0.5 * 2**30, (free0 - free1) / 2**30  # per-restart keys / points of 150 000 restarts x 4
     got = [None] * len(robots)
 
     def run(k):

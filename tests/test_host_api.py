@@ -213,7 +213,7 @@ int main(int argc, char **argv) {
     /* referenced, not called (they need a GPU) */
     void *fns[] = {(void *)optik_robot_ik, (void *)optik_robot_fk, (void *)optik_robot_joint_jacobian,
                    (void *)optik_robot_diff_ik, (void *)optik_robot_random_configuration,
-                   (void *)optik_robot_from_urdf_str, (void *)optik_hip_ik_batch, (void *)optik_hip_engine_run};
+                   (void *)optik_robot_from_urdf_str, (void *)optik_hip_ik_batch, (void *)optik_hip_ik_host};
     printf("%d\n", (int)(sizeof fns / sizeof fns[0]));
     optik_robot_free(r);
     return 0;

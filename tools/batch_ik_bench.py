@@ -32,7 +32,7 @@ def main():
         return m
     targets = np.array([mat(p) for p in pose])
     cfg = SolverConfig(solution_mode="speed", max_time=0.0, max_restarts=R)
-    robot.ik_batch(cfg, targets, x0s)  # warm-up at full size (the first call allocates the engine's pool)
+    robot.ik_batch(cfg, targets, x0s)  # warm-up at full size (the first call allocates the launch workspace)
     dt = 1e30
     for _ in range(3):
         t0 = time.perf_counter()

@@ -81,39 +81,5 @@ def main():
             print("    calls by quads taking part (0..16): " + " ".join(f"{100.0 * c / totp:.1f}" for c in h[49:66]))
 
 
-def engine_profile():
-    """NNLS-kernel phases of the streaming engine: load / solve / store cycles per wave pass."""
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-                           "-shared", "-Wno-unused-value", "-pthread", "-DOPTIK_PROFILE", "-x", "hip",
-                           os.path.join(CSRC, "ik_kernels.hip"), os.path.join(CSRC, "robot_host.cpp"), "-o", LIB])
-    from optik_amd import _native as nat
-    nat.LIB_PATH = LIB
-    import numpy as np
-    import torch
-    from optik_amd import Robot
-    rb = Robot.from_urdf_file(os.path.join(ROOT, "optik_amd", "robots", "panda.urdf"), "panda_link0", "panda_link8")
-    hc = rb.hip_chain("cuda:0")
-    rng = np.random.default_rng(0)
-    lb, ub = (np.array(v) for v in rb.joint_limits())
-    K, R = 4, 65536
-    tgt = hc.fk_batch(torch.tensor(rng.uniform(lb, ub, size=(K, len(lb))).T.copy(), device="cuda:0")).T.contiguous()
-    x0 = torch.tensor(rng.uniform(lb, ub, size=(K, len(lb))), device="cuda:0")
-    cfg = nat.make_config("speed")
-    bufs = [hc.alloc_ik_buffers(1, R) for _ in range(K)]
-    for i in range(K):
-        hc.engine_submit(cfg, tgt[i:i + 1], x0[i:i + 1], 0, R, bufs=bufs[i])
-    trips = hc.engine_run()
-    out = (C.c_ulonglong * 8)()
-    nat.lib().optik_hip_phase_profile.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
-    nat.check(nat.lib().optik_hip_phase_profile(hc._h, out))
-    v = list(out)
-    n = max(v[3], 1)
-    print(f"engine nnls kernel: {n} wave passes over {trips} trips: load {v[0]/n:.0f}  solve {v[1]/n:.0f}  store {v[2]/n:.0f} cycles per pass")
-
-
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "engine":
-        engine_profile()
-        sys.exit(0)
     main()

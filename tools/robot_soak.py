@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak of the host API: a few thousand mixed calls (single ik() short and long, Speed / Quality
 batches of several sizes, fk) on one robot -- answers identical from cycle to cycle, device memory
-flat (job buffers, staging blocks and the engine pool are allocated once or freed per call).
+flat (job buffers, staging blocks and launch workspaces are allocated once or freed per call).
 Usage: python tools/robot_soak.py [cycles]"""
 import os
 import sys
