@@ -710,27 +710,38 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
     }
     OPTIK_PROF_DECL;  // (-DOPTIK_PROFILE: slots 0 refill, 1 eval, 4 bookkeeping + BFGS, 5 direction, 6 NNLS of it, 3 publish, 7 trips)
 
-    unsigned n_exec = 0;  // (Tail) evaluations the wave's quads executed
     QuadStop st{&wq_in, ia, ib, false, false, ~0ull};
+    unsigned long long ticket = ~0ull;  // (Tail) the quad's place in the spill list while it waits for that entry
     for (;;) {
         OPTIK_PROF_BEGIN();
         int32_t ret = 0;
         bool pending = false;  // (Tail) the restart resumes at a deferred direction search, not at an evaluation
         // ---- refill: quads without a restart pull the next work item (the leader fetches) ----------
         if constexpr (Tail::on) {
+            // (a free quad draws a ticket -- its place in the spill list -- and keeps it until that entry has been written,
+            // or until no wave can write one any more: the list fills while this wave is already consuming it)
             if (wave_any(want)) {
                 const Tail &tl = *reload_barrier_lds(tail_in);
                 const int qr = quad_lane_now();
-                unsigned long long e = fetch_items(tl.cursor, want && qr == 0);
+                const bool draw = want && ticket == ~0ull;
+                unsigned long long e = fetch_items(tl.cursor, draw && qr == 0);
                 e = quad_get_u64(e, 0);
-                if (want) {
+                ticket = draw ? e : ticket;
+                // (the quad's leader looks: four lanes reading at different moments could disagree)
+                unsigned slot_in = 0;
+                int got = 0;  // 1: the entry is there, 0: not yet, -1: it never will be
+                if (want && qr == 0) got = tl.poll(ticket, slot_in);
+                got = quad_get(got, 0);
+                slot_in = (unsigned)quad_get((int)slot_in, 0);
+                if (want && got != 0) {
                     want = false;
-                    if (e < (unsigned long long)*tl.count) {
-                        active = tl.template import<N>(tl.list[e], qr, x, x0, g, sv, Lr, dg, pa, pb, ia, ib, first, pending, ret,
-                                                       xb, xp);
+                    ticket = ~0ull;
+                    if (got > 0) {
+                        active = tl.template import<N>(slot_in, qr, x, x0, g, sv, Lr, dg, pa, pb, ia, ib, first, pending, ret, xb, xp);
                         want = !active;  // (an empty slot in the list: take the next entry)
                     }
                 }
+                if (!wave_any(active)) tl.idle();  // (every quad of the wave is waiting: do not hammer the counters)
             }
         } else if (wave_any(want)) {
             // (the launch parameters live in LDS: every region of a trip re-reads what it needs through a
@@ -791,7 +802,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
             const unsigned rlo = (unsigned)quad_get(ib, 0), rhi = (unsigned)quad_get(ib, 1);
             if (active && ret == 0) {
                 const Tail &tl = *reload_barrier_lds(tail_in);
-                const auto &J = tl.jobs[job];
+                const auto &J = tl.job(job);
                 const unsigned long long index = J.restart_begin + (((unsigned long long)rhi << 32) | rlo);
                 // lib.rs:308: abandon when timed out or another restart of the target succeeded
                 bool stop = false;
@@ -826,7 +837,6 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
         ret = quad_get(ret, 0);
         const bool stepping = active && ret == 0;
         const bool do_eval = stepping && !pending;
-        if constexpr (Tail::on) n_exec += (unsigned)__popcll(__ballot(do_eval)) / QUAD;
         double gn[NS];
         double fn = 0.0;
         OPTIK_SCHED_FENCE();
@@ -846,7 +856,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
             OPTIK_SCHED_FENCE();
             // (the target pose is re-read for every evaluation: seven L1 / L2 hits instead of 14 registers)
             const double *target7;
-            if constexpr (Tail::on) target7 = (*reload_barrier_lds(tail_in)).jobs[job].targets + (size_t)tslot * 7;
+            if constexpr (Tail::on) target7 = (*reload_barrier_lds(tail_in)).job(job).targets + (size_t)tslot * 7;
             else target7 = (*reload_barrier_lds(&wq_in)).targets + (size_t)tslot * 7;
             const EvalParams &ep = *reload_barrier_lds(&ep_in);
 #ifndef OPTIK_QUAD_EXP_NO_EVAL
@@ -1222,9 +1232,9 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
             unsigned long long o_restarts, o_begin, o_stride;
             bool o_quality;
             if constexpr (Tail::on) {
-                const auto &J = (*reload_barrier_lds(tail_in)).jobs[job];
+                const auto &J = (*reload_barrier_lds(tail_in)).job(job);
                 o_x0 = J.x0; o_x = J.out_x; o_f = J.out_f; o_key = J.out_key; o_status = J.out_status; o_evals = J.out_evals;
-                o_fs = J.first_success; o_restarts = J.n_restarts; o_begin = J.restart_begin; o_stride = J.n_items;
+                o_fs = J.first_success; o_restarts = J.n_restarts; o_begin = J.restart_begin; o_stride = J.total_items;
                 o_quality = J.quality != 0;
             } else {
                 const WorkQueue &wq = *reload_barrier_lds(&wq_in);
@@ -1308,10 +1318,6 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
         OPTIK_PROF_END(3);
     }
     OPTIK_PROF_FLUSH(wq_in.prof);
-    if constexpr (Tail::on) {
-        const Tail &tl = *reload_barrier_lds(tail_in);
-        if (tl.exec_evals && n_exec && (threadIdx.x & 63u) == 0) atomicAdd(tl.exec_evals + (blockIdx.x % 64u), (unsigned long long)n_exec);
-    }
 #undef xb
 #undef xp
 #undef blk

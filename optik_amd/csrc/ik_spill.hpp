@@ -1,28 +1,40 @@
-// ik_spill.hpp -- the last restarts of a lane-per-restart launch, finished by the quad solver.
+// ik_spill.hpp -- the last restarts of a lane-per-restart launch, finished by the quad solver inside the same kernel.
 //
 // A launch of ik_lane_kernel (ik_lane64.hpp: one restart per lane, 64 per wave) ends with its longest restart: once
 // the work queue is dry a wave keeps running for the few lanes that still hold one, and a trip with few live lanes
-// costs most of a full one (~49 us) -- 3.8 ms of fill + drain per launch in round 4, a third of a lone 65 536-restart
-// launch.  The reference keeps every rayon worker busy until the index range is exhausted
-// (/root/reference/crates/optik/src/lib.rs:297-300); here the stragglers leave their waves instead:
+// costs most of a full one (~40 us) -- 3.8 ms of fill + drain per launch in round 4, and a lone 65 536-restart launch
+// is nothing but drain.  The reference keeps every rayon worker busy until the index range is exhausted
+// (/root/reference/crates/optik/src/lib.rs:297-300); here the waves change FORM for the launch's end:
 //
-//   * when the queue is dry and at most SPILL_AT of a wave's lanes still hold a restart, those lanes write the
+//   * when the queue is dry and at most `spill_at` of a wave's lanes still hold a restart, those lanes write the
 //     restart's SLSQP state -- at the trip boundary, i.e. in front of an evaluation -- to a slot of the spill pool
-//     (slot = the lane's own global number: no allocation), append the slot to the launch's spill list and the wave
-//     exits;
-//   * the tail kernel (ik_quad_kernel.hip: ik_quad_tail_kernel), queued behind the lane kernel on the same stream,
-//     runs the quad solver (ik_quad.hpp: four lanes per restart, ~13 us per iteration instead of ~49) fed from that
-//     list instead of the work queue: a quad that is free pulls the next entry, reads the state from the slot planes
-//     (each lane its own joints / rows) and carries on where the lane left off -- same arithmetic, same bits.
+//     (slot = the lane's own global number: no allocation) and append the slot to the launch's spill list;
+//   * the wave then runs the quad solver (ik_quad.hpp: four lanes per restart, sixteen restarts per wave, ~13 us per
+//     iteration instead of ~40) fed from that list: a quad that is free draws a ticket, waits for that list entry,
+//     reads the state from the slot planes (each lane its own joints / rows) and carries on where the lane left off --
+//     same arithmetic, same bits.  The list is shared by the launch's waves: a wave whose own restarts were short
+//     finishes those of its neighbours, and the launch ends when every wave has left the lane form and the list is
+//     consumed.
+//
+// (A first version ran the tail as a second kernel behind the launch: the spilled restarts then WAIT for the launch's
+// last wave, and every threshold was slower than no spill at all -- profiles/r5c_spill_sweep.txt.)
 //
 // A restart is spilled in one of two states (the lane form's state at the top of its loop):
 //   SP_FIRST   seeded, not evaluated yet
 //   SP_TRIAL   a line-search trial point waiting for its evaluation (x = x0 + alpha s already formed)
 // (a lane whose last direction was not a descent direction -- reset B and search again, 5e-5 of the trips -- keeps
-// its wave for one more trip: the spill waits until no lane is in that state).
+// its wave in the lane form for one more trip: the spill waits until no lane is in that state).
+//
+// Protocol (all counters in the launch's queue block, zero before the launch and put back by its selection kernel):
+//   count   entries RESERVED in the list (a spilling wave adds its lane count, then writes data and entries)
+//   list    the slot of each entry; SPILL_NONE until written (store-release after the slot's planes), put back to
+//           SPILL_NONE by the quad that consumes it
+//   cursor  tickets handed out
+//   done    waves that have left the lane form (no reservation can follow once it equals the grid size)
 #pragma once
 
-#include "ik_launch.hpp"
+#include "ik_slsqp.hpp"
+#include "ik_solve.hpp"
 
 namespace optik {
 
@@ -35,9 +47,9 @@ struct SpillLayout {
     // int32 planes
     static constexpr int STATE = 0, LINE = 1, IRESET = 2, NEVALS = 3, NI = 4;
 };
-constexpr int SPILL_ND_MAX = SpillLayout<7>::ND;  // (the lane-per-restart form is built for n <= 7)
-constexpr int SPILL_NI = 4;
+static_assert(SPILL_ND_MAX == SpillLayout<7>::ND && SPILL_NI == SpillLayout<7>::NI, "the pool is sized for n <= 7 (ik_solve.hpp)");
 enum : int { SP_EMPTY = 0, SP_FIRST = 1, SP_TRIAL = 2 };
+constexpr unsigned SPILL_NONE = 0xffffffffu;  // a list entry that has not been written (yet)
 
 #define SPILL_D(P, plane, k) (P).d[(size_t)((plane) + (k)) * (P).C + slot]
 #define SPILL_I(P, plane) (P).i32[(size_t)(plane) * (P).C + slot]
@@ -84,13 +96,29 @@ namespace optik {
 struct SpillTail {
     static constexpr bool on = true;
     SpillPool pool;
-    const WorkQueue *wq;  // the launch's queue record (the tail kernel's LDS copy)
-    const unsigned int *list;
-    const unsigned int *count;
+    const WorkQueue *wq;  // the launch's queue record (the kernel's LDS copy)
     unsigned long long *cursor;
-    unsigned long long deadline;  // wall_clock64() ticks (the lane kernel's, absolute), 0 = none
+    unsigned long long deadline;  // wall_clock64() ticks (absolute), 0 = none
+    unsigned n_waves;             // waves of the launch: `done` reaches this when the last one has left the lane form
 
     OPTIK_DEV const WorkQueue &job(int) const { return *wq; }
+
+    // Is the list entry of `ticket` there?  1 (slot = its slot; the entry is put back to SPILL_NONE), 0 not yet,
+    // -1 it never will be: every wave has left the lane form and fewer entries were reserved.
+    OPTIK_DEV int poll(unsigned long long ticket, unsigned &slot) const {
+        // (done first: if it is complete, the count read after it is final)
+        const unsigned long long dn = __hip_atomic_load(pool.done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long cnt = __hip_atomic_load(pool.count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket < cnt) {
+            const unsigned v = __hip_atomic_load(pool.list + ticket, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            if (v == SPILL_NONE) return 0;
+            __hip_atomic_store(pool.list + ticket, SPILL_NONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            slot = v;
+            return 1;
+        }
+        return dn >= (unsigned long long)n_waves ? -1 : 0;
+    }
+    OPTIK_DEV void idle() const { __builtin_amdgcn_s_sleep(16); }
 
     // The restart of `slot_u` into the quad's registers (lane q: joints / rows q, q + 4).  Returns whether
     // the slot held one.
