@@ -33,7 +33,6 @@ Options &opt() {
         Options v;
         v.solve_kernel = solve_kernel_from(std::getenv("OPTIK_SOLVE_KERNEL"));
         if (const char *e = std::getenv("OPTIK_WIDE_FORM")) v.wide_form = std::strcmp(e, "hbm") == 0 ? 1 : 0;
-        if (const char *e = std::getenv("OPTIK_SPILL_AT")) v.spill_at = std::atoi(e) < 0 ? 0 : (std::atoi(e) > 64 ? 64 : std::atoi(e));
         if (const char *e = std::getenv("OPTIK_RANDOM_RANGE_RULE"))
             if (std::strcmp(e, "new_inclusive") == 0 || std::strcmp(e, "1") == 0) v.range_rule = OPTIK_HIP_RANGE_NEW_INCLUSIVE;
         return v;
@@ -171,10 +170,6 @@ void optik_hip_chain_destroy(optik_hip_chain *ch) {
     if (ch->tmp_f) hipFree(ch->tmp_f);
     if (ch->tmp_key) hipFree(ch->tmp_key);
     if (ch->queue) hipFree(ch->queue);
-    if (ch->spill_d) hipFree(ch->spill_d);
-    if (ch->spill_i32) hipFree(ch->spill_i32);
-    if (ch->spill_item) hipFree(ch->spill_item);
-    if (ch->spill_list) hipFree(ch->spill_list);
     if (ch->hw_dev) hipFree(ch->hw_dev);
     if (ch->hw_pin) hipHostFree(ch->hw_pin);
     if (ch->hw_claim) hipHostFree(ch->hw_claim);
@@ -263,11 +258,10 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         HIP_TRY(hipMalloc(&ch->tile_recs, sizeof(TileRec) * (size_t)n_tiles));
         ch->tile_cap = (size_t)n_tiles;
     }
-    constexpr size_t QB = sizeof(unsigned long long) * optik_hip_chain::QUEUE_WORDS;
-    if (!ch->queue) { HIP_TRY(hipMalloc(&ch->queue, QB)); ch->queue_clean = false; }
+    if (!ch->queue) { HIP_TRY(hipMalloc(&ch->queue, sizeof(unsigned long long))); ch->queue_clean = false; }
     // (the words are only known to be clean to a launch queued behind the selection kernel that cleaned them)
     if (stream != ch->clean_stream) { ch->queue_clean = false; ch->fs_clean = 0; }
-    if (!ch->queue_clean) HIP_TRY(hipMemsetAsync(ch->queue, 0, QB, stream));
+    if (!ch->queue_clean) HIP_TRY(hipMemsetAsync(ch->queue, 0, sizeof(unsigned long long), stream));
     ch->queue_clean = false;  // (until this launch's selection kernel has put it back)
     const bool early = (flags & OPTIK_HIP_IK_EARLY_EXIT) && cfg->solution_mode == 2;
     size_t fs_clean_after = ch->fs_clean;  // (a launch without early exit leaves the words alone)
@@ -455,30 +449,6 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
         lds = lds_form ? wide_lds_bytes() : (int)sizeof(WideChainDev);
         HIP_TRY(wide_solve_launch(grid, stream, w, lds_form, opt().wide_form != 2));
     } else if (lanek) {
-        // The launch's waves end in their second form -- the quad solver on the restarts still running when the queue
-        // is dry (ik_spill.hpp): a pool slot per resident lane.  Not for launches with fewer than a full wave of lanes
-        // per workgroup (latency-sized launches: nothing to balance).
-        const int spill_at = opt().spill_at;
-        const bool spill = spill_at > 0 && lanes == WAVE;
-        if (spill) {
-            const size_t C = (size_t)grid * WAVE;
-            if (C > ch->spill_C) {
-                if (ch->spill_d) { HIP_TRY(hipFree(ch->spill_d)); HIP_TRY(hipFree(ch->spill_i32)); HIP_TRY(hipFree(ch->spill_item)); HIP_TRY(hipFree(ch->spill_list)); }
-                ch->spill_d = nullptr; ch->spill_i32 = nullptr; ch->spill_item = nullptr; ch->spill_list = nullptr; ch->spill_C = 0;
-                HIP_TRY(hipMalloc(&ch->spill_d, sizeof(double) * SPILL_ND_MAX * C));
-                HIP_TRY(hipMalloc(&ch->spill_i32, sizeof(int32_t) * SPILL_NI * C));
-                HIP_TRY(hipMalloc(&ch->spill_item, sizeof(unsigned long long) * C));
-                HIP_TRY(hipMalloc(&ch->spill_list, sizeof(unsigned int) * C));
-                // (every entry "not written": a consumer puts its entry back, so this is needed once)
-                HIP_TRY(hipMemsetAsync(ch->spill_list, 0xff, sizeof(unsigned int) * C, stream));
-                ch->spill_C = C;
-            }
-            a.spill.d = ch->spill_d; a.spill.i32 = ch->spill_i32; a.spill.item = ch->spill_item; a.spill.C = ch->spill_C;
-            a.spill.list = ch->spill_list;
-            a.spill.count = ch->queue + 1; a.spill.cursor = ch->queue + 2; a.spill.done = ch->queue + 3;
-            a.spill.spill_at = spill_at;
-            a.spill.pad = opt().spill_quads < 1 ? 1 : (opt().spill_quads > 16 ? 16 : opt().spill_quads);
-        }
         HIP_TRY(lane_solve_launch(ch->n, ch->tip, grid, stream, a, &lds));
     } else if (quadk) {
         HIP_TRY(quad_solve_launch(ch->n, ch->tip, grid, stream, a, &lds, quad_latency));
@@ -524,8 +494,6 @@ static long long *option_slot(const char *name, int **islot) {
     if (!std::strcmp(name, "wide_form")) { *islot = &o.wide_form; return nullptr; }
     if (!std::strcmp(name, "range_rule")) { *islot = &o.range_rule; return nullptr; }
     if (!std::strcmp(name, "stop_x_legacy")) { *islot = &o.stop_x_legacy; return nullptr; }
-    if (!std::strcmp(name, "spill_at")) { *islot = &o.spill_at; return nullptr; }
-    if (!std::strcmp(name, "spill_quads")) { *islot = &o.spill_quads; return nullptr; }
     return nullptr;
 }
 int optik_hip_set_option(const char *name, long long value) {

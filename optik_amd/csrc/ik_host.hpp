@@ -50,7 +50,7 @@ struct SelectLaunch {
     double *win_key;
     // the launch's work-item counter and first-success words, put back to their initial values by the last
     // kernel of the launch so that the next launch needs no fill commands in front of it (null: leave them)
-    unsigned long long *reset_queue;  // (optik_hip_chain::QUEUE_WORDS words)
+    unsigned long long *reset_queue;
     unsigned long long *reset_fs;  // [T]
 };
 constexpr int SEL_TILE = 4096;  // restarts per 256-thread selection block
@@ -67,9 +67,6 @@ struct Options {
     int wide_form = 0;               // OPTIK_WIDE_FORM = lds | hbm: the general solver's form (9 .. 16 joints); 2: one-lane LDS form
     int range_rule = OPTIK_HIP_RANGE_SINGLE_INCLUSIVE;  // OPTIK_RANDOM_RANGE_RULE = new_inclusive: rand 0.9.2 reading of new chains
     int stop_x_legacy = 0;           // (no environment name) nlopt_stop_x of NLopt 2.5: no zero-step rule
-    int spill_quads = 16;            // (no environment name) quads of a wave that take spilled restarts in its second form
-    int spill_at = 32;               // OPTIK_SPILL_AT: a lane-per-restart wave hands its last restarts to the quad solver when
-                                     // the queue is dry and at most this many of its lanes hold one (0: never; ik_spill.hpp)
 };
 Options &opt();  // (ik_capi.hip)
 
@@ -165,16 +162,7 @@ struct optik_hip_chain {
     // scratch per-restart buffers when the caller does not provide them
     double *tmp_x = nullptr, *tmp_f = nullptr, *tmp_key = nullptr;
     size_t tmp_cols = 0;
-    // work-item counter of the in-flight launch; behind it (one allocation, put back together by the launch's last
-    // kernel) the spill list's length, the tail kernel's hand-out cursor and the lane kernel's deadline (ik_spill.hpp)
-    unsigned long long *queue = nullptr;
-    static constexpr int QUEUE_WORDS = 4;
-    // the spill pool of lane-per-restart launches: planes over spill_C slots (one per resident lane), the slot list
-    double *spill_d = nullptr;
-    int32_t *spill_i32 = nullptr;
-    unsigned long long *spill_item = nullptr;
-    unsigned int *spill_list = nullptr;
-    size_t spill_C = 0;
+    unsigned long long *queue = nullptr;  // work-item counter of the in-flight launch
     unsigned long long *prof = nullptr;   // phase timers (OPTIK_PROFILE builds)
     double *hw_dev = nullptr, *hw_pin = nullptr;  // optik_hip_ik_host: device block and pinned staging
     size_t hw_cap = 0;                            // doubles

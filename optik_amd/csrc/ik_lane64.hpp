@@ -42,7 +42,6 @@
 #include "ik_lane.hpp"
 #include "ik_solve.hpp"
 #include "ik_nnls_quad.hpp"
-#include "ik_spill.hpp"
 
 namespace optik {
 
@@ -152,8 +151,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
                            const double (&scale)[MAX_DOF], const WorkQueue &wq,
                            double *nnls_lds /* lane64_block_lds<N>() doubles, the last 16 zero */,
                            double *rec_lds /* lane64_rec_lds<N>() doubles */, int *lor_lds /* 64 ints: lane of rank */,
-                           int *where_lds /* 64 ints: by rank, 0x100 | the quad whose block holds the problem's answer */,
-                           const SpillPool *spill = nullptr /* where the wave leaves its last restarts (ik_spill.hpp), or null */) {
+                           int *where_lds /* 64 ints: by rank, 0x100 | the quad whose block holds the problem's answer */) {
     typedef Lane64Geom<N> G;
     constexpr int NL = N * (N + 1) / 2;
     constexpr int NS = (N > 4) ? 2 : 1;
@@ -174,7 +172,6 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
     unsigned long long item = 0, index = 0;
     unsigned tslot = 0;
     bool active = false, want = lane < wq.lanes;
-    bool dry = false;  // (wave-uniform) a fetch has come back empty: the launch's queue is dry
 #pragma unroll
     for (int i = 0; i < N; ++i) { x[i] = 0.0; x0[i] = 0.0; g[i] = 0.0; s[i] = 0.0; xbest[i] = 0.0; xprev[i] = 0.0; }
 #pragma unroll
@@ -199,7 +196,6 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
             // (asking for the items one refill ahead, so that no refill waits for its own atomic add on the launch's one
             // counter, measured nothing: 32.35 against 32.29 M restarts/s)
             const unsigned long long it = fetch_items(wq.next_item, want);
-            dry = dry || wave_any(want && it >= wq.total_items);
             if (want) {
                 want = false;
                 if (it < wq.total_items) {
@@ -228,27 +224,6 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
             }
         }
         if (!wave_any(active)) break;
-        // ---- the wave's last restarts leave it for the quad solver (ik_spill.hpp) --------------------------
-        // (the queue is dry and few lanes still hold a restart: a trip with few live lanes costs most of a full one)
-        if (spill && dry) {
-            const unsigned long long am = __ballot(active);
-            const int n_act = (int)__popcll(am);
-            if (n_act <= spill->spill_at && !wave_any(active && again)) {
-                // (entries are reserved first, written after their slots: a consumer waits for the entry itself)
-                unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(spill->count, (unsigned long long)n_act);
-                base = __shfl(base, 0);
-                if (active) {
-                    const size_t slot = (size_t)blockIdx.x * 64u + (unsigned)lane;
-                    spill_export<N>(*spill, slot, first, x, x0, g, s, xbest, xprev, l, f0, h3, alpha, fprev, minf, line, ireset,
-                                    nevals, item);
-                    __threadfence();
-                    __hip_atomic_store(spill->list + base + (unsigned long long)__popcll(am & ((1ull << lane) - 1ull)),
-                                       (unsigned)slot, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                break;
-            }
-        }
         LANE_PROF(0);
 
         int32_t ret = 0;

@@ -6,7 +6,6 @@
 #include <hip/hip_runtime.h>
 
 #include "ik_launch.hpp"
-#define OPTIK_SPILL_TAIL 1  // (this kernel's second form: the quad solver on the launch's last restarts, ik_spill.hpp)
 #include "ik_lane64.hpp"
 
 namespace optik {
@@ -15,8 +14,7 @@ template <int N, bool TIP>
 __global__ __launch_bounds__(64, 1) void ik_lane_kernel(const SolveLaunch a) {
     __shared__ ChainDev sch;
     __shared__ __attribute__((aligned(16))) double nnls_lds[lane64_block_lds<N>()];
-    // (the packed problems of the lane form; x_best / x_prev of the quad form the wave ends in)
-    __shared__ __attribute__((aligned(16))) double rec_lds[lane64_rec_lds<N>() > quad_lane_lds() ? lane64_rec_lds<N>() : quad_lane_lds()];
+    __shared__ __attribute__((aligned(16))) double rec_lds[lane64_rec_lds<N>()];
     __shared__ int lor_lds[64], where_lds[64];
     // (the launch parameters in LDS, as in ik_quad_kernel: ~125 SGPRs otherwise)
     __shared__ __attribute__((aligned(8))) uint32_t launch_lds[(sizeof(SolveLaunch) + 3) / 4];
@@ -31,35 +29,14 @@ __global__ __launch_bounds__(64, 1) void ik_lane_kernel(const SolveLaunch a) {
     SolveLaunch &L = *reinterpret_cast<SolveLaunch *>(launch_lds);
     if (threadIdx.x == 0) L.wq.deadline = L.deadline_ticks ? wall_clock64() + L.deadline_ticks : 0ull;
     __syncthreads();
-    lane64_wave<N, TIP>(sch, L.ep, L.sp, L.key, L.scale, L.wq, nnls_lds, rec_lds, lor_lds, where_lds,
-                        L.spill.d ? &L.spill : nullptr);
-    if (!a.spill.d) return;
-    // ---- the launch's end: this wave in its second form (ik_spill.hpp) ------------------------------------------
-    // It has left the lane form -- its last restarts, if any, are in the spill pool -- and now runs the quad solver on
-    // entries of the launch's spill list, its own and its neighbours', until every wave has left the lane form and
-    // the list is consumed.
-    __threadfence();
-    if (threadIdx.x == 0) atomicAdd(a.spill.done, 1ull);
-    static_assert(lane64_block_lds<N>() == quad_wave_lds<N>(), "the sixteen NNLS blocks serve both forms");
-    __shared__ __attribute__((aligned(8))) uint32_t tail_lds[(sizeof(SpillTail) + 3) / 4];
-    SpillTail &T = *reinterpret_cast<SpillTail *>(tail_lds);
-    if (threadIdx.x == 0) {
-        T.pool = a.spill;
-        L.wq.lanes = a.spill.pad;  // (how many of the wave's quads take restarts: the fewer, the shorter an iteration)
-        T.wq = &L.wq;
-        T.cursor = a.spill.cursor;
-        T.deadline = L.wq.deadline;
-        T.n_waves = gridDim.x;
-    }
-    __syncthreads();
-    quad_wave<N, TIP, SpillTail>(sch, L.ep, L.sp, L.key, L.scale, L.wq, nnls_lds, rec_lds, &T);
+    lane64_wave<N, TIP>(sch, L.ep, L.sp, L.key, L.scale, L.wq, nnls_lds, rec_lds, lor_lds, where_lds);
 }
 
 int lane_solve_waves_per_cu() { return 4; }
 
 hipError_t lane_solve_launch(int n, bool tip, int grid, hipStream_t stream, const SolveLaunch &a, int *lds_bytes) {
     if (lds_bytes)
-        *lds_bytes = (int)(sizeof(ChainDev) + sizeof(SolveLaunch) + 128 * sizeof(int) + sizeof(SpillTail)
+        *lds_bytes = (int)(sizeof(ChainDev) + sizeof(SolveLaunch) + 128 * sizeof(int)
                            + sizeof(double) * (lane64_block_lds<7>() + lane64_rec_lds<7>()));
 #define CALL_LANE(NN)                                                                                  \
     case NN:                                                                                           \

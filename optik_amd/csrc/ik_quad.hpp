@@ -16,8 +16,7 @@
 // quad_perm moves (ik_lane.hpp), never through LDS; the LDS of the solver is the 1 KB block per quad
 // that holds the matrix of the bounded dual problem while ik_nnls_quad.hpp solves it -- and, while
 // the quad evaluates, what the evaluation does not touch -- plus x_best / x_prev of every lane.
-// The restarts come from the launch's work queue, or (a Tail: ik_spill.hpp) mid-flight from the spill pool
-// of a lane-per-restart launch whose last restarts are handed over.
+// The restarts come from the launch's work queue.
 //
 // Bit-exactness (the contract of DESIGN.md section 2): every sum the reference / oracle forms
 // sequentially is formed here in the SAME ORDER from the same products -- either inside one lane
@@ -637,12 +636,6 @@ constexpr int quad_wave_lds() { return nnls_quad_wave_lds<N>(); }
 // eight registers for the whole life of the kernel)
 constexpr int quad_lane_lds() { return 4 * 64; }
 
-// Where the restarts come from: the work queue of a launch (NoTail: seeds drawn in the kernel), or a pool
-// of restarts spilled mid-flight by another kernel (a Tail: see ik_spill.hpp).
-struct NoTail {
-    static constexpr bool on = false;
-};
-
 // Early exit inside a trip (ik_nnls_quad.hpp: Stop): the restart's first-success word is looked at once per
 // direction pass and once per loop trip of the NNLS as well -- a trip with a direction reset or a long active-set
 // search takes several times an evaluation, and a launch with early exit ends when its slowest abandoned restart
@@ -671,12 +664,11 @@ struct QuadStop {
     }
 };
 
-template <int N, bool TIP, class Tail = NoTail>
+template <int N, bool TIP>
 OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const SolveParams &sp_in, const uint32_t (&key)[8],
                          const double (&scale)[MAX_DOF], const WorkQueue &wq_in,
                          double *nnls_lds /* quad_wave_lds<N>() doubles, the last 16 zero */,
-                         double *lane_lds /* quad_lane_lds() doubles: x_best, x_prev of every lane */,
-                         const Tail *tail_in = nullptr) {
+                         double *lane_lds /* quad_lane_lds() doubles: x_best, x_prev of every lane */) {
     constexpr int NS = QuadDims<N>::NS, NM = QuadDims<N>::NM;
     constexpr int CPL = 4;
     const bool member = (int)((threadIdx.x & 63u) / QUAD) < wq_in.lanes;  // wq.lanes = restarts (quads) a wave holds at a time
@@ -711,39 +703,11 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
     OPTIK_PROF_DECL;  // (-DOPTIK_PROFILE: slots 0 refill, 1 eval, 4 bookkeeping + BFGS, 5 direction, 6 NNLS of it, 3 publish, 7 trips)
 
     QuadStop st{&wq_in, ia, ib, false, false, ~0ull};
-    unsigned long long ticket = ~0ull;  // (Tail) the quad's place in the spill list while it waits for that entry
     for (;;) {
         OPTIK_PROF_BEGIN();
         int32_t ret = 0;
-        bool pending = false;  // (Tail) the restart resumes at a deferred direction search, not at an evaluation
         // ---- refill: quads without a restart pull the next work item (the leader fetches) ----------
-        if constexpr (Tail::on) {
-            // (a free quad draws a ticket -- its place in the spill list -- and keeps it until that entry has been written,
-            // or until no wave can write one any more: the list fills while this wave is already consuming it)
-            if (wave_any(want)) {
-                const Tail &tl = *reload_barrier_lds(tail_in);
-                const int qr = quad_lane_now();
-                const bool draw = want && ticket == ~0ull;
-                unsigned long long e = fetch_items(tl.cursor, draw && qr == 0);
-                e = quad_get_u64(e, 0);
-                ticket = draw ? e : ticket;
-                // (the quad's leader looks: four lanes reading at different moments could disagree)
-                unsigned slot_in = 0;
-                int got = 0;  // 1: the entry is there, 0: not yet, -1: it never will be
-                if (want && qr == 0) got = tl.poll(ticket, slot_in);
-                got = quad_get(got, 0);
-                slot_in = (unsigned)quad_get((int)slot_in, 0);
-                if (want && got != 0) {
-                    want = false;
-                    ticket = ~0ull;
-                    if (got > 0) {
-                        active = tl.template import<N>(slot_in, qr, x, x0, g, sv, Lr, dg, pa, pb, ia, ib, first, pending, ret, xb, xp);
-                        want = !active;  // (an empty slot in the list: take the next entry)
-                    }
-                }
-                if (!wave_any(active)) tl.idle();  // (every quad of the wave is waiting: do not hammer the counters)
-            }
-        } else if (wave_any(want)) {
+        if (wave_any(want)) {
             // (the launch parameters live in LDS: every region of a trip re-reads what it needs through a
             // laundered pointer, so that none of them is carried -- and spilled -- across the other regions)
             const WorkQueue &wq = *reload_barrier_lds(&wq_in);
@@ -797,46 +761,29 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
         OPTIK_PROF_COUNT(7, 1);
 
         const unsigned tslot = (unsigned)quad_get(ia, 3);
-        const int job = Tail::on ? quad_get(ib, 3) : 0;
-        if constexpr (Tail::on) {
-            const unsigned rlo = (unsigned)quad_get(ib, 0), rhi = (unsigned)quad_get(ib, 1);
-            if (active && ret == 0) {
-                const Tail &tl = *reload_barrier_lds(tail_in);
-                const auto &J = tl.job(job);
-                const unsigned long long index = J.restart_begin + (((unsigned long long)rhi << 32) | rlo);
-                // lib.rs:308: abandon when timed out or another restart of the target succeeded
-                bool stop = false;
-                if (J.first_success) {
-                    const unsigned long long fs = __hip_atomic_load(J.first_success + tslot, __ATOMIC_RELAXED,
-                                                                    __HIP_MEMORY_SCOPE_AGENT);
-                    stop = J.find_any ? (fs != ~0ull) : (fs < index);
-                }
-                if (tl.deadline && (unsigned long long)wall_clock64() > tl.deadline) stop = true;
-                if (stop) ret = RES_FORCED_STOP;
+        {
+        const unsigned rlo = (unsigned)quad_get(ib, 0), rhi = (unsigned)quad_get(ib, 1);
+        if (active) {
+            const WorkQueue &wq = *reload_barrier_lds(&wq_in);
+            const unsigned long long index = wq.restart_begin + (((unsigned long long)rhi << 32) | rlo);
+            // lib.rs:308: abandon when timed out or another restart of the target succeeded
+            bool stop = false;
+            if (wq.first_success) {
+                const unsigned long long fs = __hip_atomic_load(wq.first_success + tslot, __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_AGENT);
+                stop = wq.find_any ? (fs != ~0ull) : (fs < index);
+                st.seen = fs;
             }
-        } else {
-            const unsigned rlo = (unsigned)quad_get(ib, 0), rhi = (unsigned)quad_get(ib, 1);
-            if (active) {
-                const WorkQueue &wq = *reload_barrier_lds(&wq_in);
-                const unsigned long long index = wq.restart_begin + (((unsigned long long)rhi << 32) | rlo);
-                // lib.rs:308: abandon when timed out or another restart of the target succeeded
-                bool stop = false;
-                if (wq.first_success) {
-                    const unsigned long long fs = __hip_atomic_load(wq.first_success + tslot, __ATOMIC_RELAXED,
-                                                                    __HIP_MEMORY_SCOPE_AGENT);
-                    stop = wq.find_any ? (fs != ~0ull) : (fs < index);
-                    st.seen = fs;
-                }
-                if (wq.deadline && (unsigned long long)wall_clock64() > wq.deadline) stop = true;
-                if (stop) ret = RES_FORCED_STOP;
-            }
-            st.enabled = (*reload_barrier_lds(&wq_in)).first_success != nullptr;
-            st.hit = false;
+            if (wq.deadline && (unsigned long long)wall_clock64() > wq.deadline) stop = true;
+            if (stop) ret = RES_FORCED_STOP;
+        }
+        st.enabled = (*reload_barrier_lds(&wq_in)).first_success != nullptr;
+        st.hit = false;
         }
         // (the four lanes may have read first_success / the clock at different moments: the leader decides)
         ret = quad_get(ret, 0);
         const bool stepping = active && ret == 0;
-        const bool do_eval = stepping && !pending;
+        const bool do_eval = stepping;
         double gn[NS];
         double fn = 0.0;
         OPTIK_SCHED_FENCE();
@@ -855,9 +802,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
             }
             OPTIK_SCHED_FENCE();
             // (the target pose is re-read for every evaluation: seven L1 / L2 hits instead of 14 registers)
-            const double *target7;
-            if constexpr (Tail::on) target7 = (*reload_barrier_lds(tail_in)).job(job).targets + (size_t)tslot * 7;
-            else target7 = (*reload_barrier_lds(&wq_in)).targets + (size_t)tslot * 7;
+            const double *target7 = (*reload_barrier_lds(&wq_in)).targets + (size_t)tslot * 7;
             const EvalParams &ep = *reload_barrier_lds(&ep_in);
 #ifndef OPTIK_QUAD_EXP_NO_EVAL
 #ifdef OPTIK_QUAD_EXP_DUP_EVAL
@@ -895,7 +840,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
 
         // ---- NLopt bookkeeping and Kraft's line search (labels 100 / 220), replicated scalars ------
         OPTIK_PROF_BEGIN();
-        bool need_dir = stepping && pending, reset = false, do_bfgs = false;  // (a deferred direction resumes at its LSQ call)
+        bool need_dir = false, reset = false, do_bfgs = false;
         const SolveParams &sp = *reload_barrier_lds(&sp_in);
         double u[NS];
 #pragma unroll
@@ -1008,10 +953,8 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
         while (wave_any(need_dir)) {
             OPTIK_PROF_COUNT(2, 1);  // (direction passes: more than one per trip when some quad has to reset and search again)
             const SolveParams &sp = *reload_barrier_lds(&sp_in);
-            if constexpr (!Tail::on) {
-                if (st.poll(need_dir)) { ret = RES_FORCED_STOP; need_dir = false; }
-                if (!wave_any(need_dir)) break;
-            }
+            if (st.poll(need_dir)) { ret = RES_FORCED_STOP; need_dir = false; }
+            if (!wave_any(need_dir)) break;
             bool pass = need_dir;
             const bool sx0 = stop_x_quad<N>(sp, x, x0);
             const int qd = quad_lane_now();
@@ -1128,11 +1071,8 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                 int iters;
                 double xv[CPL];
 #ifndef OPTIK_QUAD_EXP_NO_NNLS
-                if constexpr (Tail::on)
-                    nnls_quad<N>(need_nnls, ids, bk, nnls_lds + QUADS_PER_WAVE * NnlsQuadGeom<N>::STRIDE, xv, nmode, rnorm, iters);
-                else
-                    nnls_quad<N, NoPipe, QuadStop>(need_nnls, ids, bk, nnls_lds + QUADS_PER_WAVE * NnlsQuadGeom<N>::STRIDE, xv,
-                                                   nmode, rnorm, iters, nullptr, &st);
+                nnls_quad<N, NoPipe, QuadStop>(need_nnls, ids, bk, nnls_lds + QUADS_PER_WAVE * NnlsQuadGeom<N>::STRIDE, xv,
+                                               nmode, rnorm, iters, nullptr, &st);
 #else
                 for (int k = 0; k < CPL; ++k) xv[k] = bk[k]; iters = 0;
 #endif
@@ -1224,24 +1164,14 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
             const double minf = quad_get(pb, 0);
             const int nevals = quad_get(ia, 2);
             const unsigned long long rr = ((unsigned long long)(unsigned)quad_get(ib, 1) << 32) | (unsigned)quad_get(ib, 0);
-            // where the restart's results go: the launch's outputs, or (Tail) those of the restart's job
-            const double *o_x0;
-            double *o_x, *o_f, *o_key;
-            int32_t *o_status, *o_evals;
-            unsigned long long *o_fs;
-            unsigned long long o_restarts, o_begin, o_stride;
-            bool o_quality;
-            if constexpr (Tail::on) {
-                const auto &J = (*reload_barrier_lds(tail_in)).job(job);
-                o_x0 = J.x0; o_x = J.out_x; o_f = J.out_f; o_key = J.out_key; o_status = J.out_status; o_evals = J.out_evals;
-                o_fs = J.first_success; o_restarts = J.n_restarts; o_begin = J.restart_begin; o_stride = J.total_items;
-                o_quality = J.quality != 0;
-            } else {
-                const WorkQueue &wq = *reload_barrier_lds(&wq_in);
-                o_x0 = wq.x0; o_x = wq.out_x; o_f = wq.out_f; o_key = wq.out_key; o_status = wq.out_status; o_evals = wq.out_evals;
-                o_fs = wq.first_success; o_restarts = wq.n_restarts; o_begin = wq.restart_begin; o_stride = wq.total_items;
-                o_quality = wq.quality != 0;
-            }
+            // where the restart's results go: the launch's outputs
+            const WorkQueue &wq = *reload_barrier_lds(&wq_in);
+            const double *const o_x0 = wq.x0;
+            double *const o_x = wq.out_x, *const o_f = wq.out_f, *const o_key = wq.out_key;
+            int32_t *const o_status = wq.out_status, *const o_evals = wq.out_evals;
+            unsigned long long *const o_fs = wq.first_success;
+            const unsigned long long o_restarts = wq.n_restarts, o_begin = wq.restart_begin, o_stride = wq.total_items;
+            const bool o_quality = wq.quality != 0;
             const unsigned long long item = (unsigned long long)tslot * o_restarts + rr;  // output column
             const unsigned long long index = o_begin + rr;
             bool val[NS];
@@ -1268,7 +1198,6 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                 for (int i = 0; i < N; ++i) acc += quad_get(d2[i >> 2], i);
                 kq = __builtin_sqrt(acc);
             }
-            const unsigned slot_u = Tail::on ? (unsigned)quad_get(ib, 2) : 0u;
             if (ended) {
                 if (o_x) {
 #pragma unroll
@@ -1289,27 +1218,26 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                         }
                     }
                     if (o_key) o_key[item] = k;
-                    if constexpr (Tail::on) (*reload_barrier_lds(tail_in)).template release<N>(slot_u);
                 }
-                if constexpr (!Tail::on) {
-                    // a single call under the first-success rule: the answer goes to the host right away (WorkQueue::claim)
-                    const WorkQueue &wqc = *reload_barrier_lds(&wq_in);
-                    if (wqc.claim) {
-                        first_in = quad_get(first_in, 0);
-                        if (first_in) {
-                            double *cx = reinterpret_cast<double *>(wqc.claim) + 3;
+                {
+                // a single call under the first-success rule: the answer goes to the host right away (WorkQueue::claim)
+                const WorkQueue &wqc = *reload_barrier_lds(&wq_in);
+                if (wqc.claim) {
+                    first_in = quad_get(first_in, 0);
+                    if (first_in) {
+                        double *cx = reinterpret_cast<double *>(wqc.claim) + 3;
 #pragma unroll
-                            for (int s = 0; s < NS; ++s)
-                                if (val[s]) cx[jc[s]] = xb[s * 64];
-                            if (qf == 0) {
-                                wqc.claim[1] = index;
-                                reinterpret_cast<double *>(wqc.claim)[2] = minf;
-                            }
-                            __threadfence_system();
-                            if (qf == 0)
-                                __hip_atomic_store(wqc.claim, wqc.claim_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                        for (int s = 0; s < NS; ++s)
+                            if (val[s]) cx[jc[s]] = xb[s * 64];
+                        if (qf == 0) {
+                            wqc.claim[1] = index;
+                            reinterpret_cast<double *>(wqc.claim)[2] = minf;
                         }
+                        __threadfence_system();
+                        if (qf == 0)
+                            __hip_atomic_store(wqc.claim, wqc.claim_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                     }
+                }
                 }
                 active = false;
                 want = true;

@@ -75,7 +75,7 @@ __device__ void select_publish(const SelectLaunch &a, int t, double key, unsigne
                 (found && a.out_x) ? a.out_x[(size_t)i * a.ld + col] : __builtin_nan("");
     }
     if (a.reset_fs) a.reset_fs[t] = ~0ull;
-    if (a.reset_queue && t == 0) { a.reset_queue[0] = 0ull; a.reset_queue[1] = 0ull; a.reset_queue[2] = 0ull; a.reset_queue[3] = 0ull; }
+    if (a.reset_queue && t == 0) *a.reset_queue = 0ull;
 }
 
 // Stage 2: one 64-lane block per target reduces the tile records and gathers the winner.

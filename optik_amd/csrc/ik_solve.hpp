@@ -183,25 +183,6 @@ struct WorkQueue {
     unsigned long long claim_seq;
 };
 
-// Where the waves of the lane-per-restart kernel leave the restarts still running when the launch's queue is dry,
-// for the quad solver -- the same waves, in their second form -- to finish (ik_spill.hpp).  Plain data: planes of
-// doubles / ints over C slots (slot = a lane's global number), the list of slots that hold a restart and the
-// launch's counters.  d == nullptr: the launch does not spill.
-constexpr int SPILL_ND_MAX = 6 * 7 + 7 * 8 / 2 + 5;  // doubles per slot of a 7-joint chain (ik_spill.hpp: SpillLayout<7>::ND)
-constexpr int SPILL_NI = 4;                          // ints per slot
-struct SpillPool {
-    double *d;                   // [SpillLayout::ND][C]
-    int32_t *i32;                // [SpillLayout::NI][C]
-    unsigned long long *item;    // [C] output column of the slot's restart (target * n_restarts + restart)
-    unsigned long long C;
-    unsigned int *list;          // [C] entry -> slot; SPILL_NONE while unwritten (and again once consumed)
-    unsigned long long *count;   // entries reserved (zero before the launch)
-    unsigned long long *cursor;  // tickets handed out (zero before the launch)
-    unsigned long long *done;    // waves that have left the lane form (zero before the launch)
-    int spill_at;                // a wave changes form when at most this many of its lanes still hold a restart
-    int pad;
-};
-
 // Wave-aggregated fetch of one work item per requesting lane: one atomic per wave.
 OPTIK_DEV unsigned long long fetch_items(unsigned long long *counter, bool want) {
     const unsigned long long mask = __ballot(want);

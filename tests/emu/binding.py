@@ -27,7 +27,7 @@ def _clang():
 def build(force=False):
     deps = [SRC, os.path.join(HERE, "lane_emu.hpp")] + [
         os.path.join(CSRC, h) for h in ("ik_quad.hpp", "ik_lane64.hpp", "ik_lane.hpp", "ik_platform.hpp", "ik_math.hpp", "ik_eval.hpp", "ik_slsqp.hpp",
-                                        "ik_solve.hpp", "ik_nnls_quad.hpp", "ik_nnls_first.hpp", "ik_host_params.hpp", "ik_spill.hpp")]
+                                        "ik_solve.hpp", "ik_nnls_quad.hpp", "ik_nnls_first.hpp", "ik_host_params.hpp")]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
         return LIB
     subprocess.check_call([_clang(), "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
@@ -46,7 +46,7 @@ def lib():
         dp = C.POINTER(C.c_double)
         ip = C.POINTER(C.c_int32)
         L.quad_emu_solve.argtypes = [dp, dp, C.c_int, C.c_int, dp, dp, C.POINTER(nat.SolverConfigC), dp, dp, dp,
-                                     C.c_uint64, C.c_uint64, C.c_int, C.c_int, dp, dp, dp, ip, ip, C.c_int, C.c_int, ip]
+                                     C.c_uint64, C.c_uint64, C.c_int, C.c_int, dp, dp, dp, ip, ip, C.c_int]
         _lib = L
     return _lib
 
@@ -55,10 +55,8 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def solve(chain, cfg, target7, x0, begin, end, quads=1, range_rule=0, ee_offset7=None, lane64=False, spill_at=0):
-    """chain: dict(types, origins[J,7], axes[J,3], lb, ub).  Returns dict(x[R,n], f, key, status, evals, spilled).
-    spill_at > 0 (lane64): the wave's last restarts -- at most that many, once the queue is dry -- leave it for the
-    quad solver (ik_spill.hpp); `spilled` = how many did."""
+def solve(chain, cfg, target7, x0, begin, end, quads=1, range_rule=0, ee_offset7=None, lane64=False):
+    """chain: dict(types, origins[J,7], axes[J,3], lb, ub).  Returns dict(x[R,n], f, key, status, evals)."""
     origins = np.ascontiguousarray(chain["origins"], dtype=np.float64)
     n = len(chain["lb"])
     axes = np.ascontiguousarray(np.asarray(chain["axes"], dtype=np.float64)[:n])
@@ -70,12 +68,10 @@ def solve(chain, cfg, target7, x0, begin, end, quads=1, range_rule=0, ee_offset7
     out_x = np.zeros((n, R))
     out_f, out_key = np.zeros(R), np.zeros(R)
     status, evals = np.zeros(R, dtype=np.int32), np.zeros(R, dtype=np.int32)
-    spilled = C.c_int32(0)
     rc = lib().quad_emu_solve(_dp(origins), _dp(axes), n, origins.shape[0], _dp(lb), _dp(ub), C.byref(cfg), _dp(tg),
                               _dp(x0), _dp(ee) if ee is not None else None, begin, end, quads, range_rule,
                               _dp(out_x), _dp(out_f), _dp(out_key), status.ctypes.data_as(C.POINTER(C.c_int32)),
-                              evals.ctypes.data_as(C.POINTER(C.c_int32)), 1 if lane64 else 0, int(spill_at),
-                              C.byref(spilled))
+                              evals.ctypes.data_as(C.POINTER(C.c_int32)), 1 if lane64 else 0)
     if rc:
         raise RuntimeError(f"quad_emu_solve rc={rc}")
-    return dict(x=out_x.T.copy(), f=out_f, key=out_key, status=status, evals=evals, spilled=spilled.value)
+    return dict(x=out_x.T.copy(), f=out_f, key=out_key, status=status, evals=evals)

@@ -187,5 +187,3 @@ inline unsigned long long atomicMin(unsigned long long *p, unsigned long long v)
 #define __hip_atomic_load(ptr, order, scope) __atomic_load_n((ptr), (order))
 #define __hip_atomic_store(ptr, val, order, scope) __atomic_store_n((ptr), (val), (order))
 inline void __threadfence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
-inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
-inline void __builtin_amdgcn_s_sleep(int) { std::this_thread::yield(); }

@@ -6,7 +6,6 @@
 //
 // Not part of the product: nothing under optik_amd/ or bench.py builds, loads or calls this.
 #define OPTIK_LANE_EMU 1
-#define OPTIK_SPILL_TAIL 1
 #include <thread>
 #include <vector>
 
@@ -36,41 +35,22 @@ void run_wave(const ChainDev &ch, const EvalParams &ep, const SolveParams &sp, c
 }
 
 // the lane-per-restart form (ik_lane64.hpp): `lanes` emulated lanes (a multiple of 4), each with its own restart
-// spill_at > 0: once the queue is dry the wave writes its last restarts -- at most spill_at of them -- to the spill pool and
-// finishes them in its second form, the quad solver (ik_spill.hpp).  *n_spilled = how many went that way.
 template <int N, bool TIP>
 void run_wave_lane64(const ChainDev &ch, const EvalParams &ep, const SolveParams &sp, const uint32_t (&key)[8],
-                     const double (&scale)[MAX_DOF], const WorkQueue &wq, int lanes, int spill_at, int *n_spilled) {
+                     const double (&scale)[MAX_DOF], const WorkQueue &wq, int lanes) {
     optik_emu::Wave wave;
     wave.lanes = lanes;
     std::vector<double> lds((size_t)lane64_block_lds<N>(), 0.0), rec((size_t)lane64_rec_lds<N>(), 0.0);
     std::vector<int> lor(64, 0), where(64, 0);
-    // the spill pool: one slot per lane of the (one) emulated workgroup
-    std::vector<double> pd((size_t)SPILL_ND_MAX * 64, 0.0);
-    std::vector<int32_t> pi((size_t)SPILL_NI * 64, 0);
-    std::vector<unsigned long long> pitem(64, 0);
-    std::vector<unsigned int> plist(64, SPILL_NONE);
-    unsigned long long count = 0, cursor = 0, done = 0;
-    SpillPool pool{pd.data(), pi.data(), pitem.data(), 64, plist.data(), &count, &cursor, &done, spill_at, 0};
-    // (the device kernel's wrapper, ik_lane_kernel.hip: after the lane form the wave runs the quad solver on the list)
-    std::vector<double> lane_lds((size_t)quad_lane_lds(), 0.0);
-    SpillTail tail{pool, &wq, &cursor, 0ull, 1u};
     std::vector<std::thread> th;
     for (int lane = 0; lane < wave.lanes; ++lane) {
         th.emplace_back([&, lane]() {
             optik_emu::t_wave = &wave;
             threadIdx.x = (unsigned)lane;
-            blockIdx.x = 0;
-            lane64_wave<N, TIP>(ch, ep, sp, key, scale, wq, lds.data(), rec.data(), lor.data(), where.data(),
-                                spill_at > 0 ? &pool : nullptr);
-            if (spill_at <= 0) return;
-            __threadfence();
-            if (lane == 0) atomicAdd(&done, 1ull);
-            quad_wave<N, TIP, SpillTail>(ch, ep, sp, key, scale, wq, lds.data(), lane_lds.data(), &tail);
+            lane64_wave<N, TIP>(ch, ep, sp, key, scale, wq, lds.data(), rec.data(), lor.data(), where.data());
         });
     }
     for (auto &t : th) t.join();
-    if (n_spilled) *n_spilled = (int)count;
 }
 
 }  // namespace
@@ -105,9 +85,7 @@ int quad_emu_lane_moves(int *out) {
 int quad_emu_solve(const double *origins, const double *axes, int n, int n_joints, const double *lb, const double *ub,
                    const optik_solver_config *cfg, const double *target7, const double *x0, const double *ee_offset7,
                    uint64_t restart_begin, uint64_t restart_end, int quads, int range_rule, double *out_x, double *out_f,
-                   double *out_key, int32_t *out_status, int32_t *out_evals, int lane64 /* 1: ik_lane64.hpp, 4 * quads lanes */,
-                   int spill_at /* lane64: > 0 = the wave's last restarts go through ik_spill.hpp */, int *n_spilled) {
-    if (n_spilled) *n_spilled = 0;
+                   double *out_key, int32_t *out_status, int32_t *out_evals, int lane64 /* 1: ik_lane64.hpp, 4 * quads lanes */) {
     if (n < 1 || n > 8 || quads < 1 || quads > 16 || restart_end <= restart_begin) return -1;
     if (lane64 && n > 7) return -1;
     ChainDev ch;
@@ -157,8 +135,8 @@ int quad_emu_solve(const double *origins, const double *axes, int n, int n_joint
         break;
 #define RUN64(NN)                                                                            \
     case NN:                                                                                 \
-        if (ch.has_tip) run_wave_lane64<NN, true>(ch, ep, sp, key, scale, wq, 4 * quads, spill_at, n_spilled);    \
-        else run_wave_lane64<NN, false>(ch, ep, sp, key, scale, wq, 4 * quads, spill_at, n_spilled);              \
+        if (ch.has_tip) run_wave_lane64<NN, true>(ch, ep, sp, key, scale, wq, 4 * quads);    \
+        else run_wave_lane64<NN, false>(ch, ep, sp, key, scale, wq, 4 * quads);              \
         break;
     if (lane64) {
         switch (n) {

@@ -81,24 +81,6 @@ def test_lane_per_restart_form_bit_equal_to_the_oracle(emu, oracle, chains, robo
     _assert_same(got, ref, n)
 
 
-@pytest.mark.parametrize("robot,R,quads,spill_at", [("panda", 40, 4, 16), ("panda", 24, 4, 8), ("ur10", 36, 3, 12),
-                                                    ("panda_hand", 20, 2, 8), ("panda3", 24, 2, 4), ("panda", 16, 4, 16)])
-def test_spilled_restarts_finish_on_the_quad_solver_with_the_same_bits(emu, oracle, chains, robot, R, quads, spill_at):
-    """ik_spill.hpp: once the queue is dry and at most spill_at lanes of the lane-per-restart wave still hold a restart,
-    those restarts -- mid line search, or (R <= lanes: the queue is dry at once) not even evaluated -- are written to
-    the spill pool and the quad solver carries on from there: every restart still equals the oracle bit for bit."""
-    from optik_amd import _native as nat
-    d, ch, tgt, x0 = _case(oracle, chains, robot, 21)
-    n = len(d["lb"])
-    got = emu.solve(d, nat.make_config(solution_mode="quality"), tgt, x0, 0, R, quads=quads, lane64=True, spill_at=spill_at)
-    ref = oracle.ik(ch, oracle.make_config(solution_mode="quality"), tgt, x0, 0, R, n_threads=4, early_exit=False,
-                    per_restart=True)
-    assert 0 < got["spilled"] <= spill_at, got["spilled"]
-    _assert_same(got, ref, n)
-    ok = ref["success"] != 0
-    assert np.array_equal(np.isinf(got["key"]), ~ok)
-
-
 def test_quality_key_weights_and_tight_tolerance(emu, oracle, chains):
     """SolutionMode::Quality's key ||x - x0|| (an ordered sum over the quad), the reference test's
     non-trivial weights (tests/test_gradient.rs:37-38) and tol_f = 1e-12 (tests/test_ik.rs:99)."""
