@@ -82,7 +82,7 @@ ROBOT_SPECS = {"panda": ("panda.urdf", "panda_link0", "panda_link8"),
 
 
 def command_key(args, world):
-    """Identifies the workload a PMC pass was taken on (tools/profile_round.sh writes the same key)."""
+    """Identifies the workload a PMC pass was taken on (tools/profile_kernel_path.sh / pmc_kernel_path.py write the same key)."""
     return (f"robot={args.robot},restarts={args.restarts},steps={args.steps},warmup={args.warmup},"
             f"mode={args.mode},scaling={args.scaling},targets={args.targets},path=kernel,gpus={world}")
 
@@ -190,6 +190,19 @@ def device_uuid(index):
         return str(torch.cuda.get_device_properties(index).uuid)
     except Exception:  # noqa: BLE001 (older torch: no uuid attribute)
         return None
+
+
+def check_distinct_devices(rank_devices, one_device):
+    """Every rank of a multi-GPU line must sit on its own physical GPU: by UUID where torch reports one, else by device
+    index.  OPTIK_BENCH_ONE_DEVICE=1 (tests on a one-GPU box) lifts the check."""
+    world = len(rank_devices)
+    if one_device or world < 2:
+        return
+    uuids = [d.get("uuid") for d in rank_devices]
+    ids = uuids if all(u is not None for u in uuids) else [d["device"] for d in rank_devices]
+    if len(set(ids)) != world:
+        raise SystemExit(f"ranks share a physical GPU ({ids}): refusing to report {world} GPUs "
+                         "(OPTIK_BENCH_ONE_DEVICE=1 allows it for tests)")
 
 
 def inprocess_main(args):
@@ -673,12 +686,7 @@ def main():
         rank_devices = [None] * world
         dist.all_gather_object(rank_devices, me)
         backend_name = str(dist.get_backend())
-        uuids = [d["uuid"] for d in rank_devices]
-        if not one_device and world > 1:
-            ids = uuids if all(u is not None for u in uuids) else [d["device"] for d in rank_devices]
-            if len(set(ids)) != world:
-                raise SystemExit(f"ranks share a physical GPU ({ids}): refusing to report {world} GPUs "
-                                 "(OPTIK_BENCH_ONE_DEVICE=1 allows it for tests)")
+        check_distinct_devices(rank_devices, one_device)
     else:
         rank_devices = [me]
         backend_name = None

@@ -29,7 +29,7 @@ UNITS = [("ik_capi.hip", "ik_capi.o", []),          # chains, options, the resta
          # with: together with -disable-machine-licm it crashes this compiler on the quad kernel; without, it compiles
          # and is 3 % slower on both quad objects)
          # (the latency forms without the machine-LICM pass as well since round 4: 206 -> 201 us per single ik() call,
-         # 673 -> 662 us deterministic, tools/single_call_variants.sh; in round 3 the default pipeline was the faster one there)
+         # 673 -> 662 us deterministic, round 4: profiles/r4g_single_call.txt; in round 3 the default pipeline was the faster one there)
          ("ik_quad_kernel.hip", "ik_quad_latency.o",
           ["-DOPTIK_QUAD_PART=1", "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
          ("ik_quad_kernel.hip", "ik_quad_throughput.o",

@@ -89,6 +89,15 @@ constexpr int LANE64_CLASSES = OPTIK_LANE_CLASSES;  // predicted pass classes 1 
 #define LANE64_MAX_RUNNING 14     // hand-over as soon as this few of the sixteen quads are still solving (and problems wait).  Since the first pass
                                   // runs per lane a call seldom has more problems than quads: 6: -1 %, 10: -0.4 %, 13 .. 15: the same
 #endif
+// (refill, tools/ab_kernel_path.sh, M restarts/s at the driver's command, three interleaved runs each: neither 32.38,
+// reserve 8 alone 32.52, kept target alone 32.41, both 32.79, reserve 16 + kept target 32.79 -- profiles/r5i_ab_refill.txt;
+// 64 items per atomic handed out over many refills: 31.8, the waves that still hold items when the queue is dry end late)
+#ifndef OPTIK_LANE_RESERVE
+#define OPTIK_LANE_RESERVE 8      // work items a wave draws AHEAD of the refill that hands them out (0: every refill waits for its own atomic)
+#endif
+#ifndef OPTIK_LANE_KEEP_TARGET
+#define OPTIK_LANE_KEEP_TARGET 1  // 1: a lane whose next restart has the target of its last one keeps the pose it holds
+#endif
 #ifndef OPTIK_LANE_REFILL
 #define OPTIK_LANE_REFILL 4       // idle lanes a wave accumulates before it refills (the seed generation runs for the whole wave)
 #endif
@@ -170,8 +179,14 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
     bool again = false;    // the last direction was not a descent direction: reset B and search again, no evaluation
     Pose target;
     unsigned long long item = 0, index = 0;
-    unsigned tslot = 0;
+    unsigned tslot = OPTIK_LANE_KEEP_TARGET ? ~0u : 0u;  // (~0: the lane holds no target pose yet)
     bool active = false, want = lane < wq.lanes;
+#if OPTIK_LANE_RESERVE > 0
+    unsigned long long rbase = 0, rend = 0;  // (wave-uniform) the items the wave has drawn and not handed out yet
+    unsigned long long pend = 0;             // (lane 0) the base of the reserve that is on its way
+    bool r_pending = false;
+    bool dry = false;                        // (wave-uniform) an item past the launch's last one has been handed out
+#endif
 #pragma unroll
     for (int i = 0; i < N; ++i) { x[i] = 0.0; x0[i] = 0.0; g[i] = 0.0; s[i] = 0.0; xbest[i] = 0.0; xprev[i] = 0.0; }
 #pragma unroll
@@ -193,18 +208,49 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
         // (the seed generation runs for the whole wave: wait until several lanes are idle -- or none is busy)
         const unsigned n_want = (unsigned)__popcll(__ballot(want));
         if (n_want >= (unsigned)(wq.lanes < OPTIK_LANE_REFILL ? wq.lanes : OPTIK_LANE_REFILL) || (n_want > 0 && !wave_any(active))) {
-            // (asking for the items one refill ahead, so that no refill waits for its own atomic add on the launch's one
-            // counter, measured nothing: 32.35 against 32.29 M restarts/s)
+#if OPTIK_LANE_RESERVE > 0
+            // The wave keeps a RESERVE of work items: the atomic on the launch's one counter (a device-scope round trip of
+            // microseconds, with nothing to cover it at one wave per SIMD) was issued a trip or more ago, right after the
+            // previous refill; only a refill that wants more than the reserve holds waits for a second, synchronous one.
+            unsigned long long it;
+            {
+                if (r_pending) { rbase = __shfl(pend, 0); rend = rbase + OPTIK_LANE_RESERVE; r_pending = false; }
+                const unsigned long long wm = __ballot(want);
+                const unsigned rank = (unsigned)__popcll(wm & ((1ull << lane) - 1ull));
+                const unsigned long long have = rend - rbase;
+                const unsigned long long take = n_want < have ? n_want : have;
+                it = rbase + rank;
+                rbase += take;
+                if (wave_any(want && rank >= take)) {
+                    const unsigned long long it2 = fetch_items(wq.next_item, want && rank >= take);
+                    if (rank >= take) it = it2;
+                }
+                dry = dry || wave_any(want && it >= wq.total_items);
+            }
+#else
             const unsigned long long it = fetch_items(wq.next_item, want);
+#endif
+#ifdef OPTIK_PROF_REFILL_SPLIT  // (diagnostic: the wait for the work counter under slot 0, the rest of the refill under slot 5)
+            { const unsigned long long it_ = it; asm volatile("" :: "v"(it_)); }
+            LANE_PROF(0);
+#endif
             if (want) {
                 want = false;
                 if (it < wq.total_items) {
                     unsigned long long r;
+#if OPTIK_LANE_KEEP_TARGET
+                    const unsigned tprev = tslot;
+#endif
                     if (wq.restart_major) { r = it / wq.n_targets; tslot = (unsigned)(it - r * wq.n_targets); }
                     else { tslot = (unsigned)(it / wq.n_restarts); r = it - (unsigned long long)tslot * wq.n_restarts; }
                     item = (unsigned long long)tslot * wq.n_restarts + r;  // output column
                     index = wq.restart_begin + r;
+#if OPTIK_LANE_KEEP_TARGET
+                    // (a target-major launch: nearly every lane's next restart has the target of its last one)
+                    if (tslot != tprev) target = load_pose(wq.targets + (size_t)tslot * 7);
+#else
                     target = load_pose(wq.targets + (size_t)tslot * 7);
+#endif
                     // lib.rs:366-370: restart 0 starts from the caller's seed
                     restart_seed<N>(key, ch.lb, scale, index, x);
                     if (index == 0) {
@@ -223,8 +269,19 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
                 }
             }
         }
+#if OPTIK_LANE_RESERVE > 0
+        // (the next refill's items are asked for NOW -- a trip or more before they are handed out)
+        if (!r_pending && rbase == rend && !dry) {
+            if (lane == 0) pend = atomicAdd(wq.next_item, (unsigned long long)OPTIK_LANE_RESERVE);
+            r_pending = true;
+        }
+#endif
         if (!wave_any(active)) break;
+#ifdef OPTIK_PROF_REFILL_SPLIT
+        LANE_PROF(5);
+#else
         LANE_PROF(0);
+#endif
 
         int32_t ret = 0;
         if (active) {

@@ -66,4 +66,13 @@ extern "C" int optik_hip_lane_nnls_hist(unsigned long long *out66) {
     unsigned long long z[66] = {0};
     return hipMemcpyToSymbol(HIP_SYMBOL(optik::g_quad_nnls_hist), z, sizeof z) == hipSuccess ? 0 : -1;
 }
+// ... and the cycles of those loop trips by quads solving (18 words: ik_nnls_quad.hpp g_quad_nnls_tripcyc) + the 8 part counters
+extern "C" int optik_hip_lane_nnls_cycles(unsigned long long *out26) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out26, HIP_SYMBOL(optik::g_quad_nnls_tripcyc), 18 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out26 + 18, HIP_SYMBOL(optik::g_quad_nnls_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long z[18] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(optik::g_quad_nnls_prof), z, 8 * sizeof(unsigned long long));
+    return hipMemcpyToSymbol(HIP_SYMBOL(optik::g_quad_nnls_tripcyc), z, sizeof z) == hipSuccess ? 0 : -1;
+}
 #endif

@@ -54,6 +54,8 @@ constexpr int nnls_quad_wave_lds() { return 16 * NnlsQuadGeom<N>::STRIDE + 16; }
 __device__ unsigned long long g_quad_nnls_prof[8];
 // [0, 17): loop trips by the number of quads still solving; [17, 49): calls by loop trips; [49, 66): calls by quads taking part
 __device__ unsigned long long g_quad_nnls_hist[66];
+// wave cycles of the loop trips by the number of quads solving at the trip's start (0..16), then of the hand-overs [17]
+__device__ unsigned long long g_quad_nnls_tripcyc[18];
 #define QNNLS_PROBE(slot) do { const unsigned long long now_ = __builtin_readcyclecounter(); np_[slot] += now_ - nt_; nt_ = now_; } while (0)
 #define QNNLS_COUNT(slot, n) np_[slot] += (n)
 #else
@@ -253,10 +255,9 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
         QNNLS_COUNT(4, 1);
 #ifdef OPTIK_DEVICE_PROFILE
         ++trips_;
-        {
-            const int n_run_ = __popcll(__ballot(phase < 4)) / 4;
-            if ((threadIdx.x & 63u) == 0) atomicAdd(&g_quad_nnls_hist[n_run_], 1ull);
-        }
+        const int n_run_ = __popcll(__ballot(phase < 4)) / 4;
+        if ((threadIdx.x & 63u) == 0) atomicAdd(&g_quad_nnls_hist[n_run_], 1ull);
+        const unsigned long long trip_t0_ = __builtin_readcyclecounter();
 #endif
         QNNLS_PROBE(7);
         // ---------------- steps two .. five --------------------------------------------
@@ -604,6 +605,9 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
             lds_sync();
             QNNLS_PROBE(3);
         }
+#ifdef OPTIK_DEVICE_PROFILE
+        if ((threadIdx.x & 63u) == 0) atomicAdd(&g_quad_nnls_tripcyc[n_run_], __builtin_readcyclecounter() - trip_t0_);
+#endif
     }
 #ifdef OPTIK_DEVICE_PROFILE
     if ((threadIdx.x & 63u) == 0) {

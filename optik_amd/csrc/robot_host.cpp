@@ -545,7 +545,7 @@ int optik_robot_ik_pose(const optik_robot *r, const CSolverConfig *config, const
     // the call returns on the first success the launch's tail no longer counts: 201 -> 194 us per call, 221 -> 216 us
     // back to back); 128 under the deterministic rule (parallelism 1: the answer is the lowest successful index,
     // nearly always below ten, and only the restarts below it decide when the launch ends: 685 -> 660 us per call,
-    // tools/single_call_variants.sh)
+    // profiles/r4g_single_call.txt)
 #ifndef OPTIK_FIRST_PER_CU
 #define OPTIK_FIRST_PER_CU 4  // (tools/build_lib_variant.py fpcN -DOPTIK_FIRST_PER_CU=N --only=robot_host.o: the comparison above)
 #endif

@@ -34,7 +34,7 @@ def build(force=False):
                            "-I", HERE, "-I", CSRC, "-Wno-unused-value", "-Wno-psabi",
                            # (the emulated waves are a few lanes wide: the per-lane first NNLS pass of ik_nnls_first.hpp, which the
                            # device only runs on trips with more than 24 problems, runs on every trip here)
-                           "-DOPTIK_LANE_FIRST_PASS_MIN=0", SRC, "-o", LIB])
+                           "-DOPTIK_LANE_FIRST_PASS_MIN=0", *os.environ.get("OPTIK_EMU_EXTRA_FLAGS", "").split(), SRC, "-o", LIB])
     return LIB
 
 

@@ -53,3 +53,18 @@ def test_pmc_record_of_the_default_command_has_the_shape_bench_reads():
     kp = recs[key]["kernel_path"]
     for f in ("hbm_bytes_per_restart", "f64_flops_per_restart", "launches", "valu_busy", "valu_active_lane_frac"):
         assert f in kp, f
+
+
+def test_ranks_sharing_a_gpu_are_refused():
+    """A line that says N GPUs needs N physical GPUs: distinct UUIDs (device indices where torch reports none)."""
+    import pytest
+    import bench
+    ok = [{"rank": r, "device": r, "uuid": f"GPU-{r:04x}"} for r in range(8)]
+    bench.check_distinct_devices(ok, False)
+    bench.check_distinct_devices([{"rank": 0, "device": 0, "uuid": None}, {"rank": 1, "device": 1, "uuid": None}], False)
+    shared = [dict(ok[0]), dict(ok[1], uuid=ok[0]["uuid"])]
+    with pytest.raises(SystemExit, match="share a physical GPU"):
+        bench.check_distinct_devices(shared, False)
+    with pytest.raises(SystemExit, match="share a physical GPU"):
+        bench.check_distinct_devices([{"rank": 0, "device": 0, "uuid": None}, {"rank": 1, "device": 0, "uuid": None}], False)
+    bench.check_distinct_devices(shared, True)  # OPTIK_BENCH_ONE_DEVICE=1: the one-GPU test box

@@ -108,6 +108,28 @@ def test_plain_gpus_flag_spawns_the_ranks_itself():
     assert len({d["pid"] for d in b["config"]["rank_devices"]}) == 2
     assert b["config"]["winner_index_per_step"] == a["config"]["winner_index_per_step"]
     assert len(b["config"]["value_reps"]) == 2 and b["config"]["value_min"] <= b["value"] <= b["config"]["value_max"]
+    # first-contact evidence of a multi-rank run: every rank's device identity, the latency of each collective
+    assert all("uuid" in d and "name" in d for d in b["config"]["rank_devices"])
+    cu = b["config"]["collective_us"]
+    assert set(cu) == {"all_reduce_min_int64_8B", "all_reduce_sum_f64_64B", "barrier"} and all(v > 0 for v in cu.values())
+    assert a["config"]["collective_us"] is None
+
+
+@pytest.mark.gpu
+def test_headline_command_on_two_ranks_also_times_configs_4_and_5():
+    """The driver's scaling sweep runs ONE command per N: with N > 1 the headline line carries config 4 (Quality, strong)
+    and config 5 (targets cut per rank) as well -- here two ranks sharing the box's GPU over gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(OPTIK_BENCH_BACKEND="gloo", OPTIK_BENCH_ONE_DEVICE="1")
+    two = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--reps", "2",
+                          "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-3000:]
+    b = _line(two.stdout)
+    oc = b["config"]["other_configs"]
+    assert b["n_gpus"] == 2 and set(oc) == {"config4_strong_quality", "config5_targets"}
+    assert oc["config4_strong_quality"]["restarts_per_gpu"] == (1 << 22) // 2 and oc["config4_strong_quality"]["restarts_per_s"] > 0
+    assert all(w >= 0 for w in oc["config4_strong_quality"]["winner_index_per_step"])
+    assert oc["config5_targets"]["targets_per_gpu"] == 2048 and oc["config5_targets"]["ik_calls_per_s"] > 0
 
 
 @pytest.mark.gpu

@@ -29,6 +29,8 @@ cfg = nat.make_config(solution_mode="speed", tol_f=1e-6)
 bufs = hc.alloc_ik_buffers(K, R)
 h = (C.c_ulonglong * 66)()
 nat.lib().optik_hip_lane_nnls_hist(h)  # (reset)
+cyc = (C.c_ulonglong * 26)()
+nat.lib().optik_hip_lane_nnls_cycles(cyc)  # (reset)
 hc.ik_batch(cfg, targets, x0, 0, R, bufs=bufs, per_restart=True)
 torch.cuda.synchronize()
 assert hc.last_launch()["lds_bytes"] > 30000
@@ -42,3 +44,11 @@ print(f"mean quads solving per loop trip {16 * util:.2f} of 16 = {100 * util:.1f
 calls = max(sum(h[17:49]), 1)
 print(f"calls {calls}, loop trips per call {tot / calls:.2f}")
 print("calls by loop trips (0..31+), %: " + " ".join(f"{100.0 * c / calls:.1f}" for c in h[17:49]))
+nat.lib().optik_hip_lane_nnls_cycles(cyc)
+cyc = list(cyc)
+tc = cyc[:17]
+print("wave cycles per loop trip by quads solving (1..16): " + " ".join(f"{(tc[k] / trips[k]) if trips[k] else 0:.0f}" for k in range(1, 17)))
+ct = max(sum(tc), 1)
+print("share of the loop's cycles by quads solving (1..16), %: " + " ".join(f"{100.0 * tc[k] / ct:.1f}" for k in range(1, 17)))
+print(f"loop cycles per call {ct / calls:.0f}; parts (cycles per call): steps 2-4 {cyc[18] / calls:.0f}, step 5 {cyc[19] / calls:.0f}, "
+      f"steps 6-10 {cyc[20] / calls:.0f}, step 11 {cyc[21] / calls:.0f}, hand-over / loop head {cyc[25] / calls:.0f}")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Wave cycles per part of a trip of the lane-per-restart form (ik_lane64.hpp: LANE_PROF) on the bench workload; needs a
--DOPTIK_PROFILE build of ik_kernels.o and ik_lane_kernel.o:
-  python tools/build_lib_variant.py prof2 -DOPTIK_PROFILE --only=ik_kernels.o,ik_lane_kernel.o
+-DOPTIK_PROFILE build of ik_capi.o and ik_lane_kernel.o:
+  python tools/build_lib_variant.py prof2 -DOPTIK_PROFILE --only=ik_capi.o,ik_lane_kernel.o
   OPTIK_PROF_LIB=optik_amd/csrc/variants/prof2.so python tools/lane_phase_profile.py"""
 import ctypes as C
 import os

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Folds the rocprofv3 passes of tools/profile_kernel_path.sh into one record for the solve kernel of
-`bench.py --path kernel`: over the launches of the TIMED repetitions (the last `reps` launches of the
+`bench.py`: over the launches of the TIMED repetitions (the last `reps` launches of the
 kernel; the warm-up launch has a different size), per launch and per restart:
 
   FETCH_SIZE / WRITE_SIZE (KB, separate passes) -> HBM bytes per restart = (2 FETCH + WRITE) x 1024 /
@@ -68,3 +68,13 @@ rec["kernel_ms_under_profiler"] = sum(dur.values()) / max(len(dur), 1)
 rec["bench_value_unprofiled"] = line["value"]
 json.dump(rec, open(f"{out}/pmc_kernel_path.json", "w"), indent=1)
 print(json.dumps(rec, indent=1))
+# ... and into the round's by-command file (what bench.py reads roofline.traffic and the VALU scalars from): copy
+# gpurun_out/r5_pmc_by_command.json to profiles/ to make it the record of that command
+by_cmd = "gpurun_out/r5_pmc_by_command.json"
+try:
+    doc = json.load(open(by_cmd))
+except (OSError, ValueError):
+    doc = {"note": "PMC records of bench.py commands (tools/profile_kernel_path.sh: FETCH_SIZE, WRITE_SIZE and two SQ passes, "
+                   "each its own rocprofv3 run with --kernel-trace only), keyed by bench.py's command key", "commands": {}}
+doc["commands"][rec["key"]] = {"kernel_path": rec}
+json.dump(doc, open(by_cmd, "w"), indent=1)

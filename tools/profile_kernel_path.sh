@@ -11,7 +11,9 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT/stats $OUT/fetch $OUT/write $OUT/sq $OUT/sq2
-CMD="python bench.py --path kernel --no-cpu-baseline $*"
+# (the repetition count is pinned: under the profiler a repetition takes longer, and pmc_kernel_path.py picks the timed
+# launches as the LAST `reps` launches of the kernel in every pass)
+CMD="python bench.py --path kernel --no-cpu-baseline --no-other-configs --reps 5 $*"
 $CMD > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o bench -- $CMD > $OUT/stats/bench_stdout.txt 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $OUT/fetch -o bench -- $CMD > $OUT/fetch/bench_stdout.txt 2>&1
