@@ -436,6 +436,8 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
                     if (found && ql == 0) lds_col_store<N>(blk + CS * (j - 1), nc);
                 }
                 // the transformation applied to the lane's columns still in Z (pivot row nsetp, rows below)
+                // (asking for the lane's next column before this one is stored -- the compiler cannot know that they are
+                // distinct blocks of LDS -- measured nothing: 32.69 against 32.74 M restarts/s, profiles/r5k_ab_pref.txt)
 #pragma unroll
                 for (int k = 0; k < CPL; ++k) {
                     dvecm cv = lds_col_load<N>(colp[k]);

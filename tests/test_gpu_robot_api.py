@@ -644,7 +644,7 @@ def test_set_parallelism_selects_find_any(oracle, chains):
 
 def test_first_success_calls_return_early_and_leave_a_consistent_chain(oracle, chains):
     """Under the first-success rule a single ik() returns when the first restart has succeeded and its launch ends
-    behind the call (ik_kernels.hip: optik_hip_ik_host, claim block).  Back-to-back calls, a call without any
+    behind the call (ik_capi.hip: optik_hip_ik_host, claim block).  Back-to-back calls, a call without any
     solution (the launch then ends the ordinary way) and a deterministic call right behind an early return all give
     answers the oracle reproduces by restart index."""
     from optik_amd import Robot, SolverConfig
@@ -679,7 +679,7 @@ def test_first_success_calls_return_early_and_leave_a_consistent_chain(oracle, c
 
 def test_early_return_then_a_launch_on_another_stream(oracle, chains):
     """A launch on a stream of its own shares the chain's workspace with the launch an early-returned call left
-    running on the null stream: it waits for that one (ik_kernels.hip: claim_pending) and gives the oracle's bits."""
+    running on the null stream: it waits for that one (ik_capi.hip: claim_pending) and gives the oracle's bits."""
     import torch
     from optik_amd import _native as nat
     from optik_amd import device
@@ -701,6 +701,32 @@ def test_early_return_then_a_launch_on_another_stream(oracle, chains):
                         per_restart=True)
         assert np.array_equal(out["status"].cpu().numpy(), ref["status"])
         assert_bit_equal(out["x"].cpu().numpy(), ref["xs"].T.copy())
+
+
+def test_early_return_then_a_staged_many_target_host_call(oracle, chains):
+    """optik_hip_ik_host stages more than 16 targets through pinned block 0; a first-success call that returned early may
+    have left a launch running whose selection kernel still writes its winner into that block -- inside the region the
+    targets are staged in (poses 2-3 of the next call were overwritten, silently).  The staged call now waits
+    for that launch: every target's winner equals the winner of the same call made on a fresh chain."""
+    from optik_amd import _native as nat
+    from optik_amd import device
+    d, ch = chains["panda"]
+    rng = np.random.default_rng(91)
+    cfg = nat.make_config(solution_mode="speed")
+    T = 24
+    tg = np.array([oracle.fk(ch, rng.uniform(d["lb"], d["ub"]))[1] for _ in range(T)])
+    x0 = rng.uniform(d["lb"], d["ub"], size=(T, 7))
+    fresh = device.HipChain(**d)
+    want = fresh.ik_host(cfg, tg, x0, 0, 64, flags=nat.IK_EARLY_EXIT)
+    hc = device.HipChain(**d)
+    for trial in range(6):
+        # (both pinned blocks get used by early-returning calls, so the next staged call meets one still in flight)
+        for k in range(2):
+            early = hc.ik_host(cfg, tg[k:k + 1], x0[k:k + 1], 0, 1024, flags=nat.IK_EARLY_EXIT | nat.IK_FIND_ANY)
+            assert int(early["win_idx"][0]) >= 0
+        got = hc.ik_host(cfg, tg, x0, 0, 64, flags=nat.IK_EARLY_EXIT)
+        assert np.array_equal(got["win_idx"], want["win_idx"]), trial
+        assert_bit_equal(got["win_x"], want["win_x"], "staged call after early returns")
 
 
 def test_first_success_calls_from_many_threads_and_robots(oracle, chains):
