@@ -98,24 +98,9 @@ constexpr int LANE64_CLASSES = OPTIK_LANE_CLASSES;  // predicted pass classes 1 
 #ifndef OPTIK_LANE_KEEP_TARGET
 #define OPTIK_LANE_KEEP_TARGET 1  // 1: a lane whose next restart has the target of its last one keeps the pose it holds
 #endif
-#ifndef OPTIK_LANE_SUSPEND_AT
-#define OPTIK_LANE_SUSPEND_AT 0   // the NNLS call parks the problems still running when at most this many quads are (0: never)
-#endif
 #ifndef OPTIK_LANE_REFILL
 #define OPTIK_LANE_REFILL 4       // idle lanes a wave accumulates before it refills (the seed generation runs for the whole wave)
 #endif
-
-// Problems an NNLS call parked for the wave's next call (OPTIK_LANE_SUSPEND_AT > 0): per slot the state of the problem
-// besides its quad's block -- b (m <= 8 doubles), the pivot weight, the permutation's bits, |P| and the pass count --,
-// the quad that holds it, whether its owner lane still wants it this trip, and where the owner finds its answer.
-constexpr int LANE64_SUSP_MAX = 4;
-struct Lane64Susp {
-    double st[LANE64_SUSP_MAX][12];
-    int quad[LANE64_SUSP_MAX];
-    int owner_ok[LANE64_SUSP_MAX];
-    int where[LANE64_SUSP_MAX];
-    int pad[LANE64_SUSP_MAX];
-};
 
 // The wave's problems in rank order through its sixteen quads (ik_nnls_quad.hpp: Pipe): what lane64_wave hands to the
 // NNLS -- the answers of finished quads back to their owner lanes, the next problems into the idle quads.
@@ -124,71 +109,14 @@ struct Lane64Pipe {
     static constexpr bool on = true;
     static constexpr bool warm_start = true;
     static constexpr int MAX_RUNNING = LANE64_MAX_RUNNING;
-    static constexpr int SUSPEND_AT = OPTIK_LANE_SUSPEND_AT;
-    int n_prob, next, hold;  // problems, the next rank to hand out (wave-uniform), the rank the quad holds or -1 (64 + slot: a resumed problem)
+    int n_prob, next, hold;  // problems, the next rank to hand out (wave-uniform), the rank the quad holds or -1
     int qi, ql, lane, rank;
     bool has, got;
     double *bk;
     int *lor, *where;
     Expand *expand_fn;
     ReadBack *read_fn;
-    // (OPTIK_LANE_SUSPEND_AT > 0) the parking area, the slots in use (wave-uniform, lives in lane64_wave), the slot whose
-    // problem this quad holds from the previous call (-1: none), and what the owner lane learns: parked again, in which slot
-    Lane64Susp *sus = nullptr;
-    int *n_susp = nullptr;
-    int rslot = -1;
-    bool *parked = nullptr;
-    int *pslot = nullptr;
     OPTIK_DEV bool more() const { return next < n_prob; }
-    OPTIK_DEV int &answer_word(int r) const { return r >= 64 ? sus->where[r - 64] : where[r]; }
-    // the quad's problem (at the top of a pass) stays in its block for the wave's next call
-    OPTIK_DEV bool suspend(bool at_pass_top, const double *sb, unsigned long long indx_bits, int nsetp, int iter) {
-        const bool cand = at_pass_top && hold >= 0;
-        const unsigned long long cm = __ballot(cand);
-        const int j = *n_susp + (int)__popcll(cm & ((1ull << (lane & ~3)) - 1ull)) / QUAD;
-        const bool ok = cand && j < LANE64_SUSP_MAX;
-        if (!wave_any(ok)) return false;
-        if (ok && ql == 0) {
-            constexpr int m = N + 1;
-#pragma unroll
-            for (int r = 0; r <= m; ++r) sus->st[j][r] = sb[r];
-            double ib, nb;
-            const unsigned long long packed = (unsigned long long)(unsigned)nsetp | ((unsigned long long)(unsigned)iter << 32);
-            __builtin_memcpy(&ib, &indx_bits, 8);
-            __builtin_memcpy(&nb, &packed, 8);
-            sus->st[j][10] = ib;
-            sus->st[j][11] = nb;
-            sus->quad[j] = qi;
-            answer_word(hold) = 0x200 | j;
-        }
-        lds_sync();
-        if (has && !got) {
-            const int w = answer_word(rank);
-            if (w & 0x200) { *parked = true; *pslot = w & 0xff; got = true; }
-        }
-        lds_sync();
-        if (ok) hold = -1;
-        *n_susp += (int)__popcll(__ballot(ok)) / QUAD;
-        return ok;
-    }
-    // ... and carries on in this one
-    OPTIK_DEV bool resume(double *sb, unsigned long long &indx_bits, int &nsetp, int &iter) {
-        *n_susp = 0;  // (every slot is consumed: its problem resumes, or its owner has gone)
-        if (rslot < 0) return false;
-        const int rs = rslot;
-        rslot = -1;  // (from here on an ordinary quad: free again once this problem is done)
-        constexpr int m = N + 1;
-#pragma unroll
-        for (int r = 0; r <= m; ++r) sb[r] = sus->st[rs][r];
-        const double ib = sus->st[rs][10], nb = sus->st[rs][11];
-        unsigned long long packed;
-        __builtin_memcpy(&indx_bits, &ib, 8);
-        __builtin_memcpy(&packed, &nb, 8);
-        nsetp = (int)(unsigned)(packed & 0xffffffffull);
-        iter = (int)(unsigned)(packed >> 32);
-        hold = 64 + rs;
-        return true;
-    }
     // (warm start, ik_nnls_first.hpp: wst receives Q e_m, the pivot weight and the multiplier of a problem whose first
     // column is already in, wj that column's id -- 0: the problem starts at step two)
     template <bool WARM>
@@ -201,17 +129,17 @@ struct Lane64Pipe {
                 bk[Lane64Geom<N>::META] = (double)mode;
                 bk[Lane64Geom<N>::META + 1] = rn;
                 bk[Lane64Geom<N>::META + 2] = (double)passes;
-                answer_word(hold) = 0x100 | qi;
+                where[hold] = 0x100 | qi;
             }
             lds_sync();
             if (has && !got) {
-                const int w = answer_word(rank);
+                const int w = where[rank];
                 if (w & 0x100) { (*read_fn)(w & 0xff); got = true; }
             }
             lds_sync();  // (before the blocks are rewritten)
             if (fin) hold = -1;
         }
-        const bool free_q = idle && hold < 0 && rslot < 0;  // (a quad that holds a parked problem is passed by)
+        const bool free_q = idle && hold < 0;
         const unsigned long long fm = __ballot(free_q);
         const int mine = (int)__popcll(fm & ((1ull << (lane & ~3)) - 1ull)) / QUAD;
         const int pr = next + mine;
@@ -232,8 +160,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
                            const double (&scale)[MAX_DOF], const WorkQueue &wq,
                            double *nnls_lds /* lane64_block_lds<N>() doubles, the last 16 zero */,
                            double *rec_lds /* lane64_rec_lds<N>() doubles */, int *lor_lds /* 64 ints: lane of rank */,
-                           int *where_lds /* 64 ints: by rank, 0x100 | the quad whose block holds the problem's answer */,
-                           Lane64Susp *sus_lds = nullptr /* OPTIK_LANE_SUSPEND_AT > 0: the parking area of NNLS problems */) {
+                           int *where_lds /* 64 ints: by rank, 0x100 | the quad whose block holds the problem's answer */) {
     typedef Lane64Geom<N> G;
     constexpr int NL = N * (N + 1) / 2;
     constexpr int NS = (N > 4) ? 2 : 1;
@@ -250,9 +177,6 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
     int pred = 1;          // solve passes of the restart's previous bounded problem
     bool first = true;
     bool again = false;    // the last direction was not a descent direction: reset B and search again, no evaluation
-    bool susp = false;     // (OPTIK_LANE_SUSPEND_AT) the restart's bounded problem is parked in a quad: no evaluation, the search resumes
-    int sslot = 0;         // ... in this slot of the parking area
-    int n_susp = 0;        // (wave-uniform) slots of the parking area in use
     Pose target;
     unsigned long long item = 0, index = 0;
     unsigned tslot = OPTIK_LANE_KEEP_TARGET ? ~0u : 0u;  // (~0: the lane holds no target pose yet)
@@ -372,7 +296,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
             if (stop) ret = RES_FORCED_STOP;
         }
         const bool stepping = active && ret == 0;
-        const bool do_eval = stepping && !again && !susp;
+        const bool do_eval = stepping && !again;
         double gn[N];
         double fn = 0.0;
         OPTIK_SCHED_FENCE_LANE64();
@@ -391,7 +315,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
         LANE_PROF(1);
 
         // ---- NLopt bookkeeping and Kraft's line search (labels 100 / 220), per lane ---------------------
-        bool need_dir = stepping && (again || susp), reset = stepping && again;
+        bool need_dir = stepping && again, reset = stepping && again;
         again = false;
         if (do_eval) {
             f = fn;
@@ -542,7 +466,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
             // (only when the wave has more problems than quads: with fewer, a call is as long as its longest problem
             // whatever is taken out of it, and the pass costs the whole wave ~800 instructions)
             if ((int)__popcll(__ballot(has_any)) > OPTIK_LANE_FIRST_PASS_MIN) {
-                if (has_any && !susp) {
+                if (has_any) {
                     const int fp = nnls_first_pass<N>(rec_lds + lane, y1_id, y1_val, rn1);
                     solved1 = fp == FIRST_SOLVED;
                     warm1 = OPTIK_LANE_WARM_START && fp == FIRST_WARM;
@@ -550,10 +474,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
             }
             OPTIK_SCHED_FENCE();
 #endif
-            // (a restart whose problem is parked in a quad: not a new problem -- it waits for that quad's answer)
-            const bool resumed = OPTIK_LANE_SUSPEND_AT > 0 && susp && has_any;
-            const bool has = has_any && !solved1 && !resumed;
-            susp = false;
+            const bool has = has_any && !solved1;
             OPTIK_SCHED_FENCE_LANE64();
             LANE_PROF(2);
 
@@ -577,19 +498,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
             }
             if (has) lor_lds[rank] = lane | (warm1 ? (y1_id << 8) : 0);  // (lane of rank; the column that is already in, or 0)
             where_lds[lane] = 0;  // (no problem of this trip is solved yet)
-            int rslot = -1;
-#if OPTIK_LANE_SUSPEND_AT > 0
-            if (lane < LANE64_SUSP_MAX) { sus_lds->owner_ok[lane] = 0; sus_lds->where[lane] = 0; }
             lds_sync();
-            if (resumed) sus_lds->owner_ok[sslot] = 1;
-#endif
-            lds_sync();
-#if OPTIK_LANE_SUSPEND_AT > 0
-            // (the quad that holds a parked problem whose owner still wants it)
-#pragma unroll
-            for (int j = 0; j < LANE64_SUSP_MAX; ++j)
-                if (j < n_susp && sus_lds->quad[j] == (lane >> 2) && sus_lds->owner_ok[j]) rslot = j;
-#endif
 
             double y[2 * N];
 #pragma unroll
@@ -689,15 +598,11 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
                 // and the idle quads take the next problems -- a problem that needs more passes than its class
                 // predicted keeps ITS quad busy, not the wave (ik_nnls_quad.hpp: Pipe).
                 typedef Lane64Pipe<N, decltype(expand), decltype(read_back)> Pipe;
-                bool parked = false;
-                Pipe pipe{n_prob, 0, -1, qi, ql, lane, resumed ? 64 + sslot : rank, has || resumed, false, bk, lor_lds, where_lds,
-                          &expand, &read_back};
-                pipe.sus = sus_lds; pipe.n_susp = &n_susp; pipe.rslot = rslot; pipe.parked = &parked; pipe.pslot = &sslot;
+                Pipe pipe{n_prob, 0, -1, qi, ql, lane, rank, has, false, bk, lor_lds, where_lds, &expand, &read_back};
                 int iters, qmode;
                 double xv[4], qrnorm;
                 nnls_quad<N, Pipe>(false, ids, bk, nnls_lds + 16 * NnlsQuadGeom<N>::STRIDE, xv, qmode,
                                                             qrnorm, iters, &pipe);
-                susp = parked;  // (no answer this trip: the lane sits the next evaluation out and asks again)
             }
 #else
             for (int r0 = 0; r0 < n_prob; r0 += nq) {
@@ -773,7 +678,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
                 lsq_finish<N>(E, fv, lo, hi, sn);
             }
             OPTIK_SCHED_FENCE_LANE64();
-            if (need_dir && !susp) {
+            if (need_dir) {
                 if (lmode != 1) {
                     // NLopt: modes 5,6,7 -> ROUNDOFF_LIMITED; 3,4,9 -> FAILURE
                     ret = (lmode == 5 || lmode == 6 || lmode == 7) ? RES_ROUNDOFF_LIMITED : RES_FAILURE;
@@ -798,7 +703,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
             lds_sync();  // (the records are read: the next trip may rewrite them)
         }
         OPTIK_SCHED_FENCE_LANE64();
-        if (stepping && ret == 0 && !again && !susp) {
+        if (stepping && ret == 0 && !again) {
             // label 190: next trial point x = x0 + alpha * s, clipped (NLopt)
             ++line;
             h3 = alpha * h3;
@@ -842,7 +747,6 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
             active = false;
             want = true;
             again = false;
-            susp = false;
         }
 #ifdef OPTIK_PROFILE
         LANE_PROF(3);

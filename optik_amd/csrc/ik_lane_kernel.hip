@@ -29,12 +29,7 @@ __global__ __launch_bounds__(64, 1) void ik_lane_kernel(const SolveLaunch a) {
     SolveLaunch &L = *reinterpret_cast<SolveLaunch *>(launch_lds);
     if (threadIdx.x == 0) L.wq.deadline = L.deadline_ticks ? wall_clock64() + L.deadline_ticks : 0ull;
     __syncthreads();
-#if OPTIK_LANE_SUSPEND_AT > 0
-    __shared__ __attribute__((aligned(8))) Lane64Susp sus_lds;
-    lane64_wave<N, TIP>(sch, L.ep, L.sp, L.key, L.scale, L.wq, nnls_lds, rec_lds, lor_lds, where_lds, &sus_lds);
-#else
     lane64_wave<N, TIP>(sch, L.ep, L.sp, L.key, L.scale, L.wq, nnls_lds, rec_lds, lor_lds, where_lds);
-#endif
 }
 
 int lane_solve_waves_per_cu() { return 4; }

@@ -96,10 +96,7 @@ struct NoPipe {
     static constexpr bool on = false;
     static constexpr bool warm_start = false;
     static constexpr int MAX_RUNNING = 0;
-    static constexpr int SUSPEND_AT = 0;
     OPTIK_DEV bool more() const { return false; }
-    OPTIK_DEV bool suspend(bool, const double *, unsigned long long, int, int) { return false; }
-    OPTIK_DEV bool resume(double *, unsigned long long &, int &, int &) { return false; }
     template <bool WARM>
     OPTIK_DEV bool event(bool, int, double, int, double *, int &) { return false; }
 };
@@ -151,7 +148,6 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
         if (live && isc[k]) xs[ids[k] - 1] = 0.0;
     }
     int rem_jj = 0;  // step eleven: position being removed
-    int iter_in = 0; // (Pipe::SUSPEND_AT) the problem's pass count when this call took it up
     // phases: 0 = step two (recompute duals, then choose), 1 = step three (choose again),
     // 2 = step six (solve), 3 = step eleven (remove), 4 = done
     int phase = live ? 0 : 4;
@@ -239,59 +235,16 @@ OPTIK_DEV void nnls_quad(bool live, const int (&ids)[4], double *blk, const doub
                     }
                 }
             }
-            iter_in = iter;
         }
         lds_sync();
     };
     if constexpr (Pipe::on && Pipe::warm_start) hand_over(std::true_type{});
-    if constexpr (Pipe::on && Pipe::SUSPEND_AT > 0) {
-        // problems the wave's previous call parked in their quads carry on (after the hand-over above, which passes
-        // their quads by: the state they take is live only from here)
-        double sb[m + 1];
-        unsigned long long sindx = 0;
-        int snsetp = 0, siter = 0;
-        if (pipe->resume(sb, sindx, snsetp, siter)) {
-#pragma unroll
-            for (int r = 0; r < m; ++r) b[r] = sb[r];
-            up = sb[m];
-            indx.v = sindx;
-            nsetp = snsetp; npp1 = snsetp + 1; iter = siter; mode = 1;
-            iter_in = siter;
-            rem_jj = 0;
-            phase = 0;
-#pragma unroll
-            for (int k = 0; k < CPL; ++k) {
-                // (the column's position: where the permutation holds its id)
-                int p = ids[k];
-#pragma unroll
-                for (int q = 1; q <= n; ++q) p = (isc[k] && indx.get(q) == ids[k]) ? q : p;
-                pos[k] = p;
-                inZ[k] = isc[k] && p > snsetp;
-                wv[k] = 0.0;
-                xv[k] = (isc[k] && !inZ[k]) ? xs[ids[k] - 1] : 0.0;
-            }
-        }
-        lds_sync();
-    }
     for (;;) {
         if constexpr (Pipe::on) {
             const int n_run = (int)__popcll(__ballot(phase < 4)) / QUAD;
             if (n_run == 0 || (n_run <= Pipe::MAX_RUNNING && pipe->more())) {
                 hand_over(std::false_type{});
                 if (!wave_any(phase < 4)) break;
-            } else if constexpr (Pipe::SUSPEND_AT > 0) {
-                // The call's tail: a trip with one or two quads solving costs 40 - 50 % of a full one.  A problem that is still
-                // running when at most SUSPEND_AT quads are -- and nothing waits -- stays in its quad's block for the wave's
-                // NEXT call (its owner lane sits out a trip): parked at the top of a pass, where b, the permutation, the
-                // size of set P and the pass count are its whole state besides the block.
-                if (n_run <= Pipe::SUSPEND_AT && !pipe->more()) {
-                    double sb[m + 1];
-#pragma unroll
-                    for (int r = 0; r < m; ++r) sb[r] = b[r];
-                    sb[m] = up;
-                    // (only a problem that has completed a pass in THIS call: one parked as soon as it resumes would never end)
-                    if (pipe->suspend(phase == 0 && iter > iter_in, sb, indx.v, nsetp, iter)) phase = 4;
-                }
             }
         } else {
             if constexpr (Stop::on) {

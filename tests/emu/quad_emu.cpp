@@ -42,18 +42,12 @@ void run_wave_lane64(const ChainDev &ch, const EvalParams &ep, const SolveParams
     wave.lanes = lanes;
     std::vector<double> lds((size_t)lane64_block_lds<N>(), 0.0), rec((size_t)lane64_rec_lds<N>(), 0.0);
     std::vector<int> lor(64, 0), where(64, 0);
-    Lane64Susp sus;
-    std::memset(&sus, 0, sizeof sus);
     std::vector<std::thread> th;
     for (int lane = 0; lane < wave.lanes; ++lane) {
         th.emplace_back([&, lane]() {
             optik_emu::t_wave = &wave;
             threadIdx.x = (unsigned)lane;
-#if OPTIK_LANE_SUSPEND_AT > 0
-            lane64_wave<N, TIP>(ch, ep, sp, key, scale, wq, lds.data(), rec.data(), lor.data(), where.data(), &sus);
-#else
             lane64_wave<N, TIP>(ch, ep, sp, key, scale, wq, lds.data(), rec.data(), lor.data(), where.data());
-#endif
         });
     }
     for (auto &t : th) t.join();
