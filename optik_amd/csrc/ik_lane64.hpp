@@ -100,6 +100,7 @@ constexpr int LANE64_CLASSES = OPTIK_LANE_CLASSES;  // predicted pass classes 1 
 #endif
 #ifndef OPTIK_LANE_REFILL
 #define OPTIK_LANE_REFILL 4       // idle lanes a wave accumulates before it refills (the seed generation runs for the whole wave)
+                                  // (with the reserve, round 5: 2 / 3 / 4 / 6 idle lanes 32.86 / 32.84 / 32.82 / 32.56 M: profiles/r5m_ab_refill_threshold.txt)
 #endif
 
 // The wave's problems in rank order through its sixteen quads (ik_nnls_quad.hpp: Pipe): what lane64_wave hands to the
