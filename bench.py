@@ -193,16 +193,23 @@ def device_uuid(index):
 
 
 def check_distinct_devices(rank_devices, one_device):
-    """Every rank of a multi-GPU line must sit on its own physical GPU: by UUID where torch reports one, else by device
-    index.  OPTIK_BENCH_ONE_DEVICE=1 (tests on a one-GPU box) lifts the check."""
+    """Every rank of a multi-GPU line must sit on its own physical GPU.  The ranks of one node are told apart by their
+    device index (LOCAL_RANK -> device); the UUID torch reports is the second witness: ranks that share an index -- or
+    that report distinct indices AND distinct-looking UUIDs that nevertheless collide pairwise with the same index --
+    are refused.  (Equal UUIDs on distinct indices are only reported, `uuid_warning`: a runtime that hands every device
+    the same placeholder must not cost the node its scaling run.)  OPTIK_BENCH_ONE_DEVICE=1 (tests on a one-GPU box)
+    lifts the check.  Returns the warning or None."""
     world = len(rank_devices)
     if one_device or world < 2:
-        return
-    uuids = [d.get("uuid") for d in rank_devices]
-    ids = uuids if all(u is not None for u in uuids) else [d["device"] for d in rank_devices]
-    if len(set(ids)) != world:
-        raise SystemExit(f"ranks share a physical GPU ({ids}): refusing to report {world} GPUs "
+        return None
+    idx = [d["device"] for d in rank_devices]
+    if len(set(idx)) != world:
+        raise SystemExit(f"ranks share a physical GPU (device indices {idx}): refusing to report {world} GPUs "
                          "(OPTIK_BENCH_ONE_DEVICE=1 allows it for tests)")
+    uuids = [d.get("uuid") for d in rank_devices]
+    if all(u is not None for u in uuids) and len(set(uuids)) != world:
+        return f"distinct device indices {idx} but repeated UUIDs {uuids}"
+    return None
 
 
 def inprocess_main(args):
@@ -686,10 +693,11 @@ def main():
         rank_devices = [None] * world
         dist.all_gather_object(rank_devices, me)
         backend_name = str(dist.get_backend())
-        check_distinct_devices(rank_devices, one_device)
+        uuid_warning = check_distinct_devices(rank_devices, one_device)
     else:
         rank_devices = [me]
         backend_name = None
+        uuid_warning = None
 
     from optik_amd import _native as nat
     for kv in args.set_option:
@@ -806,7 +814,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": workload, "command_key": key,
-                       "world": world, "backend": backend_name, "rccl_version": rccl_version, "rank_devices": rank_devices,
+                       "world": world, "backend": backend_name, "rccl_version": rccl_version, "rank_devices": rank_devices, "uuid_warning": uuid_warning,
                        # what the process group executed in every timed repetition (None: no process group)
                        "collectives": (["barrier", "all_reduce MIN int64 (key)", "all_reduce MIN int64 (index)",
                                         "all_reduce SUM f64 (winner x)", "all_reduce SUM f64 (winner f)",

@@ -56,15 +56,16 @@ def test_pmc_record_of_the_default_command_has_the_shape_bench_reads():
 
 
 def test_ranks_sharing_a_gpu_are_refused():
-    """A line that says N GPUs needs N physical GPUs: distinct UUIDs (device indices where torch reports none)."""
+    """A line that says N GPUs needs N physical GPUs: distinct device indices; repeated UUIDs on distinct indices are
+    reported, not fatal (a runtime that gives every device one placeholder must not cost the node its scaling run)."""
     import pytest
     import bench
     ok = [{"rank": r, "device": r, "uuid": f"GPU-{r:04x}"} for r in range(8)]
-    bench.check_distinct_devices(ok, False)
-    bench.check_distinct_devices([{"rank": 0, "device": 0, "uuid": None}, {"rank": 1, "device": 1, "uuid": None}], False)
-    shared = [dict(ok[0]), dict(ok[1], uuid=ok[0]["uuid"])]
+    assert bench.check_distinct_devices(ok, False) is None
+    assert bench.check_distinct_devices([{"rank": 0, "device": 0, "uuid": None}, {"rank": 1, "device": 1, "uuid": None}], False) is None
+    same_uuid = [dict(ok[0]), dict(ok[1], uuid=ok[0]["uuid"])]
+    assert "repeated UUIDs" in bench.check_distinct_devices(same_uuid, False)
+    shared = [dict(ok[0]), dict(ok[1], device=0)]
     with pytest.raises(SystemExit, match="share a physical GPU"):
         bench.check_distinct_devices(shared, False)
-    with pytest.raises(SystemExit, match="share a physical GPU"):
-        bench.check_distinct_devices([{"rank": 0, "device": 0, "uuid": None}, {"rank": 1, "device": 0, "uuid": None}], False)
-    bench.check_distinct_devices(shared, True)  # OPTIK_BENCH_ONE_DEVICE=1: the one-GPU test box
+    assert bench.check_distinct_devices(shared, True) is None  # OPTIK_BENCH_ONE_DEVICE=1: the one-GPU test box

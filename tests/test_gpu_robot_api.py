@@ -202,6 +202,47 @@ def test_c_abi_ik_returns_malloced_buffer(ur3e):
     assert not bool(L.optik_robot_ik(ur3e._h, C.byref(cfg), far, x0))   # NULL = no solution
 
 
+def test_c_path_feeds_the_kernels_the_iteratively_converted_target(oracle, chains):
+    """optik_robot_ik (the reference's C symbol) converts the 4x4 target with nalgebra's ITERATIVE from_matrix
+    (optik-cpp/src/lib.rs:141-142), optik_robot_ik_ex / the Python front end with the closed form
+    (optik-py/src/lib.rs:8-15): each returns, bit for bit, what the oracle returns for THAT pose -- and over 40 targets
+    the two readings do not always return the same joint angles (last bits of the target decide long restarts)."""
+    import ctypes as C
+    from optik_amd import Robot
+    from optik_amd import _native as nat
+    L = nat.lib()
+    dp = C.POINTER(C.c_double)
+    L.optik_pose_from_matrix.argtypes = [dp, C.c_uint32, dp]
+    L.optik_robot_ik_pose.argtypes = [C.c_void_p, C.POINTER(nat.SolverConfigC), dp, C.c_uint32, dp, dp, dp, dp,
+                                      C.POINTER(C.c_uint64)]
+    robot = Robot.from_urdf_file(os.path.join(ROBOTS, "panda.urdf"), "panda_link0", "panda_link8")
+    robot.set_parallelism(1)  # (the deterministic rule: the lowest successful index)
+    d, ch = chains["panda"]
+    rng = np.random.default_rng(123)
+    cfg = nat.make_config("speed", 0.0, 96)
+    ocfg = oracle.make_config(solution_mode="speed", max_restarts=96)
+    differ = 0
+    for trial in range(40):
+        m = np.array(robot.fk(rng.uniform(d["lb"], d["ub"])))
+        mc = np.ascontiguousarray(m.T).ravel()
+        x0 = rng.uniform(d["lb"], d["ub"])
+        got = {}
+        for flags in (0, 4):  # 4 = OPTIK_POSE_FROM_MATRIX
+            p7 = np.zeros(7)
+            assert L.optik_pose_from_matrix(mc.ctypes.data_as(dp), flags, p7.ctypes.data_as(dp)) == 0
+            x, f, idx = np.zeros(7), C.c_double(0.0), C.c_uint64(0)
+            rc = L.optik_robot_ik_pose(robot._h, C.byref(cfg), mc.ctypes.data_as(dp), flags, x0.ctypes.data_as(dp), None,
+                                       x.ctypes.data_as(dp), C.byref(f), C.byref(idx))
+            ref = oracle.ik(ch, ocfg, p7, x0, 0, 96, n_threads=4, early_exit=True)
+            assert (rc == 0) == bool(ref["found"])
+            if rc == 0:
+                assert idx.value == ref["winner"]
+                assert_bit_equal(x, ref["x"], f"trial {trial} flags {flags}")
+            got[flags] = x.copy()
+        differ += not np.array_equal(got[0], got[4])
+    assert differ > 0
+
+
 def test_ik_batch_of_41000_targets_equals_individual_calls(panda):
     """A Speed batch of tens of thousands of targets (one launch per round, robot_host.cpp:ik_batch_on_device;
     rounds 1-4 ran batches of this size on a streaming engine): the same answers as ik() target by target."""
