@@ -194,10 +194,9 @@ def device_uuid(index):
 
 def check_distinct_devices(rank_devices, one_device):
     """Every rank of a multi-GPU line must sit on its own physical GPU.  The ranks of one node are told apart by their
-    device index (LOCAL_RANK -> device); the UUID torch reports is the second witness: ranks that share an index -- or
-    that report distinct indices AND distinct-looking UUIDs that nevertheless collide pairwise with the same index --
-    are refused.  (Equal UUIDs on distinct indices are only reported, `uuid_warning`: a runtime that hands every device
-    the same placeholder must not cost the node its scaling run.)  OPTIK_BENCH_ONE_DEVICE=1 (tests on a one-GPU box)
+    device index (LOCAL_RANK -> device): ranks that share one are refused.  The UUID torch reports is the second witness:
+    equal UUIDs on distinct indices are reported (`config.uuid_warning`), not fatal -- a runtime that hands every device
+    the same placeholder must not cost the node its scaling run.  OPTIK_BENCH_ONE_DEVICE=1 (tests on a one-GPU box)
     lifts the check.  Returns the warning or None."""
     world = len(rank_devices)
     if one_device or world < 2:
@@ -711,10 +710,14 @@ def main():
     headline = args.robot == "panda" and not T and mode == "speed" and args.scaling == "weak" and R == 65536
     others = None
     if not args.no_other_configs and headline:
-        if world > 1:
-            others = other_configs_multi_gpu(ctx, args)
-        elif not args.force_distributed:
-            others = other_configs_one_gpu(ctx, args, primary)
+        # (a failure here -- the same on every rank: same code, same sizes -- must not cost the headline line)
+        try:
+            if world > 1:
+                others = other_configs_multi_gpu(ctx, args)
+            elif not args.force_distributed:
+                others = other_configs_one_gpu(ctx, args, primary)
+        except Exception as e:  # noqa: BLE001
+            others = {"error": f"{type(e).__name__}: {e}"[:300]}
     coll_us = collective_latency(ctx)
 
     if rank == 0:
