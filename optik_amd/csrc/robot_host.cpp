@@ -321,7 +321,7 @@ void quat_from_matrix_iterative(const double M[3][3], double &w, double &i, doub
                 rot_from_axis_angle(axes, eps_disturbance, Rp);
                 mat3_mul(pert, Rp, pert);
                 n1 = diff_norm_squared(M, pert);
-                if (std::fabs(n0 - n1) > eps) break;  // abs_diff_ne!(.., epsilon = f64::EPSILON)
+                if (!(std::fabs(n0 - n1) <= eps)) break;  // abs_diff_ne!(.., epsilon = f64::EPSILON): true for NaN too
             }
             if (n0 < n1) break;  // a minimum: done
             const double t = axes[0];  // perturbation_axes.yzx()

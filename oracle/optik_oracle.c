@@ -458,7 +458,7 @@ void ok_quat_from_matrix(const double m[9], int iterative, double q[4]) {
                 rot_axis_angle(ax, disturb, rp);
                 m3_mul(pert, rp, pert);
                 n1 = m3_diff_norm2(m, pert);
-                if (fabs(n0 - n1) > eps) break;
+                if (!(fabs(n0 - n1) <= eps)) break; /* abs_diff_ne!: true for NaN too */
             }
             if (n0 < n1) break;
             const double t = ax[0]; ax[0] = ax[1]; ax[1] = ax[2]; ax[2] = t; /* yzx */

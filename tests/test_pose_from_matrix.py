@@ -97,3 +97,14 @@ def test_identity_and_non_rotations_terminate(oracle):
         q = _host(m, POSE_FROM_MATRIX)[3:]
         assert np.array_equal(q.view(np.uint64), oracle.quat_from_matrix(1.01 * R, True).view(np.uint64))
         assert np.abs(_rot_of(q / np.linalg.norm(q)) - R).max() < 1e-9
+
+
+def test_degenerate_matrices_terminate(oracle):
+    """nalgebra's iteration has no iteration cap (usize::MAX); this one stops after 100 000 steps: a matrix of NaNs, the
+    zero matrix and a reflection come back (with whatever quaternion the iteration ends on) instead of hanging the call."""
+    for R in (np.full((3, 3), np.nan), np.zeros((3, 3)), np.diag([1.0, 1.0, -1.0])):
+        m = np.eye(4)
+        m[:3, :3] = R
+        q = _host(m, POSE_FROM_MATRIX)[3:]
+        ref = oracle.quat_from_matrix(R, True)
+        assert np.array_equal(q.view(np.uint64), ref.view(np.uint64))
