@@ -555,7 +555,13 @@ int optik_robot_ik_pose(const optik_robot *r, const CSolverConfig *config, const
     // (a big round is one launch of the lane-per-restart form and worth ~1 M restarts, because every launch pays its
     // own few ms of drain; rounds 1-3 ran them on a streaming engine that the lane form beat at every size in round 4
     // and that was retired in round 5: profiles/r5a_engine_retire_probe.txt)
-    const uint64_t big_batch = (uint64_t)1 << 20;  // restarts per GPU per big round
+#ifndef OPTIK_QUALITY_BATCH_LOG2
+#define OPTIK_QUALITY_BATCH_LOG2 22
+#endif
+    // restarts per GPU per big round: 1 M under Speed (a round that finds a solution ends the call); 4 M under Quality,
+    // which runs every restart anyway -- one drain (~3.5 ms) per 4 M instead of per 1 M: a 4 M-restart call 138 -> 129 ms
+    // (288 MB of per-restart keys, points and residuals per device)
+    const uint64_t big_batch = (uint64_t)1 << (quality ? OPTIK_QUALITY_BATCH_LOG2 : 20);
     const uint64_t big_from = 262144;              // (from this many restarts left on: rounds of big_batch)
     const size_t G = device_count(r);
     const uint32_t speed_flags = OPTIK_HIP_IK_EARLY_EXIT | (r->parallelism != 1 ? OPTIK_HIP_IK_FIND_ANY : 0u);
