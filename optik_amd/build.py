@@ -6,9 +6,12 @@ the reference-compatible host API (include/optik.h, ``optik_robot_*``).
 """
 from __future__ import annotations
 
+import json
 import os
+import re
 import shutil
 import subprocess
+import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
 
@@ -63,7 +66,96 @@ def _hipcc():
 def _unit_cmd(hipcc, src, objname, extra):
     sp = os.path.join(CSRC, src)
     obj = os.path.join(CSRC, objname)
-    return [hipcc, *FLAGS, *extra, "-MD", "-MF", obj + ".d", "-x", "hip", "-c", sp, "-o", obj]
+    # (-Rpass-analysis: a remark per kernel with its registers / scratch / LDS -- the toolchain guard below reads it)
+    return [hipcc, *FLAGS, *extra, "-Rpass-analysis=kernel-resource-usage", "-MD", "-MF", obj + ".d", "-x", "hip", "-c", sp, "-o", obj]
+
+
+# ---- toolchain-regression guard ------------------------------------------------------------------------------------
+# The two throughput kernels live at the edge of the register file: ik_lane_kernel<7, *> uses
+# 256 VGPR + 249 AGPR of the 512 a lone wave may have, ik_quad_kernel<7, *, 2> 255 of the 256 two waves per SIMD leave
+# each.  A compiler update (or an innocent edit) that spills either to scratch costs a large part of the rate and nothing
+# would say so.  Every compile therefore records what the compiler reports per kernel (<object>.res), and build() refuses
+# a library whose kernels break the limits below (OPTIK_ALLOW_RESOURCE_REGRESSION=1: warns instead).
+RESOURCE_LIMITS = [
+    # (kernel-name regex, {field: maximum})
+    (r"^optik::ik_lane_kernel<7, (true|false)>$", {"scratch": 0, "registers": 512}),
+    (r"^optik::ik_quad_kernel<7, (true|false), 2>$", {"scratch": 0, "vgpr": 256}),
+]
+
+
+def _demangle(names):
+    try:
+        out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
+    except OSError:
+        return list(names)
+    return [(d or n) for n, d in zip(names, out + [""] * len(names))]
+
+
+def parse_resource_remarks(stderr_text):
+    """{kernel name: {vgpr, agpr, sgpr, scratch, lds, occupancy}} from -Rpass-analysis=kernel-resource-usage remarks."""
+    rows, cur = [], None
+    for ln in stderr_text.splitlines():
+        m = re.search(r"remark: +(.*?) \[-Rpass", ln)
+        if not m:
+            continue
+        t = m.group(1).strip()
+        if t.startswith("Function Name:"):
+            cur = {"mangled": t.split(":", 1)[1].strip()}
+            rows.append(cur)
+        elif cur is not None and ":" in t:
+            k, v = t.split(":", 1)
+            cur[k.strip()] = v.strip()
+    names = _demangle([r["mangled"] for r in rows])
+    out = {}
+    for r, name in zip(rows, names):
+        name = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+
+        def num(key):
+            try:
+                return int(r.get(key, "-1"))
+            except ValueError:
+                return -1
+        out[name] = {"vgpr": num("VGPRs"), "agpr": num("AGPRs"), "sgpr": num("TotalSGPRs"),
+                     "scratch": num("ScratchSize [bytes/lane]"), "lds": num("LDS Size [bytes/block]"),
+                     "occupancy": num("Occupancy [waves/SIMD]")}
+        out[name]["registers"] = max(out[name]["vgpr"], 0) + max(out[name]["agpr"], 0)
+    return out
+
+
+def kernel_resources():
+    """What the compiler reported for every kernel of the library as built ({} for units compiled before the guard)."""
+    res = {}
+    for _, objname, _ in UNITS:
+        try:
+            with open(os.path.join(CSRC, objname + ".res")) as fh:
+                res.update(json.load(fh))
+        except (OSError, ValueError):
+            pass
+    return res
+
+
+def check_resources(resources=None, limits=None):
+    """Violations of RESOURCE_LIMITS as a list of strings; a guarded kernel that is missing from the record is one too."""
+    resources = kernel_resources() if resources is None else resources
+    bad = []
+    for pat, lim in (RESOURCE_LIMITS if limits is None else limits):
+        hits = [k for k in resources if re.match(pat, k)]
+        if not hits:
+            bad.append(f"no kernel matching {pat} in the compiler's resource report")
+        for k in hits:
+            for field, mx in lim.items():
+                if resources[k].get(field, -1) > mx or resources[k].get(field, -1) < 0:
+                    bad.append(f"{k}: {field} = {resources[k].get(field)} (limit {mx}); all: {resources[k]}")
+    return bad
+
+
+def toolchain_version(hipcc=None):
+    """First lines of `hipcc --version` (HIP version + clang version): what profiles/perf_floor.json is keyed by."""
+    try:
+        out = subprocess.run([hipcc or _hipcc(), "--version"], capture_output=True, text=True).stdout.splitlines()
+    except (OSError, RuntimeError):
+        return None
+    return " | ".join(ln.strip() for ln in out[:2])
 
 
 def _dep_files(obj):
@@ -118,7 +210,17 @@ def _compile(job):
     if verbose:
         print(" ".join(cmd), flush=True)
     t0 = time.perf_counter()
-    subprocess.check_call(cmd, cwd=CSRC)
+    p = subprocess.run(cmd, cwd=CSRC, stderr=subprocess.PIPE, text=True)
+    # (the compiler's own diagnostics, without the resource remarks and their source excerpts)
+    noise = [ln for ln in p.stderr.splitlines()
+             if not ("-Rpass-analysis=kernel-resource-usage" in ln or re.match(r"^\s*\d* *\|", ln) or "remark" in ln)]
+    if p.returncode != 0:
+        sys.stderr.write(p.stderr)
+        raise subprocess.CalledProcessError(p.returncode, cmd)
+    if noise and verbose:
+        sys.stderr.write("\n".join(noise) + "\n")
+    with open(cmd[-1] + ".res", "w") as fh:
+        json.dump(parse_resource_remarks(p.stderr), fh, indent=0, sort_keys=True)
     with open(cmd[-1] + ".flags", "w") as fh:
         fh.write(" ".join(cmd[1:]))
     return cmd[-1], time.perf_counter() - t0
@@ -138,11 +240,23 @@ def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -
             for obj, dt in ex.map(_compile, todo):
                 if verbose:
                     print(f"  {os.path.basename(obj)}: {dt:.1f} s", flush=True)
+    bad = check_resources()
+    if bad:
+        msg = ("toolchain-regression guard (optik_amd/build.py: RESOURCE_LIMITS) -- " + toolchain_version(hipcc) + ":\n  "
+               + "\n  ".join(bad))
+        if os.environ.get("OPTIK_ALLOW_RESOURCE_REGRESSION") == "1":
+            sys.stderr.write("WARNING: " + msg + "\n")
+        else:
+            raise RuntimeError(msg + "\n(OPTIK_ALLOW_RESOURCE_REGRESSION=1 links the library anyway)")
     objs = [os.path.join(CSRC, objname) for _, objname, _ in UNITS]
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", *objs, "-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
+    with open(os.path.join(CSRC, "toolchain.json"), "w") as fh:
+        json.dump({"hipcc": toolchain_version(hipcc), "built": time.strftime("%Y-%m-%d %H:%M:%S"),
+                   "guarded_kernels": {k: v for k, v in kernel_resources().items()
+                                       if any(re.match(p, k) for p, _ in RESOURCE_LIMITS)}}, fh, indent=1)
     if verbose:
         print(f"built {len(todo)} of {len(UNITS)} units + link in {time.perf_counter() - t0:.1f} s "
               f"({'forced' if force else 'stale units only'})")

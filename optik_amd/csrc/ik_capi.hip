@@ -513,7 +513,7 @@ int optik_hip_ik_host(optik_hip_chain *ch, const optik_solver_config *cfg, const
                       const double *x0, int32_t T, const double *ee_offset7, uint64_t restart_begin,
                       uint64_t restart_end, uint32_t flags, double deadline_s, double *win_x, double *win_f,
                       uint64_t *win_idx, double *win_key) {
-    if (!ch || !targets || !x0 || T < 1) return fail(OPTIK_HIP_EINVAL, "bad argument");
+    if (!ch || !cfg || !targets || !x0 || T < 1) return fail(OPTIK_HIP_EINVAL, "bad argument");  // (cfg is read below, before ik_batch_locked's own check)
     // the launch workspace of the chain is in use until the copies below are done
     std::lock_guard<std::mutex> host_lock(ch->host_mu);
     BIND_DEVICE(ch);

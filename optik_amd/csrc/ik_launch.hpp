@@ -8,22 +8,6 @@
 
 namespace optik {
 
-// Where the lane-per-restart kernel leaves the restarts still running when its queue is dry, for the quad solver to
-// finish (ik_spill.hpp).  Plain data: planes of doubles / ints over C slots (slot = a lane's global number), the
-// list of slots that hold a restart and its length.  d == nullptr: the launch does not spill.
-struct SpillPool {
-    double *d;                   // [SpillLayout::ND][C]
-    int32_t *i32;                // [SpillLayout::NI][C]
-    unsigned long long *item;    // [C] output column of the slot's restart (target * n_restarts + restart)
-    unsigned long long C;
-    unsigned int *list;          // [C] slots holding a restart ...
-    unsigned int *count;         // ... how many (appended to by the spilling waves; zero before the launch)
-    unsigned long long *cursor;  // the tail kernel's hand-out counter (zero before the launch)
-    unsigned long long *deadline;  // the lane kernel's absolute deadline (wall_clock64 ticks, 0 = none), for the tail
-    int spill_at;                // a wave spills when at most this many of its lanes still hold a restart
-    int pad;
-};
-
 struct SolveLaunch {
     const ChainDev *chain;
     EvalParams ep;
@@ -32,7 +16,6 @@ struct SolveLaunch {
     double scale[MAX_DOF];  // rand UniformFloat scale per joint
     WorkQueue wq;
     unsigned long long deadline_ticks;  // relative to kernel start, 0 = none
-    SpillPool spill;        // (lane-per-restart kernel and its tail)
 };
 
 __device__ __forceinline__ void stage_chain(ChainDev &dst, const ChainDev *src) {
@@ -55,8 +38,5 @@ int quad_solve_waves_per_cu(int n);
 // per SIMD
 hipError_t lane_solve_launch(int n, bool tip, int grid, hipStream_t stream, const SolveLaunch &a, int *lds_bytes);
 int lane_solve_waves_per_cu();
-// the spilled restarts of a lane-per-restart launch on the quad solver (n <= 7, the two-waves-per-SIMD build): queued
-// behind that launch on the same stream; `a` is the launch's own record (a.wq.lanes is set to 16 quads per wave here)
-hipError_t quad_tail_launch(int n, bool tip, int grid, hipStream_t stream, const SolveLaunch &a);
 
 }  // namespace optik

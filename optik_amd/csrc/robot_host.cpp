@@ -198,32 +198,9 @@ std::vector<int> devices_from_env() {
     return ids;
 }
 
-// 4x4 column-major homogeneous matrix -> pose7 as the pyo3 path does it (optik-py/src/lib.rs:8-15:
-// try_convert::<Matrix4, Isometry3> = UnitQuaternion::from_rotation_matrix's closed-form branches).  The C path's
-// iterative UnitQuaternion::from_matrix is pose7_from_mat16_iterative below: the same rotation, last bits apart.
-void pose7_from_mat16(const double *m, double *p) {
-    auto M = [&](int r, int c) { return m[c * 4 + r]; };
-    p[0] = M(0, 3); p[1] = M(1, 3); p[2] = M(2, 3);
-    const double tr = M(0, 0) + M(1, 1) + M(2, 2);
-    double w, i, j, k;
-    if (tr > 0.0) {
-        const double d = std::sqrt(tr + 1.0) * 2.0;
-        w = 0.25 * d; i = (M(2, 1) - M(1, 2)) / d; j = (M(0, 2) - M(2, 0)) / d; k = (M(1, 0) - M(0, 1)) / d;
-    } else if (M(0, 0) > M(1, 1) && M(0, 0) > M(2, 2)) {
-        const double d = std::sqrt(1.0 + M(0, 0) - M(1, 1) - M(2, 2)) * 2.0;
-        w = (M(2, 1) - M(1, 2)) / d; i = 0.25 * d; j = (M(0, 1) + M(1, 0)) / d; k = (M(0, 2) + M(2, 0)) / d;
-    } else if (M(1, 1) > M(2, 2)) {
-        const double d = std::sqrt(1.0 + M(1, 1) - M(0, 0) - M(2, 2)) * 2.0;
-        w = (M(0, 2) - M(2, 0)) / d; i = (M(0, 1) + M(1, 0)) / d; j = 0.25 * d; k = (M(1, 2) + M(2, 1)) / d;
-    } else {
-        const double d = std::sqrt(1.0 + M(2, 2) - M(0, 0) - M(1, 1)) * 2.0;
-        w = (M(1, 0) - M(0, 1)) / d; i = (M(0, 2) + M(2, 0)) / d; j = (M(1, 2) + M(2, 1)) / d; k = 0.25 * d;
-    }
-    const double nrm = std::sqrt(w * w + i * i + j * j + k * k);  // UnitQuaternion::new_normalize
-    p[3] = i / nrm; p[4] = j / nrm; p[5] = k / nrm; p[6] = w / nrm;
-}
-
-// UnitQuaternion::from_rotation_matrix (nalgebra 0.34, not vendored): the four closed-form branches, no normalisation.
+// UnitQuaternion::from_rotation_matrix (nalgebra 0.34, not vendored): the four closed-form branches.  It ends in
+// Self::new_unchecked(res): NO normalisation -- both bindings' conversions go through it, so one function serves both
+// (round 5 normalised on the Python path only: ADVICE r5).
 void quat_from_rotation(const double R[3][3], double &w, double &i, double &j, double &k) {
     const double tr = R[0][0] + R[1][1] + R[2][2];
     if (tr > 0.0) {
@@ -239,6 +216,18 @@ void quat_from_rotation(const double R[3][3], double &w, double &i, double &j, d
         const double d = std::sqrt(1.0 + R[2][2] - R[0][0] - R[1][1]) * 2.0;
         w = (R[1][0] - R[0][1]) / d; i = (R[0][2] + R[2][0]) / d; j = (R[1][2] + R[2][1]) / d; k = 0.25 * d;
     }
+}
+
+// 4x4 column-major homogeneous matrix -> pose7 as the pyo3 path does it (optik-py/src/lib.rs:8-15:
+// try_convert::<Matrix4, Isometry3> -> Isometry3::from_superset_unchecked -> UnitQuaternion::from_rotation_matrix on the
+// upper-left block, as it stands).  The C path's iterative UnitQuaternion::from_matrix is pose7_from_mat16_iterative
+// below: the same rotation, last bits apart.
+void pose7_from_mat16(const double *m, double *p) {
+    double R[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) R[r][c] = m[c * 4 + r];
+    p[0] = m[12]; p[1] = m[13]; p[2] = m[14];
+    quat_from_rotation(R, p[6], p[3], p[4], p[5]);
 }
 
 // Rotation3::from_axis_angle (nalgebra: Rodrigues' formula entry by entry; angle == 0 -> identity).
@@ -561,7 +550,10 @@ int optik_robot_ik_pose(const optik_robot *r, const CSolverConfig *config, const
     // restarts per GPU per big round: 1 M under Speed (a round that finds a solution ends the call); 4 M under Quality,
     // which runs every restart anyway -- one drain (~3.5 ms) per 4 M instead of per 1 M: a 4 M-restart call 138 -> 129 ms
     // (288 MB of per-restart keys, points and residuals per device)
-    const uint64_t big_batch = (uint64_t)1 << (quality ? OPTIK_QUALITY_BATCH_LOG2 : 20);
+    // Under a time budget the rounds stay at 1 M: a launch that meets its deadline still has to fetch, seed and publish
+    // every item left and the selection runs over the whole round, so the overshoot of max_time grows with the round
+    // (ADVICE r5); the 4 M rounds' gain was measured without a deadline.
+    const uint64_t big_batch = (uint64_t)1 << ((quality && !(config->max_time > 0.0)) ? OPTIK_QUALITY_BATCH_LOG2 : 20);
     const uint64_t big_from = 262144;              // (from this many restarts left on: rounds of big_batch)
     const size_t G = device_count(r);
     const uint32_t speed_flags = OPTIK_HIP_IK_EARLY_EXIT | (r->parallelism != 1 ? OPTIK_HIP_IK_FIND_ANY : 0u);

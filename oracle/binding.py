@@ -113,6 +113,20 @@ def use_native_build() -> str:
     return "gcc " + " ".join(NATIVE_FLAGS)
 
 
+def use_libm_build() -> str:
+    """The libm-sensitivity study only: the oracle with ok_sincos / ok_atan2_q1 routed to glibc's sincos / atan2
+    (-DOK_PLATFORM_LIBM: what f64::sin_cos / f64::atan2 bind on Linux, math.rs:54,76,113,144) into
+    liboptik_oracle_libm.so; lib() loads it.  NOT what any parity test compares the GPU with."""
+    global _lib, _lib_path
+    out = os.path.join(_HERE, "liboptik_oracle_libm.so")
+    src = os.path.join(_HERE, "optik_oracle.c")
+    deps = (src, os.path.join(_HERE, "optik_oracle.h"))
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.check_call(["gcc", *NATIVE_FLAGS, "-DOK_PLATFORM_LIBM", "-shared", "-o", out, src, "-lm", "-lpthread"])
+    _lib, _lib_path = None, out
+    return "gcc " + " ".join(NATIVE_FLAGS) + " -DOK_PLATFORM_LIBM"
+
+
 def use_portable_build():
     global _lib, _lib_path
     _lib, _lib_path = None, _LIB_PATH

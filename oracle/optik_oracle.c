@@ -122,6 +122,14 @@ static double k_cos(double x, double y) {
 /* sin and cos of x, |x| < ~1e6 (joint angles).  Cody-Waite reduction with
  * the three-part pi/2 of e_rem_pio2.c, second iteration always taken. */
 void ok_sincos(double x, double *s, double *c) {
+#ifdef OK_PLATFORM_LIBM
+    /* The libm-sensitivity study only (tests/test_oracle_libm_sensitivity.py): what the
+     * reference itself calls on Linux -- f64::sin_cos binds glibc's sincos (math.rs:76,113,144; nalgebra's
+     * from_axis_angle under kinematics.rs:245-248).  The GPU kernels cannot reproduce glibc's bits; the default
+     * build below is the sequence they share with this file. */
+    sincos(x, s, c);
+    return;
+#endif
     const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00,
                  pio2_1t = 6.07710050650619224932e-11, pio2_2 = 6.07710050630396597660e-11,
                  pio2_2t = 2.02226624879595063154e-21;
@@ -150,6 +158,9 @@ void ok_sincos(double x, double *s, double *c) {
 /* atan2(y, x) for y > 0, x >= 0 (the only use: math.rs:54 after the w >= 0
  * flip).  s_atan.c argument reduction + polynomial on t = y / x. */
 double ok_atan2_q1(double y, double x) {
+#ifdef OK_PLATFORM_LIBM
+    return atan2(y, x); /* f64::atan2 (math.rs:54): glibc's, for the libm-sensitivity study only */
+#endif
     static const double aT[11] = {
         3.33333333333329318027e-01, -1.99999999998764832476e-01, 1.42857142725034663711e-01,
         -1.11111104054623557880e-01, 9.09088713343650656196e-02, -7.69187620504482999495e-02,

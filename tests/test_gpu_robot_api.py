@@ -770,6 +770,25 @@ def test_early_return_then_a_staged_many_target_host_call(oracle, chains):
         assert_bit_equal(got["win_x"], want["win_x"], "staged call after early returns")
 
 
+def test_null_config_through_the_c_abi_fails_cleanly(chains):
+    """optik_hip_ik_host reads cfg->solution_mode before the launch's own argument check: a NULL config used to be a
+    segfault; it is EINVAL with a message like every other bad argument."""
+    import ctypes as C
+    from optik_amd import _native as nat
+    from optik_amd import device
+    d, _ = chains["panda"]
+    hc = device.HipChain(**d)
+    dp = C.POINTER(C.c_double)
+    tg = np.zeros((1, 7)); tg[0, 6] = 1.0
+    x0 = np.zeros((1, 7))
+    out = np.zeros(16)
+    idx = np.zeros(1, dtype=np.uint64)
+    rc = nat.lib().optik_hip_ik_host(hc._h, None, tg.ctypes.data_as(dp), x0.ctypes.data_as(dp), 1, None, 0, 64, 0, 0.0,
+                                     out.ctypes.data_as(dp), out[8:].ctypes.data_as(dp),
+                                     idx.ctypes.data_as(C.POINTER(C.c_uint64)), out[9:].ctypes.data_as(dp))
+    assert rc != 0
+
+
 def test_first_success_calls_from_many_threads_and_robots(oracle, chains):
     """Early-return calls (first-success rule) from several host threads on several robots of one device: every
     launch one of them leaves behind queues in front of the others' launches on the null stream.  Every answer is
