@@ -47,7 +47,9 @@ The JSON line carries:
                 operations of a restart (oracle/optik_oracle_flops.cpp) at this line's rate against the
                 no-FMA ceiling, the PMC instruction counts sit beside it
   cpu_baseline  the CPU oracle (a port of the reference algorithm, NOT the reference binary) timed on this
-                host's cores (1 thread = BASELINE config 1, half, all) on a bounded sample
+                host's cores (1 thread = BASELINE config 1, half, all) on a bounded sample; `single_ik_ms` (one ik()
+                call: 1 thread, and all cores under the reference's find_any rule) and `config5_ik_calls_per_s` on the
+                targets of the GPU legs of the same names.  Runs BETWEEN the GPU legs (headline first, other configs last)
   config.other_configs   (N = 1, the default command) BASELINE configs 3, 4's one-GPU shard and 5, the isolated
                 config-2 launch and a single ik() through the C ABI, each in a short run of its own
 """
@@ -123,10 +125,14 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(robot_name, chain_tables, target7, x0, mode, seconds_budget=15.0):
+def cpu_baseline(robot_name, chain_tables, target7, x0, mode, seconds_budget=15.0, user_inputs=None):
     """Times the CPU oracle (checker code, used here only as the reported baseline) at 1 thread (BASELINE config 1),
     half the usable cores (the reference's advice, README.md:90-91) and all of them, and counts the f64 operations
-    of a restart with the oracle's counting build (the algorithmic flops of the secondary roofline)."""
+    of a restart with the oracle's counting build (the algorithmic flops of the secondary roofline).
+    With `user_inputs` (the targets of the GPU legs `single_ik` and `config5_all_4096_targets`) also the two figures a user
+    of the reference would ask for (examples/example.rs:16-42): the time of ONE ik() call -- 1 thread, and all cores under
+    the reference's own multi-thread rule (find_any, lib.rs:409-412) on persistent workers -- and ik() calls/s over
+    config 5's 4 096 targets, one call per target on all cores."""
     from oracle import binding as ob
     ch = ob.make_chain(**chain_tables)
     cfg = ob.make_config(solution_mode=mode, tol_f=1e-6)
@@ -162,13 +168,62 @@ def cpu_baseline(robot_name, chain_tables, target7, x0, mode, seconds_budget=15.
         sample.append(f"{th} thread(s): restarts 0..{n - 1} in {dt:.1f} s")
         if th == cores:
             winner = int(res["winner"]) if res["found"] else -1
-    return {"value": by_threads[str(cores)], "unit": "restarts/s", "cores": cores, "kind": "port",
+    user = cpu_user_figures(ob, ch, cores, user_inputs) if user_inputs is not None else {}
+    return {"value": by_threads[str(cores)], "unit": "restarts/s", "cores": cores, "kind": "port", **user,
             # (BASELINE.json config 1 is the 1-thread figure; the reference advises half the cores)
             "value_1_thread": by_threads["1"], "value_half_cores": by_threads[str(max(1, cores // 2))],
             "by_threads": by_threads, "build": flags, "oracle_flops": flops,
             "sample": f"{robot_name}: the bench target, SolutionMode {mode}, every restart run to termination, threads "
                       f"pulling indices from a shared counter; " + "; ".join(sample),
             "winner": winner}
+
+
+def cpu_user_figures(ob, ch, cores, inp):
+    """The CPU oracle on the SAME inputs as the GPU legs `single_ik` (300 Robot.ik() calls, default SolverConfig) and
+    `config5_all_4096_targets` (4 096 targets x at most 256 restarts, Speed, early exit).  ~1 s."""
+    import threading
+    pose7, x0s = inp["pose7"], inp["x0s"]
+    lo, hi = inp["single_ik_range"]
+    dcfg = ob.make_config(solution_mode="speed")  # SolverConfig::default: max_time 0.1 s is never reached on these targets
+
+    def calls(n_threads, rule):
+        lat, solved = [], 0
+        for t in range(lo, hi):
+            t0 = time.perf_counter()
+            r = ob.ik(ch, dcfg, pose7[t], x0s[t], 0, 1 << 20, n_threads=n_threads, early_exit=rule)
+            lat.append(time.perf_counter() - t0)
+            solved += bool(r["found"])
+        lat.sort()
+        return {"median_ms": lat[len(lat) // 2] * 1e3, "p90_ms": lat[int(len(lat) * 0.9)] * 1e3, "solved": solved,
+                "calls": len(lat)}
+    single = {"1_thread": calls(1, True)}
+    if cores > 1:
+        ob.pool_start(cores)
+        try:
+            single[f"{cores}_threads_find_any"] = calls(cores, "find_any")
+        finally:
+            ob.pool_stop()
+    single["workload"] = ("the 300 targets of config.other_configs.single_ik, one ok_ik call each through ctypes: 1 thread (restarts in "
+                          "index order, early exit), and all usable cores under the reference's find_any rule (lib.rs:409-412: the "
+                          "first success in time wins, the others stop at their next objective call) on persistent worker threads")
+    # config 5: one call per target (1 thread each, restart indices 0..255, early exit), the targets spread over the cores
+    T = len(pose7)
+    c5cfg = ob.make_config(solution_mode="speed", max_restarts=256)
+    found = [False] * T
+
+    def work(a, b):
+        for t in range(a, b):
+            found[t] = ob.ik(ch, c5cfg, pose7[t], x0s[t], 0, 256, n_threads=1, early_exit=True)["found"]
+    th = [threading.Thread(target=work, args=(k * T // cores, (k + 1) * T // cores)) for k in range(cores)]
+    t0 = time.perf_counter()
+    [x.start() for x in th]
+    [x.join() for x in th]
+    dt = time.perf_counter() - t0
+    return {"single_ik_ms": single,
+            "config5_ik_calls_per_s": T / dt,
+            "config5": {"targets": T, "seconds": dt, "solved": int(sum(bool(v) for v in found)), "threads": cores,
+                        "workload": "the 4 096 targets of config.other_configs.config5_all_4096_targets (host-API leg), one ok_ik call per "
+                                    "target (Speed, restart indices 0..255 in order, early exit), the targets cut over the cores"}}
 
 
 def spawn_ranks(n):
@@ -450,7 +505,25 @@ def run_workload(ctx, robot_name, mode, scaling, T, R, K, W, reps, find_any=Fals
     return res
 
 
-def other_configs_one_gpu(ctx, args, primary):
+def user_inputs(ctx):
+    """The targets of the two user-facing legs (a single ik(), config 5 through the host API): 4 096 reachable Panda poses
+    FK(q), q and the seeds uniform in the limits -- as pose7 (for the CPU oracle) and as 4x4 matrices (for Robot.ik)."""
+    robot, hc = ctx.robot("panda")
+    rng = np.random.default_rng(5)
+    lb, ub = (np.array(v) for v in robot.joint_limits())
+    T = 4096
+    pose = hc.fk_batch(torch.tensor(rng.uniform(lb, ub, size=(T, 7)).T.copy(), device=ctx.dev)).T.cpu().numpy()
+    i, j, k, w = pose[:, 3], pose[:, 4], pose[:, 5], pose[:, 6]
+    m = np.zeros((T, 4, 4))
+    m[:, 0, 0] = w*w+i*i-j*j-k*k; m[:, 0, 1] = 2*(i*j-w*k); m[:, 0, 2] = 2*(w*j+i*k)
+    m[:, 1, 0] = 2*(w*k+i*j); m[:, 1, 1] = w*w-i*i+j*j-k*k; m[:, 1, 2] = 2*(j*k-w*i)
+    m[:, 2, 0] = 2*(i*k-w*j); m[:, 2, 1] = 2*(w*i+j*k); m[:, 2, 2] = w*w-i*i-j*j+k*k
+    m[:, :3, 3] = pose[:, :3]
+    m[:, 3, 3] = 1.0
+    return {"pose7": pose, "m": m, "x0s": rng.uniform(lb, ub, size=(T, 7)), "single_ik_range": (64, 64 + 300)}
+
+
+def other_configs_one_gpu(ctx, args, primary, user):
     """N = 1, the default command: the rest of BASELINE.json's configurations and the latency figures, each in a
     short run of its own (about ten seconds in all), so that the driver's ONE line carries the whole contract."""
     from optik_amd import SolverConfig
@@ -518,27 +591,17 @@ def other_configs_one_gpu(ctx, args, primary):
                      "ms_per_batch_deterministic": r5["elapsed"] / 2 * 1e3, "ms_per_batch_find_any": r5f["elapsed"] / 2 * 1e3,
                      "solved_targets_of": [r5["solved_targets"], 2 * T]}
     # ... and the same 4096 through the host API (numpy in, numpy out: PCIe and the 4x4 -> pose conversion included)
-    rng = np.random.default_rng(5)
-    lb, ub = (np.array(v) for v in robot.joint_limits())
     T = 4096
-    pose = hc.fk_batch(torch.tensor(rng.uniform(lb, ub, size=(T, 7)).T.copy(), device=dev)).T.cpu().numpy()
-    i, j, k, w = pose[:, 3], pose[:, 4], pose[:, 5], pose[:, 6]
-    m = np.zeros((T, 4, 4))
-    m[:, 0, 0] = w*w+i*i-j*j-k*k; m[:, 0, 1] = 2*(i*j-w*k); m[:, 0, 2] = 2*(w*j+i*k)
-    m[:, 1, 0] = 2*(w*k+i*j); m[:, 1, 1] = w*w-i*i+j*j-k*k; m[:, 1, 2] = 2*(j*k-w*i)
-    m[:, 2, 0] = 2*(i*k-w*j); m[:, 2, 1] = 2*(w*i+j*k); m[:, 2, 2] = w*w-i*i-j*j+k*k
-    m[:, :3, 3] = pose[:, :3]
-    m[:, 3, 3] = 1.0
-    x0s = rng.uniform(lb, ub, size=(T, 7))
+    m, x0s = user["m"], user["x0s"]
     scfg = SolverConfig(solution_mode="speed", max_time=0.0, max_restarts=256)
     med, _ = timed(lambda: robot.ik_batch_arrays(scfg, m, x0s), 5)
     out["config5_all_4096_targets"]["ik_calls_per_s_host_api"] = T / med
     # a single ik() through the C ABI (the reference's own timing loop: examples/example.rs:16-42), default SolverConfig
     lat, n_solved = [], 0
     dcfg = SolverConfig()
-    for t in range(64):
+    for t in range(user["single_ik_range"][0]):
         robot.ik(dcfg, m[t], x0s[t].tolist())
-    for t in range(64, 64 + 300):
+    for t in range(*user["single_ik_range"]):
         t0 = time.perf_counter()
         r = robot.ik(dcfg, m[t], x0s[t].tolist())
         lat.append(time.perf_counter() - t0)
@@ -632,7 +695,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip config.other_configs (profiling runs: only the headline workload's kernels in the trace)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=13.0,
+                    help="budget of the restarts/s legs of cpu_baseline (the user-facing legs add ~1 s)")
     args = ap.parse_args()
     if args.restarts is None:
         args.restarts = 256 if args.targets else 65536
@@ -708,14 +772,28 @@ def main():
     primary = run_workload(ctx, args.robot, mode, args.scaling, T, R, K, W, args.reps, args.find_any, min_timed_s=2.0)
     # the other workloads of the same invocation (every rank takes part in the multi-rank ones)
     headline = args.robot == "panda" and not T and mode == "speed" and args.scaling == "weak" and R == 65536
+    want_others = not args.no_other_configs and headline
+    # Order of the legs at N = 1: GPU (the headline above), CPU (the oracle baseline), GPU (the other configurations) -- the
+    # driver's 5-s GPU-busy sampler then meets GPU work at both ends of the run instead of ~11 s of CPU work at its end.
+    user = None
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not T:
+        if want_others and not args.force_distributed:
+            try:
+                user = user_inputs(ctx)
+            except Exception:  # noqa: BLE001
+                user = None
+        cpu = cpu_baseline(args.robot, primary["robot"].chain_tables(), primary["targets"][W].cpu().numpy(),
+                           primary["x0_host"][W], mode, args.cpu_seconds, user)
+        cpu["gpu_winner_same_target"] = int(primary["winners"][0, 0].item())
     others = None
-    if not args.no_other_configs and headline:
+    if want_others:
         # (a failure here -- the same on every rank: same code, same sizes -- must not cost the headline line)
         try:
             if world > 1:
                 others = other_configs_multi_gpu(ctx, args)
             elif not args.force_distributed:
-                others = other_configs_one_gpu(ctx, args, primary)
+                others = other_configs_one_gpu(ctx, args, primary, user or user_inputs(ctx))
         except Exception as e:  # noqa: BLE001
             others = {"error": f"{type(e).__name__}: {e}"[:300]}
     coll_us = collective_latency(ctx)
@@ -736,11 +814,6 @@ def main():
             kname = "wide_solve_kernel" if wide_hbm else "wide_solve_coop_kernel"
         kp = (pmc or {}).get("kernel_path")
         traffic, traffic_note, secondary = None, f"no PMC pass of this command under profiles/ (key: {key})", None
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline and not T:
-            cpu = cpu_baseline(args.robot, robot.chain_tables(), primary["targets"][W].cpu().numpy(),
-                               primary["x0_host"][W], mode, args.cpu_seconds)
-            cpu["gpu_winner_same_target"] = int(winners[0, 0].item())
         oflops = ((cpu or {}).get("oracle_flops") or {}).get("per_restart")
         if kp or oflops:
             secondary = {"bound": "valu_f64", "peak": F64_VALU_PEAK_TFLOPS, "peak_no_fma": F64_VALU_NOFMA_TFLOPS, "unit": "TFLOP/s"}
@@ -844,6 +917,11 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
         }
+        if cpu and others is not None and "single_ik" in others and "single_ik_ms" in cpu:
+            # the CPU figure beside each user-facing GPU figure (same targets): a GPU/CPU ratio is not credit -- for one default
+            # ik() call the MI355X is on par with ONE host thread, which is what section 8.3 of DESIGN.md says it must be
+            others["single_ik"]["cpu_median_ms"] = {k: v["median_ms"] for k, v in cpu["single_ik_ms"].items() if isinstance(v, dict)}
+            others["config5_all_4096_targets"]["cpu_ik_calls_per_s"] = cpu["config5_ik_calls_per_s"]
         if cpu and others is not None:
             others["config1_cpu_1_thread"] = {"workload": "Panda, the bench target, the CPU oracle on ONE host thread (BASELINE config 1: "
                                                           "plumbing, no GPU)", "restarts_per_s": cpu["value_1_thread"],

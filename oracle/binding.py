@@ -109,6 +109,7 @@ def use_native_build() -> str:
                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     except (OSError, subprocess.CalledProcessError):
         return "portable: -O3 -ffp-contract=off (native build failed)"
+    pool_stop()
     _lib, _lib_path = None, out
     return "gcc " + " ".join(NATIVE_FLAGS)
 
@@ -123,12 +124,14 @@ def use_libm_build() -> str:
     deps = (src, os.path.join(_HERE, "optik_oracle.h"))
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.check_call(["gcc", *NATIVE_FLAGS, "-DOK_PLATFORM_LIBM", "-shared", "-o", out, src, "-lm", "-lpthread"])
+    pool_stop()
     _lib, _lib_path = None, out
     return "gcc " + " ".join(NATIVE_FLAGS) + " -DOK_PLATFORM_LIBM"
 
 
 def use_portable_build():
     global _lib, _lib_path
+    pool_stop()
     _lib, _lib_path = None, _LIB_PATH
 
 
@@ -145,6 +148,7 @@ def use_flops_build() -> str:
     deps = (src, os.path.join(_HERE, "optik_oracle.c"), os.path.join(_HERE, "optik_oracle.h"))
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.check_call(["g++", *FLOPS_FLAGS, "-shared", "-o", out, src, "-lm", "-lpthread"], cwd=_HERE)
+    pool_stop()
     _lib, _lib_path = None, out
     return "g++ " + " ".join(FLOPS_FLAGS)
 
@@ -203,6 +207,8 @@ def lib():
         L.ok_ik.restype = C.c_int
         L.ok_lsq_direction.argtypes = [C.c_int, dp, dp, dp, dp, dp]
         L.ok_lsq_direction.restype = C.c_int
+        L.ok_pool_start.argtypes = [C.c_int]
+        L.ok_pool_start.restype = C.c_int
         _lib = L
     return _lib
 
@@ -371,8 +377,10 @@ def ik(chain: Chain, cfg: Config, target7, x0, restart_begin: int, restart_end: 
     x = np.zeros(n)
     f = C.c_double(0.0)
     pr = (RestartResult * cnt)() if per_restart else None
+    # (early_exit: False / True = the deterministic reading; "find_any" or 2 = the reference's multi-thread rule)
+    ee_mode = 2 if early_exit in (2, "find_any") else int(bool(early_exit))
     found = lib().ok_ik(C.byref(chain), C.byref(cfg), C.byref(tgt), C.byref(ee_off), _dp(x0),
-                        restart_begin, restart_end, n_threads, int(early_exit),
+                        restart_begin, restart_end, n_threads, ee_mode,
                         C.byref(winner), _dp(x), C.byref(f), pr, C.byref(n_run))
     out = dict(found=bool(found), winner=winner.value, x=x, f=f.value, n_run=n_run.value)
     if per_restart:
@@ -383,6 +391,16 @@ def ik(chain: Chain, cfg: Config, target7, x0, restart_begin: int, restart_end: 
                    evals=raw["n_evals"].copy(), iters=raw["n_iters"].copy(),
                    fs=raw["f"].copy(), xs=raw["x"][:, :n].copy())
     return out
+
+
+def pool_start(n_threads: int) -> int:
+    """Persistent worker threads for ik(..., n_threads == n) (rayon's pool); pool_stop() / a build switch ends them."""
+    return int(lib().ok_pool_start(int(n_threads)))
+
+
+def pool_stop():
+    if _lib is not None:
+        _lib.ok_pool_stop()
 
 
 def lsq_direction(l_packed, g, lo, hi):

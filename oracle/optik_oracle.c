@@ -1288,6 +1288,10 @@ static int stop_x(int n, const double *x, const double *oldx, double xtol_abs) {
 #define OK_MAX_EVALS_CAP 100000
 
 /* nlopt_slsqp() driver + the closure of lib.rs:301-391 for one restart. */
+/* find_any runs (ok_ik with early_exit == 2, the baseline leg of bench.py): the word the objective callback
+ * looks at before every evaluation -- lib.rs:308 `if should_exit.load() { force_stop }`.  NULL: never stop. */
+static __thread const int *ok_tls_should_exit = NULL;
+
 void ok_solve_restart(const ok_chain *c, const ok_config *cfg, const ok_pose *target,
                       const ok_pose *ee_offset, const double *x0, uint64_t restart_index,
                       ok_restart_result *out, double *trace, int trace_cap, int *trace_len) {
@@ -1314,6 +1318,10 @@ void ok_solve_restart(const ok_chain *c, const ok_config *cfg, const ok_pose *ta
     /* NLopt: "eval once before calling slsqp the first time" */
     int do_eval = 1, want_grad = 1;
     for (;;) {
+        if (do_eval && ok_tls_should_exit && __atomic_load_n(ok_tls_should_exit, __ATOMIC_RELAXED)) {
+            ret = OK_RES_FORCED_STOP; /* lib.rs:308-311 */
+            break;
+        }
         if (do_eval) {
             st.f = ok_eval(c, target, ee_offset, cfg->linear_weight, cfg->angular_weight, st.x,
                            want_grad ? st.g : NULL);
@@ -1387,7 +1395,8 @@ typedef struct {
     const double *x0;
     uint64_t begin, end;
     uint64_t next;          /* shared restart counter (rayon analogue) */
-    int early_exit;
+    int early_exit;         /* 1: deterministic reading (lowest index wins); 2: find_any (lib.rs:409-412) */
+    int any_found;          /* find_any: the reference's should_exit word (lib.rs:269, 382-384) */
     uint64_t first_success; /* lowest successful index seen so far (Speed) */
     ok_restart_result *per_restart;
     /* winner state */
@@ -1413,28 +1422,86 @@ static void *ik_worker(void *arg) {
         /* Speed + early exit: restarts above a known success cannot win (the
          * reference's should_exit flag, lib.rs:308,382-384, in its 1-thread
          * deterministic reading: lowest index wins). */
-        if (speed && job->early_exit
+        if (speed && job->early_exit == 1
             && i > __atomic_load_n(&job->first_success, __ATOMIC_RELAXED))
             break;
+        /* find_any (the reference's own multi-thread rule): ANY success ends every other restart at its next
+         * objective call -- the answer is whichever restart got there first */
+        if (speed && job->early_exit == 2) {
+            if (__atomic_load_n(&job->any_found, __ATOMIC_RELAXED)) break;
+            ok_tls_should_exit = &job->any_found;
+        }
         ok_restart_result r;
         ok_solve_restart(job->c, job->cfg, job->target, job->ee_offset, job->x0, i, &r, NULL, 0,
                          NULL);
+        ok_tls_should_exit = NULL;
         if (job->per_restart) job->per_restart[i - job->begin] = r;
         pthread_mutex_lock(&job->mu);
         job->n_run += 1;
         if (r.success) {
             double key = speed ? (double)i : dist_to_seed(n, r.x, job->x0);
-            int better = !job->have || key < job->key || (key == job->key && i < job->winner);
+            int better = !job->have || (job->early_exit != 2 && (key < job->key || (key == job->key && i < job->winner)));
             if (better) {
                 job->have = 1; job->winner = i; job->key = key; job->f = r.f;
                 memcpy(job->x, r.x, sizeof job->x);
             }
             if (speed && i < job->first_success)
                 __atomic_store_n(&job->first_success, i, __ATOMIC_RELAXED);
+            if (speed && job->early_exit == 2) __atomic_store_n(&job->any_found, 1, __ATOMIC_RELAXED);
         }
         pthread_mutex_unlock(&job->mu);
     }
     return NULL;
+}
+
+/* A persistent pool of worker threads for ok_ik (the baseline leg of bench.py: rayon keeps its workers between calls,
+ * lib.rs:297-300; creating sixteen threads per call costs more than a Panda ik() takes).  ok_pool_start(n): n workers
+ * parked on a condition variable; ok_ik(..., n_threads == n) then hands them the job instead of creating threads. */
+#define OK_POOL_MAX 256
+static struct {
+    pthread_t th[OK_POOL_MAX];
+    int n, quit, pending;
+    unsigned long gen;
+    ik_job *job;
+    pthread_mutex_t mu;
+    pthread_cond_t go, done;
+} ok_pool = {.n = 0, .mu = PTHREAD_MUTEX_INITIALIZER, .go = PTHREAD_COND_INITIALIZER, .done = PTHREAD_COND_INITIALIZER};
+
+static void *ok_pool_worker(void *arg) {
+    (void)arg;
+    unsigned long seen = 0;
+    for (;;) {
+        pthread_mutex_lock(&ok_pool.mu);
+        while (ok_pool.gen == seen && !ok_pool.quit) pthread_cond_wait(&ok_pool.go, &ok_pool.mu);
+        if (ok_pool.quit) { pthread_mutex_unlock(&ok_pool.mu); return NULL; }
+        seen = ok_pool.gen;
+        ik_job *job = ok_pool.job;
+        pthread_mutex_unlock(&ok_pool.mu);
+        ik_worker(job);
+        pthread_mutex_lock(&ok_pool.mu);
+        if (--ok_pool.pending == 0) pthread_cond_signal(&ok_pool.done);
+        pthread_mutex_unlock(&ok_pool.mu);
+    }
+}
+
+void ok_pool_stop(void) {
+    if (!ok_pool.n) return;
+    pthread_mutex_lock(&ok_pool.mu);
+    ok_pool.quit = 1;
+    pthread_cond_broadcast(&ok_pool.go);
+    pthread_mutex_unlock(&ok_pool.mu);
+    for (int t = 0; t < ok_pool.n; ++t) pthread_join(ok_pool.th[t], NULL);
+    ok_pool.n = 0; ok_pool.quit = 0;
+}
+
+int ok_pool_start(int n_threads) {
+    ok_pool_stop();
+    if (n_threads < 2) return 0;
+    if (n_threads > OK_POOL_MAX) n_threads = OK_POOL_MAX;
+    for (int t = 0; t < n_threads; ++t)
+        if (pthread_create(&ok_pool.th[t], NULL, ok_pool_worker, NULL) != 0) { ok_pool.n = t; ok_pool_stop(); return -1; }
+    ok_pool.n = n_threads;
+    return n_threads;
 }
 
 int ok_ik(const ok_chain *c, const ok_config *cfg, const ok_pose *target,
@@ -1445,12 +1512,20 @@ int ok_ik(const ok_chain *c, const ok_config *cfg, const ok_pose *target,
     memset(&job, 0, sizeof job);
     job.c = c; job.cfg = cfg; job.target = target; job.ee_offset = ee_offset; job.x0 = x0;
     job.begin = restart_begin; job.end = restart_end; job.next = restart_begin;
-    job.early_exit = early_exit && !per_restart;
+    job.early_exit = per_restart ? 0 : early_exit;
     job.first_success = UINT64_MAX;
     job.per_restart = per_restart;
     pthread_mutex_init(&job.mu, NULL);
     if (n_threads <= 1) {
         ik_worker(&job);
+    } else if (ok_pool.n == n_threads) {
+        pthread_mutex_lock(&ok_pool.mu);
+        ok_pool.job = &job;
+        ok_pool.pending = ok_pool.n;
+        ++ok_pool.gen;
+        pthread_cond_broadcast(&ok_pool.go);
+        while (ok_pool.pending) pthread_cond_wait(&ok_pool.done, &ok_pool.mu);
+        pthread_mutex_unlock(&ok_pool.mu);
     } else {
         pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
         for (int t = 0; t < n_threads; ++t) pthread_create(&th[t], NULL, ik_worker, &job);

@@ -149,12 +149,19 @@ void ok_solve_restart(const ok_chain *c, const ok_config *cfg, const ok_pose *ta
  * Returns 1 and fills winner/x/f when any restart succeeded, else 0.
  * per_restart (optional) receives every restart's result (no early exit is
  * taken when it is non-NULL or when early_exit == 0).  n_threads >= 1: restart
- * indices are handed out dynamically from a shared counter (rayon analogue). */
+ * indices are handed out dynamically from a shared counter (rayon analogue).
+ * early_exit == 2 (Speed): the reference's own multi-thread rule, find_any (lib.rs:409-412): the first success in
+ * TIME wins and every other restart stops at its next objective call (lib.rs:308) -- a valid answer, not a fixed
+ * one; used by bench.py's CPU baseline only, never by a parity test. */
 int ok_ik(const ok_chain *c, const ok_config *cfg, const ok_pose *target,
           const ok_pose *ee_offset, const double *x0, uint64_t restart_begin,
           uint64_t restart_end, int n_threads, int early_exit, uint64_t *winner,
           double *x_out, double *f_out, ok_restart_result *per_restart,
           uint64_t *n_restarts_run);
+
+/* Persistent worker threads for ok_ik calls with n_threads == n (what rayon's pool is to Robot::ik); 0 stops them. */
+int ok_pool_start(int n_threads);
+void ok_pool_stop(void);
 
 /* Direction sub-problem of one SLSQP major iteration, exposed for tests:
  * min 1/2 s'LDL's + g's  s.t. lo <= s <= hi   via Kraft's LSQ->LSI->LDP->NNLS.
