@@ -181,7 +181,6 @@ def cpu_baseline(robot_name, chain_tables, target7, x0, mode, seconds_budget=15.
 def cpu_user_figures(ob, ch, cores, inp):
     """The CPU oracle on the SAME inputs as the GPU legs `single_ik` (300 Robot.ik() calls, default SolverConfig) and
     `config5_all_4096_targets` (4 096 targets x at most 256 restarts, Speed, early exit).  ~1 s."""
-    import threading
     pose7, x0s = inp["pose7"], inp["x0s"]
     lo, hi = inp["single_ik_range"]
     dcfg = ob.make_config(solution_mode="speed")  # SolverConfig::default: max_time 0.1 s is never reached on these targets
@@ -206,24 +205,22 @@ def cpu_user_figures(ob, ch, cores, inp):
     single["workload"] = ("the 300 targets of config.other_configs.single_ik, one ok_ik call each through ctypes: 1 thread (restarts in "
                           "index order, early exit), and all usable cores under the reference's find_any rule (lib.rs:409-412: the "
                           "first success in time wins, the others stop at their next objective call) on persistent worker threads")
-    # config 5: one call per target (1 thread each, restart indices 0..255, early exit), the targets spread over the cores
+    # config 5: one call per target (1 thread each, restart indices 0..255, early exit), the targets handed out to the
+    # cores from a shared counter -- in C (ok_ik_many): sixteen Python threads calling through ctypes spend their time on
+    # the interpreter lock, not on the solver
     T = len(pose7)
     c5cfg = ob.make_config(solution_mode="speed", max_restarts=256)
-    found = [False] * T
-
-    def work(a, b):
-        for t in range(a, b):
-            found[t] = ob.ik(ch, c5cfg, pose7[t], x0s[t], 0, 256, n_threads=1, early_exit=True)["found"]
-    th = [threading.Thread(target=work, args=(k * T // cores, (k + 1) * T // cores)) for k in range(cores)]
-    t0 = time.perf_counter()
-    [x.start() for x in th]
-    [x.join() for x in th]
-    dt = time.perf_counter() - t0
+    # (the best of three passes: the first one also wakes the host's idle cores)
+    found, dt = None, float("inf")
+    for _ in range(3):
+        found, _, d1 = ob.ik_many(ch, c5cfg, pose7, x0s, 256, cores)
+        dt = min(dt, d1)
     return {"single_ik_ms": single,
             "config5_ik_calls_per_s": T / dt,
             "config5": {"targets": T, "seconds": dt, "solved": int(sum(bool(v) for v in found)), "threads": cores,
-                        "workload": "the 4 096 targets of config.other_configs.config5_all_4096_targets (host-API leg), one ok_ik call per "
-                                    "target (Speed, restart indices 0..255 in order, early exit), the targets cut over the cores"}}
+                        "workload": "the 4 096 targets of config.other_configs.config5_all_4096_targets (host-API leg), one single-threaded "
+                                    "ok_ik per target (Speed, restart indices 0..255 in order, early exit), the targets handed out to the "
+                                    "cores from a shared counter (ok_ik_many, in C)"}}
 
 
 def spawn_ranks(n):

@@ -393,6 +393,28 @@ def ik(chain: Chain, cfg: Config, target7, x0, restart_begin: int, restart_end: 
     return out
 
 
+def ik_many(chain: Chain, cfg: Config, targets7, x0s, n_restarts: int, n_threads: int):
+    """T independent ik() calls in C (one thread per call, targets handed out to n_threads): found [T] (bool), xs [T, n]."""
+    targets7 = _f64(targets7)
+    x0s = _f64(x0s)
+    T, n = targets7.shape[0], chain.n_pos
+    tg = (Pose * T)()
+    for t in range(T):
+        tg[t].t[:] = targets7[t, :3].tolist()
+        tg[t].q[:] = targets7[t, 3:].tolist()
+    ee = Pose.make()
+    found = np.zeros(T, dtype=np.int32)
+    xs = np.zeros((T, n))
+    L = lib()
+    L.ok_ik_many.argtypes = [C.POINTER(Chain), C.POINTER(Config), C.POINTER(Pose), C.POINTER(Pose), C.POINTER(C.c_double),
+                             C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    t0 = __import__("time").perf_counter()
+    L.ok_ik_many(C.byref(chain), C.byref(cfg), tg, C.byref(ee), _dp(x0s), T, int(n_restarts), int(n_threads),
+                 found.ctypes.data_as(C.POINTER(C.c_int32)), _dp(xs))
+    dt = __import__("time").perf_counter() - t0
+    return found != 0, xs, dt
+
+
 def pool_start(n_threads: int) -> int:
     """Persistent worker threads for ik(..., n_threads == n) (rayon's pool); pool_stop() / a build switch ends them."""
     return int(lib().ok_pool_start(int(n_threads)))

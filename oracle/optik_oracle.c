@@ -1540,3 +1540,38 @@ int ok_ik(const ok_chain *c, const ok_config *cfg, const ok_pose *target,
     if (f_out) *f_out = job.f;
     return 1;
 }
+
+/* Many independent ik() calls (BASELINE config 5 on the CPU, bench.py's baseline leg): target t of T gets one
+ * single-threaded ok_ik over restart indices [0, n_restarts) with early exit; the targets are handed out to
+ * n_threads threads from a shared counter (what a user of the reference would write with rayon over targets). */
+typedef struct {
+    const ok_chain *c; const ok_config *cfg; const ok_pose *targets; const ok_pose *ee_offset; const double *x0s;
+    uint64_t n_restarts; int T; int next; int32_t *found; double *xs;
+} many_job;
+
+static void *many_worker(void *arg) {
+    many_job *job = (many_job *)arg;
+    const int n = job->c->n_pos;
+    for (;;) {
+        int t = __atomic_fetch_add(&job->next, 1, __ATOMIC_RELAXED);
+        if (t >= job->T) break;
+        uint64_t w = 0; double f = 0.0;
+        double x[SQ_N];
+        int ok = ok_ik(job->c, job->cfg, &job->targets[t], job->ee_offset, job->x0s + (size_t)t * (size_t)n, 0,
+                       job->n_restarts, 1, 1, &w, x, &f, NULL, NULL);
+        job->found[t] = ok;
+        if (ok && job->xs) memcpy(job->xs + (size_t)t * (size_t)n, x, (size_t)n * sizeof(double));
+    }
+    return NULL;
+}
+
+int ok_ik_many(const ok_chain *c, const ok_config *cfg, const ok_pose *targets, const ok_pose *ee_offset,
+               const double *x0s, int T, uint64_t n_restarts, int n_threads, int32_t *found, double *xs) {
+    many_job job = {c, cfg, targets, ee_offset, x0s, n_restarts, T, 0, found, xs};
+    if (n_threads <= 1) { many_worker(&job); return 0; }
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    for (int t = 0; t < n_threads; ++t) pthread_create(&th[t], NULL, many_worker, &job);
+    for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
+    free(th);
+    return 0;
+}

@@ -159,6 +159,11 @@ int ok_ik(const ok_chain *c, const ok_config *cfg, const ok_pose *target,
           double *x_out, double *f_out, ok_restart_result *per_restart,
           uint64_t *n_restarts_run);
 
+/* T independent single-threaded ik() calls (restart indices 0 .. n_restarts-1 each, Speed early exit) spread over
+ * n_threads threads; found[t] = solved, xs (optional) [T][n].  bench.py's CPU figure for BASELINE config 5. */
+int ok_ik_many(const ok_chain *c, const ok_config *cfg, const ok_pose *targets, const ok_pose *ee_offset,
+               const double *x0s, int T, uint64_t n_restarts, int n_threads, int32_t *found, double *xs);
+
 /* Persistent worker threads for ok_ik calls with n_threads == n (what rayon's pool is to Robot::ik); 0 stops them. */
 int ok_pool_start(int n_threads);
 void ok_pool_stop(void);
