@@ -72,7 +72,7 @@ F64_VALU_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 16 f64 lanes/clk x 2 (FMA) x 
 # ... and what this path can reach at best: -ffp-contract=off (rustc never fuses a*b+c, and the
 # bit-exactness contract with the oracle forbids it) makes every f64 instruction ONE flop
 F64_VALU_NOFMA_TFLOPS = 39.3
-PMC_FILES = [os.path.join(ROOT, "profiles", f"r{r}_pmc_by_command.json") for r in (5, 4, 3, 2)]
+PMC_FILES = [os.path.join(ROOT, "profiles", f"r{r}_pmc_by_command.json") for r in (6, 5, 4)]
 PMC_FILE = PMC_FILES[0]
 ROBOT_SPECS = {"panda": ("panda.urdf", "panda_link0", "panda_link8"),
                "ur10": ("ur10.urdf", "base_link", "ee_link"),

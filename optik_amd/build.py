@@ -263,6 +263,15 @@ def build(force: bool = False, verbose: bool = False, jobs: int | None = None) -
     return LIB
 
 
+def print_resources():
+    """Registers / scratch / LDS / occupancy of every kernel of the library as built (what the compiler reported)."""
+    print("%-44s %5s %5s %5s %9s %7s %10s" % ("kernel", "VGPR", "AGPR", "SGPR", "scratch B", "LDS B", "waves/SIMD"))
+    for name, r in sorted(kernel_resources().items()):
+        print("%-44s %5d %5d %5d %9d %7d %10d" % (name, r["vgpr"], r["agpr"], r["sgpr"], r["scratch"], r["lds"], r["occupancy"]))
+    print("# " + str(toolchain_version()))
+
+
 if __name__ == "__main__":
-    import sys
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--resources" in sys.argv:
+        print_resources()

@@ -69,8 +69,8 @@ rec["bench_value_unprofiled"] = line["value"]
 json.dump(rec, open(f"{out}/pmc_kernel_path.json", "w"), indent=1)
 print(json.dumps(rec, indent=1))
 # ... and into the round's by-command file (what bench.py reads roofline.traffic and the VALU scalars from): copy
-# gpurun_out/r5_pmc_by_command.json to profiles/ to make it the record of that command
-by_cmd = "gpurun_out/r5_pmc_by_command.json"
+# gpurun_out/r6_pmc_by_command.json to profiles/ to make it the record of that command
+by_cmd = "gpurun_out/r6_pmc_by_command.json"
 try:
     doc = json.load(open(by_cmd))
 except (OSError, ValueError):
