@@ -1464,8 +1464,10 @@ static struct {
     unsigned long gen;
     ik_job *job;
     pthread_mutex_t mu;
+    pthread_mutex_t user;  /* one ok_ik call at a time hands a job to the pool */
     pthread_cond_t go, done;
-} ok_pool = {.n = 0, .mu = PTHREAD_MUTEX_INITIALIZER, .go = PTHREAD_COND_INITIALIZER, .done = PTHREAD_COND_INITIALIZER};
+} ok_pool = {.n = 0, .mu = PTHREAD_MUTEX_INITIALIZER, .user = PTHREAD_MUTEX_INITIALIZER, .go = PTHREAD_COND_INITIALIZER,
+             .done = PTHREAD_COND_INITIALIZER};
 
 static void *ok_pool_worker(void *arg) {
     (void)arg;
@@ -1519,6 +1521,7 @@ int ok_ik(const ok_chain *c, const ok_config *cfg, const ok_pose *target,
     if (n_threads <= 1) {
         ik_worker(&job);
     } else if (ok_pool.n == n_threads) {
+        pthread_mutex_lock(&ok_pool.user);
         pthread_mutex_lock(&ok_pool.mu);
         ok_pool.job = &job;
         ok_pool.pending = ok_pool.n;
@@ -1526,6 +1529,7 @@ int ok_ik(const ok_chain *c, const ok_config *cfg, const ok_pose *target,
         pthread_cond_broadcast(&ok_pool.go);
         while (ok_pool.pending) pthread_cond_wait(&ok_pool.done, &ok_pool.mu);
         pthread_mutex_unlock(&ok_pool.mu);
+        pthread_mutex_unlock(&ok_pool.user);
     } else {
         pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
         for (int t = 0; t < n_threads; ++t) pthread_create(&th[t], NULL, ik_worker, &job);
