@@ -364,7 +364,7 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     const bool quadk = !widek;
     // the throughput form for n <= 7: one restart per lane, bounded sub-problems in class order (ik_lane64.hpp)
     // (the default from one full load of the chip on -- 64 restarts for each of its four waves per CU: below that a
-    // launch is as long as its longest restart, and the quad solver's trip is the shorter one; lane_vs_quad_probe.py (a tool of rounds 3-5: git history))
+    // launch is as long as its longest restart, and the quad solver's trip is the shorter one; lane_vs_quad_probe.py (a rounds 3-5 tool: git history))
     bool lanek = quadk && ch->n <= 7 && sk != SK_QUAD;
     const bool lane_forced = lanek && sk == SK_LANE64;
     // Persistent waves, each pulling work items until the queue is dry: as many as a CU holds
@@ -402,7 +402,7 @@ static int ik_batch_locked(optik_hip_chain *ch, const optik_solver_config *cfg, 
     // The general solver's two forms (ik_wide.hpp): one restart per wave with its arrays in LDS and the wave's 64
     // lanes working on it together, or a restart per lane with the HBM workspace.  The first has the short
     // dependent chain and no HBM traffic, the second 64 times the restarts in flight -- and the first wins at
-    // every size and joint count measured (wide_chain_bench.py (a tool of rounds 3-5: git history), 262 144 restarts: 1.31 / 0.88 / 0.83 / 1.26 M
+    // every size and joint count measured (wide_chain_bench.py (a rounds 3-5 tool: git history), 262 144 restarts: 1.31 / 0.88 / 0.83 / 1.26 M
     // restarts/s at 9 / 10 / 12 / 16 joints against 1.05 / 0.66 / 0.42 / 0.40 M; a launch on the HBM form takes
     // 50 - 100 ms however small it is).  Option wide_form = hbm selects the HBM form (tests, comparisons).
     bool wide_lds = false;

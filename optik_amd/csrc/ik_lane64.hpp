@@ -196,7 +196,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
     target.q = Q4{0, 0, 0, 1};
 
     // (-DOPTIK_PROFILE: wave cycles per part of a trip -- 0 refill, 1 evaluation, 4 bookkeeping + BFGS, 5 LSQ factor +
-    // records, 2 first NNLS pass, 6 ranking + NNLS, 3 LDP tail .. publish, 7 trips; phase_profile.py (a tool of rounds 3-5: git history) lane)
+    // records, 2 first NNLS pass, 6 ranking + NNLS, 3 LDP tail .. publish, 7 trips; phase_profile.py (a rounds 3-5 tool: git history) lane)
 #ifdef OPTIK_PROFILE
     unsigned long long lp_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long lt_ = __builtin_readcyclecounter();
@@ -301,7 +301,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
         double gn[N];
         double fn = 0.0;
         OPTIK_SCHED_FENCE_LANE64();
-#ifdef OPTIK_LANE_EXP_DUP_EVAL  // (cost-by-duplication experiments, lane_dup_costs.sh (a tool of rounds 3-5: git history): same results, the phase runs twice)
+#ifdef OPTIK_LANE_EXP_DUP_EVAL  // (cost-by-duplication experiments, lane_dup_costs.sh (a rounds 3-5 tool: git history): same results, the phase runs twice)
         if (do_eval) {
             double xx[N], g0[N];
 #pragma unroll

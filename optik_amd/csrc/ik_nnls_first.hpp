@@ -1,7 +1,7 @@
 // ik_nnls_first.hpp -- the FIRST pass of Lawson-Hanson's NNLS on a lane's own bounded sub-problem, per lane.
 //
 // Of the bounded sub-problems the kernels solve, 45 % end after one solve pass with one active bound
-// (nnls_pass_hist.py (a tool of rounds 3-5: git history): the column with the largest dual enters, its multiplier comes out positive, no other
+// (nnls_pass_hist.py (a rounds 3-5 tool: git history): the column with the largest dual enters, its multiplier comes out positive, no other
 // dual is positive afterwards).  The quad NNLS (ik_nnls_quad.hpp) spends two loop trips of a four-lane quad on each of
 // them -- a third of its quad-trips -- at one wave per SIMD and sixteen unrelated problems per instruction.  Here
 // every lane of the lane-per-restart form runs that first pass on its OWN problem, 64 problems per instruction,

@@ -48,7 +48,7 @@ template <int N>
 constexpr int nnls_quad_wave_lds() { return 16 * NnlsQuadGeom<N>::STRIDE + 16; }
 
 // -DOPTIK_PROFILE: wave cycles per part of the loop below, summed over all waves into g_quad_nnls_prof
-// (phase_profile.py (a tool of rounds 3-5: git history)): 0 steps two-four, 1 step five, 2 steps six-ten, 3 step eleven, 4 loop trips,
+// (phase_profile.py (a rounds 3-5 tool: git history)): 0 steps two-four, 1 step five, 2 steps six-ten, 3 step eleven, 4 loop trips,
 // 5 calls, 6 Givens steps
 #ifdef OPTIK_DEVICE_PROFILE
 __device__ unsigned long long g_quad_nnls_prof[8];

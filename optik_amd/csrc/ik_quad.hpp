@@ -806,7 +806,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
             const EvalParams &ep = *reload_barrier_lds(&ep_in);
 #ifndef OPTIK_QUAD_EXP_NO_EVAL
 #ifdef OPTIK_QUAD_EXP_DUP_EVAL
-            // (cost-by-duplication experiments, quad_dup_costs.sh (a tool of rounds 3-5: git history): the phase runs twice on the same inputs,
+            // (cost-by-duplication experiments, quad_dup_costs.sh (a rounds 3-5 tool: git history): the phase runs twice on the same inputs,
             // the results are those of the second run -- same bits, the time difference is the phase's cost)
             {
                 double gn0[NS];

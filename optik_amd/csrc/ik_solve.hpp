@@ -31,7 +31,7 @@ enum : int32_t {
 constexpr int MAX_EVALS_CAP = 100000;  // same safety cap as the oracle
 constexpr unsigned REFILL_BATCH = 8;   // idle lanes a wave accumulates before it refills
 
-// Optional per-wave phase timers (build with -DOPTIK_PROFILE; phase_profile.py (a tool of rounds 3-5: git history)).
+// Optional per-wave phase timers (build with -DOPTIK_PROFILE; phase_profile.py (a rounds 3-5 tool: git history)).
 #ifdef OPTIK_PROFILE
 #define OPTIK_PROF_DECL unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long prof_t_ = 0
 #define OPTIK_PROF_BEGIN() prof_t_ = __builtin_readcyclecounter()

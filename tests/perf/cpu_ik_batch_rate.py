@@ -2,7 +2,7 @@
 """CPU side of BASELINE config 5: T independent ik() calls (reachable random targets, random
 seeds, SolutionMode::Speed, up to 256 restarts each, early exit) on the CPU oracle, one target
 per call, on the host's usable cores.  Prints ik() calls/s.  The oracle is checker code; it is
-only timed here as a baseline (the GPU figure: batch_ik_bench.py (a tool of rounds 3-5: git history))."""
+only timed here as a baseline (the GPU figure: batch_ik_bench.py (a rounds 3-5 tool: git history))."""
 import os
 import sys
 import threading

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Builds optik_amd/csrc/variants/<name>.so: the library with every translation unit compiled with the
 product's own flags (optik_amd/build.py:UNITS) plus extra defines -- e.g. the -DOPTIK_PROFILE build that
-phase_profile.py (a tool of rounds 3-5: git history) loads through OPTIK_PROF_LIB.  Units are compiled in parallel; objects are kept under
+phase_profile.py (a rounds 3-5 tool: git history) loads through OPTIK_PROF_LIB.  Units are compiled in parallel; objects are kept under
 variants/<name>/ and reused while their flags and sources are unchanged.  hipcc cross-compiles without a GPU.
 
 Usage: python tools/build_lib_variant.py <name> [-DFLAG ...] [--only=object.o[,object.o]]
