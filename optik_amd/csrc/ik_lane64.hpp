@@ -231,10 +231,6 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
 #else
             const unsigned long long it = fetch_items(wq.next_item, want);
 #endif
-#ifdef OPTIK_PROF_REFILL_SPLIT  // (diagnostic: the wait for the work counter under slot 0, the rest of the refill under slot 5)
-            { const unsigned long long it_ = it; asm volatile("" :: "v"(it_)); }
-            LANE_PROF(0);
-#endif
             if (want) {
                 want = false;
                 if (it < wq.total_items) {
@@ -278,11 +274,7 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
         }
 #endif
         if (!wave_any(active)) break;
-#ifdef OPTIK_PROF_REFILL_SPLIT
-        LANE_PROF(5);
-#else
         LANE_PROF(0);
-#endif
 
         int32_t ret = 0;
         if (active) {
@@ -301,16 +293,6 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
         double gn[N];
         double fn = 0.0;
         OPTIK_SCHED_FENCE_LANE64();
-#ifdef OPTIK_LANE_EXP_DUP_EVAL  // (cost-by-duplication experiments, lane_dup_costs.sh (a rounds 3-5 tool: git history): same results, the phase runs twice)
-        if (do_eval) {
-            double xx[N], g0[N];
-#pragma unroll
-            for (int i = 0; i < N; ++i) { xx[i] = x[i]; asm volatile("" : "+v"(xx[i])); }
-            const double f0_ = eval_fg<N, TIP>(ch, ep, target, xx, g0);
-            asm volatile("" :: "v"(f0_), "v"(g0[0]), "v"(g0[N - 1]));
-        }
-        OPTIK_SCHED_FENCE_LANE64();
-#endif
         if (do_eval) fn = eval_fg<N, TIP>(ch, ep, target, x, gn);
         OPTIK_SCHED_FENCE_LANE64();
         LANE_PROF(1);
@@ -370,18 +352,6 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
 #pragma unroll
                         for (int i = 0; i < N; ++i) { u[i] = gn[i] - g[i]; g[i] = gn[i]; }
                         OPTIK_SCHED_FENCE_LANE64();
-#ifdef OPTIK_LANE_EXP_DUP_BFGS
-                        {
-                            double l2[NL], u2[N];
-#pragma unroll
-                            for (int i = 0; i < NL; ++i) { l2[i] = l[i]; asm volatile("" : "+v"(l2[i])); }
-#pragma unroll
-                            for (int i = 0; i < N; ++i) u2[i] = u[i];
-                            bfgs_update<N>(l2, s, u2);
-#pragma unroll
-                            for (int i = 0; i < NL; ++i) asm volatile("" :: "v"(l2[i]));
-                        }
-#endif
                         bfgs_update<N>(l, s, u);
                         OPTIK_SCHED_FENCE_LANE64();
                         need_dir = true;
@@ -416,27 +386,6 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
 #pragma unroll
                 for (int j = 0; j < N; ++j) E[i][j] = 0.0;
             }
-#ifdef OPTIK_LANE_EXP_DUP_LSQ
-            {
-                double gg[N], E0[N][N], f0_[N], lo[N], hi[N];
-#pragma unroll
-                for (int i = 0; i < N; ++i) {
-                    gg[i] = g[i]; asm volatile("" : "+v"(gg[i]));
-                    f0_[i] = 0.0; lo[i] = ch.lb[i] - x[i]; hi[i] = ch.ub[i] - x[i];
-#pragma unroll
-                    for (int j = 0; j < N; ++j) E0[i][j] = 0.0;
-                }
-                const int m0 = lsq_factor<N>(l, gg, E0, f0_);
-                double acc_ = 0.0;
-                const bool n0 = lsq_bound_rows<N>(E0, f0_, lo, hi, [&](int i, const double (&row)[N], double h_lo, double h_hi) {
-#pragma unroll
-                    for (int j = i; j < N; ++j) acc_ += row[j];
-                    acc_ += h_lo + h_hi;
-                });
-                asm volatile("" :: "v"(m0), "v"((int)n0), "v"(acc_));
-            }
-            OPTIK_SCHED_FENCE_LANE64();
-#endif
             int lmode = lsq_factor<N>(l, g, E, fv);
             OPTIK_SCHED_FENCE_LANE64();
             // rows of E^-1 and the bound rows they give: into the lane's packed problem in LDS
@@ -588,10 +537,6 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
                 rnorm = ob[G::META + 1];
                 pred = (int)ob[G::META + 2];
             };
-#ifdef OPTIK_LANE_EXP_DUP_NNLS
-          for (int dup_ = 0; dup_ < 2; ++dup_) {
-            asm volatile("" : "+s"(dup_));
-#endif
 #if OPTIK_LANE_PIPE
             {
                 // The wave's problems in rank order through its sixteen quads, the rounds overlapping: whenever at most
@@ -626,9 +571,6 @@ OPTIK_DEV void lane64_wave(const ChainDev &ch, const EvalParams &ep, const Solve
                 if (has && rank >= r0 && rank < r0 + nq) read_back(rank - r0);
                 lds_sync();  // (before the next round rewrites the blocks)
             }
-#endif
-#ifdef OPTIK_LANE_EXP_DUP_NNLS
-          }
 #endif
             OPTIK_SCHED_FENCE_LANE64();
             LANE_PROF(6);

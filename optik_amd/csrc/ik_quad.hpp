@@ -804,24 +804,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
             // (the target pose is re-read for every evaluation: seven L1 / L2 hits instead of 14 registers)
             const double *target7 = (*reload_barrier_lds(&wq_in)).targets + (size_t)tslot * 7;
             const EvalParams &ep = *reload_barrier_lds(&ep_in);
-#ifndef OPTIK_QUAD_EXP_NO_EVAL
-#ifdef OPTIK_QUAD_EXP_DUP_EVAL
-            // (cost-by-duplication experiments, quad_dup_costs.sh (a rounds 3-5 tool: git history): the phase runs twice on the same inputs,
-            // the results are those of the second run -- same bits, the time difference is the phase's cost)
-            {
-                double gn0[NS];
-                double xx[NS];
-#pragma unroll
-                for (int s = 0; s < NS; ++s) { xx[s] = x[s]; asm volatile("" : "+v"(xx[s])); }
-                double f0 = eval_quad<N, TIP>(ch, ep, target7, xx, gn0, bp + 4 * pi);
-                asm volatile("" :: "v"(f0), "v"(gn0[0]), "v"(gn0[NS - 1]));
-                OPTIK_SCHED_FENCE();
-            }
-#endif
             fn = eval_quad<N, TIP>(ch, ep, target7, x, gn, bp + 4 * pi);
-#else
-            fn = target7[0]; gn[0] = x[0]; if (NS > 1) gn[NS - 1] = x[NS - 1];
-#endif
             OPTIK_SCHED_FENCE();
             // (through a pointer the compiler knows nothing about: otherwise it forwards the stored values to
             // these loads, i.e. keeps them in registers across the evaluation after all)
@@ -921,29 +904,7 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
             ia = (qr == 2) ? nevals : ia;
         }
         OPTIK_SCHED_FENCE();
-#ifndef OPTIK_QUAD_EXP_NO_BFGS
-#ifdef OPTIK_QUAD_EXP_DUP_BFGS
-        if (wave_any(do_bfgs)) {
-            double Lr2[NS][NM], dg2[NS], u2[NS];
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                dg2[s] = dg[s]; u2[s] = u[s];
-                asm volatile("" : "+v"(dg2[s]), "+v"(u2[s]));
-#pragma unroll
-                for (int i = 0; i < NM; ++i) Lr2[s][i] = Lr[s][i];
-            }
-            bfgs_quad<N>(do_bfgs, Lr2, dg2, sv, u2);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                asm volatile("" :: "v"(dg2[s]), "v"(u2[s]));
-#pragma unroll
-                for (int i = 0; i < NM; ++i) asm volatile("" :: "v"(Lr2[s][i]));
-            }
-            OPTIK_SCHED_FENCE();
-        }
-#endif
         if (wave_any(do_bfgs)) bfgs_quad<N>(do_bfgs, Lr, dg, sv, u);
-#endif
         OPTIK_SCHED_FENCE();
         OPTIK_PROF_END(4);
 
@@ -993,30 +954,6 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                 for (int i = 0; i < NM; ++i) Ec[s][i] = 0.0;
             }
             OPTIK_SCHED_FENCE();
-#ifdef OPTIK_QUAD_EXP_DUP_LSQ
-            {
-                double gg[NS], Ec0[NS][NM], Ed0[NS], fv0[NS], row0[NS][N], hl0[NS], hh0[NS];
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    gg[s] = g[s]; asm volatile("" : "+v"(gg[s]));
-                    fv0[s] = 0.0; Ed0[s] = 1.0;
-#pragma unroll
-                    for (int i = 0; i < NM; ++i) Ec0[s][i] = 0.0;
-#pragma unroll
-                    for (int j = 0; j < N; ++j) row0[s][j] = 0.0;
-                }
-                int m0 = lsq_factor_quad<N>(Lr, dg, gg, Ec0, Ed0, fv0);
-                bool n0 = bound_rows_quad<N>(Ec0, Ed0, fv0, lo, hi, row0, hl0, hh0);
-                asm volatile("" :: "v"(m0), "v"((int)n0));
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    asm volatile("" :: "v"(hl0[s]), "v"(hh0[s]));
-#pragma unroll
-                    for (int j = 0; j < N; ++j) asm volatile("" :: "v"(row0[s][j]));
-                }
-                OPTIK_SCHED_FENCE();
-            }
-#endif
             int lmode = lsq_factor_quad<N>(Lr, dg, g, Ec, Ed, fv);
             OPTIK_SCHED_FENCE();
             double row[NS][N], h_lo[NS], h_hi[NS];
@@ -1041,11 +978,6 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                 // bound, h_lo below it) and, negated, column N + r + 1 (upper bound, h_hi below it)
                 // (the lane number is made opaque here: the column ids and the dozen LDS addresses
                 // derived from them are loop invariants the compiler would otherwise hoist and spill)
-#ifdef OPTIK_QUAD_EXP_DUP_NNLS
-              for (int dup_ = 0; dup_ < 2; ++dup_) {
-                asm volatile("" : "+s"(dup_));
-                lds_sync();
-#endif
                 const int qn = quad_lane_now();
                 double *const bk = blk;
                 int ids[CPL];
@@ -1070,17 +1002,10 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
                 }
                 int iters;
                 double xv[CPL];
-#ifndef OPTIK_QUAD_EXP_NO_NNLS
                 nnls_quad<N, NoPipe, QuadStop>(need_nnls, ids, bk, nnls_lds + QUADS_PER_WAVE * NnlsQuadGeom<N>::STRIDE, xv,
                                                nmode, rnorm, iters, nullptr, &st);
-#else
-                for (int k = 0; k < CPL; ++k) xv[k] = bk[k]; iters = 0;
-#endif
 #pragma unroll
                 for (int s = 0; s < NS; ++s) { ylo[s] = xv[s]; yhi[s] = xv[2 + s]; }
-#ifdef OPTIK_QUAD_EXP_DUP_NNLS
-              }
-#endif
 #ifdef OPTIK_PROFILE
                 OPTIK_PROF_COUNT(6, __builtin_readcyclecounter() - t_nn);
 #endif
@@ -1091,18 +1016,6 @@ OPTIK_DEV void quad_wave(const ChainDev &ch, const EvalParams &ep_in, const Solv
             double sn[NS];
 #pragma unroll
             for (int s = 0; s < NS; ++s) sn[s] = 0.0;
-#ifdef OPTIK_QUAD_EXP_DUP_FIN
-            {
-                double s0[NS], yl[NS];
-#pragma unroll
-                for (int s = 0; s < NS; ++s) { s0[s] = 0.0; yl[s] = ylo[s]; asm volatile("" : "+v"(yl[s])); }
-                int m0 = 0;
-                if (wave_any(need_nnls)) m0 = ldp_quad<N>(nmode, rnorm, row, h_lo, h_hi, yl, yhi, s0);
-                lsq_finish_quad<N>(Ec, Ed, fv, lo, hi, s0);
-                asm volatile("" :: "v"(m0), "v"(s0[0]), "v"(s0[NS - 1]));
-                OPTIK_SCHED_FENCE();
-            }
-#endif
             if (wave_any(need_nnls)) {
                 const int m2 = ldp_quad<N>(nmode, rnorm, row, h_lo, h_hi, ylo, yhi, sn);
                 if (need_nnls) lmode = m2;
