@@ -780,9 +780,13 @@ def main():
                 user = user_inputs(ctx)
             except Exception:  # noqa: BLE001
                 user = None
-        cpu = cpu_baseline(args.robot, primary["robot"].chain_tables(), primary["targets"][W].cpu().numpy(),
-                           primary["x0_host"][W], mode, args.cpu_seconds, user)
-        cpu["gpu_winner_same_target"] = int(primary["winners"][0, 0].item())
+        # (a failure of the baseline leg -- no compiler on the host, say -- must not cost the headline line either)
+        try:
+            cpu = cpu_baseline(args.robot, primary["robot"].chain_tables(), primary["targets"][W].cpu().numpy(),
+                               primary["x0_host"][W], mode, args.cpu_seconds, user)
+            cpu["gpu_winner_same_target"] = int(primary["winners"][0, 0].item())
+        except Exception as e:  # noqa: BLE001
+            cpu = {"error": f"{type(e).__name__}: {e}"[:300], "kind": "port"}
     others = None
     if want_others:
         # (a failure here -- the same on every rank: same code, same sizes -- must not cost the headline line)
@@ -915,11 +919,11 @@ def main():
             "cpu_baseline": cpu,
         }
         if cpu and others is not None and "single_ik" in others and "single_ik_ms" in cpu:
-            # the CPU figure beside each user-facing GPU figure (same targets): a GPU/CPU ratio is not credit -- for one default
-            # ik() call the MI355X is on par with ONE host thread, which is what section 8.3 of DESIGN.md says it must be
+            # the CPU figure beside each user-facing GPU figure (same targets): a GPU/CPU ratio is not credit -- one default
+            # ik() call takes the MI355X ~2.6 x as long as ONE host thread, which is what section 8.3 of DESIGN.md says it must
             others["single_ik"]["cpu_median_ms"] = {k: v["median_ms"] for k, v in cpu["single_ik_ms"].items() if isinstance(v, dict)}
             others["config5_all_4096_targets"]["cpu_ik_calls_per_s"] = cpu["config5_ik_calls_per_s"]
-        if cpu and others is not None:
+        if cpu and "value_1_thread" in cpu and others is not None:
             others["config1_cpu_1_thread"] = {"workload": "Panda, the bench target, the CPU oracle on ONE host thread (BASELINE config 1: "
                                                           "plumbing, no GPU)", "restarts_per_s": cpu["value_1_thread"],
                                               "winner": cpu["winner"], "gpu_winner_same_target": cpu["gpu_winner_same_target"]}
